@@ -1,0 +1,385 @@
+/*
+ * oracle/lfold.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the observable behaviour of `RNALfold -L <span>` as the reference
+ * calls it (/root/reference/miR_PREFeR.py:3053-3064, consumer :1541-1599).  The algorithm itself
+ * lives in a third-party dependency that is NOT in the reference tree as source: ViennaRNA
+ * RNALfold, bundled only as binaries.  This file restates the published algorithm (Hofacker et
+ * al. local folding, Zuker/Stiegler recursions, Turner-2004 nearest-neighbour model) in the
+ * "vienna-2.1.2" flavour: Turner-2004 tables, default dangles = 2, "short backtrack"
+ * enumeration of locally optimal structures.  Behavioural spec: SURVEY.md Appendix B / B2.
+ *
+ * Parity pinning: byte-for-byte against the outputs of the reference's bundled
+ * dependency/Mac/osx-10.9/RNALfold-2.1.2 binary run in the build container
+ * (tests/golden/tools/gen_fold_golden.py -> tests/golden/fold_*.json).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <ctype.h>
+#include "energy_params_t2004.h"
+#include "oracle.h"
+
+#define TURN 3
+#define MAXLOOP 30
+#define INF T04_INF
+
+static const int PAIR[5][5] = {
+    /*      N  A  C  G  U */
+    /*N*/ {0, 0, 0, 0, 0},
+    /*A*/ {0, 0, 0, 0, 5},
+    /*C*/ {0, 0, 0, 1, 0},
+    /*G*/ {0, 0, 2, 0, 3},
+    /*U*/ {0, 6, 0, 4, 0}};
+static const int RTYPE[8] = {0, 2, 1, 4, 3, 6, 5, 7};
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int clamp0(int v) { return v > 0 ? 0 : v; }
+
+typedef struct {
+    int n, M;
+    char *seq;      /* 1-based upper-case RNA string, seq[0] unused */
+    int *S;         /* 0..n+1 */
+    int *c, *fML;   /* (n+2) x (M+2) banded: [i*(M+2) + (j-i)] */
+    int *f3;        /* 0..n+M+3 */
+    unsigned char *pt; /* pair type, same banding */
+} Fold;
+
+#define IDX(F, i, j) ((size_t)(i) * ((F)->M + 2) + ((j) - (i)))
+
+static int ptype(const Fold *F, int i, int j) {
+    int d = j - i;
+    if (d <= TURN || d > F->M - 1 || i < 1 || j > F->n) return 0;
+    return F->pt[IDX(F, i, j)];
+}
+
+static int loop_extrap(int base30, int size) { return base30 + (int)(T04_LXC * log((double)size / 30.)); }
+
+/* hairpin closed by (i,j); spec: SURVEY.md App. B2 "Hairpin" */
+static int E_hairpin(const Fold *F, int i, int j, int type) {
+    int u = j - i - 1;
+    int e = (u <= 30) ? T04_hairpin[u] : loop_extrap(T04_hairpin[30], u);
+    const char *p = F->seq + i;
+    if (u == 4) {
+        for (int k = 0; k < T04_N_TETRALOOPS; k++)
+            if (!strncmp(p, T04_Tetraloops[k], 6)) return T04_Tetraloop_E[k];
+    } else if (u == 6) {
+        for (int k = 0; k < T04_N_HEXALOOPS; k++)
+            if (!strncmp(p, T04_Hexaloops[k], 8)) return T04_Hexaloop_E[k];
+    } else if (u == 3) {
+        for (int k = 0; k < T04_N_TRILOOPS; k++)
+            if (!strncmp(p, T04_Triloops[k], 5)) return T04_Triloop_E[k];
+        return e + (type > 2 ? T04_TerminalAU : 0);
+    }
+    return e + T04_mismatchH[type][F->S[i + 1]][F->S[j - 1]];
+}
+
+/* interior loop / bulge / stack; type2 is already rtype'd. spec: App. B "Loop" + B2 deltas */
+static int E_intloop(int n1, int n2, int type, int type2, int si1, int sj1, int sp1, int sq1) {
+    int nl = imax(n1, n2), ns = imin(n1, n2), e;
+    if (nl == 0) return T04_stack[type][type2];
+    if (ns == 0) {
+        e = (nl <= MAXLOOP) ? T04_bulge[nl] : loop_extrap(T04_bulge[30], nl);
+        if (nl == 1) e += T04_stack[type][type2];
+        else {
+            if (type > 2) e += T04_TerminalAU;
+            if (type2 > 2) e += T04_TerminalAU;
+        }
+        return e;
+    }
+    if (ns == 1) {
+        if (nl == 1) return T04_int11[type][type2][si1][sj1];
+        if (nl == 2) {
+            if (n1 == 1) return T04_int21[type][type2][si1][sq1][sj1];
+            return T04_int21[type2][type][sq1][si1][sp1];
+        }
+        e = (nl + 1 <= MAXLOOP) ? T04_internal_loop[nl + 1] : loop_extrap(T04_internal_loop[30], nl + 1);
+        e += imin(T04_MAX_NINIO, (nl - ns) * T04_ninio);
+        e += T04_mismatch1nI[type][si1][sj1] + T04_mismatch1nI[type2][sq1][sp1];
+        return e;
+    }
+    if (ns == 2) {
+        if (nl == 2) return T04_int22[type][type2][si1][sp1][sq1][sj1];
+        if (nl == 3) {
+            e = T04_internal_loop[5] + T04_ninio;
+            e += T04_mismatch23I[type][si1][sj1] + T04_mismatch23I[type2][sq1][sp1];
+            return e;
+        }
+    }
+    {
+        int u = nl + ns;
+        e = (u <= MAXLOOP) ? T04_internal_loop[u] : loop_extrap(T04_internal_loop[30], u);
+        e += imin(T04_MAX_NINIO, (nl - ns) * T04_ninio);
+        e += T04_mismatchI[type][si1][sj1] + T04_mismatchI[type2][sq1][sp1];
+    }
+    return e;
+}
+
+/* a = 5' neighbour base or -1, b = 3' neighbour base or -1 */
+static int E_mlstem(int type, int a, int b) {
+    int e = 0;
+    if (a >= 0 && b >= 0) e += clamp0(T04_mismatchM[type][a][b]);
+    else if (a >= 0) e += clamp0(T04_dangle5[type][a]);
+    else if (b >= 0) e += clamp0(T04_dangle3[type][b]);
+    if (type > 2) e += T04_TerminalAU;
+    return e + T04_ML_intern;
+}
+static int E_extloop(int type, int a, int b) {
+    int e = 0;
+    if (a >= 0 && b >= 0) e += clamp0(T04_mismatchExt[type][a][b]);
+    else if (a >= 0) e += clamp0(T04_dangle5[type][a]);
+    else if (b >= 0) e += clamp0(T04_dangle3[type][b]);
+    if (type > 2) e += T04_TerminalAU;
+    return e;
+}
+
+static int cget(const Fold *F, int i, int j) {
+    int d = j - i;
+    if (d <= TURN || d > F->M || i < 1 || j > F->n) return INF;
+    return F->c[IDX(F, i, j)];
+}
+static int mget(const Fold *F, int i, int j) {
+    int d = j - i;
+    if (d <= TURN || d > F->M || i < 1 || j > F->n) return INF;
+    return F->fML[IDX(F, i, j)];
+}
+
+static int DML(const Fold *F, int a, int b) {
+    int dec = INF;
+    for (int k = a + 1 + TURN; k <= b - 2 - TURN; k++) dec = imin(dec, mget(F, a, k) + mget(F, k + 1, b));
+    return dec;
+}
+
+static int ext_term(const Fold *F, int i, int k, int type) {
+    return E_extloop(type, i > 1 ? F->S[i - 1] : -1, k < F->n ? F->S[k + 1] : -1);
+}
+
+static void fill(Fold *F) {
+    const int n = F->n, M = F->M;
+    for (int i = n - TURN - 1; i >= 1; i--) {
+        for (int j = i + TURN + 1; j <= n && j <= i + M; j++) {
+            int type = ptype(F, i, j), newc = INF;
+            if (type) {
+                newc = E_hairpin(F, i, j, type);
+                int pmax = imin(j - 2 - TURN, i + MAXLOOP + 1);
+                for (int p = i + 1; p <= pmax; p++) {
+                    int minq = j - i + p - MAXLOOP - 2;
+                    if (minq < p + 1 + TURN) minq = p + 1 + TURN;
+                    for (int q = minq; q < j; q++) {
+                        int t2 = ptype(F, p, q);
+                        if (!t2) continue;
+                        t2 = RTYPE[t2];
+                        int e = E_intloop(p - i - 1, j - q - 1, type, t2, F->S[i + 1], F->S[j - 1], F->S[p - 1], F->S[q + 1]);
+                        newc = imin(newc, e + cget(F, p, q));
+                    }
+                }
+                int dec = DML(F, i + 1, j - 1);
+                newc = imin(newc, dec + T04_ML_closing + E_mlstem(RTYPE[type], F->S[j - 1], F->S[i + 1]));
+            }
+            F->c[IDX(F, i, j)] = newc;
+            int m = imin(mget(F, i + 1, j) + T04_ML_BASE, mget(F, i, j - 1) + T04_ML_BASE);
+            if (type) m = imin(m, newc + E_mlstem(type, i > 1 ? F->S[i - 1] : -1, j < n ? F->S[j + 1] : -1));
+            m = imin(m, DML(F, i, j));
+            F->fML[IDX(F, i, j)] = m;
+        }
+        /* f3 */
+        int best = F->f3[i + 1];
+        for (int j = i + TURN + 1; j <= n && j <= i + M; j++) {
+            int type = ptype(F, i, j);
+            if (type) best = imin(best, F->f3[j + 1] + cget(F, i, j) + ext_term(F, i, j, type));
+        }
+        F->f3[i] = best;
+    }
+}
+
+typedef struct { int i, j, ml; } Sector;
+
+/* Backtrack one local structure starting at `start`, exterior sector end `jend`.
+ * Writes a NUL-terminated dot-bracket string (positions start..) into out; returns its length.
+ * spec: SURVEY.md App. B "Backtrack" with the B2 deltas (descending exterior partner scan). */
+static int backtrack(const Fold *F, int start, int jend, char *out, int cap) {
+    const int n = F->n;
+    int len0 = imin(n - start, F->M + 1) + 2;
+    if (len0 + 1 > cap) len0 = cap - 1;
+    memset(out, '-', len0);
+    out[len0] = 0;
+    Sector st[1024];
+    int s = 0;
+    st[++s] = (Sector){start, jend, 0};
+    while (s > 0) {
+        int i = st[s].i, j = st[s].j, ml = st[s].ml;
+        s--;
+        if (j < i + TURN + 1) continue;
+        int k;
+        if (ml == 0) {
+            int fij = F->f3[i];
+            if (fij == F->f3[i + 1]) { st[++s] = (Sector){i + 1, j, 0}; continue; }
+            int traced = 0;
+            for (k = j; k >= i + TURN + 1; k--) {
+                int type = ptype(F, i, k);
+                if (type) {
+                    int cc = cget(F, i, k) + ext_term(F, i, k, type);
+                    if (fij == cc + F->f3[k + 1]) { traced = i; break; }
+                }
+            }
+            if (!traced) return -1;
+            if (j == n) st[++s] = (Sector){k + 1, j, 0};
+            j = k;
+            out[i - start] = '(';
+            out[j - start] = ')';
+            if (j < n) out[j + 1 - start] = '.';
+        } else {
+            int fij = mget(F, i, j);
+            if (mget(F, i, j - 1) + T04_ML_BASE == fij) { st[++s] = (Sector){i, j - 1, 1}; continue; }
+            if (mget(F, i + 1, j) + T04_ML_BASE == fij) { st[++s] = (Sector){i + 1, j, 1}; continue; }
+            int type = ptype(F, i, j);
+            int ok = 0;
+            if (type) {
+                int e = cget(F, i, j) + E_mlstem(type, i > 1 ? F->S[i - 1] : -1, j < n ? F->S[j + 1] : -1);
+                if (e == fij) ok = 1;
+            }
+            if (!ok) {
+                for (k = i + 1 + TURN; k <= j - 2 - TURN; k++)
+                    if (fij == mget(F, i, k) + mget(F, k + 1, j)) break;
+                if (k > j - 2 - TURN) return -2;
+                st[++s] = (Sector){i, k, 1};
+                st[++s] = (Sector){k + 1, j, 1};
+                continue;
+            }
+            out[i - start] = '(';
+            out[j - start] = ')';
+        }
+        /* repeat1: (i,j) is a pair; follow interior loops */
+        for (;;) {
+            int type = ptype(F, i, j);
+            int cij = cget(F, i, j);
+            if (cij == E_hairpin(F, i, j, type)) break;
+            int found = 0;
+            int pmax = imin(j - 2 - TURN, i + MAXLOOP + 1);
+            for (int p = i + 1; p <= pmax && !found; p++) {
+                int minq = j - i + p - MAXLOOP - 2;
+                if (minq < p + 1 + TURN) minq = p + 1 + TURN;
+                for (int q = j - 1; q >= minq; q--) {
+                    int t2 = ptype(F, p, q);
+                    if (!t2) continue;
+                    t2 = RTYPE[t2];
+                    int e = E_intloop(p - i - 1, j - q - 1, type, t2, F->S[i + 1], F->S[j - 1], F->S[p - 1], F->S[q + 1]);
+                    if (cij == e + cget(F, p, q)) {
+                        out[p - start] = '(';
+                        out[q - start] = ')';
+                        i = p; j = q; found = 1;
+                        break;
+                    }
+                }
+            }
+            if (found) continue;
+            /* multiloop */
+            int mm = T04_ML_closing + E_mlstem(RTYPE[type], F->S[j - 1], F->S[i + 1]);
+            for (k = i + 2 + TURN; k <= j - 3 - TURN; k++)
+                if (cij == mget(F, i + 1, k) + mget(F, k + 1, j - 1) + mm) break;
+            if (k > j - 3 - TURN) return -3;
+            st[++s] = (Sector){i + 1, k, 1};
+            st[++s] = (Sector){k + 1, j - 1, 1};
+            break;
+        }
+    }
+    int L = len0;
+    while (L > 1 && out[L - 1] == '-') L--;
+    out[L] = 0;
+    for (int x = 0; x < L; x++) if (out[x] == '-') out[x] = '.';
+    return L;
+}
+
+static void emit(OracleFoldResult *R, const char *body, int lead_dot, int energy, int start) {
+    if (R->n_lines >= ORACLE_MAX_LINES) { R->overflow = 1; return; }
+    OracleFoldLine *l = &R->lines[R->n_lines++];
+    int o = 0;
+    if (lead_dot) l->ss[o++] = '.';
+    strncpy(l->ss + o, body, ORACLE_MAX_SS - o - 1);
+    l->ss[ORACLE_MAX_SS - 1] = 0;
+    l->len = (int)strlen(l->ss);
+    l->energy = energy;
+    l->start = start;
+}
+
+int oracle_lfold(const char *seq_in, int n, int span, OracleFoldResult *R) {
+    Fold F;
+    memset(R, 0, sizeof(*R));
+    if (n < 1) return 0;
+    F.n = n; F.M = span;
+    F.seq = (char *)calloc(n + 16, 1);
+    F.S = (int *)calloc(n + 2, sizeof(int));
+    for (int i = 1; i <= n; i++) {
+        char ch = (char)toupper((unsigned char)seq_in[i - 1]);
+        if (ch == 'T') ch = 'U';
+        F.seq[i] = ch;
+        F.S[i] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
+    }
+    F.S[0] = F.S[n]; F.S[n + 1] = F.S[1];
+    size_t cells = (size_t)(n + 2) * (span + 2);
+    F.c = (int *)malloc(cells * sizeof(int));
+    F.fML = (int *)malloc(cells * sizeof(int));
+    F.pt = (unsigned char *)calloc(cells, 1);
+    F.f3 = (int *)calloc(n + span + 8, sizeof(int));
+    for (size_t x = 0; x < cells; x++) F.c[x] = F.fML[x] = INF;
+    for (int i = 1; i <= n; i++)
+        for (int j = i + TURN + 1; j <= n && j - i <= span - 1; j++) F.pt[IDX(&F, i, j)] = (unsigned char)PAIR[F.S[i]][F.S[j]];
+    fill(&F);
+
+    /* enumeration of locally optimal structures; spec: App. B "Enumeration" + B2 short backtrack */
+    char *prev = (char *)malloc(n + 8), *cur = (char *)malloc(n + 8);
+    int have_prev = 0, prev_i = 0, do_bt = 0, rc = 0;
+    for (int i = n - TURN - 1; i >= 1; i--) {
+        if (F.f3[i] != F.f3[i + 1]) do_bt = 1;
+        else if (do_bt) {
+            int lind = i + 1, fij = F.f3[i + 1], pp, traced = 0;
+            while (fij == F.f3[lind + 1]) lind++;
+            for (pp = lind + TURN; pp <= lind + span; pp++) {
+                int type = ptype(&F, lind, pp);
+                if (!type) continue;
+                int cc = cget(&F, lind, pp) + ext_term(&F, lind, pp, type);
+                if (fij == cc + F.f3[pp + 1]) { traced = 1; break; }
+            }
+            if (!traced) { rc = -10; break; }
+            int L = backtrack(&F, lind, imin(n, pp + 2), cur, n + 8);
+            if (L < 0) { rc = L; break; }
+            if (have_prev) {
+                int lp = (int)strlen(prev);
+                int off = prev_i - i;
+                int differ = (off > L) ? 1 : (strncmp(cur + off, prev, lp) != 0);
+                if (i + L < prev_i + lp || differ)
+                    emit(R, prev, 1, F.f3[prev_i] - F.f3[prev_i + lp - 1], prev_i - 1);
+            }
+            char *t = prev; prev = cur; cur = t;
+            have_prev = 1; prev_i = lind; do_bt = 0;
+        }
+        if (i == 1) {
+            if (have_prev) {
+                int lp = (int)strlen(prev);
+                emit(R, prev, 1, F.f3[prev_i] - F.f3[prev_i + lp - 1], prev_i - 1);
+                have_prev = 0;
+            }
+            if (do_bt) {
+                int lind = 1, fij = F.f3[1], pp, traced = 0;
+                for (pp = lind + TURN; pp <= lind + span; pp++) {
+                    int type = ptype(&F, lind, pp);
+                    if (!type) continue;
+                    int cc = cget(&F, lind, pp) + ext_term(&F, lind, pp, type);
+                    if (fij == cc + F.f3[pp + 1]) { traced = 1; break; }
+                }
+                if (!traced) { rc = -11; break; }
+                int L = backtrack(&F, 1, imin(n, pp + 2), cur, n + 8);
+                if (L < 0) { rc = L; break; }
+                emit(R, cur, 0, F.f3[1] - F.f3[L], 1);
+            }
+        }
+    }
+    R->mfe = F.f3[1];
+    free(prev); free(cur);
+    free(F.seq); free(F.S); free(F.c); free(F.fML); free(F.pt); free(F.f3);
+    return rc;
+}
