@@ -1,0 +1,36 @@
+// Device-side energy model for the L-bounded local fold (replaces the RNALfold subprocess,
+// reference call site /root/reference/miR_PREFeR.py:3053-3064).  Turner-2004 nearest-neighbour
+// parameters, "vienna-2.1.2" flavour (dangles = 2).  Integers in 0.01 kcal/mol.
+#pragma once
+#include <stdint.h>
+
+#define MIRP_TURN 3
+#define MIRP_MAXLOOP 30
+#define MIRP_INF 10000000
+#define MIRP_HP_MAX 3104          // hairpin size table (log-extrapolated above 30 on the host)
+
+struct FoldParams {
+    int stack[8][8];
+    int bulge[31];
+    int internal_loop[31];
+    int mismatchI[8][5][5];
+    int mismatchH[8][5][5];
+    int mismatchM[8][5][5];       // clamped <= 0
+    int mismatch1nI[8][5][5];
+    int mismatch23I[8][5][5];
+    int mismatchExt[8][5][5];     // clamped <= 0
+    int dangle5[8][5];            // clamped <= 0
+    int dangle3[8][5];            // clamped <= 0
+    int int11[8][8][5][5];
+    int int21[8][8][5][5][5];
+    int int22[8][8][5][5][5][5];
+    int hairpinE[MIRP_HP_MAX];
+    int tetraE[16], triE[2], hexaE[4];
+    char tetra[16][8];
+    char tri[2][8];
+    char hexa[4][12];
+    int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
+};
+
+// Fills *p from the generated Turner-2004 tables (host side, mirp_params.cpp).
+void mirp_fill_fold_params(FoldParams* p);

@@ -1,0 +1,156 @@
+// C-ABI layer of libmirprefer.so (see include/mirprefer.h).  Host orchestration only: device
+// buffers, streams, kernel launches.  There is NO CPU fallback: every entry point fails loudly
+// if no gfx950 device / HIP runtime is usable.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "mirp_internal.h"
+
+#define MIRP_ABI_VERSION 1
+#define MIRP_NMAX 3096
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct mirp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+    FoldParams* d_params = nullptr;
+    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status;
+};
+
+static int fail(mirp_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail((c), -2, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int mirp_abi_version(void) { return MIRP_ABI_VERSION; }
+
+extern "C" int mirp_create(int device, mirp_ctx** out) {
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -3;  // no GPU: fail loudly, no fallback
+    if (device < 0 || device >= ndev) return -4;
+    mirp_ctx* c = new mirp_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return -2; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -2; }
+    FoldParams* hp = new FoldParams();
+    mirp_fill_fold_params(hp);
+    if (hipMalloc((void**)&c->d_params, sizeof(FoldParams)) != hipSuccess ||
+        hipMemcpy(c->d_params, hp, sizeof(FoldParams), hipMemcpyHostToDevice) != hipSuccess) {
+        delete hp; delete c; return -2;
+    }
+    delete hp;
+    *out = c;
+    return 0;
+}
+
+extern "C" void mirp_destroy(mirp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
+    c->nlines.release(); c->mfe.release(); c->status.release();
+    if (c->d_params) (void)hipFree(c->d_params);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* mirp_last_error(const mirp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" void mirp_free(void* p) { std::free(p); }
+
+extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
+                               int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride_out,
+                               int32_t** n_lines, int32_t** mfe, int32_t** status) {
+    if (!c) return -1;
+    if (!seqs || !offsets || n_seqs < 0 || !lines || !ss || !ss_stride_out || !n_lines || !mfe || !status)
+        return fail(c, -1, "mirp_fold_batch: null argument");
+    if (span < 1 || max_lines < 1) return fail(c, -1, "mirp_fold_batch: bad span/max_lines");
+    HIPCHK(c, hipSetDevice(c->device));
+    int n_max = 1;
+    for (int i = 0; i < n_seqs; i++) {
+        int64_t n = offsets[i + 1] - offsets[i];
+        if (n < 0) return fail(c, -1, "mirp_fold_batch: offsets not monotone");
+        if (n > MIRP_NMAX) return fail(c, -5, "mirp_fold_batch: sequence longer than MIRP_NMAX");
+        n_max = std::max<int>(n_max, (int)n);
+    }
+    const int stride = ((n_max + 3 + 7) / 8) * 8;
+    *ss_stride_out = stride;
+    const size_t nl = (size_t)n_seqs * max_lines;
+    MirpFoldLine* h_lines = (MirpFoldLine*)std::calloc(std::max<size_t>(nl, 1), sizeof(MirpFoldLine));
+    char* h_ss = (char*)std::calloc(std::max<size_t>(nl * stride, 1), 1);
+    int32_t* h_nl = (int32_t*)std::calloc(std::max(n_seqs, 1), sizeof(int32_t));
+    int32_t* h_mfe = (int32_t*)std::calloc(std::max(n_seqs, 1), sizeof(int32_t));
+    int32_t* h_st = (int32_t*)std::calloc(std::max(n_seqs, 1), sizeof(int32_t));
+    auto bail = [&](int code, const std::string& m) {
+        std::free(h_lines); std::free(h_ss); std::free(h_nl); std::free(h_mfe); std::free(h_st);
+        return fail(c, code, m);
+    };
+    if (!h_lines || !h_ss || !h_nl || !h_mfe || !h_st) return bail(-6, "mirp_fold_batch: host allocation failed");
+    if (n_seqs > 0) {
+        const size_t total = (size_t)offsets[n_seqs] - (size_t)offsets[0];
+        if (c->seqs.ensure(total + 16) || c->offs.ensure(sizeof(long long) * (n_seqs + 1)))
+            return bail(-6, "device allocation failed (inputs)");
+        std::vector<long long> rel(n_seqs + 1);
+        for (int i = 0; i <= n_seqs; i++) rel[i] = offsets[i] - offsets[0];
+        if (hipMemcpyAsync(c->seqs.p, seqs + offsets[0], total, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->offs.p, rel.data(), sizeof(long long) * (n_seqs + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            return bail(-2, "H2D copy failed");
+        // batches bound the structure-text buffer
+        const size_t per_win = (size_t)max_lines * stride;
+        int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_seqs, ((size_t)1 << 30) / per_win));
+        const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_max, span);
+        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
+        if (c->ws.ensure((size_t)slots * slot_ints * 4) || c->lines.ensure(sizeof(MirpFoldLine) * (size_t)batch * max_lines) ||
+            c->ss.ensure((size_t)batch * per_win) || c->nlines.ensure(4 * (size_t)n_seqs) || c->mfe.ensure(4 * (size_t)n_seqs) ||
+            c->status.ensure(4 * (size_t)n_seqs))
+            return bail(-6, "device allocation failed (workspace/outputs)");
+        if (mirp::fold_generic_lds_bytes(n_max, max_lines) > 64 * 1024) return bail(-5, "LDS budget exceeded (max_lines too large)");
+        for (int b0 = 0; b0 < n_seqs; b0 += batch) {
+            const int nb = std::min(batch, n_seqs - b0);
+            const int grid = std::min(nb, slots);
+            // windows of this batch are addressed relative to b0: shift the pointers
+            mirp::launch_fold_generic(c->stream, grid, c->d_params, (const unsigned char*)c->seqs.p, (const long long*)c->offs.p + b0,
+                                      nullptr, nb, span, n_max, (int*)c->ws.p, slot_ints, max_lines, stride, (MirpFoldLine*)c->lines.p,
+                                      (char*)c->ss.p, (int*)c->nlines.p + b0, (int*)c->mfe.p + b0, (int*)c->status.p + b0);
+            if (hipGetLastError() != hipSuccess) return bail(-2, "fold kernel launch failed");
+            if (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->lines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
+                               hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(h_ss + (size_t)b0 * per_win, c->ss.p, (size_t)nb * per_win, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+                return bail(-2, "D2H copy failed");
+            if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(-2, "fold kernel execution failed");
+        }
+        if (hipMemcpy(h_nl, c->nlines.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_mfe, c->mfe.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_st, c->status.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess)
+            return bail(-2, "D2H copy failed");
+    }
+    *lines = h_lines; *ss = h_ss; *n_lines = h_nl; *mfe = h_mfe; *status = h_st;
+    return 0;
+}

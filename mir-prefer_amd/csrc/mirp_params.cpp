@@ -1,0 +1,40 @@
+// Host-side construction of the device energy model from the generated Turner-2004 tables.
+#include "fold_params.h"
+#include "energy_params_t2004.h"
+#include <cmath>
+#include <cstring>
+
+static inline int clamp0(int v) { return v > 0 ? 0 : v; }
+
+void mirp_fill_fold_params(FoldParams* p) {
+    std::memset(p, 0, sizeof(*p));
+    std::memcpy(p->stack, T04_stack, sizeof(p->stack));
+    std::memcpy(p->bulge, T04_bulge, sizeof(p->bulge));
+    std::memcpy(p->internal_loop, T04_internal_loop, sizeof(p->internal_loop));
+    std::memcpy(p->mismatchI, T04_mismatchI, sizeof(p->mismatchI));
+    std::memcpy(p->mismatchH, T04_mismatchH, sizeof(p->mismatchH));
+    std::memcpy(p->mismatch1nI, T04_mismatch1nI, sizeof(p->mismatch1nI));
+    std::memcpy(p->mismatch23I, T04_mismatch23I, sizeof(p->mismatch23I));
+    for (int t = 0; t < 8; t++)
+        for (int a = 0; a < 5; a++) {
+            p->dangle5[t][a] = clamp0(T04_dangle5[t][a]);
+            p->dangle3[t][a] = clamp0(T04_dangle3[t][a]);
+            for (int b = 0; b < 5; b++) {
+                p->mismatchM[t][a][b] = clamp0(T04_mismatchM[t][a][b]);
+                p->mismatchExt[t][a][b] = clamp0(T04_mismatchExt[t][a][b]);
+            }
+        }
+    std::memcpy(p->int11, T04_int11, sizeof(p->int11));
+    std::memcpy(p->int21, T04_int21, sizeof(p->int21));
+    std::memcpy(p->int22, T04_int22, sizeof(p->int22));
+    for (int u = 0; u < MIRP_HP_MAX; u++)
+        p->hairpinE[u] = (u <= 30) ? T04_hairpin[u] : T04_hairpin[30] + (int)(T04_LXC * std::log((double)u / 30.));
+    for (int k = 0; k < T04_N_TETRALOOPS; k++) { std::strncpy(p->tetra[k], T04_Tetraloops[k], 7); p->tetraE[k] = T04_Tetraloop_E[k]; }
+    for (int k = 0; k < T04_N_TRILOOPS; k++) { std::strncpy(p->tri[k], T04_Triloops[k], 7); p->triE[k] = T04_Triloop_E[k]; }
+    for (int k = 0; k < T04_N_HEXALOOPS; k++) { std::strncpy(p->hexa[k], T04_Hexaloops[k], 11); p->hexaE[k] = T04_Hexaloop_E[k]; }
+    p->ML_closing = T04_ML_closing;
+    p->ML_intern = T04_ML_intern;
+    p->TerminalAU = T04_TerminalAU;
+    p->ninio = T04_ninio;
+    p->MAX_NINIO = T04_MAX_NINIO;
+}
