@@ -1,0 +1,61 @@
+"""Record layouts shared by the ctypes C-ABI (include/mirprefer.h) and the host stage drivers, plus the
+text renderings the reference writes into its stage artefacts (depth file, FASTA headers)."""
+import numpy as np
+
+DEPTH_DTYPE = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("dp", "<i4"), ("dm", "<i4")])
+PEAK_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("strand", "<i4")])
+MATURE_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("strand", "<i4"), ("depth", "<i4")])
+WINDOW_DTYPE = np.dtype([("tid", "<i4"), ("ws", "<i4"), ("we", "<i4"), ("strand", "<i4"), ("loc_s", "<i4"), ("loc_e", "<i4"),
+                         ("tag", "<i4"), ("n_peaks", "<i4"), ("peak_off", "<i8"), ("n_matures", "<i4"), ("_pad0", "<i4"),
+                         ("mature_off", "<i8"), ("seq_off", "<i8"), ("seq_len", "<i4"), ("_pad1", "<i4")], align=False)
+LOCUS_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("n_windows", "<i4"), ("w", "<i4", (2, 2)),
+                        ("peak_first", "<i8"), ("n_peaks", "<i4"), ("_pad", "<i4")])
+
+STRAND = "+-"
+TAG = "0LR"
+
+
+def depth_text(depth, contig_names):
+    """bam.depth.cut<CUT> text: `chr\\tpos\\td+\\td-` (miR_PREFeR.py:937-949)."""
+    return "".join("%s\t%d\t%d\t%d\n" % (contig_names[r["tid"]], r["pos"], r["dp"], r["dm"]) for r in depth)
+
+
+def peaks_to_dict(peaks, contig_names):
+    """dict_contigs of gen_contig_typeA (miR_PREFeR.py:952-962)."""
+    d = {}
+    for p in peaks:
+        d.setdefault(contig_names[p["tid"]], []).append((int(p["start"]), int(p["end"]), STRAND[p["strand"]]))
+    return d
+
+
+def loci_to_dict(loci, peaks, contig_names, precursor_len=300):
+    """dict_loci of gen_candidate_region_typeA (miR_PREFeR.py:1302-1316)."""
+    d = {}
+    for lc in loci:
+        pk = [(int(p["start"]), int(p["end"]), STRAND[p["strand"]]) for p in peaks[lc["peak_first"]:lc["peak_first"] + lc["n_peaks"]]]
+        # a single-peak region is the peak tuple itself, strand included (r_now = contiglist[0], miR_PREFeR.py:1259)
+        info = [pk[0] if len(pk) == 1 else (int(lc["start"]), int(lc["end"]))]
+        for k in range(lc["n_windows"]):
+            win = (int(lc["w"][k][0]), int(lc["w"][k][1]))
+            if lc["end"] - lc["start"] > precursor_len:
+                win = info[0]  # extend_region returns [region] itself (miR_PREFeR.py:1276-1277)
+            info.append((win, pk))
+        d.setdefault(contig_names[lc["tid"]], []).append(info)
+    return d
+
+
+def mature_tuple(m):
+    if m["strand"] < 0:
+        return (0, 0, 0, 0)
+    return (int(m["start"]), int(m["end"]), STRAND[m["strand"]], int(m["depth"]))
+
+
+def fasta_header(w, wpeaks, matures, contig_names):
+    """`>chr:ws-we strand locS-locE tag peaks M:..` (miR_PREFeR.py:1124-1140, 1162-1178)."""
+    pk = wpeaks[w["peak_off"]:w["peak_off"] + w["n_peaks"]]
+    other = ";".join("%d,%d,%s" % (p["start"], p["end"], STRAND[p["strand"]]) for p in pk)
+    h = ">%s:%d-%d %s %d-%d %s %s" % (contig_names[w["tid"]], w["ws"], w["we"], STRAND[w["strand"]], w["loc_s"], w["loc_e"], TAG[w["tag"]], other)
+    for m in matures[w["mature_off"]:w["mature_off"] + w["n_matures"]]:
+        t = mature_tuple(m)
+        h += " M:%d-%d/%s/%d" % (t[0], t[1], t[2], t[3])
+    return h

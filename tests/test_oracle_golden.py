@@ -1,0 +1,218 @@
+"""Pins the CPU oracle (oracle/*.c) against golden vectors produced by the REAL reference stack
+(miR_PREFeR.py under the py3 shim + bundled samtools 0.1.18 + bundled RNALfold 2.1.2); CPU only."""
+import numpy as np
+import pytest
+
+from mir_prefer_amd import records
+from tests import golden_util as gu
+
+CASES = ["mini", "mini3"]
+
+
+def test_lfold_matches_rnalfold212(oracle):
+    gold = gu.load_json("fold_rnalfold212.json.gz")
+    n = 0
+    for case in gold["cases"]:
+        for seq, exp in zip(case["seqs"], case["expected"]):
+            got = oracle.lfold(seq, case["span"])
+            assert got["mfe"] == exp["mfe"], seq
+            assert [list(l) for l in got["lines"]] == exp["lines"], seq
+            n += 1
+    assert n >= 300
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request, oracle):
+    c = gu.load_pipeline_case(request.param)
+    cfg = c["exp"]["config"]
+    depth, peaks = oracle.coverage_peaks(c["alns"], c["contig_lens"], cfg["READS_DEPTH_CUTOFF"])
+    order = np.argsort(np.array(c["contig_names"], dtype=object), kind="stable").astype(np.int32)  # sorted(dict_contigs)
+    win = oracle.make_windows(peaks, c["alns"], c["contigs"], order, cfg["MAX_GAP"], cfg["PRECURSOR_LEN"], cfg["READS_DEPTH_CUTOFF"] * 0.5)
+    c = dict(c)
+    c.update(depth=depth, peaks=peaks, win=win, cfg=cfg)
+    return c
+
+
+def test_depth_file(case):
+    assert records.depth_text(case["depth"], case["contig_names"]) == case["exp"]["depth_cut"]
+
+
+def test_peaks(case):
+    assert records.peaks_to_dict(case["peaks"], case["contig_names"]) == gu.unjson(case["exp"]["dict_contigs"])
+
+
+def test_loci_and_windows(case):
+    got = records.loci_to_dict(case["win"]["loci"], case["peaks"], case["contig_names"], case["cfg"]["PRECURSOR_LEN"])
+    exp = gu.unjson(case["exp"]["dict_loci"])
+    exp = {k: v for k, v in exp.items() if v}
+    assert got == exp
+
+
+def _fasta_entries(case):
+    return [e for p in case["exp"]["pieces"] for e in p["fasta"]]
+
+
+def test_fasta_entries(case):
+    w = case["win"]
+    exp = _fasta_entries(case)
+    assert len(w["windows"]) == len(exp)
+    for k, (win, (hdr, seq)) in enumerate(zip(w["windows"], exp)):
+        assert records.fasta_header(win, w["wpeaks"], w["matures"], case["contig_names"]) == hdr, k
+        got = w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes().decode()
+        assert got == seq, k
+
+
+def test_matures_match_alndump(case):
+    w = case["win"]
+    dumps = [gu.unjson(d) for p in case["exp"]["pieces"] for d in p["alndump"]]
+    assert len(dumps) == len(w["windows"])
+    for win, d in zip(w["windows"], dumps):
+        key, tag, _info, matures = d
+        assert key == [case["contig_names"][win["tid"]], (int(win["ws"]), int(win["we"])), records.STRAND[win["strand"]]]
+        assert tag == records.TAG[win["tag"]]
+        got = [records.mature_tuple(m) for m in w["matures"][win["mature_off"]:win["mature_off"] + win["n_matures"]]]
+        assert got == [tuple(m) for m in matures]
+
+
+def _ref_lines(text):
+    """RNALfold output text -> per entry list of (ss, energy_dcal, start)"""
+    entries = []
+    for line in text.splitlines():
+        if line.startswith(">"):
+            entries.append([])
+            continue
+        sp = line.split()
+        if len(sp) >= 3:
+            e = line[line.index(" (") + 2:line.rindex(")")]
+            entries[-1].append((sp[0], int(round(float(e) * 100)), int(sp[-1])))
+    return entries
+
+
+def test_fold_of_pipeline_windows(case, oracle):
+    w = case["win"]
+    ref = [e for p in case["exp"]["pieces"] for e in _ref_lines(p["rnalfold_out"])]
+    assert len(ref) == len(w["windows"])
+    for win, exp in zip(w["windows"], ref):
+        seq = w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes()
+        got = oracle.lfold(seq, case["cfg"]["PRECURSOR_LEN"])
+        assert got["lines"] == exp
+
+
+def test_structures(case, oracle):
+    ref_lines = [e for p in case["exp"]["pieces"] for e in _ref_lines(p["rnalfold_out"])]
+    ref_structs = [gu.unjson(s) for p in case["exp"]["pieces"] for s in p["structures"]]
+    assert len(ref_lines) == len(ref_structs)
+    nsub = 0
+    for lines, (which, peak, structs) in zip(ref_lines, ref_structs):
+        got = oracle.structures_from_lines(lines, 55)
+        assert got == [tuple(s) for s in structs]
+        nsub += len(got)
+    assert nsub > 0
+
+
+def test_maturestar_and_expression(case, oracle):
+    from tests.oracle_binding import MS_CODES
+    w = case["win"]["windows"]
+    allow3 = case["cfg"]["ALLOW_3NT_OVERHANG"] == "Y"
+    ns = len(case["sample_names"])
+    n_ok = 0
+    base = 0
+    for p in case["exp"]["pieces"]:
+        for (wi, mature, foldstart, ss, r, ex) in p["maturestar_expr"]:
+            win = w[base + wi]
+            m0, m1, strand, mdepth = mature
+            if strand == 0:
+                continue  # the (0,0,0,0) fallback mature; the reference passes strand=0 -> '-' branch, length 0 anyway
+            sidx = records.STRAND.index(strand)
+            got = oracle.maturestar(ss, m0, m1, foldstart, int(win["ws"]), int(win["we"]), sidx)
+            r = gu.unjson(r)
+            if isinstance(r, str):
+                assert MS_CODES[got.code] == r, (ss, mature)
+                continue
+            assert got.code == 0, (ss, mature, MS_CODES[got.code], r)
+            assert (got.star_s, got.star_e, got.fold_s, got.fold_e) == tuple(r[:4])
+            assert bool(got.prime5) == r[5] and got.total_dots == r[7] and got.total_bps == r[8]
+            assert ss[got.star_l0:got.star_l1] == r[4] and ss[got.mat_l0:got.mat_l1] == r[6]
+            ex = gu.unjson(ex)
+            e = oracle.expression(case["alns"], ns, int(win["tid"]), int(win["ws"]), int(win["we"]), r[2], r[3], m0, m1, r[0], r[1], sidx, allow3)
+            assert not e.exception
+            assert e.total_this_strand == ex["total_depth_just_this_strand"] and e.total_anti == ex["total_depth_anti"]
+            assert e.total_mature == ex["total_depth_mature"] and e.total_isoform == ex["total_depth_isoform"]
+            assert e.total_star == ex["total_depth_star"]
+            assert e.mature_star_distance == ex["mature_star_distance"]
+            assert e.ratio_total == ex["mature_star_ratio_total"] and e.ratio_both == ex["mature_star_ratio_total_both_strand"]
+            assert e.ratio_iso == ex["mature_iso_star_ratio_total"]
+            assert list(e.total_imperfect) == ex["total_depth_imperfect_star"]
+            for si, sname in enumerate(case["sample_names"]):
+                ps = ex["per_sample"][sname]
+                assert e.reads_pre[si] == ps["reads_pre"] and e.reads_mature[si] == ps["reads_mature"] and e.reads_star[si] == ps["reads_star"]
+                assert e.reads_antisense[si] == ps["reads_antisense"] and e.reads_isoform[si] == ps["reads_mature_isoform"]
+                assert e.reads_inside[si] == ps["reads_mature_inside"] and e.bases_with_reads_start[si] == ps["bases_with_reads_start"]
+                assert e.ratio_start[si] == ps["ratio_bases_with_reads_start"]
+                if allow3:
+                    assert list(e.imperfect[si]) == ps["reads_star_imperfect"]
+            if "max_imperfect_star" in ex:
+                assert e.has_imperfect_key and e.max_imperfect == ex["max_imperfect_star"] and e.imperfect_start == ex["imperfect_star_start"]
+                if ex["max_imperfect_star"]:
+                    assert e.imperfect_end == ex["imperfect_star_end"] and e.imperfect_which == ex["imperfect_star_which"]
+            else:
+                assert not e.has_imperfect_key
+            n_ok += 1
+        base += len(p["fasta"])
+    assert n_ok > 10
+
+
+def run_predict(case, oracle, structs_per_window):
+    """filter_next_loci pairing (miR_PREFeR.py:2350-2432) over the oracle's check_loci; returns (decisions, result_raw)."""
+    cfg = case["cfg"]
+    w = case["win"]
+    params = (len(case["sample_names"]), cfg["MIN_MATURE_LEN"], cfg["MAX_MATURE_LEN"], 1 if cfg["ALLOW_3NT_OVERHANG"] == "Y" else 0,
+              1 if cfg["ALLOW_NO_STAR_EXPRESSION"] == "Y" else 0, 55)
+
+    def check(k):
+        win = w["windows"][k]
+        mats = w["matures"][win["mature_off"]:win["mature_off"] + win["n_matures"]]
+        return oracle.check_loci(structs_per_window[k], mats, win, case["alns"], params)
+
+    decisions, result = [], []
+    k = 0
+    n = len(w["windows"])
+    while k < n:
+        if w["windows"][k]["tag"] == 0:
+            r = check(k); decisions.append(r); k += 1
+            if r:
+                result.append((k - 1, r[0]))
+        else:
+            r = check(k); decisions.append(r)
+            if r:
+                result.append((k, r[0]))
+            else:
+                r2 = check(k + 1); decisions.append(r2)
+                if r2:
+                    result.append((k + 1, r2[0]))
+            k += 2
+    return decisions, result
+
+
+def mirna_record(m, contig_names):
+    return [contig_names[m.tid], m.fold_s, m.fold_e, m.mat_s, m.mat_e, m.star_s, m.star_e, m.ss.decode(), records.STRAND[m.strand], bool(m.has_star)]
+
+
+def test_decisions_and_result(case, oracle):
+    ref_lines = [e for p in case["exp"]["pieces"] for e in _ref_lines(p["rnalfold_out"])]
+    structs = [oracle.structures_from_lines(l, 55) for l in ref_lines]
+    # decisions are per piece in the fixture; piece boundaries never split an L/R pair
+    decisions, result = run_predict(case, oracle, structs)
+    exp_dec = [d for p in case["exp"]["pieces"] for d in p["decisions"]]
+    assert len(decisions) == len(exp_dec)
+    for got, exp in zip(decisions, exp_dec):
+        assert bool(got) == exp["pass"]
+        if got:
+            em = gu.unjson(exp["mirnas"])
+            assert len(got) == len(em)
+            for g, e in zip(got, em):
+                assert mirna_record(g, case["contig_names"]) == e[:10]
+                assert g.total_depth_mature == e[10]["total_depth_mature"] and g.total_depth_star == e[10]["total_depth_star"]
+    exp_res = gu.unjson(case["exp"]["result_raw"])
+    assert [mirna_record(m, case["contig_names"]) for _, m in result] == [e[:10] for e in exp_res]
+    assert len(exp_res) > 5
