@@ -29,6 +29,41 @@ typedef struct {
     int32_t printed; /* 0 if RNALfold's containment rule suppresses the line */
 } MirpFoldLine;
 
+/* One ungapped alignment (`<len>M`), 16 bytes.  Arrays of these are sorted stably by (tid, pos) over the
+ * sample-ordered concatenation: the order of the reference's combined sorted BAM (MP:667-713, 807-859). */
+typedef struct {
+    int32_t tid;      /* contig index in @SQ order (MP:500-509) */
+    int32_t pos;      /* 1-based leftmost position */
+    uint32_t depth;   /* N of the read id `sample_rA_xN` (MP:242-253) */
+    uint16_t len;     /* read length */
+    uint8_t strand;   /* 0 '+', 1 '-' (flag & 16, MP:1445) */
+    uint8_t sample;   /* index into the sample-name list (MP:3300-3308) */
+} MirpAln;
+
+typedef struct { int32_t tid, pos, dp, dm; } MirpDepthPos;        /* one line of bam.depth.cut<CUT> (MP:946-949) */
+typedef struct { int32_t tid, start, end, strand; } MirpPeak;      /* [start,end) 1-based; dict_contigs entry (MP:961) */
+typedef struct { int32_t start, end, strand, depth; } MirpMature;  /* MP:1484; strand -1 = the (0,0,0,0) fallback (MP:1476) */
+/* One FASTA entry handed to the folder (MP:1124-1142, 1184-1192). */
+typedef struct {
+    int32_t tid, ws, we, strand, loc_s, loc_e;
+    int32_t tag;                       /* 0 / 1 = 'L' / 2 = 'R' (MP:1116-1120) */
+    int32_t n_peaks; int64_t peak_off; /* header peak list */
+    int32_t n_matures; int32_t pad0; int64_t mature_off;
+    int64_t seq_off; int32_t seq_len; int32_t pad1;
+} MirpWindow;
+typedef struct { int32_t tid, start, end, n_windows; int32_t w[2][2]; int64_t peak_first; int32_t n_peaks; int32_t pad; } MirpLocus; /* dict_loci entry (MP:1312-1316) */
+
+#define MIRP_MAX_SAMPLES 16
+#define MIRP_MAX_MIRNA_PER_WINDOW 8
+typedef struct { int32_t n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen; } MirpPredictParams;
+/* One entry of check_loci's `miRNAs` list (MP:2296-2343); the structure text is line `line` of the window's fold
+ * output, characters [ss_off, ss_off+ss_len). */
+typedef struct {
+    int32_t window, tid, fold_s, fold_e, mat_s, mat_e, star_s, star_e, strand, has_star;
+    int32_t line, ss_off, ss_len, reserved;
+    int32_t total_depth_mature, total_depth_star;
+} MirpMirna;
+
 int mirp_create(int device, mirp_ctx** out);
 void mirp_destroy(mirp_ctx* ctx);
 const char* mirp_last_error(const mirp_ctx* ctx);
@@ -46,6 +81,18 @@ int mirp_abi_version(void);
 int mirp_fold_batch(mirp_ctx* ctx, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
                     int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t** n_lines,
                     int32_t** mfe, int32_t** status);
+
+
+/*
+ * Replaces: the per-window loop of filter_next_loci / check_loci (MP:2350-2432, 2206-2347) with its two
+ * `samtools view` subprocesses per window (MP:2002-2031), given the fold output of mirp_fold_batch.
+ * Out: mirnas[n_windows*MIRP_MAX_MIRNA_PER_WINDOW] (first n_mirnas[w] valid per window; entry 0 is the one
+ * the reference keeps, MP:2494), status[w] (0 ok, >0 capacity flag).
+ */
+int mirp_predict_batch(mirp_ctx* ctx, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
+                       const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
+                       int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* params, MirpMirna** mirnas,
+                       int32_t** n_mirnas, int32_t** status);
 
 #ifdef __cplusplus
 }

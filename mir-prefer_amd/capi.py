@@ -47,6 +47,9 @@ def load_library():
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp),
                                     C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_fold_batch.restype = C.c_int
+    lib.mirp_predict_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp,
+                                       C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.mirp_predict_batch.restype = C.c_int
     _lib = lib
     return lib
 
@@ -87,6 +90,20 @@ class Context:
     def fold_batch(self, seqs, span, max_lines=96):
         """RNALfold -L replacement. seqs: list of str/bytes. Returns a list (per sequence) of
         dicts {lines: [(ss, energy, start), ...] (printed only), mfe, status}."""
+        raw = self.fold_batch_raw(seqs, span, max_lines)
+        out = []
+        for w in range(len(seqs)):
+            ls = []
+            for k in range(int(raw["n_lines"][w])):
+                ln = raw["lines"][w, k]
+                if not ln["printed"]:
+                    continue
+                ls.append((raw["ss"][w, k, :int(ln["len"])].tobytes().decode(), int(ln["energy"]), int(ln["start"])))
+            out.append({"lines": ls, "mfe": int(raw["mfe"][w]), "status": int(raw["status"][w])})
+        return out
+
+    def fold_batch_raw(self, seqs, span, max_lines=96):
+        """As fold_batch but returns the C-ABI arrays: lines[n,max_lines], ss[n,max_lines,stride], n_lines, mfe, status."""
         bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
         n = len(bs)
         offs = np.zeros(n + 1, dtype=np.int64)
@@ -105,13 +122,26 @@ class Context:
         a_nl = _copy_out(self.lib, nl, np.int32, n)
         a_mfe = _copy_out(self.lib, mfe, np.int32, n)
         a_st = _copy_out(self.lib, st, np.int32, n)
-        out = []
-        for w in range(n):
-            ls = []
-            for k in range(int(a_nl[w])):
-                ln = a_lines[w, k]
-                if not ln["printed"]:
-                    continue
-                ls.append((a_ss[w, k, :int(ln["len"])].tobytes().decode(), int(ln["energy"]), int(ln["start"])))
-            out.append({"lines": ls, "mfe": int(a_mfe[w]), "status": int(a_st[w])})
-        return out
+        return {"lines": a_lines, "ss": a_ss, "stride": stride, "max_lines": max_lines, "n_lines": a_nl, "mfe": a_mfe, "status": a_st}
+
+    def predict_batch(self, windows, matures, alns, fold_raw, params):
+        """filter_next_loci/check_loci replacement. windows/matures/alns: record arrays (records.py dtypes);
+        fold_raw: output of fold_batch_raw for the same windows; params: (n_samples, min_mature_len, max_mature_len,
+        allow_3nt, allow_no_star, minlen).  Returns (mirnas[n, MAX_MIRNA_PER_WINDOW], n_mirnas[n], status[n])."""
+        from . import records
+        windows = np.ascontiguousarray(windows, dtype=records.WINDOW_DTYPE)
+        matures = np.ascontiguousarray(matures, dtype=records.MATURE_DTYPE)
+        alns = np.ascontiguousarray(alns)
+        lines = np.ascontiguousarray(fold_raw["lines"])
+        ss = np.ascontiguousarray(fold_raw["ss"])
+        nl = np.ascontiguousarray(fold_raw["n_lines"], dtype=np.int32)
+        n = len(windows)
+        pp = (C.c_int32 * 6)(*[int(x) for x in params])
+        vp = C.c_void_p
+        o, no, st = vp(), vp(), vp()
+        rc = self.lib.mirp_predict_batch(self.h, windows.ctypes.data, n, matures.ctypes.data, len(matures), alns.ctypes.data, len(alns),
+                                         lines.ctypes.data, ss.ctypes.data, int(fold_raw["stride"]), int(fold_raw["max_lines"]),
+                                         nl.ctypes.data, pp, C.byref(o), C.byref(no), C.byref(st))
+        self._check(rc, "mirp_predict_batch")
+        a_o = _copy_out(self.lib, o, records.MIRNA_DTYPE, n * records.MAX_MIRNA_PER_WINDOW).reshape(n, records.MAX_MIRNA_PER_WINDOW)
+        return a_o, _copy_out(self.lib, no, np.int32, n), _copy_out(self.lib, st, np.int32, n)

@@ -154,3 +154,69 @@ extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* off
     *lines = h_lines; *ss = h_ss; *n_lines = h_nl; *mfe = h_mfe; *status = h_st;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+template <class T>
+static T* host_alloc(size_t n) { return (T*)std::calloc(std::max<size_t>(n, 1), sizeof(T)); }
+
+struct TmpDev {
+    std::vector<void*> ptrs;
+    ~TmpDev() { for (void* p : ptrs) (void)hipFree(p); }
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+};
+
+extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
+                                  const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
+                                  int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* pp, MirpMirna** mirnas,
+                                  int32_t** n_mirnas, int32_t** status) {
+    if (!c) return -1;
+    if (!windows || !matures || !alns || !lines || !ss || !n_lines || !pp || !mirnas || !n_mirnas || !status || n_windows < 0)
+        return fail(c, -1, "mirp_predict_batch: null argument");
+    if (pp->n_samples < 1 || pp->n_samples > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_predict_batch: n_samples out of range");
+    if (ss_stride % 8 != 0) return fail(c, -1, "mirp_predict_batch: ss_stride must be a multiple of 8");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (mirp::predict_lds_bytes(max_lines, ss_stride) > 160 * 1024)
+        return fail(c, -5, "mirp_predict_batch: max_lines*ss_stride exceeds the LDS budget of the predict kernel");
+    TmpDev T;
+    const size_t nl = (size_t)n_windows * max_lines;
+    void* d_w = T.get(sizeof(MirpWindow) * n_windows);
+    void* d_m = T.get(sizeof(MirpMature) * n_matures);
+    void* d_a = T.get(sizeof(MirpAln) * n_alns);
+    void* d_l = T.get(sizeof(MirpFoldLine) * nl);
+    void* d_s = T.get(nl * ss_stride);
+    void* d_n = T.get(4 * (size_t)n_windows);
+    void* d_o = T.get(sizeof(MirpMirna) * (size_t)n_windows * MIRP_MAX_MIRNA_PER_WINDOW);
+    void* d_no = T.get(4 * (size_t)n_windows);
+    void* d_st = T.get(4 * (size_t)n_windows);
+    if (!d_w || !d_m || !d_a || !d_l || !d_s || !d_n || !d_o || !d_no || !d_st) return fail(c, -6, "device allocation failed");
+    MirpMirna* h_o = host_alloc<MirpMirna>((size_t)n_windows * MIRP_MAX_MIRNA_PER_WINDOW);
+    int32_t* h_no = host_alloc<int32_t>(n_windows);
+    int32_t* h_st = host_alloc<int32_t>(n_windows);
+    auto bail = [&](int code, const std::string& m) { std::free(h_o); std::free(h_no); std::free(h_st); return fail(c, code, m); };
+    if (n_windows > 0) {
+        if (hipMemcpyAsync(d_w, windows, sizeof(MirpWindow) * n_windows, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_m, matures, sizeof(MirpMature) * n_matures, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_a, alns, sizeof(MirpAln) * n_alns, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_l, lines, sizeof(MirpFoldLine) * nl, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_s, ss, nl * ss_stride, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_n, n_lines, 4 * (size_t)n_windows, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            return bail(-2, "H2D copy failed");
+        int grid = std::min(n_windows, c->n_cu * 16);
+        if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)d_w, n_windows, (const MirpMature*)d_m, (const MirpAln*)d_a, n_alns,
+                                 (const MirpFoldLine*)d_l, (const char*)d_s, ss_stride, max_lines, (const int*)d_n, *pp, (MirpMirna*)d_o,
+                                 (int*)d_no, (int*)d_st) != hipSuccess)
+            return bail(-2, "predict kernel launch failed");
+        if (hipMemcpyAsync(h_o, d_o, sizeof(MirpMirna) * (size_t)n_windows * MIRP_MAX_MIRNA_PER_WINDOW, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h_no, d_no, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h_st, d_st, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            return bail(-2, "predict kernel execution failed");
+    }
+    *mirnas = h_o; *n_mirnas = h_no; *status = h_st;
+    return 0;
+}

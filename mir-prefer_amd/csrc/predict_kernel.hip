@@ -1,0 +1,415 @@
+// Data-parallel predict-stage filter: dot-bracket hairpin classification, mature/star duplex
+// rules, expression rules and the per-window locus decision.  One wavefront per precursor window.
+// Replaces the per-window Python loop of filter_next_loci / check_loci
+// (/root/reference/miR_PREFeR.py = MP: a8 :1541-1724, a9 :1727-1999, a10 :2002-2163, a11 :2206-2347)
+// and its two `samtools view` subprocesses per window.
+//
+// Phase 1 (lane per RNALfold line): structure list of the window (MP:1541-1599).
+// Phase 2 (lane per structure, loop over matures): get_maturestar_info + check_expression_new.
+// Phase 3 (lane 0): the sequential "lowest normalised energy that passes" rule (MP:2246-2343).
+#include <hip/hip_runtime.h>
+#include "mirp_internal.h"
+
+namespace mirp {
+
+#define PW_MAX_STRUCTS 192   // structures per window (lines * pieces)
+#define PW_MAX_PIECES 6
+#define PW_MAX_MATURES 40
+
+struct PStruct { double ne; int start; int line; int off; int len; int type; };
+
+__device__ __forceinline__ int d_find(const char* s, char c, int a, int b) { for (int i = a; i < b; i++) if (s[i] == c) return i; return -1; }
+__device__ __forceinline__ int d_rfind(const char* s, char c, int a, int b) { for (int i = b - 1; i >= a; i--) if (s[i] == c) return i; return -1; }
+__device__ __forceinline__ int d_count(const char* s, char c, int a, int b) { int n = 0; for (int i = a; i < b; i++) n += (s[i] == c); return n; }
+__device__ __forceinline__ void d_clip(int len, int& a, int& b) {   // Python slice bounds
+    if (a < 0) { a += len; if (a < 0) a = 0; }
+    if (b < 0) { b += len; if (b < 0) b = 0; }
+    if (a > len) a = len;
+    if (b > len) b = len;
+}
+
+// partner of bracket at x inside s[0,len); -1 if unmatched
+__device__ int d_partner(const char* s, int len, int x) {
+    int depth = 0;
+    if (s[x] == '(') {
+        for (int i = x; i < len; i++) { if (s[i] == '(') depth++; else if (s[i] == ')') { if (--depth == 0) return i; } }
+    } else if (s[x] == ')') {
+        for (int i = x; i >= 0; i--) { if (s[i] == ')') depth++; else if (s[i] == '(') { if (--depth == 0) return i; } }
+    }
+    return -1;
+}
+
+__device__ bool d_is_stem_loop(const char* s, int len) {   // MP:1602-1608, minloop 3
+    int lo = d_rfind(s, '(', 0, len), fc = d_find(s, ')', 0, len);
+    return fc - lo - 1 >= 3;
+}
+
+// MP:1611-1659
+__device__ bool d_good_bifurcation(const char* s, int len) {
+    int depth = 0, bif = 0, last_pop = 0, first_bi_last = 0, second_bi_first = 0, last_pos = 0;
+    for (int idx = 0; idx < len; idx++) {
+        char ch = s[idx];
+        if (ch == '(') {
+            if (idx != 0) {
+                if (depth == 0) { if (last_pop) return false; }
+                else if (last_pop) {
+                    if (bif >= 1) return false;
+                    bif = 1; first_bi_last = last_pos; second_bi_first = idx;
+                }
+            }
+            depth++; last_pop = 0; last_pos = idx;
+        } else if (ch == ')') {
+            last_pop = 1;
+            if (depth == 0) return false;
+            depth--; last_pos = idx;
+        }
+    }
+    int a = d_partner(s, len, second_bi_first), b = d_partner(s, len, first_bi_last);
+    if (a < 0 || b < 0) return false;
+    if ((double)(a - b) / len < 0.5)
+        if ((double)b / len > 0.25)
+            if ((double)a / len < 0.75) return true;
+    return false;
+}
+
+// stat_duplex + pass_stat_duplex (MP:1815-1873) on mature_duplex = s[m0,m1), star_duplex = s[s0,s1). Returns MS code.
+__device__ int d_duplex_code(const char* s, int m0, int m1, int s0, int s1) {
+    const int ml = m1 - m0, L = ml + (s1 - s0);
+#define DCH(i) ((i) < ml ? s[m0 + (i)] : s[s0 + (i) - ml])
+    int openpos = -1, closepos = -1;
+    for (int i = 0; i < L && (openpos < 0 || closepos < 0); i++) {
+        char ch = DCH(i);
+        if (ch == '(' && openpos < 0) openpos = i;
+        if (ch == ')' && closepos < 0) closepos = i;
+    }
+    char oc = '(', cc = ')';
+    if (openpos > closepos) { oc = ')'; cc = '('; }
+    // Pairs (open idx -> close idx), visited in increasing open idx.  Opens are matched LIFO.
+    // Walk the opens in order and find each one's close with a depth counter (no arrays needed).
+    int nloops = 0, nbulges = 0, totalloop = 0, maxbulge = 0;
+    int prev_o = -1, prev_c = -1;
+    // first make sure no close pops an empty stack (the reference would raise IndexError)
+    {
+        int depth = 0;
+        for (int i = 0; i < L; i++) { char ch = DCH(i); if (ch == oc) depth++; else if (ch == cc) { if (depth == 0) return 12; depth--; } }
+    }
+    for (int i = 0; i < L; i++) {
+        if (DCH(i) != oc) continue;
+        int depth = 0, c = -1;
+        for (int j = i; j < L; j++) { char ch = DCH(j); if (ch == oc) depth++; else if (ch == cc) { if (--depth == 0) { c = j; break; } } }
+        if (c < 0) continue;   // never closed: not in dict_bp
+        if (prev_o >= 0) {
+            if (!((i - prev_o == 1) && (prev_c - c == 1))) {
+                int mb = i - prev_o - 1, sb = prev_c - c - 1;
+                if (mb == sb) { nloops++; totalloop += mb; }
+                else { nbulges++; maxbulge = max(maxbulge, max(mb, sb)); }
+            }
+        }
+        prev_o = i; prev_c = c;
+    }
+#undef DCH
+    if (nloops + nbulges > 5) return 8;
+    if (maxbulge > 2) return 9;
+    if (totalloop > 5) return 10;
+    if (nbulges > 2) return 11;
+    return 0;
+}
+
+struct MStar { int code, star_s, star_e, fold_s, fold_e; };
+
+// get_maturestar_info (MP:1876-1999). strand 0 '+', 1 '-'.
+__device__ void d_maturestar(const char* ss, int len, int m0, int m1, int foldstart, int rs, int re, int strand, MStar& o) {
+    o.code = 0; o.star_s = o.star_e = 0;
+    { int depth = 0; for (int i = 0; i < len; i++) { if (ss[i] == '(') depth++; else if (ss[i] == ')') { if (depth == 0) { o.code = 1; return; } depth--; } } }
+    int l0, l1, fg0, fg1;
+    if (strand == 0) { l0 = m0 - rs - foldstart + 1; l1 = m1 - rs - foldstart + 1; fg0 = rs + foldstart - 1; fg1 = fg0 + len; }
+    else { l0 = re - m1 - foldstart + 1; l1 = re - m0 - foldstart + 1; fg0 = re - foldstart - len + 1; fg1 = re - foldstart + 1; }
+    o.fold_s = fg0; o.fold_e = fg1;
+    if (!(m0 >= fg0 && m1 <= fg1)) { o.code = 2; return; }
+    int a = l0, b = l1; d_clip(len, a, b);
+    bool has_o = d_find(ss, '(', a, b) != -1, has_c = d_find(ss, ')', a, b) != -1;
+    if (has_o && has_c) { o.code = 3; return; }
+    if ((b > a ? b - a : 0) - d_count(ss, '.', a, b) < 14) { o.code = 4; return; }
+    char sym = '(';
+    int firstbp = d_find(ss, '(', a, b), lastbp = d_rfind(ss, '(', a, b);
+    if (firstbp == -1) { firstbp = d_find(ss, ')', a, b); lastbp = d_rfind(ss, ')', a, b); sym = ')'; }
+    if (firstbp == -1) { o.code = 4; return; }
+    int p_last = d_partner(ss, len, lastbp), p_first = d_partner(ss, len, firstbp);
+    if (p_last < 0 || p_first < 0) { o.code = 12; return; }
+    int star_start = p_last - (l1 - 1 - lastbp) + 2, star_end = p_first + (firstbp - l0) + 2 + 1;
+    if (l0 <= star_start) {
+        if (star_start - l1 < 3) { o.code = 5; return; }
+        if (star_end > len) { o.code = 6; return; }
+    }
+    if (star_start <= l0) {
+        if (l0 - star_end < 3) { o.code = 5; return; }
+        if (star_start < 0) { o.code = 6; return; }
+    }
+    int ra = l0, rb = l1 - 2; d_clip(len, ra, rb);
+    int mend = d_rfind(ss, sym, ra, rb);
+    int p_mend = mend >= 0 ? d_partner(ss, len, mend) : -1;
+    if (mend < 0 || p_mend < 0) { o.code = 12; return; }
+    int md0 = l0, md1 = mend + 1, sd0 = p_mend, sd1 = p_first + 1;
+    d_clip(len, md0, md1); d_clip(len, sd0, sd1);
+    if (md1 < md0) md1 = md0;
+    if (sd1 < sd0) sd1 = sd0;
+    int total_bps = (md1 - md0) - d_count(ss, '.', md0, md1);
+    if (total_bps < 14) { o.code = 4; return; }
+    int sa = star_start, sb = star_end; d_clip(len, sa, sb);
+    if (d_find(ss, '(', sa, sb) != -1 && d_find(ss, ')', sa, sb) != -1) { o.code = 7; return; }
+    int dc = d_duplex_code(ss, md0, md1, sd0, sd1);
+    if (dc) { o.code = dc; return; }
+    if (strand == 0) { o.star_s = rs + foldstart - 1 + star_start; o.star_e = rs + foldstart - 1 + star_end; }
+    else { o.star_s = re - foldstart - star_end + 1; o.star_e = re - foldstart - star_start + 1; }
+}
+
+__device__ __forceinline__ long long aln_lower_bound(const MirpAln* __restrict__ a, long long n, int tid, long long pos) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        long long mid = (lo + hi) >> 1;
+        MirpAln r = a[mid];
+        if (r.tid < tid || (r.tid == tid && r.pos < pos)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct ExprRes {
+    long long total_this, total_mature, total_iso, total_star; // total_star = after max with imperfect (when key present)
+    int distance, has_imp_key, imp_start, imp_end;
+    double ratio_total, ratio_iso;
+    bool too_many_start, expressed_all, exception;
+};
+
+// check_expression_new (MP:2037-2163) on reads kept by gen_mapinfo_each_sample (MP:2021)
+__device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_samples, int tid, int ws, int we, int fold_s, int fold_e,
+                             int m0, int m1, int star_s, int star_e, int strand, int allow_3nt, ExprRes& o) {
+    const int mature_len = m1 - m0, star_len = star_e - star_s, pre_len = fold_e - fold_s;
+    long long k0 = aln_lower_bound(a, na, tid, fold_s > ws ? fold_s : ws), k1 = aln_lower_bound(a, na, tid, fold_e);
+    long long tot_pre = 0, tot_mat = 0, tot_iso = 0, tot_star = 0, imp[3] = {0, 0, 0};
+    unsigned int mature_mask = 0;   // samples with reads_mature > 0
+    int starts = 0;
+    int last_pos[MIRP_MAX_SAMPLES];
+    for (int s = 0; s < MIRP_MAX_SAMPLES; s++) last_pos[s] = -1;
+    for (long long k = k0; k < k1; k++) {
+        MirpAln r = a[k];
+        if (r.pos < ws || r.pos + (int)r.len > we) continue;
+        if ((int)r.strand != strand) continue;   // antisense reads do not enter any rule used by check_loci
+        int d = (int)r.depth, rl = r.len, sp = r.pos, sm = r.sample;
+        if (last_pos[sm] != sp) { last_pos[sm] = sp; starts++; }
+        tot_pre += d;
+        if (sp == m0 && rl == mature_len) { tot_mat += d; if (d > 0) mature_mask |= 1u << sm; }
+        if (sp == star_s && rl == star_len) tot_star += d;
+        int dx = sp - m0, dl = rl - mature_len;
+        if (dx >= -3 && dx <= 3 && dl >= -3 && dl <= 3) tot_iso += d;
+        if (allow_3nt) {
+            if (sp == star_s && rl == star_len + 1) imp[0] += d;
+            else if (sp - 1 == star_s && rl == star_len - 1) imp[1] += d;
+            else if (sp - 1 == star_s && rl == star_len) imp[2] += d;
+        }
+    }
+    o.total_this = tot_pre; o.total_mature = tot_mat; o.total_iso = tot_iso;
+    o.distance = (star_s > m1) ? star_s - m1 : m0 - star_e;
+    long long max_imp = 0;
+    o.has_imp_key = 0; o.imp_start = 0; o.imp_end = 0;
+    if (tot_star == 0 && allow_3nt) {
+        o.has_imp_key = 1;
+        long long mx = imp[0] > imp[1] ? imp[0] : imp[1]; mx = mx > imp[2] ? mx : imp[2];
+        if (mx > 0) {
+            int which = (imp[0] == mx) ? 0 : (imp[1] == mx) ? 1 : 2;
+            if (which == 0) { o.imp_start = star_s; o.imp_end = star_e + 1; }
+            else if (which == 1) { o.imp_start = star_s + 1; o.imp_end = star_e; }
+            else { o.imp_start = star_s + 1; o.imp_end = star_e + 1; }
+            max_imp = mx;
+        }
+    }
+    long long st = tot_star > max_imp ? tot_star : max_imp;
+    o.total_star = st;
+    o.exception = (tot_pre == 0);
+    o.ratio_total = o.exception ? 0.0 : (double)(tot_mat + st) / (double)tot_pre;
+    o.ratio_iso = o.exception ? 0.0 : (double)(tot_iso + st) / (double)tot_pre;
+    // only the LAST sample's start counter is ever non-zero (stale loop variable, MP:2046/2068)
+    o.too_many_start = ((double)starts / pre_len) > 0.5;
+    o.expressed_all = (mature_mask == ((n_samples >= 32) ? 0xffffffffu : ((1u << n_samples) - 1u)));
+}
+
+__global__ void __launch_bounds__(64) predict_kernel(
+    const MirpWindow* __restrict__ windows, int n_windows, const MirpMature* __restrict__ matures,
+    const MirpAln* __restrict__ alns, long long n_alns, const MirpFoldLine* __restrict__ lines, const char* __restrict__ ss,
+    int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
+    MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    char* text = (char*)smem;                                           // max_lines * ss_stride
+    PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * ss_stride + 15) & ~(size_t)15)); // PW_MAX_STRUCTS
+    PStruct* slot = sts + PW_MAX_STRUCTS;                                // 64 * PW_MAX_PIECES
+    int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
+    int* ev = cnts + 64;                                                 // PW_MAX_STRUCTS * 8 (per-structure evaluation of the current mature)
+    const int lane = threadIdx.x;
+    for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
+        const MirpWindow W = windows[w];
+        const int nl = n_lines[w] < max_lines ? n_lines[w] : max_lines;
+        int st_flag = 0;
+        // stage the window's structure text (coalesced 4-byte copies)
+        {
+            const unsigned int* src = (const unsigned int*)(ss + (size_t)w * max_lines * ss_stride);
+            unsigned int* dst = (unsigned int*)text;
+            int nwords = (nl * ss_stride) / 4;
+            for (int x = lane; x < nwords; x += 64) dst[x] = src[x];
+        }
+        __syncthreads();
+        // ---- phase 1: structures (lane per line, chunks of 64 lines)
+        int nst = 0;
+        for (int lb = 0; lb < nl; lb += 64) {
+            int k = lb + lane, cnt = 0;
+            if (k < nl) {
+                MirpFoldLine ln = lines[(size_t)w * max_lines + k];
+                const char* s = text + (size_t)k * ss_stride;
+                if (ln.printed && ln.len >= pp.minlen) {
+                    double ne = ((double)ln.energy / 100.0) / (double)ln.len;
+                    if (d_is_stem_loop(s, ln.len)) {
+                        PStruct p; p.ne = ne; p.start = ln.start; p.line = k; p.off = 0; p.len = ln.len; p.type = 0;
+                        slot[lane * PW_MAX_PIECES + cnt++] = p;
+                    } else {
+                        // filter_ss (MP:1685-1724): one piece per top-level stem, [previous gap start, next stem start)
+                        int len = ln.len;
+                        int prefirst = d_find(s, '(', 0, len);
+                        if (prefirst >= 0) {
+                            int prelast = d_partner(s, len, prefirst), curfirst = prefirst, curlast = prelast, pregap0 = 0;
+                            while (curfirst != -1) {
+                                curfirst = d_find(s, '(', prelast < 0 ? len : prelast, len);
+                                int after1 = len;
+                                if (curfirst != -1) { after1 = curfirst; curlast = d_partner(s, len, curfirst); }
+                                int ps = pregap0, pl = after1 - pregap0;
+                                if (pl > 55) {
+                                    int type = -1;
+                                    if (d_is_stem_loop(s + ps, pl)) type = 0;
+                                    else if (d_good_bifurcation(s + ps, pl)) type = 1;
+                                    if (type >= 0) {
+                                        if (cnt < PW_MAX_PIECES) {
+                                            PStruct p; p.ne = ne; p.start = ln.start + ps; p.line = k; p.off = ps; p.len = pl; p.type = type;
+                                            slot[lane * PW_MAX_PIECES + cnt++] = p;
+                                        } else st_flag = 2;
+                                    }
+                                }
+                                pregap0 = prelast + 1;
+                                prelast = curlast;
+                            }
+                        }
+                    }
+                }
+            }
+            cnts[lane] = cnt;
+            __syncthreads();
+            // ordered compaction (line order, piece order)
+            int base = nst;
+            for (int l = 0; l < 64; l++) { if (l < lane) base += cnts[l]; }
+            for (int c = 0; c < cnt; c++) { if (base + c < PW_MAX_STRUCTS) sts[base + c] = slot[lane * PW_MAX_PIECES + c]; else st_flag = 2; }
+            int tot = 0;
+            for (int l = 0; l < 64; l++) tot += cnts[l];
+            nst += tot;
+            __syncthreads();
+        }
+        if (nst > PW_MAX_STRUCTS) nst = PW_MAX_STRUCTS;
+        // ---- phases 2+3 per mature, depth-descending stable order (MP:2241)
+        int nm = W.n_matures < PW_MAX_MATURES ? W.n_matures : PW_MAX_MATURES;
+        if (W.n_matures > PW_MAX_MATURES) st_flag = 3;
+        int nout = 0;
+        bool any_in_range = false;
+        for (int k = 0; k < nm; k++) { MirpMature m = matures[W.mature_off + k]; int l = m.end - m.start; if (!(l < pp.min_mature_len || l > pp.max_mature_len)) any_in_range = true; }
+        if (nst > 0 && any_in_range) {
+            for (int rank = 0; rank < nm; rank++) {
+                // rank-th mature in stable depth-descending order
+                int mi = -1;
+                for (int k = 0; k < nm; k++) {
+                    int dk = matures[W.mature_off + k].depth, r = 0;
+                    for (int j = 0; j < nm; j++) { int dj = matures[W.mature_off + j].depth; if (dj > dk || (dj == dk && j < k)) r++; }
+                    if (r == rank) { mi = k; break; }
+                }
+                MirpMature m = matures[W.mature_off + mi];
+                int ml = m.end - m.start;
+                if (ml < pp.min_mature_len || ml > pp.max_mature_len) continue;
+                for (int sb = 0; sb < nst; sb += 64) {
+                    int s = sb + lane;
+                    if (s < nst) {
+                        PStruct p = sts[s];
+                        const char* str = text + (size_t)p.line * ss_stride + p.off;
+                        MStar ms;
+                        d_maturestar(str, p.len, m.start, m.end, p.start, W.ws, W.we, m.strand, ms);
+                        int pass = 0, has_star = 0, star_s = ms.star_s, star_e = ms.star_e;
+                        long long tm = 0, ts = 0;
+                        if (ms.code == 0) {
+                            ExprRes ex;
+                            d_expression(alns, n_alns, pp.n_samples, W.tid, W.ws, W.we, ms.fold_s, ms.fold_e, m.start, m.end, ms.star_s, ms.star_e,
+                                         m.strand, pp.allow_3nt, ex);
+                            tm = ex.total_mature; ts = ex.total_star;
+                            if (!ex.exception && ex.distance > 4) {
+                                if (ex.total_star > 0) {
+                                    if (!(ex.ratio_total < 0.2)) {
+                                        pass = 1; has_star = 1;
+                                        if (ex.has_imp_key) { star_s = ex.imp_start; star_e = ex.imp_end; }
+                                    }
+                                } else if (pp.allow_no_star && !ex.too_many_start) {
+                                    if (ex.ratio_iso >= 0.8 && (ex.expressed_all || ex.total_mature >= 1000)) pass = 1;
+                                }
+                            }
+                        }
+                        int* e = ev + s * 8;
+                        e[0] = pass; e[1] = has_star; e[2] = star_s; e[3] = star_e; e[4] = ms.fold_s; e[5] = ms.fold_e;
+                        e[6] = (int)(tm > 0x7fffffffLL ? 0x7fffffffLL : tm); e[7] = (int)(ts > 0x7fffffffLL ? 0x7fffffffLL : ts);
+                    }
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    double lowest = 0.0;
+                    int best = -1;
+                    for (int s = 0; s < nst; s++) {
+                        if (sts[s].ne > lowest) continue;       // MP:2251
+                        if (ev[s * 8]) { best = s; lowest = sts[s].ne; }
+                    }
+                    if (best >= 0 && nout < MIRP_MAX_MIRNA_PER_WINDOW) {
+                        const int* e = ev + best * 8;
+                        MirpMirna r;
+                        r.window = w; r.tid = W.tid; r.fold_s = e[4]; r.fold_e = e[5]; r.mat_s = m.start; r.mat_e = m.end;
+                        r.star_s = e[2]; r.star_e = e[3]; r.strand = m.strand; r.has_star = e[1];
+                        r.line = sts[best].line; r.ss_off = sts[best].off; r.ss_len = sts[best].len; r.reserved = 0;
+                        r.total_depth_mature = e[6]; r.total_depth_star = e[7];
+                        out[(size_t)w * MIRP_MAX_MIRNA_PER_WINDOW + nout] = r;
+                        nout++;
+                    }
+                }
+                nout = __shfl(nout, 0);
+                __syncthreads();
+            }
+        }
+        if (lane == 0) { n_out[w] = nout; }
+        // any lane may have raised a capacity flag
+        {
+            int f = st_flag;
+            for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(f, o); f = t > f ? t : f; }
+            if (lane == 0) status[w] = f;
+        }
+        __syncthreads();
+    }
+}
+
+size_t predict_lds_bytes(int max_lines, int ss_stride) {
+    size_t b = (((size_t)max_lines * ss_stride + 15) & ~(size_t)15);
+    b += sizeof(PStruct) * (PW_MAX_STRUCTS + 64 * PW_MAX_PIECES);
+    b += sizeof(int) * 64;
+    b += sizeof(int) * PW_MAX_STRUCTS * 8;
+    return (b + 15) & ~(size_t)15;
+}
+
+hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
+                          const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
+                          const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status) {
+    size_t lds = predict_lds_bytes(max_lines, ss_stride);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)predict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(predict_kernel, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
+                       max_lines, n_lines, pp, out, n_out, status);
+    return hipGetLastError();
+}
+
+}  // namespace mirp

@@ -11,6 +11,10 @@ WINDOW_DTYPE = np.dtype([("tid", "<i4"), ("ws", "<i4"), ("we", "<i4"), ("strand"
 LOCUS_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("n_windows", "<i4"), ("w", "<i4", (2, 2)),
                         ("peak_first", "<i8"), ("n_peaks", "<i4"), ("_pad", "<i4")])
 
+MAX_MIRNA_PER_WINDOW = 8
+MIRNA_DTYPE = np.dtype([(n, "<i4") for n in ("window", "tid", "fold_s", "fold_e", "mat_s", "mat_e", "star_s", "star_e", "strand", "has_star",
+                                             "line", "ss_off", "ss_len", "reserved", "total_depth_mature", "total_depth_star")])
+
 STRAND = "+-"
 TAG = "0LR"
 
