@@ -94,6 +94,49 @@ int mirp_predict_batch(mirp_ctx* ctx, const MirpWindow* windows, int32_t n_windo
                        int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* params, MirpMirna** mirnas,
                        int32_t** n_mirnas, int32_t** status);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident pipeline: inputs are uploaded once, every stage leaves its results in HBM for the
+ * next one, and only what a caller asks for is copied back.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t cutoff;         /* READS_DEPTH_CUTOFF (MP:91, awk rule MP:938, weight cap MP:735) */
+    int32_t min_peak_len;   /* 19 (MP:3389, MP:956) */
+    int32_t max_gap;        /* MAX_GAP (MP:92, MP:1263) */
+    int32_t precursor_len;  /* PRECURSOR_LEN (MP:90, MP:1272-1300, RNALfold -L MP:3053) */
+} MirpCandidateParams;
+
+/* Genome: contigs in @SQ order, bytes as in the FASTA (case preserved), concatenated. Replaces `samtools faidx` (MP:1100-1105). */
+int mirp_load_genome(mirp_ctx* ctx, int32_t n_contigs, const int64_t* contig_len, const uint8_t* seq_concat);
+/* Alignments sorted as described at MirpAln. Replaces the prepare-stage BAMs (MP:772-874) as device-resident records. */
+int mirp_load_alignments(mirp_ctx* ctx, const MirpAln* alns, int64_t n_alns);
+/* Replaces gen_contig_typeA + gen_candidate_region_typeA + dump_loci_seqs_and_alignment_multiprocess
+ * (MP:877-962, 1246-1371, 1065-1244). contig_order = contig indices in the order sorted(dict_contigs) visits them (MP:1309). */
+int mirp_candidate(mirp_ctx* ctx, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks, int64_t* n_loci,
+                   int64_t* n_windows);
+/* Thresholded depth lines of `samtools depth | awk` (MP:937-949), on demand (checkpoint artefact). */
+int mirp_get_depth(mirp_ctx* ctx, MirpDepthPos** depth, int64_t* n_depth);
+/* dict_contigs (MP:961) in @SQ order. */
+int mirp_get_peaks(mirp_ctx* ctx, MirpPeak** peaks, int64_t* n_peaks);
+/* dict_loci (MP:1312-1316) + the peaks array (sorted-contig order) its peak_first/n_peaks index. */
+int mirp_get_loci(mirp_ctx* ctx, MirpLocus** loci, int64_t* n_loci, MirpPeak** peaks_sorted, int64_t* n_peaks);
+/* FASTA entries + alndump payload (MP:1124-1142, 1137): windows, their header peak lists, matures and sequences
+ * (seqs[window.seq_off .. +seq_len)). wpeaks/matures are slot arrays indexed by peak_off / mature_off. */
+int mirp_get_windows(mirp_ctx* ctx, MirpWindow** windows, int64_t* n_windows, MirpPeak** wpeaks, int64_t* n_wpeaks, MirpMature** matures,
+                     int64_t* n_matures, char** seqs, int64_t* n_seq_bytes);
+/* Replaces run_fold's RNALfold subprocesses (MP:3047-3119) for the resident windows. */
+int mirp_fold(mirp_ctx* ctx, int32_t span, int32_t max_lines);
+/* Fold output of the resident windows, same layout as mirp_fold_batch. */
+int mirp_get_fold(mirp_ctx* ctx, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t* max_lines, int32_t** n_lines, int32_t** mfe,
+                  int32_t** status);
+/* Replaces gen_miRNA_loci_nopredict (MP:2435-2502) for the resident windows: per-window check_loci, the 0/(L,R) pairing
+ * of filter_next_loci (MP:2373-2432) and the "first mature only" rule (MP:2494).  Out: result[n_result] in window order,
+ * ss_text[n_result*ss_stride] NUL-terminated structure strings, n_passed[n_windows] = len(miRNAs) per FASTA entry. */
+int mirp_predict(mirp_ctx* ctx, const MirpPredictParams* params, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride,
+                 int32_t** n_passed, int64_t* n_windows);
+/* Per-stage device time of the last mirp_candidate / mirp_fold / mirp_predict calls, measured with HIP events on the
+ * context's stream: ms[0]=coverage scatter+scan, ms[1]=rest of candidate, ms[2]=fold kernel, ms[3]=predict kernel. */
+int mirp_last_timings(mirp_ctx* ctx, double ms[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,21 @@ def load_library():
     lib.mirp_predict_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict_batch.restype = C.c_int
+    i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    lib.mirp_load_genome.argtypes = [vp, C.c_int32, vp, vp]
+    lib.mirp_load_alignments.argtypes = [vp, vp, C.c_int64]
+    lib.mirp_candidate.argtypes = [vp, vp, vp, i64p, i64p, i64p]
+    lib.mirp_get_depth.argtypes = [vp, C.POINTER(vp), i64p]
+    lib.mirp_get_peaks.argtypes = [vp, C.POINTER(vp), i64p]
+    lib.mirp_get_loci.argtypes = [vp, C.POINTER(vp), i64p, C.POINTER(vp), i64p]
+    lib.mirp_get_windows.argtypes = [vp, C.POINTER(vp), i64p, C.POINTER(vp), i64p, C.POINTER(vp), i64p, C.POINTER(vp), i64p]
+    lib.mirp_fold.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
+    lib.mirp_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    for f in ("mirp_load_genome", "mirp_load_alignments", "mirp_candidate", "mirp_get_depth", "mirp_get_peaks", "mirp_get_loci",
+              "mirp_get_windows", "mirp_fold", "mirp_get_fold", "mirp_predict", "mirp_last_timings"):
+        getattr(lib, f).restype = C.c_int
     _lib = lib
     return lib
 
@@ -145,3 +160,83 @@ class Context:
         self._check(rc, "mirp_predict_batch")
         a_o = _copy_out(self.lib, o, records.MIRNA_DTYPE, n * records.MAX_MIRNA_PER_WINDOW).reshape(n, records.MAX_MIRNA_PER_WINDOW)
         return a_o, _copy_out(self.lib, no, np.int32, n), _copy_out(self.lib, st, np.int32, n)
+
+    # ---- device-resident pipeline -------------------------------------------------------------
+    def load_genome(self, contigs):
+        """contigs: list of (name, uint8 array) in @SQ order."""
+        lens = np.array([len(s) for _, s in contigs], dtype=np.int64)
+        blob = np.concatenate([s for _, s in contigs]) if contigs else np.zeros(0, np.uint8)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._check(self.lib.mirp_load_genome(self.h, len(contigs), lens.ctypes.data, blob.ctypes.data), "mirp_load_genome")
+
+    def load_alignments(self, alns):
+        alns = np.ascontiguousarray(alns)
+        assert alns.dtype.itemsize == 16
+        self._check(self.lib.mirp_load_alignments(self.h, alns.ctypes.data, len(alns)), "mirp_load_alignments")
+
+    def candidate(self, cutoff, max_gap, precursor_len, contig_order, min_peak_len=19):
+        pp = (C.c_int32 * 4)(int(cutoff), int(min_peak_len), int(max_gap), int(precursor_len))
+        order = np.ascontiguousarray(contig_order, dtype=np.int32)
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.mirp_candidate(self.h, pp, order.ctypes.data, C.byref(a), C.byref(b), C.byref(c)), "mirp_candidate")
+        self._n_windows = c.value
+        return a.value, b.value, c.value
+
+    def get_depth(self):
+        from . import records
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.mirp_get_depth(self.h, C.byref(p), C.byref(n)), "mirp_get_depth")
+        return _copy_out(self.lib, p, records.DEPTH_DTYPE, n.value)
+
+    def get_peaks(self):
+        from . import records
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.mirp_get_peaks(self.h, C.byref(p), C.byref(n)), "mirp_get_peaks")
+        return _copy_out(self.lib, p, records.PEAK_DTYPE, n.value)
+
+    def get_loci(self):
+        from . import records
+        p, n, q, m = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._check(self.lib.mirp_get_loci(self.h, C.byref(p), C.byref(n), C.byref(q), C.byref(m)), "mirp_get_loci")
+        return _copy_out(self.lib, p, records.LOCUS_DTYPE, n.value), _copy_out(self.lib, q, records.PEAK_DTYPE, m.value)
+
+    def get_windows(self):
+        from . import records
+        vp = C.c_void_p
+        w, nw, pk, npk, mt, nmt, sq, nsq = vp(), C.c_int64(), vp(), C.c_int64(), vp(), C.c_int64(), vp(), C.c_int64()
+        self._check(self.lib.mirp_get_windows(self.h, C.byref(w), C.byref(nw), C.byref(pk), C.byref(npk), C.byref(mt), C.byref(nmt),
+                                              C.byref(sq), C.byref(nsq)), "mirp_get_windows")
+        return {"windows": _copy_out(self.lib, w, records.WINDOW_DTYPE, nw.value), "wpeaks": _copy_out(self.lib, pk, records.PEAK_DTYPE, npk.value),
+                "matures": _copy_out(self.lib, mt, records.MATURE_DTYPE, nmt.value), "seq": _copy_out(self.lib, sq, np.uint8, nsq.value)}
+
+    def fold(self, span, max_lines=96):
+        self._check(self.lib.mirp_fold(self.h, int(span), int(max_lines)), "mirp_fold")
+
+    def get_fold(self):
+        vp = C.c_void_p
+        lines, ss, nl, mfe, st = vp(), vp(), vp(), vp(), vp()
+        stride, ml = C.c_int32(), C.c_int32()
+        self._check(self.lib.mirp_get_fold(self.h, C.byref(lines), C.byref(ss), C.byref(stride), C.byref(ml), C.byref(nl), C.byref(mfe), C.byref(st)),
+                    "mirp_get_fold")
+        n, stride, ml = self._n_windows, stride.value, ml.value
+        return {"lines": _copy_out(self.lib, lines, FOLD_LINE_DTYPE, n * ml).reshape(n, ml),
+                "ss": _copy_out(self.lib, ss, np.uint8, n * ml * stride).reshape(n, ml, stride), "stride": stride, "max_lines": ml,
+                "n_lines": _copy_out(self.lib, nl, np.int32, n), "mfe": _copy_out(self.lib, mfe, np.int32, n),
+                "status": _copy_out(self.lib, st, np.int32, n)}
+
+    def predict(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
+        from . import records
+        pp = (C.c_int32 * 6)(int(n_samples), int(min_mature_len), int(max_mature_len), 1 if allow_3nt else 0, 1 if allow_no_star else 0, int(minlen))
+        vp = C.c_void_p
+        res, text, npass = vp(), vp(), vp()
+        nres, nw, stride = C.c_int64(), C.c_int64(), C.c_int32()
+        self._check(self.lib.mirp_predict(self.h, pp, C.byref(res), C.byref(nres), C.byref(text), C.byref(stride), C.byref(npass), C.byref(nw)), "mirp_predict")
+        r = _copy_out(self.lib, res, records.MIRNA_DTYPE, nres.value)
+        t = _copy_out(self.lib, text, np.uint8, nres.value * stride.value).reshape(nres.value, stride.value)
+        return {"result": r, "ss": [t[i, :r[i]["ss_len"]].tobytes().decode() for i in range(len(r))],
+                "n_passed": _copy_out(self.lib, npass, np.int32, nw.value)}
+
+    def last_timings(self):
+        ms = (C.c_double * 4)()
+        self.lib.mirp_last_timings(self.h, ms)
+        return {"coverage_ms": ms[0], "candidate_rest_ms": ms[1], "fold_ms": ms[2], "predict_ms": ms[3]}

@@ -1,0 +1,556 @@
+// Candidate-stage kernels: SAM-interval -> per-base strand-split weighted coverage scan, peak (run)
+// extraction, gap-merge + precursor-window extension, window payload (sequence, candidate matures).
+// Replaces `samtools depth plus.bam minus.bam | awk '$3+$4>CUT'` and the Python line loop
+// (/root/reference/miR_PREFeR.py = MP :877-962), gen_candidate_region_typeA (MP:1246-1371) and the
+// per-window `samtools faidx` / `samtools view` subprocesses of dump_piece (MP:1070-1198, 1374-1510).
+//
+// HBM layout: the genome is one byte array (contigs back to back); coverage lives in two int32
+// difference arrays over a "guarded" coordinate space in which every contig owns len+1 slots, so a
+// read's -w lands in its contig's guard slot at worst and depth returns to 0 between contigs.
+// Algorithmic traffic: 16 B per alignment record + 16 B per base (one 4-B write and one 4-B read
+// per base and strand: memset + single-pass decoupled-look-back scan), SURVEY.md section 8d.
+#include <hip/hip_runtime.h>
+#include "mirp_internal.h"
+
+namespace mirp {
+
+// ------------------------------------------------------------------------------------------
+// a1: per-record weight min(N, CUT) scattered into the strand's difference array (MP:734-738, 870-873)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cov_scatter_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
+                                                          const long long* __restrict__ clen, int cutoff, int* __restrict__ diff_p,
+                                                          int* __restrict__ diff_m) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        MirpAln r = alns[k];
+        int w = (int)(r.depth > (unsigned)cutoff ? (unsigned)cutoff : r.depth);
+        long long L = clen[r.tid];
+        long long s = r.pos, e = (long long)r.pos + r.len;
+        if (s < 1) s = 1;
+        if (e > L + 1) e = L + 1;
+        if (s >= e || w == 0) continue;
+        int* d = r.strand ? diff_m : diff_p;
+        long long base = goff[r.tid];
+        atomicAdd(&d[base + s - 1], w);
+        atomicAdd(&d[base + e - 1], -w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2 (first half): single-pass scan of both difference arrays -> depth, threshold, run starts.
+// Decoupled look-back over 64-bit {flag, d+, d-} and {flag, n_starts, n_above} tile descriptors.
+// ------------------------------------------------------------------------------------------
+#define SCAN_NT 256
+#define SCAN_IPT 16
+#define SCAN_TILE (SCAN_NT * SCAN_IPT)
+
+__device__ __forceinline__ unsigned long long ld_status(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// pack two 31-bit non-negative values under a 2-bit flag
+__device__ __forceinline__ unsigned long long pack2(unsigned flag, unsigned a, unsigned b) {
+    return ((unsigned long long)flag << 62) | ((unsigned long long)(a & 0x7fffffffu) << 31) | (unsigned long long)(b & 0x7fffffffu);
+}
+
+// block-wide exclusive scan of (a,b) pairs across SCAN_NT threads; returns exclusive prefix, totals in tot_a/tot_b
+__device__ __forceinline__ void block_excl_scan2(int a, int b, int& ea, int& eb, int& tot_a, int& tot_b, int* sh /* 2*(NT/64)+2 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ia = a, ib = b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
+        if (lane >= o) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { sh[wave * 2] = ia; sh[wave * 2 + 1] = ib; }
+    __syncthreads();
+    int wa = 0, wb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_NT / 64; w++) {
+        int xa = sh[w * 2], xb = sh[w * 2 + 1];
+        if (w < wave) { wa += xa; wb += xb; }
+        ta += xa; tb += xb;
+    }
+    ea = wa + ia - a; eb = wb + ib - b; tot_a = ta; tot_b = tb;
+    __syncthreads();
+}
+
+struct RunStart { long long gx; int dp, dm; };
+
+__global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict__ diff_p, const int* __restrict__ diff_m, long long gtot,
+                                                           int cutoff, unsigned long long* __restrict__ stat_d,
+                                                           unsigned long long* __restrict__ stat_c, unsigned int* __restrict__ ticket,
+                                                           RunStart* __restrict__ starts, long long starts_cap,
+                                                           MirpDepthPos* __restrict__ depth_out /* nullable; global coords in .pos via hi/lo */,
+                                                           long long depth_cap, long long* __restrict__ depth_gx /* nullable */,
+                                                           unsigned long long* __restrict__ totals /* [0]=n_starts [1]=n_above */) {
+    __shared__ int sh[2 * (SCAN_NT / 64) + 2];
+    __shared__ unsigned int s_tile;
+    __shared__ int s_carry[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const unsigned int tile = s_tile;
+    const long long base = (long long)tile * SCAN_TILE;
+    // each thread owns SCAN_IPT consecutive positions: 4 x int4 loads per strand (16-B vectors, coalesced across the wave per vector)
+    int vp[SCAN_IPT], vm[SCAN_IPT];
+    const long long my0 = base + (long long)tid * SCAN_IPT;
+#pragma unroll
+    for (int v = 0; v < SCAN_IPT / 4; v++) {
+        long long x = my0 + v * 4;
+        if (x + 3 < gtot) {
+            int4 a = *reinterpret_cast<const int4*>(diff_p + x);
+            int4 b = *reinterpret_cast<const int4*>(diff_m + x);
+            vp[v * 4] = a.x; vp[v * 4 + 1] = a.y; vp[v * 4 + 2] = a.z; vp[v * 4 + 3] = a.w;
+            vm[v * 4] = b.x; vm[v * 4 + 1] = b.y; vm[v * 4 + 2] = b.z; vm[v * 4 + 3] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                vp[v * 4 + j] = (x + j < gtot) ? diff_p[x + j] : 0;
+                vm[v * 4 + j] = (x + j < gtot) ? diff_m[x + j] : 0;
+            }
+        }
+    }
+    int sp = 0, sm = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) { sp += vp[j]; sm += vm[j]; }
+    int ep, em, tp, tm;
+    block_excl_scan2(sp, sm, ep, em, tp, tm, sh);
+    // ---- look-back #1: depth carried into this tile
+    if (tid == 0) st_status(&stat_d[tile], pack2(tile == 0 ? 2u : 1u, (unsigned)tp, (unsigned)tm));
+    if (tid < 64) {
+        unsigned cp = 0, cm = 0;
+        if (tile > 0) {
+            long long idx = (long long)tile - 1;
+            while (true) {
+                long long j = idx - lane;
+                unsigned long long v = 0;
+                unsigned flag = 3;
+                if (j >= 0) { do { v = ld_status(&stat_d[j]); flag = (unsigned)(v >> 62); } while (flag == 0); }
+                unsigned long long pm = __ballot(flag == 2);
+                int stop = pm ? (__ffsll((long long)pm) - 1) : 64;
+                unsigned a = (j >= 0 && lane <= stop) ? (unsigned)((v >> 31) & 0x7fffffffu) : 0u;
+                unsigned b = (j >= 0 && lane <= stop) ? (unsigned)(v & 0x7fffffffu) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                cp += a; cm += b;
+                if (pm || idx - 64 < 0) break;
+                idx -= 64;
+            }
+            if (lane == 0) st_status(&stat_d[tile], pack2(2u, cp + (unsigned)tp, cm + (unsigned)tm));
+        }
+        if (lane == 0) { s_carry[0] = (int)(cp & 0x7fffffffu); s_carry[1] = (int)(cm & 0x7fffffffu); }
+    }
+    __syncthreads();
+    // depths are >= 0 everywhere, but tile aggregates of a *difference* array can be negative: they are
+    // carried modulo 2^31, which is exact as long as true depths stay below 2^31.
+    int dp = (int)(((unsigned)s_carry[0] + (unsigned)ep) & 0x7fffffffu), dm = (int)(((unsigned)s_carry[1] + (unsigned)em) & 0x7fffffffu);
+    // ---- per-position depth, threshold, run-start flags
+    // previous position's "above": last element of the previous thread; for thread 0 the carried-in depth
+    unsigned abovemask = 0;
+    int d_p[SCAN_IPT], d_m[SCAN_IPT];
+    {
+        int cp = dp, cm = dm;
+#pragma unroll
+        for (int j = 0; j < SCAN_IPT; j++) {
+            cp = (int)(((unsigned)cp + (unsigned)vp[j]) & 0x7fffffffu); cm = (int)(((unsigned)cm + (unsigned)vm[j]) & 0x7fffffffu);
+            d_p[j] = cp; d_m[j] = cm;
+            if ((my0 + j < gtot) && (cp + cm > cutoff)) abovemask |= 1u << j;
+        }
+    }
+    int prev_above = (dp + dm > cutoff) ? 1 : 0;   // depth just before my first position (exclusive prefix)
+    unsigned startmask = abovemask & ~((abovemask << 1) | (unsigned)prev_above);
+    int ns = __popc(startmask), na = __popc(abovemask);
+    int es, ea, ts, ta;
+    block_excl_scan2(ns, na, es, ea, ts, ta, sh);
+    // ---- look-back #2: ordered output offsets
+    if (tid == 0) st_status(&stat_c[tile], pack2(tile == 0 ? 2u : 1u, (unsigned)ts, (unsigned)ta));
+    if (tid < 64) {
+        long long cs = 0, ca = 0;
+        if (tile > 0) {
+            long long idx = (long long)tile - 1;
+            while (true) {
+                long long j = idx - lane;
+                unsigned long long v = 0;
+                unsigned flag = 3;
+                if (j >= 0) { do { v = ld_status(&stat_c[j]); flag = (unsigned)(v >> 62); } while (flag == 0); }
+                unsigned long long pm = __ballot(flag == 2);
+                int stop = pm ? (__ffsll((long long)pm) - 1) : 64;
+                int a = (j >= 0 && lane <= stop) ? (int)((v >> 31) & 0x7fffffffu) : 0;
+                int b = (j >= 0 && lane <= stop) ? (int)(v & 0x7fffffffu) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+                cs += a; ca += b;
+                if (pm || idx - 64 < 0) break;
+                idx -= 64;
+            }
+            if (lane == 0) st_status(&stat_c[tile], pack2(2u, (unsigned)(cs + ts), (unsigned)(ca + ta)));
+        }
+        if (lane == 0) { s_carry[2] = (int)cs; s_carry[3] = (int)ca; }
+    }
+    __syncthreads();
+    long long os = (long long)s_carry[2] + es, oa = (long long)s_carry[3] + ea;
+#pragma unroll
+    for (int j = 0; j < SCAN_IPT; j++) {
+        if (startmask & (1u << j)) {
+            if (os < starts_cap) { RunStart r; r.gx = my0 + j; r.dp = d_p[j]; r.dm = d_m[j]; starts[os] = r; }
+            os++;
+        }
+        if (abovemask & (1u << j)) {
+            if (depth_out && oa < depth_cap) {
+                MirpDepthPos d; d.tid = 0; d.pos = 0; d.dp = d_p[j]; d.dm = d_m[j];
+                depth_out[oa] = d; depth_gx[oa] = my0 + j;
+            }
+            oa++;
+        }
+    }
+    if ((long long)(tile + 1) * SCAN_TILE >= gtot && tid == SCAN_NT - 1) { totals[0] = (unsigned long long)os; totals[1] = (unsigned long long)oa; }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2 (second half): walk each run, strand vote (with the contig-change double count, MP:905-906 +
+// 926-929), drop runs shorter than min_len (MP:956).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int contig_of(const long long* __restrict__ goff, int n_contigs, long long gx) {
+    int lo = 0, hi = n_contigs - 1;   // last t with goff[t] <= gx
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (goff[mid] <= gx) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) run_walk_kernel(const RunStart* __restrict__ starts, long long n_runs, const int* __restrict__ diff_p,
+                                                       const int* __restrict__ diff_m, long long gtot, int cutoff,
+                                                       const long long* __restrict__ goff, int n_contigs, int min_len,
+                                                       MirpPeak* __restrict__ runs, int* __restrict__ keep) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n_runs; k += (long long)gridDim.x * blockDim.x) {
+        RunStart r = starts[k];
+        int dp = r.dp, dm = r.dm;
+        long long sum_p = dp, sum_m = dm, x = r.gx + 1;
+        for (; x < gtot; x++) {
+            dp += diff_p[x]; dm += diff_m[x];
+            if (dp + dm > cutoff) { sum_p += dp; sum_m += dm; } else break;
+        }
+        int t = contig_of(goff, n_contigs, r.gx);
+        if (k > 0) {
+            int tprev = contig_of(goff, n_contigs, starts[k - 1].gx);
+            if (tprev != t) { sum_p += r.dp; sum_m += r.dm; }
+        }
+        MirpPeak p;
+        p.tid = t; p.start = (int)(r.gx - goff[t] + 1); p.end = (int)(x - goff[t] + 1); p.strand = (sum_p > sum_m) ? 0 : 1;
+        runs[k] = p;
+        keep[k] = (p.end - p.start >= min_len) ? 1 : 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) depth_fix_kernel(MirpDepthPos* __restrict__ d, const long long* __restrict__ gx, long long n,
+                                                        const long long* __restrict__ goff, int n_contigs) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        int t = contig_of(goff, n_contigs, gx[k]);
+        d[k].tid = t; d[k].pos = (int)(gx[k] - goff[t] + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic single-block exclusive scan of int32 (small arrays: runs, regions)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) excl_scan_i32_kernel(const int* __restrict__ in, long long* __restrict__ out, long long n) {
+    __shared__ long long sh[16];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (long long b = 0; b < n; b += 1024) {
+        long long k = b + tid;
+        long long v = (k < n) ? in[k] : 0, iv = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { long long t = __shfl_up(iv, o); if (lane >= o) iv += t; }
+        if (lane == 63) sh[wave] = iv;
+        __syncthreads();
+        long long wpre = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { if (w < wave) wpre += sh[w]; tot += sh[w]; }
+        long long carry = s_carry;
+        if (k < n) out[k] = carry + wpre + iv - v;
+        __syncthreads();
+        if (tid == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = s_carry;
+}
+
+// kept runs -> peaks in @SQ order (API output) and in sorted-contig order (pipeline order, MP:1309)
+__global__ void __launch_bounds__(256) contig_peak_ranges_kernel(const MirpPeak* __restrict__ runs, long long n_runs, const long long* __restrict__ kscan,
+                                                                 int n_contigs, long long* __restrict__ csq /* [n_contigs+1] kept-start per contig */) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= n_contigs; t += gridDim.x * blockDim.x) {
+        long long lo = 0, hi = n_runs;   // first run with tid >= t
+        while (lo < hi) { long long mid = (lo + hi) >> 1; if (runs[mid].tid < t) lo = mid + 1; else hi = mid; }
+        csq[t] = kscan[lo];
+    }
+}
+__global__ void contig_dest_kernel(const long long* __restrict__ csq, const int* __restrict__ order, int n_contigs, long long* __restrict__ cdest) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        long long acc = 0;
+        for (int oi = 0; oi < n_contigs; oi++) { int t = order[oi]; cdest[t] = acc; acc += csq[t + 1] - csq[t]; }
+    }
+}
+__global__ void __launch_bounds__(256) peak_compact_kernel(const MirpPeak* __restrict__ runs, const int* __restrict__ keep, const long long* __restrict__ kscan,
+                                                           long long n_runs, const long long* __restrict__ csq, const long long* __restrict__ cdest,
+                                                           MirpPeak* __restrict__ peaks_sq, MirpPeak* __restrict__ peaks_sorted) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n_runs; k += (long long)gridDim.x * blockDim.x) {
+        if (!keep[k]) continue;
+        MirpPeak p = runs[k];
+        long long i = kscan[k];
+        peaks_sq[i] = p;
+        peaks_sorted[cdest[p.tid] + (i - csq[p.tid])] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a3: gap merge (next_region_typeA MP:1256-1270) + window extension (extend_region MP:1272-1300)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) region_head_kernel(const MirpPeak* __restrict__ P, long long n, int max_gap, int* __restrict__ head) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x)
+        head[k] = (k == 0 || P[k].tid != P[k - 1].tid || P[k].start - P[k - 1].end >= max_gap) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) region_first_kernel(const int* __restrict__ head, const long long* __restrict__ hscan, long long n,
+                                                           long long* __restrict__ rfirst /* [n_regions+1] */) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k <= n; k += (long long)gridDim.x * blockDim.x) {
+        if (k == n) rfirst[hscan[n]] = n;
+        else if (head[k]) rfirst[hscan[k]] = k;
+    }
+}
+
+__device__ __forceinline__ int extend_region(int s, int e, int L, long long seqlen, int out[2][2]) {
+    int length = e - s;
+    if (length > L + 50) return 0;
+    if (length > L) { out[0][0] = s; out[0][1] = e; return 1; }
+    if (length < 60) {
+        long long ls = (long long)s - (L - length - 25) - 25, le = (long long)e + 25;
+        long long rs = (long long)s - 25, re = (long long)e + (L - length - 25) + 25;
+        if (ls < 0) ls = 0;
+        if (le > seqlen) le = seqlen;
+        if (rs < 0) rs = 0;
+        if (re > seqlen) re = seqlen;
+        out[0][0] = (int)ls; out[0][1] = (int)le; out[1][0] = (int)rs; out[1][1] = (int)re;
+        return 2;
+    }
+    int ext = (L - length) / 2;
+    long long left = (long long)s - ext, right = (long long)e + ext;
+    if (left < 0) left = 1;
+    if (right > seqlen) right = seqlen + 1;
+    out[0][0] = (int)left; out[0][1] = (int)right;
+    return 1;
+}
+
+// per region: number of FASTA entries (incl. the both-strand L/R duplication MP:1184-1192), locus flag, slot demand
+__global__ void __launch_bounds__(256) region_count_kernel(const MirpPeak* __restrict__ P, const long long* __restrict__ rfirst, long long n_regions,
+                                                           const long long* __restrict__ clen, int L, int* __restrict__ n_entries,
+                                                           int* __restrict__ is_locus, int* __restrict__ n_slots) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n_regions; r += (long long)gridDim.x * blockDim.x) {
+        long long f = rfirst[r], l = rfirst[r + 1];
+        int ext[2][2];
+        int nwin = extend_region(P[f].start, P[l - 1].end, L, clen[P[f].tid], ext);
+        int has_p = 0, has_m = 0;
+        for (long long k = f; k < l; k++) { if (P[k].strand == 0) has_p = 1; else has_m = 1; }
+        int ne = 0;
+        if (nwin > 0) ne = (has_p != has_m) ? nwin : (nwin == 1 ? 2 : 6);
+        n_entries[r] = ne;
+        is_locus[r] = nwin > 0 ? 1 : 0;
+        n_slots[r] = ne * (int)(l - f);
+    }
+}
+
+__global__ void __launch_bounds__(256) region_emit_kernel(const MirpPeak* __restrict__ P, const long long* __restrict__ rfirst, long long n_regions,
+                                                          const long long* __restrict__ clen, int L, const long long* __restrict__ escan,
+                                                          const long long* __restrict__ lscan, const long long* __restrict__ sscan,
+                                                          MirpWindow* __restrict__ W, MirpLocus* __restrict__ loci, MirpPeak* __restrict__ wpeaks,
+                                                          int* __restrict__ roles, int seq_stride) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n_regions; r += (long long)gridDim.x * blockDim.x) {
+        long long f = rfirst[r], l = rfirst[r + 1];
+        int npk = (int)(l - f);
+        int ext[2][2];
+        int rs = P[f].start, re = P[l - 1].end, tid = P[f].tid;
+        int nwin = extend_region(rs, re, L, clen[tid], ext);
+        if (nwin == 0) continue;
+        MirpLocus lc;
+        lc.tid = tid; lc.start = rs; lc.end = re; lc.n_windows = nwin;
+        lc.w[0][0] = ext[0][0]; lc.w[0][1] = ext[0][1]; lc.w[1][0] = nwin > 1 ? ext[1][0] : 0; lc.w[1][1] = nwin > 1 ? ext[1][1] : 0;
+        lc.peak_first = f; lc.n_peaks = npk; lc.pad = 0;
+        loci[lscan[r]] = lc;
+        int has_p = 0, has_m = 0;
+        for (long long k = f; k < l; k++) { if (P[k].strand == 0) has_p = 1; else has_m = 1; }
+        long long e = escan[r], slot = sscan[r];
+        int emitted = 0;
+        auto emit = [&](int idx, int strand, int only) {
+            MirpWindow w;
+            w.tid = tid; w.ws = ext[idx][0]; w.we = ext[idx][1]; w.strand = strand; w.loc_s = rs; w.loc_e = re;
+            w.tag = nwin == 2 ? (idx == 0 ? 1 : 2) : 0;
+            w.peak_off = slot; w.n_peaks = 0;
+            for (long long k = f; k < l; k++) {
+                if (only >= 0 && P[k].strand != only) continue;
+                wpeaks[slot + w.n_peaks] = P[k]; w.n_peaks++;
+            }
+            w.n_matures = 0; w.pad0 = (int)f; w.mature_off = 2 * slot;   // pad0 carries the region's first peak until the payload kernel ran
+            w.seq_off = e * (long long)seq_stride; w.seq_len = 0; w.pad1 = npk;
+            W[e] = w;
+            roles[e] = nwin == 2 ? ((emitted & 1) ? 2 : 1) : 0;   // filter_next_loci consumes (L,R) entries pairwise (MP:2394-2403)
+            e++; slot += npk; emitted++;
+        };
+        if (has_p != has_m) {
+            for (int idx = 0; idx < nwin; idx++) emit(idx, has_p ? 0 : 1, -1);
+        } else {
+            for (int idx = 0; idx < nwin; idx++)
+                for (int s = 0; s < 2; s++)
+                    for (int j = 0; j <= idx; j++) emit(j, s, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a4-a6: window payload.  One wavefront per window: sequence gather (+ reverse complement),
+// per-position most-abundant-read table in LDS, candidate matures.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ char rc_char(char c) {   // get_complement MP:232-235: upper-case ATGCU only
+    switch (c) { case 'A': return 'U'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; case 'U': return 'A'; default: return c; }
+}
+
+__global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restrict__ W, long long n_windows, const MirpPeak* __restrict__ P,
+                                                            const MirpAln* __restrict__ alns, long long n_alns, const unsigned char* __restrict__ genome,
+                                                            const long long* __restrict__ gboff, const long long* __restrict__ clen,
+                                                            double min_mature_depth, int wmax,
+                                                            char* __restrict__ seqs, MirpMature* __restrict__ matures) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* dmax = (int*)smem;                       // [wmax]  depth of the most abundant read of the window strand at pos, 0 = none
+    unsigned short* lmax = (unsigned short*)(dmax + wmax);   // [wmax]
+    const int lane = threadIdx.x;
+    for (long long w = blockIdx.x; w < n_windows; w += gridDim.x) {
+        MirpWindow win = W[w];
+        const int tid = win.tid, ws = win.ws, we = win.we, strand = win.strand;
+        // ---- a4: samtools faidx chr:ws-(we-1): start 0 -> 1, end clamped to the contig (MP:1098-1105)
+        long long s = ws < 1 ? 1 : ws, e = (long long)we - 1;
+        if (e > clen[tid]) e = clen[tid];
+        int len = e >= s ? (int)(e - s + 1) : 0;
+        const unsigned char* g = genome + gboff[tid];
+        char* dst = seqs + win.seq_off;
+        if (strand == 0) for (int x = lane; x < len; x += 64) dst[x] = (char)g[s - 1 + x];
+        else for (int x = lane; x < len; x += 64) dst[x] = rc_char((char)g[e - 1 - x]);
+        // ---- a5: per start position, most abundant read of the window's strand; first seen wins ties (MP:1457)
+        const int width = we - ws + 1;
+        for (int x = lane; x < width; x += 64) {
+            int pos = ws + x, best_d = 0, best_l = 0;
+            long long lo = 0, hi = n_alns;
+            while (lo < hi) { long long mid = (lo + hi) >> 1; MirpAln r = alns[mid]; if (r.tid < tid || (r.tid == tid && r.pos < pos)) lo = mid + 1; else hi = mid; }
+            for (long long k = lo; k < n_alns; k++) {
+                MirpAln r = alns[k];
+                if (r.tid != tid || r.pos != pos) break;
+                if ((int)r.strand != strand) continue;
+                if ((int)r.depth > best_d) { best_d = (int)r.depth; best_l = r.len; }
+            }
+            dmax[x] = best_d; lmax[x] = (unsigned short)best_l;
+        }
+        __syncthreads();
+        // ---- a6: gen_matures_one_peak per same-strand peak of the region (MP:1472-1510)
+        if (lane == 0) {
+            int nm = 0;
+            const long long f = win.pad0;
+            const int npk = win.pad1;
+            MirpMature* out = matures + win.mature_off;
+            for (int k = 0; k < npk; k++) {
+                MirpPeak pk = P[f + k];
+                if (pk.strand != strand) continue;
+                MirpMature cand[2];
+                int n = 0;
+                MirpMature hi; hi.start = 0; hi.end = 0; hi.strand = -1; hi.depth = 0;
+                for (int pos = pk.start - 20; pos < pk.end; pos++) {
+                    if (pos < ws || pos > we) continue;
+                    int d = dmax[pos - ws];
+                    if (d <= 0) continue;
+                    int l = lmax[pos - ws];
+                    if (d > hi.depth) { hi.start = pos; hi.end = pos + l; hi.strand = strand; hi.depth = d; }
+                    if ((double)d > min_mature_depth) {
+                        MirpMature m; m.start = pos; m.end = pos + l; m.strand = strand; m.depth = d;
+                        if (n < 2) cand[n++] = m;
+                        else if (d > cand[n - 1].depth) cand[n - 1] = m;
+                    }
+                }
+                if (n == 0) cand[n++] = hi;
+                for (int x = 0; x < n; x++) out[nm++] = cand[x];
+            }
+            win.n_matures = nm; win.pad0 = 0; win.pad1 = 0; win.seq_len = len;
+            W[w] = win;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(long long n, int block, int cap) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cov_scatter_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, cutoff, diff_p, diff_m);
+}
+long long cov_scan_tiles(long long gtot) { return (gtot + SCAN_TILE - 1) / SCAN_TILE; }
+void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d,
+                     unsigned long long* stat_c, unsigned int* ticket, void* starts, long long starts_cap, MirpDepthPos* depth_out,
+                     long long depth_cap, long long* depth_gx, unsigned long long* totals) {
+    long long tiles = cov_scan_tiles(gtot);
+    hipLaunchKernelGGL(cov_scan_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, st, diff_p, diff_m, gtot, cutoff, stat_d, stat_c, ticket,
+                       (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
+}
+size_t run_start_bytes() { return sizeof(RunStart); }
+void launch_run_walk(hipStream_t st, const void* starts, long long n_runs, const int* diff_p, const int* diff_m, long long gtot, int cutoff,
+                     const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep) {
+    if (n_runs <= 0) return;
+    hipLaunchKernelGGL(run_walk_kernel, dim3(grid_for(n_runs, 256, 8192)), dim3(256), 0, st, (const RunStart*)starts, n_runs, diff_p, diff_m, gtot,
+                       cutoff, goff, n_contigs, min_len, runs, keep);
+}
+void launch_depth_fix(hipStream_t st, MirpDepthPos* d, const long long* gx, long long n, const long long* goff, int n_contigs) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(depth_fix_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, d, gx, n, goff, n_contigs);
+}
+void launch_excl_scan(hipStream_t st, const int* in, long long* out, long long n) {
+    hipLaunchKernelGGL(excl_scan_i32_kernel, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+void launch_peak_compact(hipStream_t st, const MirpPeak* runs, const int* keep, const long long* kscan, long long n_runs, int n_contigs,
+                         const int* order, long long* csq, long long* cdest, MirpPeak* peaks_sq, MirpPeak* peaks_sorted) {
+    hipLaunchKernelGGL(contig_peak_ranges_kernel, dim3(grid_for(n_contigs + 1, 256, 1024)), dim3(256), 0, st, runs, n_runs, kscan, n_contigs, csq);
+    hipLaunchKernelGGL(contig_dest_kernel, dim3(1), dim3(1), 0, st, csq, order, n_contigs, cdest);
+    if (n_runs > 0)
+        hipLaunchKernelGGL(peak_compact_kernel, dim3(grid_for(n_runs, 256, 8192)), dim3(256), 0, st, runs, keep, kscan, n_runs, csq, cdest, peaks_sq, peaks_sorted);
+}
+void launch_region_head(hipStream_t st, const MirpPeak* P, long long n, int max_gap, int* head) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(region_head_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, P, n, max_gap, head);
+}
+void launch_region_first(hipStream_t st, const int* head, const long long* hscan, long long n, long long* rfirst) {
+    hipLaunchKernelGGL(region_first_kernel, dim3(grid_for(n + 1, 256, 8192)), dim3(256), 0, st, head, hscan, n, rfirst);
+}
+void launch_region_count(hipStream_t st, const MirpPeak* P, const long long* rfirst, long long n_regions, const long long* clen, int L,
+                         int* n_entries, int* is_locus, int* n_slots) {
+    if (n_regions <= 0) return;
+    hipLaunchKernelGGL(region_count_kernel, dim3(grid_for(n_regions, 256, 8192)), dim3(256), 0, st, P, rfirst, n_regions, clen, L, n_entries, is_locus, n_slots);
+}
+void launch_region_emit(hipStream_t st, const MirpPeak* P, const long long* rfirst, long long n_regions, const long long* clen, int L,
+                        const long long* escan, const long long* lscan, const long long* sscan, MirpWindow* W, MirpLocus* loci, MirpPeak* wpeaks,
+                        int* roles, int seq_stride) {
+    if (n_regions <= 0) return;
+    hipLaunchKernelGGL(region_emit_kernel, dim3(grid_for(n_regions, 256, 8192)), dim3(256), 0, st, P, rfirst, n_regions, clen, L, escan, lscan, sscan, W,
+                       loci, wpeaks, roles, seq_stride);
+}
+void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, const MirpPeak* P, const MirpAln* alns, long long n_alns,
+                           const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
+                           MirpMature* matures) {
+    if (n_windows <= 0) return;
+    size_t lds = (size_t)wmax * 6 + 16;
+    hipLaunchKernelGGL(window_payload_kernel, dim3(grid_for(n_windows, 1, 16384)), dim3(64), lds, st, W, n_windows, P, alns, n_alns, genome, gboff, clen,
+                       min_mature_depth, wmax, seqs, matures);
+}
+
+}  // namespace mirp

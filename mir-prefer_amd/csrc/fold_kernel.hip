@@ -346,7 +346,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
 
 __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs,
-    const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints,
+    const int* __restrict__ win_lens, const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints,
     int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
     int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
         const int win = work_list ? work_list[w] : w;
         const long long o0 = offs[win];
-        const int n = (int)(offs[win + 1] - o0);
+        const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
         if (n < 1 || n > n_cap) {
             if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = n < 1 ? 0 : -40; }
             continue;
@@ -505,10 +505,10 @@ size_t fold_generic_ws_slot_ints(int n_cap, int span) {
 }
 
 void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs,
-                         const int* work_list, int n_work, int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines,
+                         const int* lens, const int* work_list, int n_work, int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines,
                          int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status) {
     size_t lds = fold_generic_lds_bytes(n_cap, max_lines);
-    hipLaunchKernelGGL(fold_generic_kernel, dim3(grid), dim3(GEN_NT), lds, stream, P, seqs, offs, work_list, n_work, span, n_cap, ws,
+    hipLaunchKernelGGL(fold_generic_kernel, dim3(grid), dim3(GEN_NT), lds, stream, P, seqs, offs, lens, work_list, n_work, span, n_cap, ws,
                        ws_slot_ints, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
 }
 

@@ -13,41 +13,11 @@
 #define MIRP_ABI_VERSION 1
 #define MIRP_NMAX 3096
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct mirp_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    int n_cu = 256;
-    FoldParams* d_params = nullptr;
-    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status;
-};
-
-static int fail(mirp_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
-    return code;
-}
-#define HIPCHK(c, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) return fail((c), -2, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
+#include "mirp_ctx.h"
 
 extern "C" int mirp_abi_version(void) { return MIRP_ABI_VERSION; }
+
+extern "C" void mirp_destroy(mirp_ctx* c);
 
 extern "C" int mirp_create(int device, mirp_ctx** out) {
     if (!out) return -1;
@@ -68,6 +38,8 @@ extern "C" int mirp_create(int device, mirp_ctx** out) {
         delete hp; delete c; return -2;
     }
     delete hp;
+    for (int i = 0; i < 4; i++)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { mirp_destroy(c); return -2; }
     *out = c;
     return 0;
 }
@@ -77,6 +49,12 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     (void)hipSetDevice(c->device);
     c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
     c->nlines.release(); c->mfe.release(); c->status.release();
+    for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,
+                      &c->keep, &c->kscan, &c->csq, &c->cdest, &c->peaks_sq, &c->peaks_sorted, &c->head, &c->hscan, &c->rfirst, &c->nent,
+                      &c->isloc, &c->nslots, &c->escan, &c->lscan, &c->sscan, &c->windows, &c->roles, &c->loci, &c->wpeaks, &c->matures,
+                      &c->wseqs, &c->woffs, &c->wlens, &c->p_out, &c->p_nout, &c->p_status, &c->p_keep, &c->p_kscan, &c->p_res, &c->p_text})
+        b->release();
+    for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -137,7 +115,7 @@ extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* off
             const int grid = std::min(nb, slots);
             // windows of this batch are addressed relative to b0: shift the pointers
             mirp::launch_fold_generic(c->stream, grid, c->d_params, (const unsigned char*)c->seqs.p, (const long long*)c->offs.p + b0,
-                                      nullptr, nb, span, n_max, (int*)c->ws.p, slot_ints, max_lines, stride, (MirpFoldLine*)c->lines.p,
+                                      nullptr, nullptr, nb, span, n_max, (int*)c->ws.p, slot_ints, max_lines, stride, (MirpFoldLine*)c->lines.p,
                                       (char*)c->ss.p, (int*)c->nlines.p + b0, (int*)c->mfe.p + b0, (int*)c->status.p + b0);
             if (hipGetLastError() != hipSuccess) return bail(-2, "fold kernel launch failed");
             if (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->lines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
@@ -159,17 +137,6 @@ extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* off
 template <class T>
 static T* host_alloc(size_t n) { return (T*)std::calloc(std::max<size_t>(n, 1), sizeof(T)); }
 
-struct TmpDev {
-    std::vector<void*> ptrs;
-    ~TmpDev() { for (void* p : ptrs) (void)hipFree(p); }
-    void* get(size_t bytes) {
-        void* p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
-        ptrs.push_back(p);
-        return p;
-    }
-};
-
 extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
                                   const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
                                   int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* pp, MirpMirna** mirnas,
@@ -182,7 +149,7 @@ extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_
     HIPCHK(c, hipSetDevice(c->device));
     if (mirp::predict_lds_bytes(max_lines, ss_stride) > 160 * 1024)
         return fail(c, -5, "mirp_predict_batch: max_lines*ss_stride exceeds the LDS budget of the predict kernel");
-    TmpDev T;
+    TmpDevice T;
     const size_t nl = (size_t)n_windows * max_lines;
     void* d_w = T.get(sizeof(MirpWindow) * n_windows);
     void* d_m = T.get(sizeof(MirpMature) * n_matures);

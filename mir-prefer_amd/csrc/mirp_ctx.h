@@ -1,0 +1,68 @@
+// Context and helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "mirp_internal.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct TmpDevice {   // scoped device allocations
+    std::vector<void*> ptrs;
+    ~TmpDevice() { for (void* p : ptrs) (void)hipFree(p); }
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+};
+
+struct mirp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+    FoldParams* d_params = nullptr;
+    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status;
+    // ---- device-resident pipeline state (mirp_pipeline.cpp)
+    int n_contigs = 0;
+    long long gtot = 0, gbytes = 0, n_alns = 0;
+    std::vector<long long> h_clen, h_goff, h_gboff;
+    DevBuf genome, clen, goff, gboff, alns, order;
+    DevBuf diff, stat, starts, totals, runs, keep, kscan, csq, cdest, peaks_sq, peaks_sorted;
+    DevBuf head, hscan, rfirst, nent, isloc, nslots, escan, lscan, sscan, windows, roles, loci, wpeaks, matures, wseqs, woffs, wlens;
+    DevBuf p_out, p_nout, p_status, p_keep, p_kscan, p_res, p_text;
+    MirpCandidateParams cand = {0, 0, 0, 0};
+    long long n_runs = 0, n_above = 0, n_peaks = 0, n_regions = 0, n_loci = 0, n_windows = 0, n_slots = 0;
+    int seq_stride = 0, fold_stride = 0, fold_max_lines = 0, fold_span = 0;
+    bool have_candidate = false, have_fold = false;
+    double ms[4] = {0, 0, 0, 0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+static inline int fail(mirp_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail((c), -2, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+

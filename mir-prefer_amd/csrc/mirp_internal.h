@@ -11,12 +11,36 @@ namespace mirp {
 size_t fold_generic_lds_bytes(int n_cap, int max_lines);
 size_t fold_generic_ws_slot_ints(int n_cap, int span);
 void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs,
-                         const int* work_list, int n_work, int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines,
+                         const int* lens, const int* work_list, int n_work, int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines,
                          int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status);
 
 size_t predict_lds_bytes(int max_lines, int ss_stride);
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status);
+
+// candidate_kernels.hip
+void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m);
+long long cov_scan_tiles(long long gtot);
+size_t run_start_bytes();
+void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d,
+                     unsigned long long* stat_c, unsigned int* ticket, void* starts, long long starts_cap, MirpDepthPos* depth_out,
+                     long long depth_cap, long long* depth_gx, unsigned long long* totals);
+void launch_run_walk(hipStream_t st, const void* starts, long long n_runs, const int* diff_p, const int* diff_m, long long gtot, int cutoff,
+                     const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep);
+void launch_depth_fix(hipStream_t st, MirpDepthPos* d, const long long* gx, long long n, const long long* goff, int n_contigs);
+void launch_excl_scan(hipStream_t st, const int* in, long long* out, long long n);
+void launch_peak_compact(hipStream_t st, const MirpPeak* runs, const int* keep, const long long* kscan, long long n_runs, int n_contigs,
+                         const int* order, long long* csq, long long* cdest, MirpPeak* peaks_sq, MirpPeak* peaks_sorted);
+void launch_region_head(hipStream_t st, const MirpPeak* P, long long n, int max_gap, int* head);
+void launch_region_first(hipStream_t st, const int* head, const long long* hscan, long long n, long long* rfirst);
+void launch_region_count(hipStream_t st, const MirpPeak* P, const long long* rfirst, long long n_regions, const long long* clen, int L,
+                         int* n_entries, int* is_locus, int* n_slots);
+void launch_region_emit(hipStream_t st, const MirpPeak* P, const long long* rfirst, long long n_regions, const long long* clen, int L,
+                        const long long* escan, const long long* lscan, const long long* sscan, MirpWindow* W, MirpLocus* loci, MirpPeak* wpeaks,
+                        int* roles, int seq_stride);
+void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, const MirpPeak* P, const MirpAln* alns, long long n_alns,
+                           const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
+                           MirpMature* matures);
 
 }  // namespace mirp

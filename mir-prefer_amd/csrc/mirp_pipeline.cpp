@@ -1,0 +1,373 @@
+// Device-resident candidate -> fold -> predict pipeline behind the C-ABI (include/mirprefer.h).
+// Host orchestration only; every stage leaves its results in HBM for the next one.
+#include <cstdio>
+#include <cstring>
+#include "mirp_ctx.h"
+
+namespace mirp {
+// small kernels local to the pipeline (window index for the folder, result selection / gather)
+__global__ void window_index_kernel(const MirpWindow* __restrict__ W, long long n, long long* __restrict__ offs, int* __restrict__ lens) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        offs[k] = W[k].seq_off;
+        lens[k] = W[k].seq_len;
+    }
+}
+// filter_next_loci pairing (MP:2373-2432): role 0 = single ('0' entry), 1 = first of an (L,R) pair, 2 = second (evaluated only if the first failed)
+__global__ void result_keep_kernel(const int* __restrict__ roles, const int* __restrict__ n_out, long long n, int* __restrict__ keep) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        int r = roles[k];
+        keep[k] = (n_out[k] > 0 && (r != 2 || n_out[k - 1] == 0)) ? 1 : 0;
+    }
+}
+__global__ void result_gather_kernel(const int* __restrict__ keep, const long long* __restrict__ kscan, long long n, const MirpMirna* __restrict__ out,
+                                     const char* __restrict__ ss, int ss_stride, int max_lines, MirpMirna* __restrict__ res, char* __restrict__ text) {
+    // one wavefront per window
+    const int lane = threadIdx.x & 63;
+    for (long long w = blockIdx.x * (long long)(blockDim.x / 64) + (threadIdx.x >> 6); w < n; w += (long long)gridDim.x * (blockDim.x / 64)) {
+        if (!keep[w]) continue;
+        MirpMirna m = out[w * MIRP_MAX_MIRNA_PER_WINDOW];
+        long long i = kscan[w];
+        if (lane == 0) res[i] = m;
+        const char* src = ss + ((size_t)w * max_lines + m.line) * ss_stride + m.ss_off;
+        char* dst = text + (size_t)i * ss_stride;
+        for (int x = lane; x < ss_stride; x += 64) dst[x] = (x < m.ss_len) ? src[x] : (char)0;
+    }
+}
+}  // namespace mirp
+
+template <class T>
+static T* host_copy(mirp_ctx* c, const void* dev, size_t n) {
+    T* h = (T*)std::calloc(std::max<size_t>(n, 1), sizeof(T));
+    if (!h) return nullptr;
+    if (n && hipMemcpy(h, dev, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) { std::free(h); return nullptr; }
+    return h;
+}
+
+static int read_ll(mirp_ctx* c, const void* dev, long long* out) {
+    if (hipMemcpyAsync(out, dev, sizeof(long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    return 0;
+}
+
+extern "C" int mirp_load_genome(mirp_ctx* c, int32_t n_contigs, const int64_t* contig_len, const uint8_t* seq_concat) {
+    if (!c) return -1;
+    if (n_contigs < 1 || !contig_len || !seq_concat) return fail(c, -1, "mirp_load_genome: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->n_contigs = n_contigs;
+    c->h_clen.assign(contig_len, contig_len + n_contigs);
+    c->h_goff.resize(n_contigs + 1); c->h_gboff.resize(n_contigs + 1);
+    long long g = 0, b = 0;
+    for (int t = 0; t < n_contigs; t++) {
+        if (contig_len[t] < 0 || contig_len[t] > 0x7ffffff0LL) return fail(c, -1, "mirp_load_genome: contig length out of range");
+        c->h_goff[t] = g; c->h_gboff[t] = b; g += contig_len[t] + 1; b += contig_len[t];
+    }
+    c->h_goff[n_contigs] = g; c->h_gboff[n_contigs] = b;
+    c->gtot = g; c->gbytes = b;
+    if (c->genome.ensure((size_t)b + 16) || c->clen.ensure(8 * (size_t)n_contigs) || c->goff.ensure(8 * (size_t)(n_contigs + 1)) ||
+        c->gboff.ensure(8 * (size_t)(n_contigs + 1)))
+        return fail(c, -6, "device allocation failed (genome)");
+    HIPCHK(c, hipMemcpy(c->genome.p, seq_concat, (size_t)b, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->clen.p, c->h_clen.data(), 8 * (size_t)n_contigs, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->goff.p, c->h_goff.data(), 8 * (size_t)(n_contigs + 1), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->gboff.p, c->h_gboff.data(), 8 * (size_t)(n_contigs + 1), hipMemcpyHostToDevice));
+    c->have_candidate = c->have_fold = false;
+    return 0;
+}
+
+extern "C" int mirp_load_alignments(mirp_ctx* c, const MirpAln* alns, int64_t n) {
+    if (!c) return -1;
+    if (n < 0 || (n > 0 && !alns)) return fail(c, -1, "mirp_load_alignments: bad argument");
+    if (c->n_contigs == 0) return fail(c, -1, "mirp_load_alignments: load the genome first");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int64_t k = 0; k < n; k++) {
+        if (alns[k].tid < 0 || alns[k].tid >= c->n_contigs) return fail(c, -1, "mirp_load_alignments: tid out of range");
+        if (k > 0 && (alns[k].tid < alns[k - 1].tid || (alns[k].tid == alns[k - 1].tid && alns[k].pos < alns[k - 1].pos)))
+            return fail(c, -1, "mirp_load_alignments: records are not sorted by (tid, pos)");
+        if (alns[k].sample >= MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_load_alignments: sample index out of range");
+    }
+    if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<int64_t>(n, 1))) return fail(c, -6, "device allocation failed (alignments)");
+    if (n) HIPCHK(c, hipMemcpy(c->alns.p, alns, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice));
+    c->n_alns = n;
+    c->have_candidate = c->have_fold = false;
+    return 0;
+}
+
+// coverage: memset + scatter + single-pass scan. depth_out optional (second run for mirp_get_depth).
+static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_cap, long long* depth_gx) {
+    const long long gtot = c->gtot;
+    const long long tiles = mirp::cov_scan_tiles(gtot);
+    if (c->diff.ensure(8 * (size_t)(gtot + 8)) || c->stat.ensure(16 * (size_t)tiles + 64) ||
+        c->starts.ensure(mirp::run_start_bytes() * (size_t)std::max<long long>(c->n_alns, 1)) || c->totals.ensure(64))
+        return fail(c, -6, "device allocation failed (coverage)");
+    int* diff_p = (int*)c->diff.p;
+    int* diff_m = diff_p + ((gtot + 3) / 4) * 4;   // keep 16-B alignment of both arrays
+    unsigned long long* stat_d = (unsigned long long*)c->stat.p;
+    unsigned long long* stat_c = stat_d + tiles;
+    unsigned int* ticket = (unsigned int*)(stat_c + tiles);
+    HIPCHK(c, hipMemsetAsync(c->diff.p, 0, 8 * (size_t)(gtot + 8), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->stat.p, 0, 16 * (size_t)tiles + 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->totals.p, 0, 64, c->stream));
+    mirp::launch_cov_scatter(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p, c->cand.cutoff,
+                             diff_p, diff_m);
+    mirp::launch_cov_scan(c->stream, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p, std::max<long long>(c->n_alns, 1),
+                          depth_out, depth_cap, depth_gx, (unsigned long long*)c->totals.p);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks_out,
+                              int64_t* n_loci_out, int64_t* n_windows_out) {
+    if (!c) return -1;
+    if (!params || !contig_order) return fail(c, -1, "mirp_candidate: null argument");
+    if (c->n_contigs == 0) return fail(c, -1, "mirp_candidate: no genome loaded");
+    if (params->precursor_len < 60 || params->precursor_len > 3000) return fail(c, -1, "Error: allowed precursor range: 60-3000");
+    if (params->cutoff < 2) return fail(c, -1, "Error: READS_DEPTH_CUTOFF should >=2.");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->cand = *params;
+    c->have_candidate = c->have_fold = false;
+    const int nc = c->n_contigs;
+    if (c->order.ensure(4 * (size_t)nc)) return fail(c, -6, "device allocation failed");
+    HIPCHK(c, hipMemcpyAsync(c->order.p, contig_order, 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    int rc = run_coverage(c, nullptr, 0, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    long long tot[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(tot, c->totals.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->n_runs = tot[0]; c->n_above = tot[1];
+    if (c->n_runs > std::max<long long>(c->n_alns, 1)) return fail(c, -7, "internal: run-start capacity exceeded");
+    const long long nr = c->n_runs;
+    const int* diff_p = (const int*)c->diff.p;
+    const int* diff_m = diff_p + ((c->gtot + 3) / 4) * 4;
+    if (c->runs.ensure(sizeof(MirpPeak) * (size_t)std::max<long long>(nr, 1)) || c->keep.ensure(4 * (size_t)std::max<long long>(nr, 1)) ||
+        c->kscan.ensure(8 * (size_t)(nr + 1)) || c->csq.ensure(8 * (size_t)(nc + 2)) || c->cdest.ensure(8 * (size_t)(nc + 2)))
+        return fail(c, -6, "device allocation failed (runs)");
+    mirp::launch_run_walk(st, c->starts.p, nr, diff_p, diff_m, c->gtot, c->cand.cutoff, (const long long*)c->goff.p, nc, c->cand.min_peak_len,
+                          (MirpPeak*)c->runs.p, (int*)c->keep.p);
+    mirp::launch_excl_scan(st, (const int*)c->keep.p, (long long*)c->kscan.p, nr);
+    long long np = 0;
+    if (read_ll(c, (const long long*)c->kscan.p + nr, &np)) return fail(c, -2, "D2H failed");
+    c->n_peaks = np;
+    if (c->peaks_sq.ensure(sizeof(MirpPeak) * (size_t)std::max<long long>(np, 1)) || c->peaks_sorted.ensure(sizeof(MirpPeak) * (size_t)std::max<long long>(np, 1)))
+        return fail(c, -6, "device allocation failed (peaks)");
+    mirp::launch_peak_compact(st, (const MirpPeak*)c->runs.p, (const int*)c->keep.p, (const long long*)c->kscan.p, nr, nc, (const int*)c->order.p,
+                              (long long*)c->csq.p, (long long*)c->cdest.p, (MirpPeak*)c->peaks_sq.p, (MirpPeak*)c->peaks_sorted.p);
+    // ---- regions
+    if (c->head.ensure(4 * (size_t)std::max<long long>(np, 1)) || c->hscan.ensure(8 * (size_t)(np + 1))) return fail(c, -6, "device allocation failed (regions)");
+    const MirpPeak* P = (const MirpPeak*)c->peaks_sorted.p;
+    mirp::launch_region_head(st, P, np, c->cand.max_gap, (int*)c->head.p);
+    mirp::launch_excl_scan(st, (const int*)c->head.p, (long long*)c->hscan.p, np);
+    long long nreg = 0;
+    if (read_ll(c, (const long long*)c->hscan.p + np, &nreg)) return fail(c, -2, "D2H failed");
+    c->n_regions = nreg;
+    const size_t r1 = (size_t)std::max<long long>(nreg, 1);
+    if (c->rfirst.ensure(8 * (r1 + 1)) || c->nent.ensure(4 * r1) || c->isloc.ensure(4 * r1) || c->nslots.ensure(4 * r1) || c->escan.ensure(8 * (r1 + 1)) ||
+        c->lscan.ensure(8 * (r1 + 1)) || c->sscan.ensure(8 * (r1 + 1)))
+        return fail(c, -6, "device allocation failed (regions)");
+    mirp::launch_region_first(st, (const int*)c->head.p, (const long long*)c->hscan.p, np, (long long*)c->rfirst.p);
+    mirp::launch_region_count(st, P, (const long long*)c->rfirst.p, nreg, (const long long*)c->clen.p, c->cand.precursor_len, (int*)c->nent.p,
+                              (int*)c->isloc.p, (int*)c->nslots.p);
+    mirp::launch_excl_scan(st, (const int*)c->nent.p, (long long*)c->escan.p, nreg);
+    mirp::launch_excl_scan(st, (const int*)c->isloc.p, (long long*)c->lscan.p, nreg);
+    mirp::launch_excl_scan(st, (const int*)c->nslots.p, (long long*)c->sscan.p, nreg);
+    long long nw = 0, nl = 0, ns = 0;
+    if (read_ll(c, (const long long*)c->escan.p + nreg, &nw) || read_ll(c, (const long long*)c->lscan.p + nreg, &nl) ||
+        read_ll(c, (const long long*)c->sscan.p + nreg, &ns))
+        return fail(c, -2, "D2H failed");
+    c->n_windows = nw; c->n_loci = nl; c->n_slots = ns;
+    c->seq_stride = ((c->cand.precursor_len + 50 + 2 + 15) / 16) * 16;
+    const size_t w1 = (size_t)std::max<long long>(nw, 1);
+    if (c->windows.ensure(sizeof(MirpWindow) * w1) || c->loci.ensure(sizeof(MirpLocus) * (size_t)std::max<long long>(nl, 1)) ||
+        c->wpeaks.ensure(sizeof(MirpPeak) * (size_t)std::max<long long>(ns, 1)) || c->matures.ensure(sizeof(MirpMature) * 2 * (size_t)std::max<long long>(ns, 1)) ||
+        c->wseqs.ensure(w1 * c->seq_stride + 16) || c->woffs.ensure(8 * (w1 + 1)) || c->wlens.ensure(4 * w1) || c->roles.ensure(4 * w1))
+        return fail(c, -6, "device allocation failed (windows)");
+    mirp::launch_region_emit(st, P, (const long long*)c->rfirst.p, nreg, (const long long*)c->clen.p, c->cand.precursor_len, (const long long*)c->escan.p,
+                             (const long long*)c->lscan.p, (const long long*)c->sscan.p, (MirpWindow*)c->windows.p, (MirpLocus*)c->loci.p,
+                             (MirpPeak*)c->wpeaks.p, (int*)c->roles.p, c->seq_stride);
+    const int wmax = c->cand.precursor_len + 52;
+    mirp::launch_window_payload(st, (MirpWindow*)c->windows.p, nw, P, (const MirpAln*)c->alns.p, c->n_alns, (const unsigned char*)c->genome.p,
+                                (const long long*)c->gboff.p, (const long long*)c->clen.p, c->cand.cutoff * 0.5 /* MP:3404 */, wmax, (char*)c->wseqs.p,
+                                (MirpMature*)c->matures.p);
+    if (nw > 0)
+        hipLaunchKernelGGL(mirp::window_index_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, st,
+                           (const MirpWindow*)c->windows.p, nw, (long long*)c->woffs.p, (int*)c->wlens.p);
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    c->ms[0] = a; c->ms[1] = b;
+    c->have_candidate = true;
+    if (n_peaks_out) *n_peaks_out = np;
+    if (n_loci_out) *n_loci_out = nl;
+    if (n_windows_out) *n_windows_out = nw;
+    return 0;
+}
+
+extern "C" int mirp_get_depth(mirp_ctx* c, MirpDepthPos** depth, int64_t* n_depth) {
+    if (!c) return -1;
+    if (!depth || !n_depth) return fail(c, -1, "mirp_get_depth: null argument");
+    if (!c->have_candidate) return fail(c, -1, "mirp_get_depth: run mirp_candidate first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long na = c->n_above;
+    TmpDevice T;
+    MirpDepthPos* d = (MirpDepthPos*)T.get(sizeof(MirpDepthPos) * (size_t)std::max<long long>(na, 1));
+    long long* gx = (long long*)T.get(8 * (size_t)std::max<long long>(na, 1));
+    if (!d || !gx) return fail(c, -6, "device allocation failed (depth)");
+    int rc = run_coverage(c, d, na, gx);
+    if (rc) return rc;
+    mirp::launch_depth_fix(c->stream, d, gx, na, (const long long*)c->goff.p, c->n_contigs);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    MirpDepthPos* h = host_copy<MirpDepthPos>(c, d, (size_t)na);
+    if (!h) return fail(c, -2, "D2H failed");
+    *depth = h; *n_depth = na;
+    return 0;
+}
+
+extern "C" int mirp_get_peaks(mirp_ctx* c, MirpPeak** peaks, int64_t* n) {
+    if (!c) return -1;
+    if (!peaks || !n) return fail(c, -1, "mirp_get_peaks: null argument");
+    if (!c->have_candidate) return fail(c, -1, "mirp_get_peaks: run mirp_candidate first");
+    HIPCHK(c, hipSetDevice(c->device));
+    MirpPeak* h = host_copy<MirpPeak>(c, c->peaks_sq.p, (size_t)c->n_peaks);
+    if (!h) return fail(c, -2, "D2H failed");
+    *peaks = h; *n = c->n_peaks;
+    return 0;
+}
+
+extern "C" int mirp_get_loci(mirp_ctx* c, MirpLocus** loci, int64_t* n_loci, MirpPeak** peaks_sorted, int64_t* n_peaks) {
+    if (!c) return -1;
+    if (!loci || !n_loci || !peaks_sorted || !n_peaks) return fail(c, -1, "mirp_get_loci: null argument");
+    if (!c->have_candidate) return fail(c, -1, "mirp_get_loci: run mirp_candidate first");
+    HIPCHK(c, hipSetDevice(c->device));
+    MirpLocus* h = host_copy<MirpLocus>(c, c->loci.p, (size_t)c->n_loci);
+    MirpPeak* hp = host_copy<MirpPeak>(c, c->peaks_sorted.p, (size_t)c->n_peaks);
+    if (!h || !hp) { std::free(h); std::free(hp); return fail(c, -2, "D2H failed"); }
+    *loci = h; *n_loci = c->n_loci; *peaks_sorted = hp; *n_peaks = c->n_peaks;
+    return 0;
+}
+
+extern "C" int mirp_get_windows(mirp_ctx* c, MirpWindow** windows, int64_t* n_windows, MirpPeak** wpeaks, int64_t* n_wpeaks, MirpMature** matures,
+                                int64_t* n_matures, char** seqs, int64_t* n_seq_bytes) {
+    if (!c) return -1;
+    if (!windows || !n_windows || !wpeaks || !n_wpeaks || !matures || !n_matures || !seqs || !n_seq_bytes) return fail(c, -1, "mirp_get_windows: null argument");
+    if (!c->have_candidate) return fail(c, -1, "mirp_get_windows: run mirp_candidate first");
+    HIPCHK(c, hipSetDevice(c->device));
+    MirpWindow* hw = host_copy<MirpWindow>(c, c->windows.p, (size_t)c->n_windows);
+    MirpPeak* hp = host_copy<MirpPeak>(c, c->wpeaks.p, (size_t)c->n_slots);
+    MirpMature* hm = host_copy<MirpMature>(c, c->matures.p, 2 * (size_t)c->n_slots);
+    char* hs = host_copy<char>(c, c->wseqs.p, (size_t)c->n_windows * c->seq_stride);
+    if (!hw || !hp || !hm || !hs) { std::free(hw); std::free(hp); std::free(hm); std::free(hs); return fail(c, -2, "D2H failed"); }
+    *windows = hw; *n_windows = c->n_windows; *wpeaks = hp; *n_wpeaks = c->n_slots; *matures = hm; *n_matures = 2 * c->n_slots;
+    *seqs = hs; *n_seq_bytes = c->n_windows * c->seq_stride;
+    return 0;
+}
+
+extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
+    if (!c) return -1;
+    if (!c->have_candidate) return fail(c, -1, "mirp_fold: run mirp_candidate first");
+    if (span < 1 || max_lines < 1) return fail(c, -1, "mirp_fold: bad span/max_lines");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long nw = c->n_windows;
+    const int n_cap = c->seq_stride;   // >= longest window
+    const int stride = ((n_cap + 3 + 7) / 8) * 8;
+    const size_t w1 = (size_t)std::max<long long>(nw, 1);
+    const size_t per_win = (size_t)max_lines * stride;
+    const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);
+    int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
+    if (c->ws.ensure((size_t)slots * slot_ints * 4) || c->lines.ensure(sizeof(MirpFoldLine) * w1 * max_lines) || c->ss.ensure(w1 * per_win) ||
+        c->nlines.ensure(4 * w1) || c->mfe.ensure(4 * w1) || c->status.ensure(4 * w1))
+        return fail(c, -6, "device allocation failed (fold)");
+    if (mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (nw > 0) {
+        int grid = (int)std::min<long long>(nw, slots);
+        mirp::launch_fold_generic(c->stream, grid, c->d_params, (const unsigned char*)c->wseqs.p, (const long long*)c->woffs.p, (const int*)c->wlens.p,
+                                  nullptr, (int)nw, span, n_cap, (int*)c->ws.p, slot_ints, max_lines, stride, (MirpFoldLine*)c->lines.p, (char*)c->ss.p,
+                                  (int*)c->nlines.p, (int*)c->mfe.p, (int*)c->status.p);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    float a = 0;
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    c->ms[2] = a;
+    c->fold_stride = stride; c->fold_max_lines = max_lines; c->fold_span = span;
+    c->have_fold = true;
+    return 0;
+}
+
+extern "C" int mirp_get_fold(mirp_ctx* c, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t* max_lines, int32_t** n_lines, int32_t** mfe,
+                             int32_t** status) {
+    if (!c) return -1;
+    if (!lines || !ss || !ss_stride || !max_lines || !n_lines || !mfe || !status) return fail(c, -1, "mirp_get_fold: null argument");
+    if (!c->have_fold) return fail(c, -1, "mirp_get_fold: run mirp_fold first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nw = (size_t)c->n_windows, ml = (size_t)c->fold_max_lines;
+    MirpFoldLine* hl = host_copy<MirpFoldLine>(c, c->lines.p, nw * ml);
+    char* hs = host_copy<char>(c, c->ss.p, nw * ml * c->fold_stride);
+    int32_t* hn = host_copy<int32_t>(c, c->nlines.p, nw);
+    int32_t* hm = host_copy<int32_t>(c, c->mfe.p, nw);
+    int32_t* ht = host_copy<int32_t>(c, c->status.p, nw);
+    if (!hl || !hs || !hn || !hm || !ht) { std::free(hl); std::free(hs); std::free(hn); std::free(hm); std::free(ht); return fail(c, -2, "D2H failed"); }
+    *lines = hl; *ss = hs; *ss_stride = c->fold_stride; *max_lines = c->fold_max_lines; *n_lines = hn; *mfe = hm; *status = ht;
+    return 0;
+}
+
+extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride,
+                            int32_t** n_passed, int64_t* n_windows) {
+    if (!c) return -1;
+    if (!pp || !result || !n_result || !ss_text || !ss_stride || !n_passed || !n_windows) return fail(c, -1, "mirp_predict: null argument");
+    if (!c->have_fold) return fail(c, -1, "mirp_predict: run mirp_fold first");
+    if (pp->n_samples < 1 || pp->n_samples > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_predict: n_samples out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (mirp::predict_lds_bytes(c->fold_max_lines, c->fold_stride) > 160 * 1024)
+        return fail(c, -5, "mirp_predict: max_lines*ss_stride exceeds the LDS budget of the predict kernel");
+    const long long nw = c->n_windows;
+    const size_t w1 = (size_t)std::max<long long>(nw, 1);
+    if (c->p_out.ensure(sizeof(MirpMirna) * w1 * MIRP_MAX_MIRNA_PER_WINDOW) || c->p_nout.ensure(4 * w1) || c->p_status.ensure(4 * w1) ||
+        c->p_keep.ensure(4 * w1) || c->p_kscan.ensure(8 * (w1 + 1)))
+        return fail(c, -6, "device allocation failed (predict)");
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    long long nres = 0;
+    if (nw > 0) {
+        int grid = (int)std::min<long long>(nw, (long long)c->n_cu * 16);
+        if (mirp::launch_predict(st, grid, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+                                 (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, *pp,
+                                 (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p) != hipSuccess)
+            return fail(c, -2, "predict kernel launch failed");
+        HIPCHK(c, hipEventRecord(c->ev[1], st));
+        hipLaunchKernelGGL(mirp::result_keep_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, st, (const int*)c->roles.p,
+                           (const int*)c->p_nout.p, nw, (int*)c->p_keep.p);
+        mirp::launch_excl_scan(st, (const int*)c->p_keep.p, (long long*)c->p_kscan.p, nw);
+        if (read_ll(c, (const long long*)c->p_kscan.p + nw, &nres)) return fail(c, -2, "D2H failed");
+        if (c->p_res.ensure(sizeof(MirpMirna) * (size_t)std::max<long long>(nres, 1)) || c->p_text.ensure((size_t)std::max<long long>(nres, 1) * c->fold_stride))
+            return fail(c, -6, "device allocation failed (result)");
+        hipLaunchKernelGGL(mirp::result_gather_kernel, dim3((unsigned)std::min<long long>((nw + 3) / 4, 8192)), dim3(256), 0, st, (const int*)c->p_keep.p,
+                           (const long long*)c->p_kscan.p, nw, (const MirpMirna*)c->p_out.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines,
+                           (MirpMirna*)c->p_res.p, (char*)c->p_text.p);
+    } else {
+        HIPCHK(c, hipEventRecord(c->ev[1], st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    float a = 0;
+    (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    c->ms[3] = a;
+    MirpMirna* hr = host_copy<MirpMirna>(c, c->p_res.p, (size_t)nres);
+    char* ht = host_copy<char>(c, c->p_text.p, (size_t)nres * c->fold_stride);
+    int32_t* hn = host_copy<int32_t>(c, c->p_nout.p, (size_t)nw);
+    if (!hr || !ht || !hn) { std::free(hr); std::free(ht); std::free(hn); return fail(c, -2, "D2H failed"); }
+    *result = hr; *n_result = nres; *ss_text = ht; *ss_stride = c->fold_stride; *n_passed = hn; *n_windows = nw;
+    return 0;
+}
+
+extern "C" int mirp_last_timings(mirp_ctx* c, double ms[4]) {
+    if (!c || !ms) return -1;
+    for (int i = 0; i < 4; i++) ms[i] = c->ms[i];
+    return 0;
+}

@@ -1,0 +1,91 @@
+"""GPU parity of the device-resident candidate -> fold -> predict pipeline (through the C-ABI) against
+(i) the golden fixtures generated from the real reference stack and (ii) the CPU oracle on a larger seeded dataset."""
+import numpy as np
+import pytest
+
+from mir_prefer_amd import records, synth
+from tests import golden_util as gu
+from tests.test_oracle_golden import _ref_lines, mirna_record, run_predict
+
+pytestmark = pytest.mark.gpu
+
+
+def _sorted_order(names):
+    return np.argsort(np.array(names, dtype=object), kind="stable").astype(np.int32)
+
+
+def _gpu_record(m, ss, names):
+    return [names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
+            records.STRAND[m["strand"]], bool(m["has_star"])]
+
+
+@pytest.mark.parametrize("name", ["mini", "mini3"])
+def test_pipeline_matches_reference_fixture(name, gpu_ctx):
+    c = gu.load_pipeline_case(name)
+    cfg, exp, names = c["exp"]["config"], c["exp"], c["contig_names"]
+    gpu_ctx.load_genome(c["contigs"])
+    gpu_ctx.load_alignments(c["alns"])
+    npk, nloci, nwin = gpu_ctx.candidate(cfg["READS_DEPTH_CUTOFF"], cfg["MAX_GAP"], cfg["PRECURSOR_LEN"], _sorted_order(names))
+    # a1-a2: depth file and peaks
+    assert records.depth_text(gpu_ctx.get_depth(), names) == exp["depth_cut"]
+    assert records.peaks_to_dict(gpu_ctx.get_peaks(), names) == gu.unjson(exp["dict_contigs"])
+    # a3: loci + windows
+    loci, psorted = gpu_ctx.get_loci()
+    want = {k: v for k, v in gu.unjson(exp["dict_loci"]).items() if v}
+    assert records.loci_to_dict(loci, psorted, names, cfg["PRECURSOR_LEN"]) == want
+    # a4-a6: FASTA entries (headers incl. matures, sequences)
+    w = gpu_ctx.get_windows()
+    entries = [e for p in exp["pieces"] for e in p["fasta"]]
+    assert len(w["windows"]) == len(entries) == nwin
+    for win, (hdr, seq) in zip(w["windows"], entries):
+        assert records.fasta_header(win, w["wpeaks"], w["matures"], names) == hdr
+        assert w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes().decode() == seq
+    # a7: fold output of every window == RNALfold 2.1.2 text
+    gpu_ctx.fold(cfg["PRECURSOR_LEN"])
+    raw = gpu_ctx.get_fold()
+    assert (raw["status"] == 0).all()
+    ref = [e for p in exp["pieces"] for e in _ref_lines(p["rnalfold_out"])]
+    for k, want_lines in enumerate(ref):
+        got = [(raw["ss"][k, j, :raw["lines"][k, j]["len"]].tobytes().decode(), int(raw["lines"][k, j]["energy"]), int(raw["lines"][k, j]["start"]))
+               for j in range(raw["n_lines"][k]) if raw["lines"][k, j]["printed"]]
+        assert got == want_lines, k
+    # a8-a11: final result list
+    out = gpu_ctx.predict(len(c["sample_names"]), cfg["MIN_MATURE_LEN"], cfg["MAX_MATURE_LEN"], cfg["ALLOW_3NT_OVERHANG"] == "Y",
+                          cfg["ALLOW_NO_STAR_EXPRESSION"] == "Y")
+    got = [_gpu_record(m, ss, names) for m, ss in zip(out["result"], out["ss"])]
+    assert got == [e[:10] for e in gu.unjson(exp["result_raw"])]
+
+
+def test_pipeline_matches_oracle_on_larger_dataset(gpu_ctx, oracle):
+    ds = synth.make_dataset([400000, 250000, 350000], 500, n_samples=3, seed=21, contig_names=["c9", "c10", "c1"], edge_cases=True)
+    names, alns = ds.contig_names, ds.sorted_alns()
+    cut, gap, L = 10, 100, 300
+    order = _sorted_order(names)
+    depth, peaks = oracle.coverage_peaks(alns, ds.contig_lens, cut)
+    win = oracle.make_windows(peaks, alns, ds.contigs, order, gap, L, cut * 0.5)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    npk, nloci, nwin = gpu_ctx.candidate(cut, gap, L, order)
+    assert np.array_equal(gpu_ctx.get_depth(), depth)
+    assert np.array_equal(gpu_ctx.get_peaks(), peaks)
+    w = gpu_ctx.get_windows()
+    assert nwin == len(win["windows"]) and nwin > 400
+    for a, b in zip(w["windows"], win["windows"]):
+        for f in ("tid", "ws", "we", "strand", "loc_s", "loc_e", "tag", "n_peaks", "n_matures", "seq_len"):
+            assert a[f] == b[f]
+        assert np.array_equal(w["wpeaks"][a["peak_off"]:a["peak_off"] + a["n_peaks"]], win["wpeaks"][b["peak_off"]:b["peak_off"] + b["n_peaks"]])
+        assert np.array_equal(w["matures"][a["mature_off"]:a["mature_off"] + a["n_matures"]], win["matures"][b["mature_off"]:b["mature_off"] + b["n_matures"]])
+        assert np.array_equal(w["seq"][a["seq_off"]:a["seq_off"] + a["seq_len"]], win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]])
+    gpu_ctx.fold(L)
+    out = gpu_ctx.predict(3, 18, 23, False, True)
+    # oracle end-to-end
+    structs = []
+    for b in win["windows"]:
+        r = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+        structs.append(oracle.structures_from_lines(r["lines"], 55))
+    case = {"cfg": {"MIN_MATURE_LEN": 18, "MAX_MATURE_LEN": 23, "ALLOW_3NT_OVERHANG": "N", "ALLOW_NO_STAR_EXPRESSION": "Y"}, "win": win,
+            "sample_names": ds.sample_names, "alns": alns}
+    _, result = run_predict(case, oracle, structs)
+    want = [mirna_record(m, names) for _, m in result]
+    got = [_gpu_record(m, ss, names) for m, ss in zip(out["result"], out["ss"])]
+    assert got == want and len(got) > 50
