@@ -8,8 +8,7 @@
 // It supports any window length up to MIRP_NMAX and any span, and is the fallback for
 // windows the LDS-resident fast kernel (fold_lds_kernel.hip) flags as out of its range.
 #include <hip/hip_runtime.h>
-#include "fold_device.h"
-#include "mirp_internal.h"
+#include "fold_epilogue.h"
 
 namespace mirp {
 
@@ -24,319 +23,6 @@ struct GTab {
     __device__ __forceinline__ int C(int d, int i) const { return c[(size_t)d * ld + i]; }
     __device__ __forceinline__ int M(int d, int i) const { return m[(size_t)d * ld + i]; }
 };
-
-struct WinCtx {
-    const FoldParams* __restrict__ P;
-    const unsigned char* S;   // LDS, 0..n+1
-    const unsigned char* seq; // LDS, upper-case RNA chars, 1-based
-    const int* f3;            // LDS, 0..n+2
-    const short* spec;        // LDS, special hairpin energy per i for u==3,4,6 at [k*ldspec + i], SHRT_MIN = none
-    int ldspec;
-    int n, D;                 // D = max pair distance (min(span-1, n-1))
-};
-
-__device__ __forceinline__ int ptype_at(const WinCtx& X, int i, int j) {
-    int d = j - i;
-    if (d <= TURN || d > X.D) return 0;
-    return pair_type(X.S[i], X.S[j]);
-}
-
-__device__ __forceinline__ int e_hairpin(const WinCtx& X, int i, int j, int type) {
-    int u = j - i - 1;
-    if (u == 4) { int s = X.spec[X.ldspec + i]; if (s != -32768) return s; }
-    else if (u == 6) { int s = X.spec[2 * X.ldspec + i]; if (s != -32768) return s; }
-    else if (u == 3) {
-        int s = X.spec[i];
-        if (s != -32768) return s;
-        return X.P->hairpinE[3] + (type > 2 ? X.P->TerminalAU : 0);
-    }
-    return X.P->hairpinE[u] + X.P->mismatchH[type][X.S[i + 1]][X.S[j - 1]];
-}
-
-__device__ __forceinline__ int ext_term(const WinCtx& X, int i, int k, int type) {
-    return e_extloop(X.P, type, i > 1 ? (int)X.S[i - 1] : -1, k < X.n ? (int)X.S[k + 1] : -1);
-}
-__device__ __forceinline__ int ml_term(const WinCtx& X, int i, int j, int type) {
-    return e_mlstem(X.P, type, i > 1 ? (int)X.S[i - 1] : -1, j < X.n ? (int)X.S[j + 1] : -1);
-}
-
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
-}
-
-// first set lane of a 64-bit ballot, or -1
-__device__ __forceinline__ int first_lane(unsigned long long mask) { return mask ? (__ffsll((long long)mask) - 1) : -1; }
-
-#define BT_STACK 96
-
-// Wave-cooperative backtrack of one locally optimal structure (all 64 lanes call it with
-// wave-uniform arguments).  buf: per-wave LDS char buffer; stk: per-wave LDS sector stack.
-// Returns string length (>0) or a negative error code.  First-match-wins search orders follow
-// SURVEY.md App. B "Backtrack" + B2 (exterior partner scan descending).
-template <class Tab>
-__device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend, int span, char* buf, int* stk) {
-    const int lane = threadIdx.x & 63;
-    const int n = X.n;
-    int len0 = (n - start < span + 1 ? n - start : span + 1) + 2;
-    for (int x = lane; x < len0; x += 64) buf[x] = '-';
-    int sp = 0;
-    if (lane == 0) { stk[0] = start; stk[1] = jend; stk[2] = 0; }
-    sp = 1;
-    __builtin_amdgcn_wave_barrier();
-    while (sp > 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        sp--;
-        int i = stk[3 * sp], j = stk[3 * sp + 1], ml = stk[3 * sp + 2];
-        i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); ml = __builtin_amdgcn_readfirstlane(ml);
-        if (j < i + TURN + 1) continue;
-        if (sp + 3 >= BT_STACK) return -20;
-        if (ml == 0) {
-            int fij = X.f3[i];
-            if (fij == X.f3[i + 1]) {
-                if (lane == 0) { stk[3 * sp] = i + 1; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 0; }
-                sp++;
-                continue;
-            }
-            int found = -1;
-            for (int kb = j; kb >= i + TURN + 1 && found < 0; kb -= 64) {
-                int k = kb - lane;
-                bool ok = false;
-                if (k >= i + TURN + 1) {
-                    int type = ptype_at(X, i, k);
-                    if (type) ok = (fij == T.C(k - i, i) + ext_term(X, i, k, type) + X.f3[k + 1]);
-                }
-                int fl = first_lane(__ballot(ok));
-                if (fl >= 0) found = kb - fl;
-            }
-            if (found < 0) return -21;
-            int k = found;
-            if (j == n) {
-                if (lane == 0) { stk[3 * sp] = k + 1; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 0; }
-                sp++;
-            }
-            j = k;
-            if (lane == 0) {
-                buf[i - start] = '(';
-                buf[j - start] = ')';
-                if (j < n) buf[j + 1 - start] = '.';
-            }
-        } else {
-            int d = j - i;
-            int fij = T.M(d, i);
-            if (T.M(d - 1, i) == fij) {
-                if (lane == 0) { stk[3 * sp] = i; stk[3 * sp + 1] = j - 1; stk[3 * sp + 2] = 1; }
-                sp++;
-                continue;
-            }
-            if (T.M(d - 1, i + 1) == fij) {
-                if (lane == 0) { stk[3 * sp] = i + 1; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 1; }
-                sp++;
-                continue;
-            }
-            int type = ptype_at(X, i, j);
-            bool ok = false;
-            if (type) ok = (T.C(d, i) + ml_term(X, i, j, type) == fij);
-            if (!ok) {
-                int found = -1;
-                for (int kb = i + 1 + TURN; kb <= j - 2 - TURN && found < 0; kb += 64) {
-                    int k = kb + lane;
-                    bool hit = false;
-                    if (k <= j - 2 - TURN) hit = (fij == T.M(k - i, i) + T.M(j - k - 1, k + 1));
-                    int fl = first_lane(__ballot(hit));
-                    if (fl >= 0) found = kb + fl;
-                }
-                if (found < 0) return -22;
-                if (lane == 0) {
-                    stk[3 * sp] = i; stk[3 * sp + 1] = found; stk[3 * sp + 2] = 1;
-                    stk[3 * sp + 3] = found + 1; stk[3 * sp + 4] = j; stk[3 * sp + 5] = 1;
-                }
-                sp += 2;
-                continue;
-            }
-            if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
-        }
-        // (i,j) is a traced pair: follow stacks / interior loops until a hairpin or a multiloop
-        for (;;) {
-            int type = ptype_at(X, i, j);
-            int cij = T.C(j - i, i);
-            if (cij == e_hairpin(X, i, j, type)) break;
-            int pmax = (j - 2 - TURN < i + MAXLOOP + 1) ? j - 2 - TURN : i + MAXLOOP + 1;
-            int fp = -1, fq = -1;
-            for (int pb = i + 1; pb <= pmax && fp < 0; pb += 2) {
-                int p = pb + (lane >> 5), q = j - 1 - (lane & 31);
-                int minq = j - i + p - MAXLOOP - 2;
-                if (minq < p + 1 + TURN) minq = p + 1 + TURN;
-                bool hit = false;
-                if (p <= pmax && q >= minq) {
-                    int t2 = pair_type(X.S[p], X.S[q]);
-                    if (t2) {
-                        t2 = rtype_of(t2);
-                        int e = e_intloop(X.P, p - i - 1, j - q - 1, type, t2, X.S[i + 1], X.S[j - 1], X.S[p - 1], X.S[q + 1]);
-                        hit = (cij == e + T.C(q - p, p));
-                    }
-                }
-                int fl = first_lane(__ballot(hit));
-                if (fl >= 0) { fp = pb + (fl >> 5); fq = j - 1 - (fl & 31); }
-            }
-            if (fp >= 0) {
-                i = fp; j = fq;
-                if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
-                continue;
-            }
-            int mm = X.P->ML_closing + e_mlstem(X.P, rtype_of(type), X.S[j - 1], X.S[i + 1]);
-            int found = -1;
-            for (int kb = i + 2 + TURN; kb <= j - 3 - TURN && found < 0; kb += 64) {
-                int k = kb + lane;
-                bool hit = false;
-                if (k <= j - 3 - TURN) hit = (cij == T.M(k - i - 1, i + 1) + T.M(j - k - 2, k + 1) + mm);
-                int fl = first_lane(__ballot(hit));
-                if (fl >= 0) found = kb + fl;
-            }
-            if (found < 0) return -23;
-            if (lane == 0) {
-                stk[3 * sp] = i + 1; stk[3 * sp + 1] = found; stk[3 * sp + 2] = 1;
-                stk[3 * sp + 3] = found + 1; stk[3 * sp + 4] = j - 1; stk[3 * sp + 5] = 1;
-            }
-            sp += 2;
-            break;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    int last = 0;
-    for (int x = lane; x < len0; x += 64)
-        if (buf[x] != '-') last = x;
-    {
-        int v = last;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
-        last = v;
-    }
-    int L = last + 1;
-    for (int x = lane; x < L; x += 64)
-        if (buf[x] == '-') buf[x] = '.';
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    return L;
-}
-
-// Shared epilogue: f3 sweep, enumeration of structure starts, parallel backtracks, RNALfold's
-// "print prev unless contained in new" rule, output records.  Called by every thread of the
-// workgroup after the tables are complete (and visible).
-template <class Tab, int NT>
-__device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /*LDS, writable*/, int* starts /*LDS [max_lines]*/,
-                              int* lens /*LDS [max_lines]*/, char* btbuf /*LDS NT/64 * bufstride*/, int bufstride,
-                              int* btstk /*LDS NT/64 * 3*BT_STACK*/, int* sh_misc /*LDS >= 4 ints*/,
-                              int win, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
-                              char* __restrict__ out_ss, int* __restrict__ out_nlines, int* __restrict__ out_mfe,
-                              int* __restrict__ out_status) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = X.n, D = X.D;
-    // ---- f3 (exterior) sweep: sequential in i, lane-parallel over the partner j (wave 0)
-    for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
-    __syncthreads();
-    if (wave == 0) {
-        for (int i = n - TURN - 1; i >= 1; i--) {
-            int best = f3[i + 1];
-            int jmax = (i + D < n) ? i + D : n;
-            for (int j = i + TURN + 1 + lane; j <= jmax; j += 64) {
-                int type = pair_type(X.S[i], X.S[j]);
-                if (type) {
-                    int e = f3[j + 1] + T.C(j - i, i) + ext_term(X, i, j, type);
-                    best = e < best ? e : best;
-                }
-            }
-            best = wave_min(best);
-            if (lane == 0) f3[i] = best;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ---- structure starts, descending: l>=2 with f3[l]!=f3[l+1] && f3[l-1]==f3[l]; l==1 with f3[1]!=f3[2]
-        int cnt = 0;
-        for (int base = n - TURN - 1; base >= 1; base -= 64) {
-            int l = base - lane;
-            bool is = false;
-            if (l >= 1) is = (f3[l] != f3[l + 1]) && (l == 1 || f3[l - 1] == f3[l]);
-            unsigned long long mask = __ballot(is);
-            int rank = __popcll(mask & ((1ull << lane) - 1ull));
-            if (is && cnt + rank < max_lines) starts[cnt + rank] = l;
-            cnt += __popcll(mask);
-        }
-        if (lane == 0) { sh_misc[0] = cnt < max_lines ? cnt : max_lines; sh_misc[1] = cnt > max_lines ? 1 : 0; sh_misc[2] = 0; }
-    }
-    __syncthreads();
-    const int nst = sh_misc[0];
-    // ---- backtracks: one wave per start
-    char* mybuf = btbuf + wave * bufstride;
-    int* mystk = btstk + wave * 3 * BT_STACK;
-    for (int k = wave; k < nst; k += NT / 64) {
-        int lind = starts[k];
-        int fij = f3[lind];
-        // "short backtrack": first partner (ascending) that realises f3[lind]
-        int pp = -1;
-        for (int pb = lind + TURN; pb <= lind + span && pp < 0; pb += 64) {
-            int q = pb + lane;
-            bool hit = false;
-            if (q <= lind + span && q <= n) {
-                int type = ptype_at(X, lind, q);
-                if (type) hit = (fij == T.C(q - lind, lind) + ext_term(X, lind, q, type) + f3[q + 1]);
-            }
-            int fl = first_lane(__ballot(hit));
-            if (fl >= 0) pp = pb + fl;
-        }
-        int L = -10;
-        if (pp >= 0) L = backtrack_wave(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
-        if (L < 0) {
-            if (lane == 0) { sh_misc[2] = L; lens[k] = 0; }
-            continue;
-        }
-        // write printed text: leading '.' for starts >= 2 (5' dangle base), none for the start-1 structure
-        int lead = lind >= 2 ? 1 : 0;
-        char* dst = out_ss + ((size_t)win * max_lines + k) * ss_stride;
-        if (L + lead + 1 > ss_stride) { if (lane == 0) { sh_misc[2] = -30; lens[k] = 0; } continue; }
-        if (lane == 0 && lead) dst[0] = '.';
-        for (int x = lane; x < L; x += 64) dst[x + lead] = mybuf[x];
-        if (lane == 0) {
-            dst[L + lead] = 0;
-            lens[k] = L;
-            MirpFoldLine ln;
-            ln.start = lead ? lind - 1 : 1;
-            ln.len = L + lead;
-            ln.energy = lead ? (f3[lind] - f3[lind + L - 1]) : (f3[1] - f3[L]);
-            ln.printed = 1;
-            out_lines[(size_t)win * max_lines + k] = ln;
-        }
-    }
-    __syncthreads();
-    // ---- RNALfold prints `prev` unless it is contained in `new` (the next start); the start-1
-    // structure never takes part as `new`, and the last start>=2 structure is always printed.
-    for (int k = wave; k + 1 < nst; k += NT / 64) {
-        int prev_i = starts[k], new_i = starts[k + 1];
-        if (new_i < 2) continue;
-        int lp = lens[k], Ln = lens[k + 1];
-        if (lp <= 0 || Ln <= 0) continue;
-        int i = new_i - 1;
-        int off = prev_i - i;
-        const char* prev = out_ss + ((size_t)win * max_lines + k) * ss_stride + 1;
-        const char* nw = out_ss + ((size_t)win * max_lines + k + 1) * ss_stride + 1;
-        bool differ = false;
-        for (int t = lane; t < lp; t += 64) {
-            char a = (off + t < Ln) ? nw[off + t] : (char)0;
-            if (a != prev[t]) differ = true;
-        }
-        bool anyd = __ballot(differ) != 0ull;
-        bool print = (i + Ln < prev_i + lp) || anyd;
-        if (lane == 0 && !print) out_lines[(size_t)win * max_lines + k].printed = 0;
-    }
-    if (tid == 0) {
-        out_nlines[win] = nst;
-        out_mfe[win] = f3[1];
-        out_status[win] = sh_misc[2] ? sh_misc[2] : (sh_misc[1] ? 1 : 0);
-    }
-    __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------
 // Generic kernel: tables in global workspace.

@@ -48,7 +48,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
-    c->nlines.release(); c->mfe.release(); c->status.release();
+    c->nlines.release(); c->mfe.release(); c->status.release(); c->carch.release(); c->fctl.release(); c->flist.release();
     for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,
                       &c->keep, &c->kscan, &c->csq, &c->cdest, &c->peaks_sq, &c->peaks_sorted, &c->head, &c->hscan, &c->rfirst, &c->nent,
                       &c->isloc, &c->nslots, &c->escan, &c->lscan, &c->sscan, &c->windows, &c->roles, &c->loci, &c->wpeaks, &c->matures,
@@ -103,21 +103,15 @@ extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* off
         // batches bound the structure-text buffer
         const size_t per_win = (size_t)max_lines * stride;
         int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_seqs, ((size_t)1 << 30) / per_win));
-        const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_max, span);
-        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
-        if (c->ws.ensure((size_t)slots * slot_ints * 4) || c->lines.ensure(sizeof(MirpFoldLine) * (size_t)batch * max_lines) ||
-            c->ss.ensure((size_t)batch * per_win) || c->nlines.ensure(4 * (size_t)n_seqs) || c->mfe.ensure(4 * (size_t)n_seqs) ||
-            c->status.ensure(4 * (size_t)n_seqs))
-            return bail(-6, "device allocation failed (workspace/outputs)");
-        if (mirp::fold_generic_lds_bytes(n_max, max_lines) > 64 * 1024) return bail(-5, "LDS budget exceeded (max_lines too large)");
+        if (c->lines.ensure(sizeof(MirpFoldLine) * (size_t)batch * max_lines) || c->ss.ensure((size_t)batch * per_win) ||
+            c->nlines.ensure(4 * (size_t)n_seqs) || c->mfe.ensure(4 * (size_t)n_seqs) || c->status.ensure(4 * (size_t)n_seqs))
+            return bail(-6, "device allocation failed (outputs)");
         for (int b0 = 0; b0 < n_seqs; b0 += batch) {
             const int nb = std::min(batch, n_seqs - b0);
-            const int grid = std::min(nb, slots);
             // windows of this batch are addressed relative to b0: shift the pointers
-            mirp::launch_fold_generic(c->stream, grid, c->d_params, (const unsigned char*)c->seqs.p, (const long long*)c->offs.p + b0,
-                                      nullptr, nullptr, nb, span, n_max, (int*)c->ws.p, slot_ints, max_lines, stride, (MirpFoldLine*)c->lines.p,
-                                      (char*)c->ss.p, (int*)c->nlines.p + b0, (int*)c->mfe.p + b0, (int*)c->status.p + b0);
-            if (hipGetLastError() != hipSuccess) return bail(-2, "fold kernel launch failed");
+            int rc = mirp_run_fold(c, (const unsigned char*)c->seqs.p, (const long long*)c->offs.p + b0, nullptr, nb, n_max, span, max_lines, stride,
+                                   (MirpFoldLine*)c->lines.p, (char*)c->ss.p, (int*)c->nlines.p + b0, (int*)c->mfe.p + b0, (int*)c->status.p + b0);
+            if (rc) return bail(rc, c->err);
             if (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->lines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
                                hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipMemcpyAsync(h_ss + (size_t)b0 * per_win, c->ss.p, (size_t)nb * per_win, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
@@ -185,5 +179,39 @@ extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_
             return bail(-2, "predict kernel execution failed");
     }
     *mirnas = h_o; *n_mirnas = h_no; *status = h_st;
+    return 0;
+}
+
+int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,
+                  int max_lines, int stride, MirpFoldLine* d_lines, char* d_ss, int* d_nlines, int* d_mfe, int* d_status) {
+    if (n_work <= 0) return 0;
+    if (mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
+    const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);
+    const int* work_list = nullptr;
+    int n_generic = n_work;
+    c->last_fallback = 0;
+    if (span <= mirp::fold_lds_max_span() && mirp::fold_lds_bytes(max_lines) <= 160 * 1024) {
+        const int grid = std::min(n_work, c->n_cu);
+        if (c->carch.ensure(2 * mirp::fold_lds_carch_shorts_per_wg() * (size_t)c->n_cu) || c->fctl.ensure(64) || c->flist.ensure(4 * (size_t)n_work))
+            return fail(c, -6, "device allocation failed (fold LDS kernel)");
+        HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 64, c->stream));
+        unsigned int* ctl = (unsigned int*)c->fctl.p;
+        hipError_t e = mirp::launch_fold_lds(c->stream, grid, c->d_params, d_seqs, d_offs, d_lens, n_work, span, (short*)c->carch.p, ctl, (int*)c->flist.p,
+                                             ctl + 4, max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
+        if (e != hipSuccess) return fail(c, -2, std::string("fold LDS kernel launch failed: ") + hipGetErrorString(e));
+        unsigned int nfb = 0;
+        HIPCHK(c, hipMemcpyAsync(&nfb, ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->last_fallback = nfb;
+        if (nfb == 0) return 0;
+        work_list = (const int*)c->flist.p;
+        n_generic = (int)nfb;
+    }
+    int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
+    slots = std::min(slots, n_generic);
+    if (c->ws.ensure((size_t)slots * slot_ints * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
+    mirp::launch_fold_generic(c->stream, slots, c->d_params, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot_ints,
+                              max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
+    HIPCHK(c, hipGetLastError());
     return 0;
 }

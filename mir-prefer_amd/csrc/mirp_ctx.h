@@ -39,7 +39,8 @@ struct mirp_ctx {
     std::string err;
     int n_cu = 256;
     FoldParams* d_params = nullptr;
-    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status;
+    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist;
+    long long last_fallback = 0;
     // ---- device-resident pipeline state (mirp_pipeline.cpp)
     int n_contigs = 0;
     long long gtot = 0, gbytes = 0, n_alns = 0;
@@ -66,3 +67,8 @@ static inline int fail(mirp_ctx* c, int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail((c), -2, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+
+// Folds n_work device-resident windows (seqs/offs/lens as the kernels expect) into the context's fold output buffers.
+// Uses the LDS-resident kernel when span allows and re-runs flagged windows (length / int16 range) with the generic kernel.
+int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,
+                  int max_lines, int stride, MirpFoldLine* d_lines, char* d_ss, int* d_nlines, int* d_mfe, int* d_status);

@@ -19,6 +19,15 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status);
 
+// fold_lds_kernel.hip
+size_t fold_lds_bytes(int max_lines);
+size_t fold_lds_carch_shorts_per_wg();
+int fold_lds_max_n();
+int fold_lds_max_span();
+hipError_t launch_fold_lds(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
+                           int n_work, int span, short* carch, unsigned int* work_counter, int* fallback_list, unsigned int* fallback_count,
+                           int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status);
+
 // candidate_kernels.hip
 void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m);
 long long cov_scan_tiles(long long gtot);

@@ -276,18 +276,14 @@ extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
     const int stride = ((n_cap + 3 + 7) / 8) * 8;
     const size_t w1 = (size_t)std::max<long long>(nw, 1);
     const size_t per_win = (size_t)max_lines * stride;
-    const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);
-    int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
-    if (c->ws.ensure((size_t)slots * slot_ints * 4) || c->lines.ensure(sizeof(MirpFoldLine) * w1 * max_lines) || c->ss.ensure(w1 * per_win) ||
-        c->nlines.ensure(4 * w1) || c->mfe.ensure(4 * w1) || c->status.ensure(4 * w1))
+    if (c->lines.ensure(sizeof(MirpFoldLine) * w1 * max_lines) || c->ss.ensure(w1 * per_win) || c->nlines.ensure(4 * w1) || c->mfe.ensure(4 * w1) ||
+        c->status.ensure(4 * w1))
         return fail(c, -6, "device allocation failed (fold)");
-    if (mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (nw > 0) {
-        int grid = (int)std::min<long long>(nw, slots);
-        mirp::launch_fold_generic(c->stream, grid, c->d_params, (const unsigned char*)c->wseqs.p, (const long long*)c->woffs.p, (const int*)c->wlens.p,
-                                  nullptr, (int)nw, span, n_cap, (int*)c->ws.p, slot_ints, max_lines, stride, (MirpFoldLine*)c->lines.p, (char*)c->ss.p,
-                                  (int*)c->nlines.p, (int*)c->mfe.p, (int*)c->status.p);
+    {
+        int rc = mirp_run_fold(c, (const unsigned char*)c->wseqs.p, (const long long*)c->woffs.p, (const int*)c->wlens.p, (int)nw, n_cap, span, max_lines,
+                               stride, (MirpFoldLine*)c->lines.p, (char*)c->ss.p, (int*)c->nlines.p, (int*)c->mfe.p, (int*)c->status.p);
+        if (rc) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
