@@ -33,8 +33,12 @@ struct LdsTables {          // int16 copies of the hot parameter tables
     short internal_loop[32];
     short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200];
     short hairpinE[LCAP];
+    unsigned int gcombo[376];           // generic interior loops (n1,n2 >= 2, n1+n2 >= 6): n1 | n2 << 5 | (il[u] + ninio term) << 10
+    unsigned short ocombo[120];         // the other classes: n1 | n2 << 5 | class << 10
+    short n_gcombo, n_ocombo;
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
 };
+#define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
 
 struct LTab {               // table accessors for the shared epilogue/backtrack
     const short* fml;       // LDS
@@ -95,7 +99,7 @@ __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     for (int d = 4; d <= LDMAX; d++) tri += (size_t)(LCAP - d);
     L.fml = take(tri * 2);
     // fill-phase scratch (c ring 32 diagonals, DML ring 3, accumulators), re-used by the epilogue for backtrack buffers/stacks
-    size_t fill_aux = (size_t)32 * LCAP * 2 + (size_t)3 * LCAP * 4 + (size_t)2 * LCAP * 4;
+    size_t fill_aux = (size_t)32 * CSTR * 2 + (size_t)3 * LCAP * 4 + (size_t)2 * LCAP * 4;
     size_t bt_aux = (size_t)LNW * (LCAP + 8) + (size_t)LNW * 3 * BT_STACK * 4;
     L.aux = take(fill_aux > bt_aux ? fill_aux : bt_aux);
     L.f3 = take((LCAP + 8) * 4);
@@ -119,12 +123,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int span, short* __restrict__ carch_all, unsigned int* __restrict__ work_counter, int* __restrict__ fallback_list,
     unsigned int* __restrict__ fallback_count, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
-    int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status) {
+    int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags, long long* __restrict__ dbg_cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsLayout LY = lds_layout(max_lines);
+    long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     short* fml = (short*)(smem + LY.fml);
-    short* cring = (short*)(smem + LY.aux);                         // [32][LCAP]
-    int* dmlring = (int*)(cring + 32 * LCAP);                       // [3][LCAP]
+    short* cring = (short*)(smem + LY.aux);                         // [32][CSTR]
+    int* dmlring = (int*)(cring + 32 * CSTR);                       // [3][LCAP]
     int* cpart = dmlring + 3 * LCAP;                                // [LCAP]
     int* mdec = cpart + LCAP;                                       // [LCAP]
     char* btbuf = (char*)(smem + LY.aux);                           // epilogue alias
@@ -156,6 +161,23 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         T.mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], (int)I16_INF);
     }
     for (int x = tid; x < LCAP; x += LNT) T.hairpinE[x] = (short)min(P->hairpinE[x], (int)I16_INF);
+    if (tid == 0) {
+        // combination tables of the interior-loop search window (n1 + n2 <= MAXLOOP)
+        int g = 0, o = 0;
+        for (int u = 6; u <= MAXLOOP; u++)
+            for (int n1 = 2; n1 <= u - 2; n1++) {
+                int n2 = u - n1, y = (n1 > n2 ? n1 - n2 : n2 - n1) * P->ninio;
+                T.gcombo[g++] = (unsigned)n1 | ((unsigned)n2 << 5) | ((unsigned)(P->internal_loop[u] + (y < P->MAX_NINIO ? y : P->MAX_NINIO)) << 10);
+            }
+        T.ocombo[o++] = 0;                                                                    // class 0: stack
+        for (int k = 1; k <= MAXLOOP; k++) T.ocombo[o++] = (unsigned short)(0 | (k << 5) | (1 << 10));   // class 1: bulge, n1 = 0
+        for (int k = 1; k <= MAXLOOP; k++) T.ocombo[o++] = (unsigned short)(k | (0 << 5) | (1 << 10));   //          bulge, n2 = 0
+        for (int k = 3; k <= MAXLOOP - 1; k++) T.ocombo[o++] = (unsigned short)(1 | (k << 5) | (2 << 10)); // class 2: 1 x n
+        for (int k = 3; k <= MAXLOOP - 1; k++) T.ocombo[o++] = (unsigned short)(k | (1 << 5) | (2 << 10)); //          n x 1
+        T.ocombo[o++] = (unsigned short)(2 | (3 << 5) | (3 << 10));                           // class 3: 2 x 3
+        T.ocombo[o++] = (unsigned short)(3 | (2 << 5) | (3 << 10));                           //          3 x 2
+        T.n_gcombo = (short)g; T.n_ocombo = (short)o;
+    }
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
     __syncthreads();
 
@@ -167,6 +189,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (win >= n_work) break;
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
+        if (dbg_cycles && tid == 0) t0 = clock64();
         if (n < 1 || n > LCAP - 2) {   // wave-uniform: empty window, or too long for this kernel (-> generic kernel)
             if (tid == 0) {
                 out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0;
@@ -224,42 +247,106 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         WinCtx X;
         X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D;
 
+        if (dbg_cycles && tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; }
         // ---- anti-diagonal wavefront
         for (int d = 4; d <= D; d++) {
             const int ncell = n - d;
             const int cur = d & 1;
             const unsigned short* clist = list + cur * LCAP;
             const int ncp = misc[2 + cur];
-            // phase A1: interior loops (incl. stacks and bulges) of paired cells; items = (cell, p)
-            for (int it = tid; it < ncp * 32; it += LNT) {
-                const int i = clist[it >> 5], j = i + d;
-                const int p = i + 1 + (it & 31);
-                int pmax = j - 2 - TURN; if (pmax > i + MAXLOOP + 1) pmax = i + MAXLOOP + 1;
-                if (p > pmax) continue;
-                int qlo = p + d - MAXLOOP - 2; if (qlo < p + 1 + TURN) qlo = p + 1 + TURN;
-                const int width = j - qlo;              // q in [qlo, j-1]
-                if (width <= 0) continue;
-                const int Sp = S[p];
-                const unsigned int* pm = pmask + Sp * 12;
-                unsigned int w0 = pm[qlo >> 5], w1 = pm[(qlo >> 5) + 1];
-                int sh = qlo & 31;
-                unsigned int bits = sh ? ((w0 >> sh) | (w1 << (32 - sh))) : w0;
-                bits &= (width >= 32) ? 0xffffffffu : ((1u << width) - 1u);
-                if (!bits) continue;
+            // The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]]: the inner-pair part of a generic interior loop
+            // is folded in when the cell is finalised, so a generic candidate costs one LDS read.  Plain c = G0 - mismatchI[code].
+            // phase A0: the four small interior loops of each paired cell (1x1, 1x2, 2x1, 2x2) read the big int11/int21/int22
+            // tables from global memory; their loads are issued here and consumed after A1/A2 so the latency is covered.
+            int sp_e[4] = {INF, INF, INF, INF};
+            int sp_i = 0;
+            if (tid < ncp && !(dbg_flags & 1)) {
+                const int i = clist[tid], j = i + d;
+                sp_i = i;
                 const int type = pair_type(S[i], S[j]);
-                const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1], n1 = p - i - 1;
-                const short* crow = cring + p;
-                int best = INF;
-                while (bits) {
-                    int b = __ffs(bits) - 1;
-                    bits &= bits - 1;
-                    int q = qlo + b;
-                    int t2 = rtype_of(pair_type(Sp, S[q]));
-                    int e = lds_intloop(T, P, n1, j - q - 1, type, t2, si1, sj1, sp1, S[q + 1]) + (int)crow[((q - p) & 31) * LCAP];
-                    best = e < best ? e : best;
+                const int si1 = S[i + 1], sj1 = S[j - 1];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    const int a = 1 + (c4 >> 1), b = 1 + (c4 & 1);       // n1 = a, n2 = b
+                    const int p = i + 1 + a, q = j - 1 - b;
+                    if (q - p >= TURN + 1) {
+                        int t2 = pair_type(S[p], S[q]);
+                        if (t2) {
+                            t2 = rtype_of(t2);
+                            const int sp1 = S[p - 1], sq1 = S[q + 1];
+                            int e;
+                            if (a == 1 && b == 1) e = P->int11[type][t2][si1][sj1];
+                            else if (a == 1 && b == 2) e = P->int21[type][t2][si1][sq1][sj1];
+                            else if (a == 2 && b == 1) e = P->int21[t2][type][sq1][si1][sp1];
+                            else e = P->int22[type][t2][si1][sp1][sq1][sj1];
+                            sp_e[c4] = e + (int)cring[((q - p) & 31) * CSTR + p] - (int)T.mismatchI[t2 * 25 + sq1 * 5 + sp1];
+                        }
+                    }
                 }
-                if (best < INF) atomicMin(&cpart[i], best);
             }
+            if (dbg_cycles) { __syncthreads(); if (tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; } }   // diagnostic: A0 issue time -> "setup"
+            // phase A1: 32 lanes per paired cell sweep the (n1,n2) combination tables
+            if (!(dbg_flags & 1)) {
+                const int sub = tid & 31;
+                const int ng = T.n_gcombo, no = T.n_ocombo;
+                for (int cidx = tid >> 5; cidx < ncp; cidx += LNT / 32) {
+                    const int i = clist[cidx], j = i + d;
+                    const int type = pair_type(S[i], S[j]);
+                    const int o_out = type * 25 + S[i + 1] * 5 + S[j - 1];
+                    const int umax = d - 2 - (TURN + 1);             // n1 + n2 <= umax keeps q - p >= TURN + 1
+                    int best = INF;
+                    // generic loops: il[u] + min(MAX_NINIO, |n1-n2|*ninio) + mismatchI(outer) + G0; the table is sorted by u,
+                    // so the admissible combinations (u <= umax) are a prefix of it
+                    {
+                        const int mo = T.mismatchI[o_out];
+                        int kmax = 0;
+                        if (umax >= 6) { int um = umax < MAXLOOP ? umax : MAXLOOP; kmax = ((um - 3) * (um - 2)) / 2 - 3; }
+                        int bg = INF;
+#pragma unroll 4
+                        for (int k = sub; k < kmax; k += 32) {
+                            const unsigned v = T.gcombo[k];
+                            const int n1 = v & 31, u = n1 + ((v >> 5) & 31);
+                            const int g0 = cring[((d - 2 - u) & 31) * CSTR + i + 1 + n1];
+                            const int e = (int)(v >> 10) + g0;
+                            bg = e < bg ? e : bg;
+                        }
+                        bg += mo;
+                        best = bg < best ? bg : best;
+                    }
+                    // stack, bulges, 1xn, 2x3 (predicated, so the four rounds can be overlapped)
+                    {
+                        const int au1 = type > 2 ? T.TerminalAU : 0;
+                        const int m1 = T.mismatch1nI[o_out], m2 = T.mismatch23I[o_out];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const int k = sub + 32 * r4;
+                            const unsigned v = T.ocombo[k < no ? k : 0];
+                            const int n1 = v & 31, n2 = (v >> 5) & 31, cls = v >> 10, u = n1 + n2;
+                            const int p = i + 1 + n1, q = j - 1 - n2;
+                            const int g0 = cring[((q - p) & 31) * CSTR + p];
+                            const bool ok = (k < no) && (u <= umax) && (g0 != I16_INF);
+                            const int t2 = rtype_of(pair_type(S[p], S[q]));
+                            const int code = t2 * 25 + S[q + 1] * 5 + S[p - 1];
+                            const int cpq = g0 - (int)T.mismatchI[code];
+                            const int st = T.stack[type * 8 + t2];
+                            const int au2 = t2 > 2 ? T.TerminalAU : 0;
+                            int y = (u - 2) * T.ninio; y = y < T.MAX_NINIO ? y : T.MAX_NINIO;
+                            const int il = T.internal_loop[u];
+                            const int e0 = st;
+                            const int e1 = T.bulge[u] + (u == 1 ? st : au1 + au2);
+                            const int e2 = il + y + m1 + T.mismatch1nI[code];
+                            const int e3 = T.internal_loop[5] + T.ninio + m2 + T.mismatch23I[code];
+                            int e = cls == 0 ? e0 : (cls == 1 ? e1 : (cls == 2 ? e2 : e3));
+                            e += cpq;
+                            if (ok && e < best) best = e;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) { int t = __shfl_xor(best, o); best = t < best ? t : best; }
+                    if (sub == 0 && best < INF) atomicMin(&cpart[i], best);
+                }
+            }
+            if (dbg_cycles) { __syncthreads(); if (tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; } }   // diagnostic: A1 time -> "epilogue" slot
             // phase A2: multiloop splits DML(i,j) over the finite range of row i / column j.
             // The split point t is wave-uniform (scalar address arithmetic); lanes = consecutive cells.
             {
@@ -267,7 +354,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int nsub = LNT / ncpad;            // >= 2 for ncell <= 512
                 const int cell = tid % ncpad;
                 const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
-                if (sub < nsub) {
+                if (sub < nsub && !(dbg_flags & 2)) {
                     const int i = cell + 1, j = i + d;
                     int tlo = 30000, rng = 0;
                     if (cell < ncell) {
@@ -276,7 +363,23 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (b >= a) { tlo = a; rng = b - a; }
                     }
                     int best = INF;
-                    for (int t = 4 + sub; t <= d - 5; t += nsub) {
+                    int t = 4 + sub;
+                    // 4 splits per trip: 8 LDS reads in flight
+                    for (; t + 3 * nsub <= d - 5; t += 4 * nsub) {
+                        int ev[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int tt = t + r * nsub, u = d - tt - 1;
+                            const int o1 = (tt - 4) * n - ((tt * (tt - 1)) / 2 - 6);
+                            const int o2 = (u - 4) * n - ((u * (u - 1)) / 2 - 6) + tt + 1;
+                            const int e = (int)fml[o1 + i] + (int)fml[o2 + i];
+                            ev[r] = ((unsigned)(tt - tlo) <= (unsigned)rng) ? e : INF;
+                        }
+                        int a0 = ev[0] < ev[1] ? ev[0] : ev[1], a1 = ev[2] < ev[3] ? ev[2] : ev[3];
+                        a0 = a0 < a1 ? a0 : a1;
+                        best = a0 < best ? a0 : best;
+                    }
+                    for (; t <= d - 5; t += nsub) {
                         const int u = d - t - 1;
                         const int o1 = (t - 4) * n - ((t * (t - 1)) / 2 - 6);
                         const int o2 = (u - 4) * n - ((u * (u - 1)) / 2 - 6) + t + 1;
@@ -288,7 +391,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (best < INF) atomicMin(&mdec[i], best);
                 }
             }
+            {
+                int e = sp_e[0] < sp_e[1] ? sp_e[0] : sp_e[1];
+                int f = sp_e[2] < sp_e[3] ? sp_e[2] : sp_e[3];
+                e = e < f ? e : f;
+                if (e < INF) atomicMin(&cpart[sp_i], e);
+            }
             __syncthreads();
+            if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
             // phase B: finalise the cells of this diagonal; build the paired list of the next one
             if (tid == 0) misc[2 + (cur ^ 1)] = 0;
             __syncthreads();
@@ -299,7 +409,15 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int md = mdec[i];
                 if (type) {
                     cv = cpart[i];
-                    int h = e_hairpin(X, i, j, type);
+                    int h;
+                    {
+                        const int u = d - 1;
+                        int sv = -32768;
+                        if (u == 4) sv = spec[nc + i]; else if (u == 6) sv = spec[2 * nc + i]; else if (u == 3) sv = spec[i];
+                        if (sv != -32768) h = sv;
+                        else if (u == 3) h = T.hairpinE[3] + (type > 2 ? T.TerminalAU : 0);
+                        else h = T.hairpinE[u] + T.mismatchH[type * 25 + S[i + 1] * 5 + S[j - 1]];
+                    }
                     cv = h < cv ? h : cv;
                     int dml = dmlring[((d + 1) % 3) * LCAP + i + 1];     // (d-2) mod 3
                     if (dml < INF) {
@@ -319,7 +437,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
                 const short c16 = cv >= INF ? (short)I16_INF : (short)cv;
                 const short m16 = m >= INF ? (short)I16_INF : (short)m;
-                cring[(d & 31) * LCAP + i] = c16;
+                {   // G0 = c + mismatchI of (i,j) seen as the inner pair of a generic interior loop
+                    short g16 = (short)I16_INF;
+                    if (cv < INF) g16 = (short)(cv + T.mismatchI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]]);
+                    cring[(d & 31) * CSTR + i] = g16;
+                }
                 carch[(size_t)d * LCAP + i] = c16;
                 fml[off[d] + i] = m16;
                 dmlring[(d % 3) * LCAP + i] = md;
@@ -331,6 +453,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 }
             }
             __syncthreads();
+            if (dbg_cycles && tid == 0) { long long t = clock64(); tB += t - t0; t0 = t; }
         }
         const int overflow = misc[1];
         __syncthreads();
@@ -342,9 +465,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             TB.fml = fml; TB.off = off; TB.carch = carch;
             fold_epilogue<LTab, LNT>(X, TB, span, f3, starts, lens, btbuf, LCAP + 8, btstk, misc + 4, win, max_lines, ss_stride, out_lines, out_ss,
                                      out_nlines, out_mfe, out_status);
+            if (dbg_cycles && tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; }
         }
         }   // window fits this kernel
         __syncthreads();
+    }
+    if (dbg_cycles && tid == 0) {
+        atomicAdd((unsigned long long*)&dbg_cycles[0], (unsigned long long)tS); atomicAdd((unsigned long long*)&dbg_cycles[1], (unsigned long long)tA);
+        atomicAdd((unsigned long long*)&dbg_cycles[2], (unsigned long long)tB); atomicAdd((unsigned long long*)&dbg_cycles[3], (unsigned long long)tE);
     }
 }
 
@@ -355,12 +483,13 @@ int fold_lds_max_span() { return LDMAX + 1; }
 
 hipError_t launch_fold_lds(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int span, short* carch, unsigned int* work_counter, int* fallback_list, unsigned int* fallback_count,
-                           int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status) {
+                           int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status,
+                           int dbg_flags, long long* dbg_cycles) {
     size_t lds = fold_lds_bytes(max_lines);
     hipError_t e = hipFuncSetAttribute((const void*)fold_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fold_lds_kernel, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, span, carch, work_counter, fallback_list,
-                       fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
+                       fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
     return hipGetLastError();
 }
 

@@ -196,13 +196,23 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             return fail(c, -6, "device allocation failed (fold LDS kernel)");
         HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 64, c->stream));
         unsigned int* ctl = (unsigned int*)c->fctl.p;
+        // diagnostics (never set in production): MIRP_FOLD_DEBUG=<flags> ablates phases (results then wrong), MIRP_FOLD_CLOCKS=1 prints phase clocks
+        const char* dbg_env = std::getenv("MIRP_FOLD_DEBUG");
+        const int dbg_flags = dbg_env ? std::atoi(dbg_env) : 0;
+        long long* dbg_cycles = std::getenv("MIRP_FOLD_CLOCKS") ? (long long*)(ctl + 8) : nullptr;
         hipError_t e = mirp::launch_fold_lds(c->stream, grid, c->d_params, d_seqs, d_offs, d_lens, n_work, span, (short*)c->carch.p, ctl, (int*)c->flist.p,
-                                             ctl + 4, max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
+                                             ctl + 4, max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status, dbg_flags, dbg_cycles);
         if (e != hipSuccess) return fail(c, -2, std::string("fold LDS kernel launch failed: ") + hipGetErrorString(e));
         unsigned int nfb = 0;
         HIPCHK(c, hipMemcpyAsync(&nfb, ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->last_fallback = nfb;
+        if (dbg_cycles) {
+            long long cyc[4];
+            HIPCHK(c, hipMemcpy(cyc, dbg_cycles, sizeof(cyc), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[mirp fold clocks] windows=%d grid=%d setup=%lld fillA=%lld fillB=%lld epilogue=%lld (sum over workgroups, s_memtime ticks)\n", n_work,
+                         grid, cyc[0], cyc[1], cyc[2], cyc[3]);
+        }
         if (nfb == 0) return 0;
         work_list = (const int*)c->flist.p;
         n_generic = (int)nfb;
