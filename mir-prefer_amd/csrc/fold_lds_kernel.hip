@@ -36,6 +36,7 @@ struct LdsTables {          // int16 copies of the hot parameter tables
     unsigned int gcombo[376];           // generic interior loops (n1,n2 >= 2, n1+n2 >= 6): n1 | n2 << 5 | (il[u] + ninio term) << 10
     unsigned short ocombo[120];         // the other classes: n1 | n2 << 5 | class << 10
     short n_gcombo, n_ocombo;
+    unsigned char rt2[28];              // rtype(pair_type(a, b)) at [a*5+b]
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
 };
 #define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         T.ocombo[o++] = (unsigned short)(2 | (3 << 5) | (3 << 10));                           // class 3: 2 x 3
         T.ocombo[o++] = (unsigned short)(3 | (2 << 5) | (3 << 10));                           //          3 x 2
         T.n_gcombo = (short)g; T.n_ocombo = (short)o;
+        for (int x = 0; x < 25; x++) T.rt2[x] = (unsigned char)rtype_of(pair_type(x / 5, x % 5));
     }
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
     __syncthreads();
@@ -254,6 +256,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int cur = d & 1;
             const unsigned short* clist = list + cur * LCAP;
             const int ncp = misc[2 + cur];
+            if (tid == 0) misc[2 + (cur ^ 1)] = 0;
             // The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]]: the inner-pair part of a generic interior loop
             // is folded in when the cell is finalised, so a generic candidate costs one LDS read.  Plain c = G0 - mismatchI[code].
             // phase A0: the four small interior loops of each paired cell (1x1, 1x2, 2x1, 2x2) read the big int11/int21/int22
@@ -313,30 +316,40 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         bg += mo;
                         best = bg < best ? bg : best;
                     }
-                    // stack, bulges, 1xn, 2x3 (predicated, so the four rounds can be overlapped)
+                    // stack, bulges, 1xn, 2x3: four class-homogeneous rounds over the 32 lanes of the cell
                     {
                         const int au1 = type > 2 ? T.TerminalAU : 0;
                         const int m1 = T.mismatch1nI[o_out], m2 = T.mismatch23I[o_out];
+                        const int tau = T.TerminalAU, nin = T.ninio, mxn = T.MAX_NINIO;
+                        const short* strow = T.stack + type * 8;
 #pragma unroll
                         for (int r4 = 0; r4 < 4; r4++) {
-                            const int k = sub + 32 * r4;
-                            const unsigned v = T.ocombo[k < no ? k : 0];
-                            const int n1 = v & 31, n2 = (v >> 5) & 31, cls = v >> 10, u = n1 + n2;
+                            int n1, n2;
+                            if (r4 == 0) { n1 = 0; n2 = sub; }                                   // stack + 3'-side bulges
+                            else if (r4 == 1) { n1 = sub + 1; n2 = 0; }                          // 5'-side bulges
+                            else if (r4 == 2) { n1 = 1; n2 = sub + 3; }                          // 1 x n
+                            else { n1 = sub < 27 ? sub + 3 : sub - 25; n2 = sub < 27 ? 1 : 30 - sub; }   // n x 1, then 2x3 (lane 27), 3x2 (lane 28)
+                            const int u = n1 + n2;
+                            bool ok = u <= umax && u <= MAXLOOP;
+                            if (r4 == 1) ok = ok && sub < 30;
+                            if (r4 == 2) ok = ok && sub < 27;
+                            if (r4 == 3) ok = ok && sub < 29;
                             const int p = i + 1 + n1, q = j - 1 - n2;
-                            const int g0 = cring[((q - p) & 31) * CSTR + p];
-                            const bool ok = (k < no) && (u <= umax) && (g0 != I16_INF);
-                            const int t2 = rtype_of(pair_type(S[p], S[q]));
-                            const int code = t2 * 25 + S[q + 1] * 5 + S[p - 1];
+                            const int g0 = ok ? (int)cring[((q - p) & 31) * CSTR + p] : (int)I16_INF;
+                            ok = ok && g0 != I16_INF;
+                            const int t2 = T.rt2[S[ok ? p : i] * 5 + S[ok ? q : j]];
+                            const int code = t2 * 25 + S[(ok ? q : j) + 1] * 5 + S[(ok ? p : i) - 1];
                             const int cpq = g0 - (int)T.mismatchI[code];
-                            const int st = T.stack[type * 8 + t2];
-                            const int au2 = t2 > 2 ? T.TerminalAU : 0;
-                            int y = (u - 2) * T.ninio; y = y < T.MAX_NINIO ? y : T.MAX_NINIO;
-                            const int il = T.internal_loop[u];
-                            const int e0 = st;
-                            const int e1 = T.bulge[u] + (u == 1 ? st : au1 + au2);
-                            const int e2 = il + y + m1 + T.mismatch1nI[code];
-                            const int e3 = T.internal_loop[5] + T.ninio + m2 + T.mismatch23I[code];
-                            int e = cls == 0 ? e0 : (cls == 1 ? e1 : (cls == 2 ? e2 : e3));
+                            int e;
+                            if (r4 <= 1) {
+                                const int st = strow[t2];
+                                e = u == 0 ? st : (int)T.bulge[u] + (u == 1 ? st : au1 + (t2 > 2 ? tau : 0));
+                            } else if (r4 == 2 || sub < 27) {
+                                int y = (u - 2) * nin; y = y < mxn ? y : mxn;
+                                e = (int)T.internal_loop[u] + y + m1 + (int)T.mismatch1nI[code];
+                            } else {
+                                e = (int)T.internal_loop[5] + nin + m2 + (int)T.mismatch23I[code];
+                            }
                             e += cpq;
                             if (ok && e < best) best = e;
                         }
@@ -363,30 +376,21 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (b >= a) { tlo = a; rng = b - a; }
                     }
                     int best = INF;
+                    // offsets of the two operand diagonals advance by second-order recurrences (scalar unit):
+                    //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1,  off(x) = (x-4) n - (x(x-1)/2 - 6)
                     int t = 4 + sub;
-                    // 4 splits per trip: 8 LDS reads in flight
-                    for (; t + 3 * nsub <= d - 5; t += 4 * nsub) {
-                        int ev[4];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int tt = t + r * nsub, u = d - tt - 1;
-                            const int o1 = (tt - 4) * n - ((tt * (tt - 1)) / 2 - 6);
-                            const int o2 = (u - 4) * n - ((u * (u - 1)) / 2 - 6) + tt + 1;
-                            const int e = (int)fml[o1 + i] + (int)fml[o2 + i];
-                            ev[r] = ((unsigned)(tt - tlo) <= (unsigned)rng) ? e : INF;
-                        }
-                        int a0 = ev[0] < ev[1] ? ev[0] : ev[1], a1 = ev[2] < ev[3] ? ev[2] : ev[3];
-                        a0 = a0 < a1 ? a0 : a1;
-                        best = a0 < best ? a0 : best;
-                    }
-                    for (; t <= d - 5; t += nsub) {
-                        const int u = d - t - 1;
-                        const int o1 = (t - 4) * n - ((t * (t - 1)) / 2 - 6);
-                        const int o2 = (u - 4) * n - ((u * (u - 1)) / 2 - 6) + t + 1;
-                        if ((unsigned)(t - tlo) <= (unsigned)rng) {
-                            int e = (int)fml[o1 + i] + (int)fml[o2 + i];
-                            best = e < best ? e : best;
-                        }
+                    int o1 = (t - 4) * n - ((t * (t - 1)) / 2 - 6);
+                    int uu = d - t - 1;
+                    int o2 = (uu - 4) * n - ((uu * (uu - 1)) / 2 - 6) + t + 1;
+                    const int s1 = nsub, ss = nsub * nsub;
+                    int inc1 = s1 * n - s1 * t - (s1 * (s1 - 1)) / 2;           // off(t+s) - off(t)
+                    int inc2 = -(s1 * n) + s1 * uu - (s1 * (s1 + 1)) / 2 + s1;  // off(uu-s) - off(uu) + s
+#pragma unroll 4
+                    for (; t <= d - 5; t += s1) {
+                        const int e = (int)fml[o1 + i] + (int)fml[o2 + i];
+                        if ((unsigned)(t - tlo) <= (unsigned)rng) best = e < best ? e : best;
+                        o1 += inc1; inc1 -= ss;
+                        o2 += inc2; inc2 -= ss;
                     }
                     if (best < INF) atomicMin(&mdec[i], best);
                 }
@@ -400,8 +404,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             __syncthreads();
             if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
             // phase B: finalise the cells of this diagonal; build the paired list of the next one
-            if (tid == 0) misc[2 + (cur ^ 1)] = 0;
-            __syncthreads();
+            // (its counter was cleared at the start of phase A, when nobody reads it)
             for (int x = tid; x < ncell; x += LNT) {
                 const int i = x + 1, j = i + d;
                 const int type = pair_type(S[i], S[j]);
