@@ -60,7 +60,8 @@ typedef struct { int32_t n_samples, min_mature_len, max_mature_len, allow_3nt, a
  * output, characters [ss_off, ss_off+ss_len). */
 typedef struct {
     int32_t window, tid, fold_s, fold_e, mat_s, mat_e, star_s, star_e, strand, has_star;
-    int32_t line, ss_off, ss_len, reserved;
+    int32_t line, ss_off, ss_len;
+    int32_t reserved; /* imperfect-star flags (MP:2146-2162): bit0 'max_imperfect_star' key present, bits1-2 which+1, bit3 max > 0 */
     int32_t total_depth_mature, total_depth_star;
 } MirpMirna;
 

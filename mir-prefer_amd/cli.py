@@ -1,0 +1,73 @@
+"""Command line of the MI355X host: same verbs, flags and config file as the reference
+(/root/reference/miR_PREFeR.py:44-78 parse_option_optparse, verbs dispatched at :3728-3774).
+
+    python -m mir_prefer_amd.cli [-L] [-k] [-d] {check|prepare|candidate|fold|predict|pipeline|recover} configfile
+"""
+import logging
+import optparse
+import os
+import shutil
+import sys
+
+ACTIONS = ["check", "prepare", "candidate", "fold", "predict", "pipeline", "recover"]
+
+
+def parse_option_optparse(argv=None):
+    usage = "Usage: %prog [options] action configfile\n\naction: one of " + ", ".join(ACTIONS)
+    parser = optparse.OptionParser(usage)
+    parser.add_option("-L", "--log", action="store_true", dest="log", help="Generate a log file.")
+    parser.add_option("-k", "--keep-tmp", action="store_true", dest="keeptmp", help="After finish the whole pipeline, do not remove the temporary folder.")
+    parser.add_option("-d", "--output-detail-for-debug", action="store_true", dest="debug", help="Output detailed information for debug.")
+    parser.add_option("--device", type="int", default=0, help="GPU index (default 0).")
+    options, args = parser.parse_args(argv)
+    if len(args) != 2:
+        parser.error("incorrect number of arguments. Run the script with -h option to see help.")
+    if args[0] not in ACTIONS:
+        parser.error("unknow command. Run the script with -h option to see help.")
+    return {"action": args[0], "config": args[1], "log": bool(options.log), "keeptmp": bool(options.keeptmp), "debug": bool(options.debug),
+            "device": options.device}
+
+
+def main(argv=None):
+    from . import capi, config, pipeline
+    o = parse_option_optparse(argv)
+    opt = config.parse_configfile(o["config"])
+    opt["OUTPUT_DETAILS_FOR_DEBUG"] = o["debug"]
+    if not opt["NAME_PREFIX"]:
+        opt["NAME_PREFIX"] = "miR-PREFeR"
+    os.makedirs(opt["OUTFOLDER"], exist_ok=True)
+    if o["log"]:
+        logging.basicConfig(filename=os.path.join(opt["OUTFOLDER"], opt["NAME_PREFIX"] + ".log"), filemode="w", level=logging.INFO,
+                            format="%(asctime)20s  %(name)10s:  %(levelname)10s  %(message)s")
+    if o["action"] == "check":
+        # tool presence check of the reference (MP:3206-3269) becomes: is the HIP library built and a GPU usable?
+        try:
+            capi.load_library()
+            ctx = capi.Context(o["device"])
+            ctx.close()
+            print("libmirprefer.so: OK (ABI %d); GPU %d: OK" % (capi.load_library().mirp_abi_version(), o["device"]))
+        except capi.MirpError as e:
+            sys.stderr.write(str(e) + "\n")
+            sys.exit(-1)
+        last = pipeline.detect_stage_last_finished(os.path.join(opt["TMPFOLDER"] or os.path.join(opt["OUTFOLDER"], opt["NAME_PREFIX"] + "_tmp"),
+                                                                opt["NAME_PREFIX"] + "_recover"))
+        print("Last finished stage: %s" % last)
+        return 0
+    try:
+        p = pipeline.Pipeline(opt, o["device"])
+        if o["action"] == "pipeline":
+            p.run_pipeline()
+            if not o["keeptmp"] and opt["DELETE_IF_SUCCESS"].upper().startswith("Y"):
+                shutil.rmtree(p.tmp, ignore_errors=True)   # run_removetmp
+        elif o["action"] == "recover":
+            p.run_recover()
+        else:
+            getattr(p, "run_" + o["action"])()
+    except capi.MirpError as e:
+        sys.stderr.write(str(e) + "\n")   # reference behaviour for a failed tool: message on stderr, exit status -1
+        sys.exit(-1)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

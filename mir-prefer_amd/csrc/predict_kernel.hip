@@ -15,6 +15,7 @@ namespace mirp {
 #define PW_MAX_STRUCTS 192   // structures per window (lines * pieces)
 #define PW_MAX_PIECES 6
 #define PW_MAX_MATURES 40
+#define EVW 10
 
 struct PStruct { double ne; int start; int line; int off; int len; int type; };
 
@@ -175,7 +176,7 @@ __device__ __forceinline__ long long aln_lower_bound(const MirpAln* __restrict__
 
 struct ExprRes {
     long long total_this, total_mature, total_iso, total_star; // total_star = after max with imperfect (when key present)
-    int distance, has_imp_key, imp_start, imp_end;
+    int distance, has_imp_key, imp_start, imp_end, imp_which /* -1 none */;
     double ratio_total, ratio_iso;
     bool too_many_start, expressed_all, exception;
 };
@@ -210,7 +211,7 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
     o.total_this = tot_pre; o.total_mature = tot_mat; o.total_iso = tot_iso;
     o.distance = (star_s > m1) ? star_s - m1 : m0 - star_e;
     long long max_imp = 0;
-    o.has_imp_key = 0; o.imp_start = 0; o.imp_end = 0;
+    o.has_imp_key = 0; o.imp_start = 0; o.imp_end = 0; o.imp_which = -1;
     if (tot_star == 0 && allow_3nt) {
         o.has_imp_key = 1;
         long long mx = imp[0] > imp[1] ? imp[0] : imp[1]; mx = mx > imp[2] ? mx : imp[2];
@@ -219,6 +220,7 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
             if (which == 0) { o.imp_start = star_s; o.imp_end = star_e + 1; }
             else if (which == 1) { o.imp_start = star_s + 1; o.imp_end = star_e; }
             else { o.imp_start = star_s + 1; o.imp_end = star_e + 1; }
+            o.imp_which = which;
             max_imp = mx;
         }
     }
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(64) predict_kernel(
     PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * ss_stride + 15) & ~(size_t)15)); // PW_MAX_STRUCTS
     PStruct* slot = sts + PW_MAX_STRUCTS;                                // 64 * PW_MAX_PIECES
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
-    int* ev = cnts + 64;                                                 // PW_MAX_STRUCTS * 8 (per-structure evaluation of the current mature)
+    int* ev = cnts + 64;                                                 // PW_MAX_STRUCTS * EVW (per-structure evaluation of the current mature)
     const int lane = threadIdx.x;
     for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
         const MirpWindow W = windows[w];
@@ -334,13 +336,15 @@ __global__ void __launch_bounds__(64) predict_kernel(
                         const char* str = text + (size_t)p.line * ss_stride + p.off;
                         MStar ms;
                         d_maturestar(str, p.len, m.start, m.end, p.start, W.ws, W.we, m.strand, ms);
-                        int pass = 0, has_star = 0, star_s = ms.star_s, star_e = ms.star_e;
+                        int pass = 0, has_star = 0, star_s = ms.star_s, star_e = ms.star_e, impf = 0;
                         long long tm = 0, ts = 0;
                         if (ms.code == 0) {
                             ExprRes ex;
                             d_expression(alns, n_alns, pp.n_samples, W.tid, W.ws, W.we, ms.fold_s, ms.fold_e, m.start, m.end, ms.star_s, ms.star_e,
                                          m.strand, pp.allow_3nt, ex);
                             tm = ex.total_mature; ts = ex.total_star;
+                            // 'max_imperfect_star' in exprinfo (MP:2161, 2631-2635): bit0 key present, bits1-2 which+1, bit3 max > 0
+                            impf = (ex.has_imp_key ? 1 : 0) | ((ex.imp_which + 1) << 1) | ((ex.imp_which >= 0) ? 8 : 0);
                             if (!ex.exception && ex.distance > 4) {
                                 if (ex.total_star > 0) {
                                     if (!(ex.ratio_total < 0.2)) {
@@ -352,9 +356,9 @@ __global__ void __launch_bounds__(64) predict_kernel(
                                 }
                             }
                         }
-                        int* e = ev + s * 8;
+                        int* e = ev + s * EVW;
                         e[0] = pass; e[1] = has_star; e[2] = star_s; e[3] = star_e; e[4] = ms.fold_s; e[5] = ms.fold_e;
-                        e[6] = (int)(tm > 0x7fffffffLL ? 0x7fffffffLL : tm); e[7] = (int)(ts > 0x7fffffffLL ? 0x7fffffffLL : ts);
+                        e[6] = (int)(tm > 0x7fffffffLL ? 0x7fffffffLL : tm); e[7] = (int)(ts > 0x7fffffffLL ? 0x7fffffffLL : ts); e[8] = impf;
                     }
                 }
                 __syncthreads();
@@ -363,14 +367,14 @@ __global__ void __launch_bounds__(64) predict_kernel(
                     int best = -1;
                     for (int s = 0; s < nst; s++) {
                         if (sts[s].ne > lowest) continue;       // MP:2251
-                        if (ev[s * 8]) { best = s; lowest = sts[s].ne; }
+                        if (ev[s * EVW]) { best = s; lowest = sts[s].ne; }
                     }
                     if (best >= 0 && nout < MIRP_MAX_MIRNA_PER_WINDOW) {
-                        const int* e = ev + best * 8;
+                        const int* e = ev + best * EVW;
                         MirpMirna r;
                         r.window = w; r.tid = W.tid; r.fold_s = e[4]; r.fold_e = e[5]; r.mat_s = m.start; r.mat_e = m.end;
                         r.star_s = e[2]; r.star_e = e[3]; r.strand = m.strand; r.has_star = e[1];
-                        r.line = sts[best].line; r.ss_off = sts[best].off; r.ss_len = sts[best].len; r.reserved = 0;
+                        r.line = sts[best].line; r.ss_off = sts[best].off; r.ss_len = sts[best].len; r.reserved = e[8];
                         r.total_depth_mature = e[6]; r.total_depth_star = e[7];
                         out[(size_t)w * MIRP_MAX_MIRNA_PER_WINDOW + nout] = r;
                         nout++;
@@ -395,7 +399,7 @@ size_t predict_lds_bytes(int max_lines, int ss_stride) {
     size_t b = (((size_t)max_lines * ss_stride + 15) & ~(size_t)15);
     b += sizeof(PStruct) * (PW_MAX_STRUCTS + 64 * PW_MAX_PIECES);
     b += sizeof(int) * 64;
-    b += sizeof(int) * PW_MAX_STRUCTS * 8;
+    b += sizeof(int) * PW_MAX_STRUCTS * EVW;
     return (b + 15) & ~(size_t)15;
 }
 

@@ -1,0 +1,60 @@
+"""GPU test of the host CLI / stage drivers on the golden datasets: same config file, stage artefacts and gff3 as the reference."""
+import gzip
+import os
+import shutil
+
+import pytest
+
+from mir_prefer_amd import cli, pipeline
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, tmp_path):
+    exp = gu.load_json(os.path.join(name, "expected.json.gz"))
+    src = os.path.join(gu.GOLD, name)
+    files = {}
+    for fn in ["genome.fa"] + [s + ".sam" for s in exp["sample_names"]]:
+        dst = tmp_path / fn
+        with gzip.open(os.path.join(src, fn + ".gz"), "rb") as fi, open(dst, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        files[fn] = str(dst)
+    cfg = tmp_path / "config"
+    c = exp["config"]
+    lines = ["FASTA_FILE = " + files["genome.fa"], "ALIGNMENT_FILE = " + ", ".join(files[s + ".sam"] for s in exp["sample_names"]),
+             "OUTFOLDER = " + str(tmp_path / "out")]
+    for k in ("PRECURSOR_LEN", "READS_DEPTH_CUTOFF", "MAX_GAP", "MIN_MATURE_LEN", "MAX_MATURE_LEN", "ALLOW_NO_STAR_EXPRESSION", "ALLOW_3NT_OVERHANG",
+              "CHECKPOINT_SIZE", "NAME_PREFIX"):
+        lines.append("%s = %s" % (k, c[k]))
+    cfg.write_text("\n".join(lines) + "\n")
+    return exp, str(cfg), tmp_path / "out"
+
+
+@pytest.mark.parametrize("name", ["mini", "mini3"])
+def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
+    exp, cfg, out = _setup(name, tmp_path)
+    assert cli.main(["-k", "pipeline", cfg]) == 0
+    prefix = exp["config"]["NAME_PREFIX"]
+    tmp = out / (prefix + "_tmp")
+    assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"]
+    assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
+    fasta = open(tmp / (prefix + ".rnalfold.in_0.fa")).read().splitlines()
+    want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]
+    assert fasta == want
+    # RNALfold-format text of the fold stage == the reference's RNALfold 2.1.2 output (sequence echo case aside)
+    got = open(tmp / (prefix + "_rnalfoldoutput_0")).read().upper().splitlines()
+    ref = "".join(p["rnalfold_out"] for p in exp["pieces"]).upper().splitlines()
+    assert [l for l in got if not l.startswith(">")] == [l for l in ref if not l.startswith(">")]
+    rec = pipeline.load_recover_file(str(tmp / (prefix + "_recover")))
+    assert rec["last_stage"] == "predict" and set(rec["finished_stages"]) == {"prepare", "candidate", "fold", "predict"}
+
+
+def test_stage_verbs_and_recover(tmp_path):
+    exp, cfg, out = _setup("mini", tmp_path)
+    with pytest.raises(SystemExit):          # fold before candidate: refused like the reference (MP:3446-3448)
+        cli.main(["fold", cfg])
+    for verb in ("prepare", "candidate"):
+        assert cli.main([verb, cfg]) == 0
+    assert cli.main(["recover", cfg]) == 0    # continues with fold + predict
+    assert open(out / "mini_miRNA.gff3").read() == exp["gff3"]
