@@ -75,11 +75,12 @@ def main():
     import torch
     import torch.distributed as dist
     from mir_prefer_amd import capi, synth
+    from mir_prefer_amd import dist as mdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -96,22 +97,16 @@ def main():
     ctx.load_alignments(alns)
 
     def gather_loci(out):
-        """Final loci list to rank 0 over RCCL: all_gather of counts, then gather of padded 64-B records."""
-        if world == 1:
-            return len(out["result"])
+        """Final loci list to rank 0 over RCCL (mir_prefer_amd.dist.gather_records: all_gather of counts, gather of padded 64-B records)."""
         rec = np.zeros((len(out["result"]), 16), dtype=np.int32)
         if len(out["result"]):
             rec[:] = np.frombuffer(out["result"].tobytes(), dtype=np.int32).reshape(-1, 16)
-        cnt = torch.tensor([rec.shape[0]], device=dev, dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        mx = max(int(c.item()) for c in cnts)
-        pad = torch.zeros((max(mx, 1), 16), device=dev, dtype=torch.int32)
-        if rec.shape[0]:
-            pad[:rec.shape[0]] = torch.from_numpy(rec).to(dev)
-        bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pad, bufs, dst=0)
-        return sum(int(c.item()) for c in cnts)
+        if not dist.is_initialized():
+            return rec.shape[0]
+        allrec = mdist.gather_records(rec, device=dev, dst=0)
+        n_all = torch.tensor([0 if allrec is None else allrec.shape[0]], device=dev, dtype=torch.int64)
+        dist.broadcast(n_all, src=0)
+        return int(n_all.item())
 
     def step():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)

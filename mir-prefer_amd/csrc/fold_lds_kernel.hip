@@ -32,8 +32,7 @@ struct LdsTables {          // int16 copies of the hot parameter tables
     short bulge[32];
     short internal_loop[32];
     short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200];
-    short hairpinE[LCAP];
-    unsigned int gcombo[376];           // generic interior loops (n1,n2 >= 2, n1+n2 >= 6): n1 | n2 << 5 | (il[u] + ninio term) << 10
+    unsigned short penK[25 * 34];       // generic interior loops: [u-6][n1] = il[u] + min(MAX_NINIO, |2 n1 - u| ninio) for 2 <= n1 <= u-2, else 65535
     unsigned short ocombo[120];         // the other classes: n1 | n2 << 5 | class << 10
     short n_gcombo, n_ocombo;
     unsigned char rt2[28];              // rtype(pair_type(a, b)) at [a*5+b]
@@ -100,7 +99,7 @@ __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     for (int d = 4; d <= LDMAX; d++) tri += (size_t)(LCAP - d);
     L.fml = take(tri * 2);
     // fill-phase scratch (c ring 32 diagonals, DML ring 3, accumulators), re-used by the epilogue for backtrack buffers/stacks
-    size_t fill_aux = (size_t)32 * CSTR * 2 + (size_t)3 * LCAP * 4 + (size_t)2 * LCAP * 4;
+    size_t fill_aux = (size_t)32 * CSTR * 2 + (size_t)3 * LCAP * 2 + (size_t)4 * LCAP * 4;   // c ring, DML ring (int16), 2 x {cpart, mdec}
     size_t bt_aux = (size_t)LNW * (LCAP + 8) + (size_t)LNW * 3 * BT_STACK * 4;
     L.aux = take(fill_aux > bt_aux ? fill_aux : bt_aux);
     L.f3 = take((LCAP + 8) * 4);
@@ -110,7 +109,7 @@ __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     L.seq = take(LCAP + 8);
     L.spec = take((size_t)3 * (LCAP + 8) * 2);
     L.pmask = take(5 * 12 * 4);
-    L.list = take((size_t)2 * LCAP * 2 + 16);
+    L.list = take((size_t)3 * LCAP * 2 + 16);
     L.off = take((LDMAX + 2) * 4);
     L.tabs = take(sizeof(LdsTables));
     L.misc = take(16 * 4);
@@ -129,10 +128,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     const LdsLayout LY = lds_layout(max_lines);
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     short* fml = (short*)(smem + LY.fml);
-    short* cring = (short*)(smem + LY.aux);                         // [32][CSTR]
-    int* dmlring = (int*)(cring + 32 * CSTR);                       // [3][LCAP]
-    int* cpart = dmlring + 3 * LCAP;                                // [LCAP]
-    int* mdec = cpart + LCAP;                                       // [LCAP]
+    unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
+    short* dmlring = (short*)(cring + 32 * CSTR);                             // [3][LCAP] int16
+    int* acc = (int*)(dmlring + 3 * LCAP);                          // [2 (diagonal parity)][2 (cpart, mdec)][LCAP]
     char* btbuf = (char*)(smem + LY.aux);                           // epilogue alias
     int* btstk = (int*)(smem + LY.aux + (((size_t)LNW * (LCAP + 8) + 15) & ~(size_t)15));
     int* f3 = (int*)(smem + LY.f3);
@@ -142,10 +140,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     unsigned char* seq = smem + LY.seq;
     short* spec = (short*)(smem + LY.spec);
     unsigned int* pmask = (unsigned int*)(smem + LY.pmask);         // [5][12]
-    unsigned short* list = (unsigned short*)(smem + LY.list);       // [2][LCAP]
+    unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LCAP], list of diagonal d in buffer d % 3
     int* off = (int*)(smem + LY.off);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
-    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 2,3: list counts, 4..: epilogue sh_misc
+    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 2..4: list counts, 8..: epilogue sh_misc
     int* starts = (int*)(smem + LY.starts);
     int* lens = (int*)(smem + LY.lens);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,15 +159,16 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         T.mismatchM[x] = (short)P->mismatchM[t][a][b]; T.mismatch1nI[x] = (short)min(P->mismatch1nI[t][a][b], (int)I16_INF);
         T.mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], (int)I16_INF);
     }
-    for (int x = tid; x < LCAP; x += LNT) T.hairpinE[x] = (short)min(P->hairpinE[x], (int)I16_INF);
     if (tid == 0) {
         // combination tables of the interior-loop search window (n1 + n2 <= MAXLOOP)
         int g = 0, o = 0;
         for (int u = 6; u <= MAXLOOP; u++)
-            for (int n1 = 2; n1 <= u - 2; n1++) {
-                int n2 = u - n1, y = (n1 > n2 ? n1 - n2 : n2 - n1) * P->ninio;
-                T.gcombo[g++] = (unsigned)n1 | ((unsigned)n2 << 5) | ((unsigned)(P->internal_loop[u] + (y < P->MAX_NINIO ? y : P->MAX_NINIO)) << 10);
+            for (int n1 = 0; n1 < 32; n1++) {
+                int v = 65535;   // inadmissible slot: biased-unsigned ring value (>= 768) + 65535 can never beat the 65535 start value
+                if (n1 >= 2 && n1 <= u - 2) { int n2 = u - n1, y = (n1 > n2 ? n1 - n2 : n2 - n1) * P->ninio; v = P->internal_loop[u] + (y < P->MAX_NINIO ? y : P->MAX_NINIO); }
+                T.penK[(u - 6) * 34 + n1] = (unsigned short)v;
             }
+        g = 375;
         T.ocombo[o++] = 0;                                                                    // class 0: stack
         for (int k = 1; k <= MAXLOOP; k++) T.ocombo[o++] = (unsigned short)(0 | (k << 5) | (1 << 10));   // class 1: bulge, n1 = 0
         for (int k = 1; k <= MAXLOOP; k++) T.ocombo[o++] = (unsigned short)(k | (0 << 5) | (1 << 10));   //          bulge, n2 = 0
@@ -212,12 +211,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         }
         for (int x = tid; x < 60; x += LNT) pmask[x] = 0u;
         for (int x = tid; x < LCAP + 8; x += LNT) { rowfin[x] = 20000; colfin[x] = 20000; }
-        for (int x = tid; x < 3 * LCAP; x += LNT) dmlring[x] = INF;
-        for (int x = tid; x < 2 * LCAP; x += LNT) cpart[x] = INF;   // cpart + mdec
+        for (int x = tid; x < 3 * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
+        for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = INF;
         if (tid == 0) {
             int o = 0;
             for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
-            misc[1] = 0; misc[2] = 0; misc[3] = 0;
+            misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0;
         }
         __syncthreads();
         if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
@@ -239,24 +238,25 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             }
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
         }
-        // paired-cell list of the first diagonal
-        if (D >= 4)
-            for (int x = tid; x < n - 4; x += LNT) {
+        // paired-cell lists of the first two diagonals (list of diagonal d lives in buffer d % 3)
+        for (int dd = 4; dd <= 5 && dd <= D; dd++)
+            for (int x = tid; x < n - dd; x += LNT) {
                 int i = x + 1;
-                if (pair_type(S[i], S[i + 4])) { int k = atomicAdd(&misc[2], 1); list[k] = (unsigned short)i; }
+                if (pair_type(S[i], S[i + dd])) { int k = atomicAdd(&misc[2 + dd % 3], 1); list[(dd % 3) * LCAP + k] = (unsigned short)i; }
             }
         __syncthreads();
         WinCtx X;
         X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D;
 
         if (dbg_cycles && tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; }
-        // ---- anti-diagonal wavefront
-        for (int d = 4; d <= D; d++) {
+        // ---- anti-diagonal wavefront, software-pipelined: phase B of diagonal d (one thread per cell) runs in the same barrier
+        // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
+        auto phaseA = [&](const int d) {
             const int ncell = n - d;
-            const int cur = d & 1;
-            const unsigned short* clist = list + cur * LCAP;
-            const int ncp = misc[2 + cur];
-            if (tid == 0) misc[2 + (cur ^ 1)] = 0;
+            const unsigned short* clist = list + (d % 3) * LCAP;
+            const int ncp = misc[2 + d % 3];
+            int* cpart = acc + (d & 1) * 2 * LCAP;
+            int* mdec = cpart + LCAP;
             // The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]]: the inner-pair part of a generic interior loop
             // is folded in when the cell is finalised, so a generic candidate costs one LDS read.  Plain c = G0 - mismatchI[code].
             // phase A0: the four small interior loops of each paired cell (1x1, 1x2, 2x1, 2x2) read the big int11/int21/int22
@@ -282,12 +282,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             else if (a == 1 && b == 2) e = P->int21[type][t2][si1][sq1][sj1];
                             else if (a == 2 && b == 1) e = P->int21[t2][type][sq1][si1][sp1];
                             else e = P->int22[type][t2][si1][sp1][sq1][sj1];
-                            sp_e[c4] = e + (int)cring[((q - p) & 31) * CSTR + p] - (int)T.mismatchI[t2 * 25 + sq1 * 5 + sp1];
+                            sp_e[c4] = e + (int)cring[((q - p) & 31) * CSTR + p] - 32768 - (int)T.mismatchI[t2 * 25 + sq1 * 5 + sp1];
                         }
                     }
                 }
             }
-            if (dbg_cycles) { __syncthreads(); if (tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; } }   // diagnostic: A0 issue time -> "setup"
             // phase A1: 32 lanes per paired cell sweep the (n1,n2) combination tables
             if (!(dbg_flags & 1)) {
                 const int sub = tid & 31;
@@ -298,23 +297,24 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int o_out = type * 25 + S[i + 1] * 5 + S[j - 1];
                     const int umax = d - 2 - (TURN + 1);             // n1 + n2 <= umax keeps q - p >= TURN + 1
                     int best = INF;
-                    // generic loops: il[u] + min(MAX_NINIO, |n1-n2|*ninio) + mismatchI(outer) + G0; the table is sorted by u,
-                    // so the admissible combinations (u <= umax) are a prefix of it
+                    // generic loops (n1, n2 >= 2, u = n1 + n2 >= 6): il[u] + min(MAX_NINIO, |n1-n2| ninio) + mismatchI(outer) + G0.
+                    // The candidates of one size u are a contiguous run of ring row d-2-u; each lane takes the sizes u = 6 + sub, 38 + ... and
+                    // walks the run with immediate offsets (straight-line: one LDS read pair + add + min per slot, no index arithmetic).
                     {
                         const int mo = T.mismatchI[o_out];
-                        int kmax = 0;
-                        if (umax >= 6) { int um = umax < MAXLOOP ? umax : MAXLOOP; kmax = ((um - 3) * (um - 2)) / 2 - 3; }
-                        int bg = INF;
-#pragma unroll 4
-                        for (int k = sub; k < kmax; k += 32) {
-                            const unsigned v = T.gcombo[k];
-                            const int n1 = v & 31, u = n1 + ((v >> 5) & 31);
-                            const int g0 = cring[((d - 2 - u) & 31) * CSTR + i + 1 + n1];
-                            const int e = (int)(v >> 10) + g0;
-                            bg = e < bg ? e : bg;
+                        unsigned bg = 65535u;
+                        const int um = umax < MAXLOOP ? umax : MAXLOOP;
+                        const int u = 6 + sub;
+                        if (u <= um) {
+                            const unsigned short* row = cring + ((d - 2 - u) & 31) * CSTR + i + 1;
+                            const unsigned short* pk = T.penK + (u - 6) * 34;   // row stride 17 dwords: conflict-free across lanes
+#pragma unroll
+                            for (int n1 = 2; n1 <= 28; n1++) {
+                                const unsigned e = (unsigned)row[n1] + (unsigned)pk[n1];
+                                bg = e < bg ? e : bg;
+                            }
                         }
-                        bg += mo;
-                        best = bg < best ? bg : best;
+                        if (bg < 65535u) { const int r = (int)bg - 32768 + mo; best = r < best ? r : best; }
                     }
                     // stack, bulges, 1xn, 2x3: four class-homogeneous rounds over the 32 lanes of the cell
                     {
@@ -335,8 +335,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             if (r4 == 2) ok = ok && sub < 27;
                             if (r4 == 3) ok = ok && sub < 29;
                             const int p = i + 1 + n1, q = j - 1 - n2;
-                            const int g0 = ok ? (int)cring[((q - p) & 31) * CSTR + p] : (int)I16_INF;
-                            ok = ok && g0 != I16_INF;
+                            const int g0u = ok ? (int)cring[((q - p) & 31) * CSTR + p] : 65535;
+                            ok = ok && g0u != 65535;
+                            const int g0 = g0u - 32768;
                             const int t2 = T.rt2[S[ok ? p : i] * 5 + S[ok ? q : j]];
                             const int code = t2 * 25 + S[(ok ? q : j) + 1] * 5 + S[(ok ? p : i) - 1];
                             const int cpq = g0 - (int)T.mismatchI[code];
@@ -359,7 +360,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (sub == 0 && best < INF) atomicMin(&cpart[i], best);
                 }
             }
-            if (dbg_cycles) { __syncthreads(); if (tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; } }   // diagnostic: A1 time -> "epilogue" slot
             // phase A2: multiloop splits DML(i,j) over the finite range of row i / column j.
             // The split point t is wave-uniform (scalar address arithmetic); lanes = consecutive cells.
             {
@@ -401,10 +401,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 e = e < f ? e : f;
                 if (e < INF) atomicMin(&cpart[sp_i], e);
             }
-            __syncthreads();
-            if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
-            // phase B: finalise the cells of this diagonal; build the paired list of the next one
-            // (its counter was cleared at the start of phase A, when nobody reads it)
+        };
+        auto phaseB = [&](const int d) {
+            const int ncell = n - d;
+            int* cpart = acc + (d & 1) * 2 * LCAP;
+            int* mdec = cpart + LCAP;
+            const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             for (int x = tid; x < ncell; x += LNT) {
                 const int i = x + 1, j = i + d;
                 const int type = pair_type(S[i], S[j]);
@@ -418,12 +420,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         int sv = -32768;
                         if (u == 4) sv = spec[nc + i]; else if (u == 6) sv = spec[2 * nc + i]; else if (u == 3) sv = spec[i];
                         if (sv != -32768) h = sv;
-                        else if (u == 3) h = T.hairpinE[3] + (type > 2 ? T.TerminalAU : 0);
-                        else h = T.hairpinE[u] + T.mismatchH[type * 25 + S[i + 1] * 5 + S[j - 1]];
+                        else if (u == 3) h = hp_u + (type > 2 ? T.TerminalAU : 0);
+                        else h = hp_u + T.mismatchH[type * 25 + S[i + 1] * 5 + S[j - 1]];
                     }
                     cv = h < cv ? h : cv;
                     int dml = dmlring[((d + 1) % 3) * LCAP + i + 1];     // (d-2) mod 3
-                    if (dml < INF) {
+                    if (dml != I16_INF) {
                         int e = dml + T.ML_closing + lds_mlstem(T, P, rtype_of(type), S[j - 1], S[i + 1]);
                         cv = e < cv ? e : cv;
                     }
@@ -441,20 +443,28 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const short c16 = cv >= INF ? (short)I16_INF : (short)cv;
                 const short m16 = m >= INF ? (short)I16_INF : (short)m;
                 {   // G0 = c + mismatchI of (i,j) seen as the inner pair of a generic interior loop
-                    short g16 = (short)I16_INF;
-                    if (cv < INF) g16 = (short)(cv + T.mismatchI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]]);
+                    unsigned short g16 = 65535;
+                    if (cv < INF) g16 = (unsigned short)(cv + T.mismatchI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] + 32768);
                     cring[(d & 31) * CSTR + i] = g16;
                 }
                 carch[(size_t)d * LCAP + i] = c16;
                 fml[off[d] + i] = m16;
-                dmlring[(d % 3) * LCAP + i] = md;
+                dmlring[(d % 3) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 if (m < INF) { if (rowfin[i] > d) rowfin[i] = (short)d; if (colfin[j] > d) colfin[j] = (short)d; }
                 cpart[i] = INF; mdec[i] = INF;
-                if (d + 1 <= D && i + d + 1 <= n && pair_type(S[i], S[i + d + 1])) {
-                    int k = atomicAdd(&misc[2 + (cur ^ 1)], 1);
-                    list[(cur ^ 1) * LCAP + k] = (unsigned short)i;
+                if (d + 2 <= D && i + d + 2 <= n && pair_type(S[i], S[i + d + 2])) {   // paired list of diagonal d+2
+                    int k = atomicAdd(&misc[2 + (d + 2) % 3], 1);
+                    list[((d + 2) % 3) * LCAP + k] = (unsigned short)i;
                 }
             }
+        };
+        if (D >= 4) phaseA(4);
+        __syncthreads();
+        if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
+        for (int d = 4; d <= D; d++) {
+            if (tid == 0) misc[2 + d % 3] = 0;   // list(d) was consumed in the previous interval; the buffer is refilled as list(d+3) in the next one
+            phaseB(d);
+            if (d + 1 <= D) phaseA(d + 1);
             __syncthreads();
             if (dbg_cycles && tid == 0) { long long t = clock64(); tB += t - t0; t0 = t; }
         }
@@ -466,7 +476,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             __threadfence_block();
             LTab TB;
             TB.fml = fml; TB.off = off; TB.carch = carch;
-            fold_epilogue<LTab, LNT>(X, TB, span, f3, starts, lens, btbuf, LCAP + 8, btstk, misc + 4, win, max_lines, ss_stride, out_lines, out_ss,
+            fold_epilogue<LTab, LNT>(X, TB, span, f3, starts, lens, btbuf, LCAP + 8, btstk, misc + 8, win, max_lines, ss_stride, out_lines, out_ss,
                                      out_nlines, out_mfe, out_status);
             if (dbg_cycles && tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; }
         }
