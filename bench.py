@@ -184,7 +184,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(seqs)
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,136 @@
+"""GPU edge cases (empty / ragged inputs, other PRECURSOR_LEN values incl. the generic-kernel path) and full-size
+(BASELINE config[1]) checks through size-independent properties plus oracle spot checks."""
+import numpy as np
+import pytest
+
+from mir_prefer_amd import records, synth
+from tests.test_oracle_golden import mirna_record, run_predict
+
+pytestmark = pytest.mark.gpu
+
+
+def _order(names):
+    return np.argsort(np.array(names, dtype=object), kind="stable").astype(np.int32)
+
+
+def _gpu_records(out, names):
+    return [[names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
+             records.STRAND[m["strand"]], bool(m["has_star"])] for m, ss in zip(out["result"], out["ss"])]
+
+
+def test_no_alignments_and_unreached_threshold(gpu_ctx):
+    ds = synth.make_dataset([5000, 3000], 0, seed=1)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(np.zeros(0, dtype=synth.ALN_DTYPE))
+    assert gpu_ctx.candidate(10, 100, 300, _order(ds.contig_names)) == (0, 0, 0)
+    assert len(gpu_ctx.get_depth()) == 0 and len(gpu_ctx.get_peaks()) == 0
+    gpu_ctx.fold(300)
+    out = gpu_ctx.predict(1, 18, 23, False, True)
+    assert len(out["result"]) == 0 and len(out["n_passed"]) == 0
+    # a single read can never form a peak: its weight is capped at CUT and the threshold is strict (SURVEY A-2)
+    one = np.array([(0, 100, 5000, 21, 0, 0)], dtype=synth.ALN_DTYPE)
+    gpu_ctx.load_alignments(one)
+    assert gpu_ctx.candidate(10, 100, 300, _order(ds.contig_names)) == (0, 0, 0)
+
+
+def test_unsorted_alignments_are_rejected(gpu_ctx):
+    from mir_prefer_amd import capi
+    ds = synth.make_dataset([5000], 0, seed=1)
+    gpu_ctx.load_genome(ds.contigs)
+    bad = np.array([(0, 200, 50, 21, 0, 0), (0, 100, 50, 21, 0, 0)], dtype=synth.ALN_DTYPE)
+    with pytest.raises(capi.MirpError):
+        gpu_ctx.load_alignments(bad)
+
+
+@pytest.mark.parametrize("L", [150, 300, 400])
+def test_other_precursor_lengths_match_oracle(L, gpu_ctx, oracle):
+    """L = 150 and 300 run the LDS-resident fold kernel, L = 400 the generic one (span > 300)."""
+    ds = synth.make_dataset([150000, 90000], 120, n_samples=2, seed=30 + L, contig_names=["k2", "k1"], edge_cases=True)
+    names, alns = ds.contig_names, ds.sorted_alns()
+    cut, gap = 8, 80
+    _, peaks = oracle.coverage_peaks(alns, ds.contig_lens, cut)
+    win = oracle.make_windows(peaks, alns, ds.contigs, _order(names), gap, L, cut * 0.5)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(cut, gap, L, _order(names))
+    assert nwin == len(win["windows"]) and nwin > 50
+    gpu_ctx.fold(L)
+    raw = gpu_ctx.get_fold()
+    assert (raw["status"] == 0).all()
+    structs = []
+    for k, b in enumerate(win["windows"]):
+        r = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+        got = [(raw["ss"][k, j, :raw["lines"][k, j]["len"]].tobytes().decode(), int(raw["lines"][k, j]["energy"]), int(raw["lines"][k, j]["start"]))
+               for j in range(raw["n_lines"][k]) if raw["lines"][k, j]["printed"]]
+        assert got == r["lines"], k
+        assert raw["mfe"][k] == r["mfe"]
+        structs.append(oracle.structures_from_lines(r["lines"], 55))
+    out = gpu_ctx.predict(2, 18, 24, True, True)
+    case = {"cfg": {"MIN_MATURE_LEN": 18, "MAX_MATURE_LEN": 24, "ALLOW_3NT_OVERHANG": "Y", "ALLOW_NO_STAR_EXPRESSION": "Y"}, "win": win,
+            "sample_names": ds.sample_names, "alns": alns}
+    _, result = run_predict(case, oracle, structs)
+    assert _gpu_records(out, names) == [mirna_record(m, names) for _, m in result]
+
+
+def test_full_size_config1_properties(gpu_ctx, oracle):
+    """BASELINE config[1] size: 30,427,671-bp contig, 12,000 loci (~20 k windows)."""
+    G = 30427671
+    ds = synth.make_dataset([G], 12000, n_samples=1, seed=2, contig_names=["Chr1"])
+    alns = ds.sorted_alns()
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    npk, nloci, nwin = gpu_ctx.candidate(10, 100, 300, np.zeros(1, np.int32))
+    depth, peaks = gpu_ctx.get_depth(), gpu_ctx.get_peaks()
+    # coverage linearity: every thresholded depth equals the brute-force weighted pile-up at that position (sampled)
+    w = np.minimum(alns["depth"], 10).astype(np.int64)
+    rng = np.random.RandomState(0)
+    for k in rng.choice(len(depth), 300, replace=False):
+        pos = depth[k]["pos"]
+        cov = (alns["pos"] <= pos) & (alns["pos"] + alns["len"] > pos)
+        assert depth[k]["dp"] == w[cov & (alns["strand"] == 0)].sum() and depth[k]["dm"] == w[cov & (alns["strand"] == 1)].sum()
+        assert depth[k]["dp"] + depth[k]["dm"] > 10
+    assert (np.diff(depth["pos"].astype(np.int64)) > 0).all()
+    # checksum: thresholded positions are exactly the union of the runs; peaks are sorted, disjoint, >= 19 long
+    assert (peaks["end"] - peaks["start"] >= 19).all() and (peaks["start"][1:] > peaks["end"][:-1]).all()
+    inpk = np.zeros(G + 2, dtype=bool)
+    for p in peaks:
+        inpk[p["start"]:p["end"]] = True
+    assert inpk[depth["pos"]].sum() == (peaks["end"] - peaks["start"]).sum()
+    # windows stay inside the contig and hold their locus
+    win = gpu_ctx.get_windows()
+    W = win["windows"]
+    assert nwin == len(W) and 15000 < nwin < 25000
+    assert (W["ws"] >= 0).all() and (W["we"] <= G + 1).all() and (W["ws"] <= W["loc_s"]).all() and (W["we"] >= W["loc_e"]).all()
+    assert (W["seq_len"] <= 350).all()
+    # fold: deterministic across launches, and identical to the oracle on a random sample of windows
+    gpu_ctx.fold(300)
+    r1 = gpu_ctx.get_fold()
+    gpu_ctx.fold(300)
+    r2 = gpu_ctx.get_fold()
+    assert (r1["status"] == 0).all()
+    for key in ("n_lines", "mfe"):
+        assert np.array_equal(r1[key], r2[key])
+    assert np.array_equal(r1["lines"], r2["lines"])
+    for k in rng.choice(nwin, 48, replace=False):
+        b = W[k]
+        ref = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), 300)
+        got = [(r1["ss"][k, j, :r1["lines"][k, j]["len"]].tobytes().decode(), int(r1["lines"][k, j]["energy"]), int(r1["lines"][k, j]["start"]))
+               for j in range(r1["n_lines"][k]) if r1["lines"][k, j]["printed"]]
+        assert got == ref["lines"] and r1["mfe"][k] == ref["mfe"]
+    # every structure line is a balanced dot-bracket string that fits its window
+    for k in rng.choice(nwin, 500, replace=False):
+        for j in range(r1["n_lines"][k]):
+            ln = r1["lines"][k, j]
+            s = r1["ss"][k, j, :ln["len"]].tobytes()
+            assert s.count(b"(") == s.count(b")") and ln["start"] >= 1 and ln["start"] + ln["len"] - 1 <= W[k]["seq_len"] + 1
+    out = gpu_ctx.predict(1, 18, 23, False, True)
+    res = out["result"]
+    assert len(res) > 1000
+    assert (res["fold_s"] < res["fold_e"]).all() and (res["mat_e"] - res["mat_s"] >= 18).all() and (res["mat_e"] - res["mat_s"] <= 23).all()
+    assert (res["mat_s"] >= res["fold_s"]).all() and (res["mat_e"] <= res["fold_e"]).all()
+    # most planted hairpins are recovered (sanity of the synthetic workload, not a parity claim)
+    found = np.zeros(G + 2, dtype=bool)
+    for m in res:
+        found[m["fold_s"]:m["fold_e"]] = True
+    hit = sum(found[(a + b) // 2] for _, a, b, _ in ds.planted)
+    assert hit > 0.6 * len(ds.planted)
