@@ -13,7 +13,30 @@ namespace mirp {
 #define MAXLOOP MIRP_MAXLOOP
 #define INF MIRP_INF
 
+// Optional LDS-resident int16 copies of the small parameter tables for the backtracks / exterior sweep (a pointer chase
+// through global memory costs ~1 us per traced pair otherwise).  int11/int21/int22 and the hairpin size table stay global.
+struct EpiTables {
+    short stack[64], bulge[32], internal_loop[32];
+    short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200], mismatchExt[200];
+    short dangle5[40], dangle3[40];
+    short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
+};
+
+__device__ inline void fill_epi_tables(EpiTables* E, const FoldParams* __restrict__ P, int tid, int nt) {
+    for (int x = tid; x < 64; x += nt) E->stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
+    for (int x = tid; x < 31; x += nt) { E->bulge[x] = (short)min(P->bulge[x], 32767); E->internal_loop[x] = (short)min(P->internal_loop[x], 32767); }
+    for (int x = tid; x < 200; x += nt) {
+        int t = x / 25, a = (x % 25) / 5, b = x % 5;
+        E->mismatchI[x] = (short)min(P->mismatchI[t][a][b], 32767); E->mismatchH[x] = (short)min(P->mismatchH[t][a][b], 32767);
+        E->mismatchM[x] = (short)P->mismatchM[t][a][b]; E->mismatch1nI[x] = (short)min(P->mismatch1nI[t][a][b], 32767);
+        E->mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], 32767); E->mismatchExt[x] = (short)P->mismatchExt[t][a][b];
+    }
+    for (int x = tid; x < 40; x += nt) { E->dangle5[x] = (short)P->dangle5[x / 5][x % 5]; E->dangle3[x] = (short)P->dangle3[x / 5][x % 5]; }
+    if (tid == 0) { E->ML_closing = (short)P->ML_closing; E->ML_intern = (short)P->ML_intern; E->TerminalAU = (short)P->TerminalAU; E->ninio = (short)P->ninio; E->MAX_NINIO = (short)P->MAX_NINIO; }
+}
+
 struct WinCtx {
+    const EpiTables* E = nullptr;   // LDS tables (optional)
     const FoldParams* __restrict__ P;
     const unsigned char* S;   // LDS, 0..n+1
     const unsigned char* seq; // LDS, upper-case RNA chars, 1-based
@@ -38,14 +61,61 @@ __device__ __forceinline__ int e_hairpin(const WinCtx& X, int i, int j, int type
         if (s != -32768) return s;
         return X.P->hairpinE[3] + (type > 2 ? X.P->TerminalAU : 0);
     }
+    if (X.E) return X.P->hairpinE[u] + X.E->mismatchH[type * 25 + X.S[i + 1] * 5 + X.S[j - 1]];
     return X.P->hairpinE[u] + X.P->mismatchH[type][X.S[i + 1]][X.S[j - 1]];
 }
 
+__device__ __forceinline__ int mlstem_x(const WinCtx& X, int type, int a, int b) {
+    if (X.E) {
+        int e = X.E->ML_intern + (type > 2 ? X.E->TerminalAU : 0);
+        if (a >= 0 && b >= 0) e += X.E->mismatchM[type * 25 + a * 5 + b];
+        else if (a >= 0) e += X.E->dangle5[type * 5 + a];
+        else if (b >= 0) e += X.E->dangle3[type * 5 + b];
+        return e;
+    }
+    return e_mlstem(X.P, type, a, b);
+}
+
 __device__ __forceinline__ int ext_term(const WinCtx& X, int i, int k, int type) {
-    return e_extloop(X.P, type, i > 1 ? (int)X.S[i - 1] : -1, k < X.n ? (int)X.S[k + 1] : -1);
+    const int a = i > 1 ? (int)X.S[i - 1] : -1, b = k < X.n ? (int)X.S[k + 1] : -1;
+    if (X.E) {
+        int e = (type > 2 ? X.E->TerminalAU : 0);
+        if (a >= 0 && b >= 0) e += X.E->mismatchExt[type * 25 + a * 5 + b];
+        else if (a >= 0) e += X.E->dangle5[type * 5 + a];
+        else if (b >= 0) e += X.E->dangle3[type * 5 + b];
+        return e;
+    }
+    return e_extloop(X.P, type, a, b);
 }
 __device__ __forceinline__ int ml_term(const WinCtx& X, int i, int j, int type) {
-    return e_mlstem(X.P, type, i > 1 ? (int)X.S[i - 1] : -1, j < X.n ? (int)X.S[j + 1] : -1);
+    return mlstem_x(X, type, i > 1 ? (int)X.S[i - 1] : -1, j < X.n ? (int)X.S[j + 1] : -1);
+}
+
+// interior loop via the LDS tables when present
+__device__ __forceinline__ int intloop_x(const WinCtx& X, int n1, int n2, int type, int type2, int si1, int sj1, int sp1, int sq1) {
+    if (!X.E) return e_intloop(X.P, n1, n2, type, type2, si1, sj1, sp1, sq1);
+    const EpiTables& T = *X.E;
+    const FoldParams* __restrict__ P = X.P;
+    int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;
+    if (nl == 0) return T.stack[type * 8 + type2];
+    if (ns == 0) {
+        int e = T.bulge[nl];
+        if (nl == 1) e += T.stack[type * 8 + type2];
+        else e += (type > 2 ? T.TerminalAU : 0) + (type2 > 2 ? T.TerminalAU : 0);
+        return e;
+    }
+    if (ns == 1) {
+        if (nl == 1) return P->int11[type][type2][si1][sj1];
+        if (nl == 2) return (n1 == 1) ? P->int21[type][type2][si1][sq1][sj1] : P->int21[type2][type][sq1][si1][sp1];
+        int x = (nl - 1) * T.ninio;
+        return T.internal_loop[nl + 1] + (x < T.MAX_NINIO ? x : T.MAX_NINIO) + T.mismatch1nI[type * 25 + si1 * 5 + sj1] + T.mismatch1nI[type2 * 25 + sq1 * 5 + sp1];
+    }
+    if (ns == 2) {
+        if (nl == 2) return P->int22[type][type2][si1][sp1][sq1][sj1];
+        if (nl == 3) return T.internal_loop[5] + T.ninio + T.mismatch23I[type * 25 + si1 * 5 + sj1] + T.mismatch23I[type2 * 25 + sq1 * 5 + sp1];
+    }
+    int x = (nl - ns) * T.ninio;
+    return T.internal_loop[nl + ns] + (x < T.MAX_NINIO ? x : T.MAX_NINIO) + T.mismatchI[type * 25 + si1 * 5 + sj1] + T.mismatchI[type2 * 25 + sq1 * 5 + sp1];
 }
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -161,7 +231,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
                     int t2 = pair_type(X.S[p], X.S[q]);
                     if (t2) {
                         t2 = rtype_of(t2);
-                        int e = e_intloop(X.P, p - i - 1, j - q - 1, type, t2, X.S[i + 1], X.S[j - 1], X.S[p - 1], X.S[q + 1]);
+                        int e = intloop_x(X, p - i - 1, j - q - 1, type, t2, X.S[i + 1], X.S[j - 1], X.S[p - 1], X.S[q + 1]);
                         hit = (cij == e + T.C(q - p, p));
                     }
                 }
@@ -173,7 +243,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
                 if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
                 continue;
             }
-            int mm = X.P->ML_closing + e_mlstem(X.P, rtype_of(type), X.S[j - 1], X.S[i + 1]);
+            int mm = X.P->ML_closing + mlstem_x(X, rtype_of(type), X.S[j - 1], X.S[i + 1]);
             int found = -1;
             for (int kb = i + 2 + TURN; kb <= j - 3 - TURN && found < 0; kb += 64) {
                 int k = kb + lane;
@@ -222,14 +292,23 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
                               int* __restrict__ out_status) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = X.n, D = X.D;
-    // ---- f3 (exterior) sweep: sequential in i, lane-parallel over the partner j (wave 0)
+    // ---- f3 (exterior) sweep.  f3[i] = min(f3[i+1], min_j c(i,j) + ext(i,j) + f3[j+1]) is sequential in i, but only through f3:
+    // rows are processed in blocks of NW = NT/64.  Step 1 (one wave per row, all in parallel): the partners j whose f3[j+1] is already
+    // final (j+1 above the block) are reduced to one partial minimum per row, and the few partners inside the block (span < NW)
+    // are fetched to LDS.  Step 2 (wave 0): the short sequential chain through the block touches LDS only.  The backtrack stacks
+    // are idle here and serve as scratch: part[NW], inner[NW][NW].
+    constexpr int NW = NT / 64;
+    int* part = btstk;
+    int* inner = btstk + NW;
     for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
     __syncthreads();
-    if (wave == 0) {
-        for (int i = n - TURN - 1; i >= 1; i--) {
-            int best = f3[i + 1];
-            int jmax = (i + D < n) ? i + D : n;
-            for (int j = i + TURN + 1 + lane; j <= jmax; j += 64) {
+    for (int i_hi = n - TURN - 1; i_hi >= 1; i_hi -= NW) {
+        const int i = i_hi - wave;
+        if (i >= 1) {
+            int best = INF;
+            const int jmax = (i + D < n) ? i + D : n;
+            const int j0 = (i + TURN + 1 > i_hi) ? i + TURN + 1 : i_hi;    // f3[j+1] final for j >= i_hi
+            for (int j = j0 + lane; j <= jmax; j += 64) {
                 int type = pair_type(X.S[i], X.S[j]);
                 if (type) {
                     int e = f3[j + 1] + T.C(j - i, i) + ext_term(X, i, j, type);
@@ -237,10 +316,38 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
                 }
             }
             best = wave_min(best);
-            if (lane == 0) f3[i] = best;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) part[wave] = best;
+            if (lane < NW) {                                             // partners inside the block: j = i+TURN+1+lane <= i_hi-1
+                const int j = i + TURN + 1 + lane;
+                int e = INF;
+                if (j <= i_hi - 1 && j <= jmax) {
+                    int type = pair_type(X.S[i], X.S[j]);
+                    if (type) e = T.C(j - i, i) + ext_term(X, i, j, type);
+                }
+                inner[wave * NW + lane] = e;
+            }
         }
+        __syncthreads();
+        if (wave == 0) {
+            const int i_lo = (i_hi - NW + 1 > 1) ? i_hi - NW + 1 : 1;
+            for (int r = i_hi; r >= i_lo; r--) {
+                const int w = i_hi - r;
+                int best = f3[r + 1];
+                const int p = part[w];
+                best = p < best ? p : best;
+                if (lane < NW) {
+                    const int e = inner[w * NW + lane];
+                    if (e < INF) { const int c = e + f3[r + TURN + 1 + lane + 1]; best = c < best ? c : best; }
+                }
+                best = wave_min(best);
+                if (lane == 0) f3[r] = best;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
         // ---- structure starts, descending: l>=2 with f3[l]!=f3[l+1] && f3[l-1]==f3[l]; l==1 with f3[1]!=f3[2]
         int cnt = 0;
         for (int base = n - TURN - 1; base >= 1; base -= 64) {

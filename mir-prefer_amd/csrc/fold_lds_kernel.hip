@@ -7,10 +7,12 @@
 //   * c keeps its last 32 anti-diagonals in an LDS ring (interior loops reach back MAXLOOP+2) and is
 //     archived once, coalesced, as int16 to a per-workgroup global slab for the exterior (f3) sweep
 //     and the backtracks;
-//   * per anti-diagonal: phase A = interior-loop candidates (work items = (paired cell, p); the q
-//     partners come from per-base partner bitmasks, so unpairable (p,q) are never visited) and
-//     multiloop splits (lane = cell, sub-ranges of the split point across wave groups), both
-//     reduced with LDS atomic min; phase B = one thread per cell finalises c, fML, DML;
+//   * per anti-diagonal: phase A = interior-loop candidates (32 lanes per paired cell; the ring stores
+//     G0 = c + inner mismatch, so a generic candidate is one LDS read; stack/bulge/1xn/2x3 in four
+//     class-homogeneous rounds; the four small loops that need the big int11/21/22 tables are issued
+//     first and consumed last) and multiloop splits (lane = cell, wave-uniform split point, scalar
+//     offsets), reduced with shuffles + LDS atomic min; phase B = one thread per cell finalises
+//     c, fML, DML and runs in the same barrier interval as phase A of the next diagonal;
 //   * INF is never read inside the split loop: fML is monotone (ML_BASE = 0), so each row/column
 //     has a first-finite distance and the split range is clipped to it;
 //   * windows whose energies leave the int16 range are flagged and re-run by the generic kernel.
@@ -43,8 +45,8 @@ struct LdsTables {          // int16 copies of the hot parameter tables
 struct LTab {               // table accessors for the shared epilogue/backtrack
     const short* fml;       // LDS
     const int* off;         // LDS: triangular offset of diagonal d (valid for d >= 4)
-    const short* carch;     // global archive of c, (d,i) -> d*LCAP + i
-    __device__ __forceinline__ int C(int d, int i) const { int v = carch[(size_t)d * LCAP + i]; return v == I16_INF ? INF : v; }
+    const short* carch;     // global archive of c, triangular like fML: (d,i) -> off[d] + i (keeps a workgroup's slab ~88 KB, L2-friendly)
+    __device__ __forceinline__ int C(int d, int i) const { int v = carch[off[d] + i]; return v == I16_INF ? INF : v; }
     __device__ __forceinline__ int M(int d, int i) const {
         if (d < 4) return INF;
         int v = fml[off[d] + i];
@@ -88,7 +90,7 @@ __device__ __forceinline__ int lds_intloop(const LdsTables& T, const FoldParams*
 }
 
 struct LdsLayout {
-    size_t fml, aux, f3, rowfin, colfin, S, seq, spec, pmask, list, off, tabs, misc, starts, lens, total;
+    size_t fml, aux, f3, rowfin, colfin, S, seq, spec, list, off, tabs, misc, starts, lens, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     LdsLayout L;
@@ -106,9 +108,8 @@ __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     L.rowfin = take((LCAP + 8) * 2);
     L.colfin = take((LCAP + 8) * 2);
     L.S = take(LCAP + 8);
-    L.seq = take(LCAP + 8);
+    L.seq = L.f3;   // staged characters are only needed while the special-hairpin table is built; f3 is epilogue-only
     L.spec = take((size_t)3 * (LCAP + 8) * 2);
-    L.pmask = take(5 * 12 * 4);
     L.list = take((size_t)3 * LCAP * 2 + 16);
     L.off = take((LDMAX + 2) * 4);
     L.tabs = take(sizeof(LdsTables));
@@ -139,7 +140,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
     short* spec = (short*)(smem + LY.spec);
-    unsigned int* pmask = (unsigned int*)(smem + LY.pmask);         // [5][12]
     unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LCAP], list of diagonal d in buffer d % 3
     int* off = (int*)(smem + LY.off);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     int* lens = (int*)(smem + LY.lens);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nc = LCAP + 8;
-    short* carch = carch_all + (size_t)blockIdx.x * (size_t)(LDMAX + 1) * LCAP;
+    short* carch = carch_all + (size_t)blockIdx.x * (size_t)(LDMAX + 1) * LCAP;   // slab capacity; only the triangle of the window is touched
 
     // ---- one-time: hot parameter tables into LDS
     for (int x = tid; x < 64; x += LNT) T.stack[x] = (short)min(P->stack[x >> 3][x & 7], (int)I16_INF);
@@ -209,7 +209,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             seq[x] = ch;
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
-        for (int x = tid; x < 60; x += LNT) pmask[x] = 0u;
         for (int x = tid; x < LCAP + 8; x += LNT) { rowfin[x] = 20000; colfin[x] = 20000; }
         for (int x = tid; x < 3 * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
         for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = INF;
@@ -229,12 +228,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     for (int k = 0; k < 16; k++) { bool m = true; for (int t = 0; t < 6; t++) m = m && (seq[x + t] == (unsigned char)P->tetra[k][t]); if (m && s4 == -32768) s4 = (short)P->tetraE[k]; }
                 if (x + 7 <= n)
                     for (int k = 0; k < 4; k++) { bool m = true; for (int t = 0; t < 8; t++) m = m && (seq[x + t] == (unsigned char)P->hexa[k][t]); if (m && s6 == -32768) s6 = (short)P->hexaE[k]; }
-                // partner masks: bit q of pmask[b] set iff base b can pair with S[q]
-                int b = S[x];
-                if (b == 1) atomicOr(&pmask[4 * 12 + (x >> 5)], 1u << (x & 31));                                        // A pairs with U
-                else if (b == 2) atomicOr(&pmask[3 * 12 + (x >> 5)], 1u << (x & 31));                                   // C pairs with G
-                else if (b == 3) { atomicOr(&pmask[2 * 12 + (x >> 5)], 1u << (x & 31)); atomicOr(&pmask[4 * 12 + (x >> 5)], 1u << (x & 31)); }  // G with C,U
-                else if (b == 4) { atomicOr(&pmask[1 * 12 + (x >> 5)], 1u << (x & 31)); atomicOr(&pmask[3 * 12 + (x >> 5)], 1u << (x & 31)); }  // U with A,G
             }
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
         }
@@ -305,7 +298,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         unsigned bg = 65535u;
                         const int um = umax < MAXLOOP ? umax : MAXLOOP;
                         const int u = 6 + sub;
-                        if (u <= um) {
+                        if (u <= um && !(dbg_flags & 4)) {
                             const unsigned short* row = cring + ((d - 2 - u) & 31) * CSTR + i + 1;
                             const unsigned short* pk = T.penK + (u - 6) * 34;   // row stride 17 dwords: conflict-free across lanes
 #pragma unroll
@@ -323,7 +316,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         const int tau = T.TerminalAU, nin = T.ninio, mxn = T.MAX_NINIO;
                         const short* strow = T.stack + type * 8;
 #pragma unroll
-                        for (int r4 = 0; r4 < 4; r4++) {
+                        for (int r4 = 0; r4 < ((dbg_flags & 8) ? 0 : 4); r4++) {
                             int n1, n2;
                             if (r4 == 0) { n1 = 0; n2 = sub; }                                   // stack + 3'-side bulges
                             else if (r4 == 1) { n1 = sub + 1; n2 = 0; }                          // 5'-side bulges
@@ -369,29 +362,68 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
                 if (sub < nsub && !(dbg_flags & 2)) {
                     const int i = cell + 1, j = i + d;
-                    int tlo = 30000, rng = 0;
+                    // per-lane finite split range [tlo, thi]; lanes without one (no cell, or a row/column that is still all-INF) are "don't care"
+                    int tlo = 4, thi = d - 5;
+                    bool live = false;
                     if (cell < ncell) {
                         int a = rowfin[i]; if (a < 4) a = 4;
                         int b = d - 1 - colfin[j]; if (b > d - 5) b = d - 5;
-                        if (b >= a) { tlo = a; rng = b - a; }
+                        if (b >= a) { tlo = a; thi = b; live = true; }
                     }
+                    // wave-wide common range: inside [TLO, THI] every live lane is valid, so the loop body needs no predicate
+                    int TLO = live ? tlo : 4, THI = live ? thi : d - 5;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { int x = __shfl_xor(TLO, o); TLO = x > TLO ? x : TLO; int y = __shfl_xor(THI, o); THI = y < THI ? y : THI; }
+                    TLO = __builtin_amdgcn_readfirstlane(TLO); THI = __builtin_amdgcn_readfirstlane(THI);
+                    const int rng = thi - tlo;
                     int best = INF;
                     // offsets of the two operand diagonals advance by second-order recurrences (scalar unit):
                     //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1,  off(x) = (x-4) n - (x(x-1)/2 - 6)
-                    int t = 4 + sub;
-                    int o1 = (t - 4) * n - ((t * (t - 1)) / 2 - 6);
-                    int uu = d - t - 1;
-                    int o2 = (uu - 4) * n - ((uu * (uu - 1)) / 2 - 6) + t + 1;
                     const int s1 = nsub, ss = nsub * nsub;
-                    int inc1 = s1 * n - s1 * t - (s1 * (s1 - 1)) / 2;           // off(t+s) - off(t)
-                    int inc2 = -(s1 * n) + s1 * uu - (s1 * (s1 + 1)) / 2 + s1;  // off(uu-s) - off(uu) + s
-#pragma unroll 4
-                    for (; t <= d - 5; t += s1) {
-                        const int e = (int)fml[o1 + i] + (int)fml[o2 + i];
-                        if ((unsigned)(t - tlo) <= (unsigned)rng) best = e < best ? e : best;
-                        o1 += inc1; inc1 -= ss;
-                        o2 += inc2; inc2 -= ss;
+                    int t = 4 + sub;
+                    int o1 = __builtin_amdgcn_readfirstlane((t - 4) * n - ((t * (t - 1)) / 2 - 6));
+                    int uu = d - t - 1;
+                    int o2 = __builtin_amdgcn_readfirstlane((uu - 4) * n - ((uu * (uu - 1)) / 2 - 6) + t + 1);
+                    int inc1 = __builtin_amdgcn_readfirstlane(s1 * n - s1 * t - (s1 * (s1 - 1)) / 2);           // off(t+s) - off(t)
+                    int inc2 = __builtin_amdgcn_readfirstlane(-(s1 * n) + s1 * uu - (s1 * (s1 + 1)) / 2 + s1);  // off(uu-s) - off(uu) + s
+                    const short* fi = fml + i;
+                    // leading edge: t < TLO (predicated)
+                    for (; t <= d - 5 && t < TLO; t += s1) {
+                        const int e = (int)fi[o1] + (int)fi[o2];
+                        if (live && (unsigned)(t - tlo) <= (unsigned)rng) best = e < best ? e : best;
+                        o1 += inc1; inc1 -= ss; o2 += inc2; inc2 -= ss;
                     }
+                    // interior: four splits per trip, eight LDS reads in flight, no predicate; the byte offsets of the two operand
+                    // diagonals are kept in SGPRs (scalar adds), so a relaxation costs two address adds, one add and one min on the VALU
+                    {
+                        const char* fb = reinterpret_cast<const char*>(fml + i);
+                        int so1 = __builtin_amdgcn_readfirstlane(o1 * 2), so2 = __builtin_amdgcn_readfirstlane(o2 * 2);
+                        int si1 = __builtin_amdgcn_readfirstlane(inc1 * 2), si2 = __builtin_amdgcn_readfirstlane(inc2 * 2);
+                        const int sss = __builtin_amdgcn_readfirstlane(ss * 2);
+#define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss))
+                        for (; t + 3 * s1 <= THI; t += 4 * s1) {
+                            const int a0 = *reinterpret_cast<const short*>(fb + so1), b0 = *reinterpret_cast<const short*>(fb + so2);
+                            MIRP_SSTEP();
+                            const int a1 = *reinterpret_cast<const short*>(fb + so1), b1 = *reinterpret_cast<const short*>(fb + so2);
+                            MIRP_SSTEP();
+                            const int a2 = *reinterpret_cast<const short*>(fb + so1), b2 = *reinterpret_cast<const short*>(fb + so2);
+                            MIRP_SSTEP();
+                            const int a3 = *reinterpret_cast<const short*>(fb + so1), b3 = *reinterpret_cast<const short*>(fb + so2);
+                            MIRP_SSTEP();
+                            int e0 = a0 + b0, e1 = a1 + b1, e2 = a2 + b2, e3 = a3 + b3;
+                            e0 = e0 < e1 ? e0 : e1; e2 = e2 < e3 ? e2 : e3; e0 = e0 < e2 ? e0 : e2;
+                            best = e0 < best ? e0 : best;
+                        }
+#undef MIRP_SSTEP
+                        o1 = so1 / 2; o2 = so2 / 2; inc1 = si1 / 2; inc2 = si2 / 2;
+                    }
+                    // trailing edge (predicated)
+                    for (; t <= d - 5; t += s1) {
+                        const int e = (int)fi[o1] + (int)fi[o2];
+                        if (live && (unsigned)(t - tlo) <= (unsigned)rng) best = e < best ? e : best;
+                        o1 += inc1; inc1 -= ss; o2 += inc2; inc2 -= ss;
+                    }
+                    if (!live) best = INF;
                     if (best < INF) atomicMin(&mdec[i], best);
                 }
             }
@@ -447,7 +479,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (cv < INF) g16 = (unsigned short)(cv + T.mismatchI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] + 32768);
                     cring[(d & 31) * CSTR + i] = g16;
                 }
-                carch[(size_t)d * LCAP + i] = c16;
+                carch[off[d] + i] = c16;
                 fml[off[d] + i] = m16;
                 dmlring[(d % 3) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 if (m < INF) { if (rowfin[i] > d) rowfin[i] = (short)d; if (colfin[j] > d) colfin[j] = (short)d; }
@@ -470,10 +502,16 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         }
         const int overflow = misc[1];
         __syncthreads();
-        if (overflow) {   // int16 range exceeded: hand the window to the generic kernel
+        if (dbg_flags & 16) {
+        } else if (overflow) {   // int16 range exceeded: hand the window to the generic kernel
             if (tid == 0) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win; out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; }
         } else {
             __threadfence_block();
+            // small parameter tables for the backtracks, built in the tail of the (now free) fill scratch
+            EpiTables* EP = reinterpret_cast<EpiTables*>(smem + LY.aux + ((((size_t)LNW * (LCAP + 8) + 15) & ~(size_t)15) + (size_t)LNW * 3 * BT_STACK * 4));
+            fill_epi_tables(EP, P, tid, LNT);
+            __syncthreads();
+            X.E = EP;
             LTab TB;
             TB.fml = fml; TB.off = off; TB.carch = carch;
             fold_epilogue<LTab, LNT>(X, TB, span, f3, starts, lens, btbuf, LCAP + 8, btstk, misc + 8, win, max_lines, ss_stride, out_lines, out_ss,
