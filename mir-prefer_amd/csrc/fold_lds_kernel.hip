@@ -280,15 +280,46 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     }
                 }
             }
-            // phase A1: 32 lanes per paired cell sweep the (n1,n2) combination tables
+            // phase A1: 32 lanes per paired cell
             if (!(dbg_flags & 1)) {
                 const int sub = tid & 31;
-                const int ng = T.n_gcombo, no = T.n_ocombo;
+                // the lane's loop size u = 6 + sub is fixed across cells: its 27 penalty taps are loaded once per diagonal (packed pairs)
+                unsigned pk2[14];
+                {
+                    const unsigned* pkp = reinterpret_cast<const unsigned*>(T.penK + (sub < 25 ? sub : 24) * 34 + 2);
+#pragma unroll
+                    for (int k = 0; k < 14; k++) pk2[k] = pkp[k];
+                }
+                // lane constants of the four non-generic rounds (the lane's (n1, n2) per round do not depend on the cell)
+                const int umax = d - 2 - (TURN + 1);             // n1 + n2 <= umax keeps q - p >= TURN + 1
+                int on1[4], on2[4], okc[4], kc[4];
+                {
+                    const int nin = T.ninio, mxn = T.MAX_NINIO;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        int n1, n2;
+                        if (r4 == 0) { n1 = 0; n2 = sub; }                                   // stack + 3'-side bulges
+                        else if (r4 == 1) { n1 = sub + 1; n2 = 0; }                          // 5'-side bulges
+                        else if (r4 == 2) { n1 = 1; n2 = sub + 3; }                          // 1 x n
+                        else { n1 = sub < 27 ? sub + 3 : sub - 25; n2 = sub < 27 ? 1 : 30 - sub; }   // n x 1, then 2x3 (lane 27), 3x2 (lane 28)
+                        const int u = n1 + n2;
+                        bool ok = u <= umax && u <= MAXLOOP;
+                        if (r4 == 1) ok = ok && sub < 30;
+                        if (r4 == 2) ok = ok && sub < 27;
+                        if (r4 == 3) ok = ok && sub < 29;
+                        on1[r4] = n1; on2[r4] = n2; okc[r4] = ok ? 1 : 0;
+                        const int uu = ok ? u : 0;
+                        int k;
+                        if (r4 <= 1) k = uu == 0 ? 0 : (int)T.bulge[uu];
+                        else if (r4 == 2 || sub < 27) { int y = (uu - 2) * nin; y = y < mxn ? y : mxn; k = (int)T.internal_loop[uu] + y; }
+                        else k = (int)T.internal_loop[5] + nin;
+                        kc[r4] = k;
+                    }
+                }
                 for (int cidx = tid >> 5; cidx < ncp; cidx += LNT / 32) {
                     const int i = clist[cidx], j = i + d;
                     const int type = pair_type(S[i], S[j]);
                     const int o_out = type * 25 + S[i + 1] * 5 + S[j - 1];
-                    const int umax = d - 2 - (TURN + 1);             // n1 + n2 <= umax keeps q - p >= TURN + 1
                     int best = INF;
                     // generic loops (n1, n2 >= 2, u = n1 + n2 >= 6): il[u] + min(MAX_NINIO, |n1-n2| ninio) + mismatchI(outer) + G0.
                     // The candidates of one size u are a contiguous run of ring row d-2-u; each lane takes the sizes u = 6 + sub, 38 + ... and
@@ -300,10 +331,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         const int u = 6 + sub;
                         if (u <= um && !(dbg_flags & 4)) {
                             const unsigned short* row = cring + ((d - 2 - u) & 31) * CSTR + i + 1;
-                            const unsigned short* pk = T.penK + (u - 6) * 34;   // row stride 17 dwords: conflict-free across lanes
 #pragma unroll
                             for (int n1 = 2; n1 <= 28; n1++) {
-                                const unsigned e = (unsigned)row[n1] + (unsigned)pk[n1];
+                                const unsigned pen = (n1 & 1) ? (pk2[(n1 - 2) >> 1] >> 16) : (pk2[(n1 - 2) >> 1] & 0xffffu);
+                                const unsigned e = (unsigned)row[n1] + pen;
                                 bg = e < bg ? e : bg;
                             }
                         }
@@ -313,20 +344,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     {
                         const int au1 = type > 2 ? T.TerminalAU : 0;
                         const int m1 = T.mismatch1nI[o_out], m2 = T.mismatch23I[o_out];
-                        const int tau = T.TerminalAU, nin = T.ninio, mxn = T.MAX_NINIO;
+                        const int tau = T.TerminalAU;
                         const short* strow = T.stack + type * 8;
 #pragma unroll
                         for (int r4 = 0; r4 < ((dbg_flags & 8) ? 0 : 4); r4++) {
-                            int n1, n2;
-                            if (r4 == 0) { n1 = 0; n2 = sub; }                                   // stack + 3'-side bulges
-                            else if (r4 == 1) { n1 = sub + 1; n2 = 0; }                          // 5'-side bulges
-                            else if (r4 == 2) { n1 = 1; n2 = sub + 3; }                          // 1 x n
-                            else { n1 = sub < 27 ? sub + 3 : sub - 25; n2 = sub < 27 ? 1 : 30 - sub; }   // n x 1, then 2x3 (lane 27), 3x2 (lane 28)
-                            const int u = n1 + n2;
-                            bool ok = u <= umax && u <= MAXLOOP;
-                            if (r4 == 1) ok = ok && sub < 30;
-                            if (r4 == 2) ok = ok && sub < 27;
-                            if (r4 == 3) ok = ok && sub < 29;
+                            const int n1 = on1[r4], n2 = on2[r4], u = n1 + n2;
+                            bool ok = okc[r4] != 0;
                             const int p = i + 1 + n1, q = j - 1 - n2;
                             const int g0u = ok ? (int)cring[((q - p) & 31) * CSTR + p] : 65535;
                             ok = ok && g0u != 65535;
@@ -337,12 +360,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             int e;
                             if (r4 <= 1) {
                                 const int st = strow[t2];
-                                e = u == 0 ? st : (int)T.bulge[u] + (u == 1 ? st : au1 + (t2 > 2 ? tau : 0));
+                                e = u == 0 ? st : kc[r4] + (u == 1 ? st : au1 + (t2 > 2 ? tau : 0));
                             } else if (r4 == 2 || sub < 27) {
-                                int y = (u - 2) * nin; y = y < mxn ? y : mxn;
-                                e = (int)T.internal_loop[u] + y + m1 + (int)T.mismatch1nI[code];
+                                e = kc[r4] + m1 + (int)T.mismatch1nI[code];
                             } else {
-                                e = (int)T.internal_loop[5] + nin + m2 + (int)T.mismatch23I[code];
+                                e = kc[r4] + m2 + (int)T.mismatch23I[code];
                             }
                             e += cpq;
                             if (ok && e < best) best = e;
