@@ -129,6 +129,12 @@ int mirp_fold(mirp_ctx* ctx, int32_t span, int32_t max_lines);
 /* Fold output of the resident windows, same layout as mirp_fold_batch. */
 int mirp_get_fold(mirp_ctx* ctx, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t* max_lines, int32_t** n_lines, int32_t** mfe,
                   int32_t** status);
+/* Per-window summary of the resident fold output (no structure text): n_lines, mfe, status as in mirp_fold_batch. */
+int mirp_get_fold_summary(mirp_ctx* ctx, int32_t** n_lines, int32_t** mfe, int32_t** status, int64_t* n_windows);
+/* Writes the fold stage artefact `<prefix>_rnalfoldoutput_<i>` in RNALfold's own text format (MP:3085-3098; consumed by MP:1541-1599):
+ * for every resident window the `>` header line taken from fasta_path (the candidate stage's FASTA), the printed structure lines
+ * "%s (%6.2f) %4d", the upper-cased T->U sequence and " (%6.2f)". */
+int mirp_write_fold_text(mirp_ctx* ctx, const char* fasta_path, const char* out_path);
 /* Replaces gen_miRNA_loci_nopredict (MP:2435-2502) for the resident windows: per-window check_loci, the 0/(L,R) pairing
  * of filter_next_loci (MP:2373-2432) and the "first mature only" rule (MP:2494).  Out: result[n_result] in window order,
  * ss_text[n_result*ss_stride] NUL-terminated structure strings, n_passed[n_windows] = len(miRNAs) per FASTA entry. */

@@ -62,6 +62,10 @@ def load_library():
     lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
     lib.mirp_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.mirp_write_fold_text.restype = C.c_int
+    lib.mirp_get_fold_summary.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
+    lib.mirp_get_fold_summary.restype = C.c_int
     for f in ("mirp_load_genome", "mirp_load_alignments", "mirp_candidate", "mirp_get_depth", "mirp_get_peaks", "mirp_get_loci",
               "mirp_get_windows", "mirp_fold", "mirp_get_fold", "mirp_predict", "mirp_last_timings"):
         getattr(lib, f).restype = C.c_int
@@ -211,6 +215,19 @@ class Context:
 
     def fold(self, span, max_lines=96):
         self._check(self.lib.mirp_fold(self.h, int(span), int(max_lines)), "mirp_fold")
+
+    def fold_summary(self):
+        vp = C.c_void_p
+        nl, mfe, st, n = vp(), vp(), vp(), C.c_int64()
+        self._check(self.lib.mirp_get_fold_summary(self.h, C.byref(nl), C.byref(mfe), C.byref(st), C.byref(n)), "mirp_get_fold_summary")
+        return {"n_lines": _copy_out(self.lib, nl, np.int32, n.value), "mfe": _copy_out(self.lib, mfe, np.int32, n.value),
+                "status": _copy_out(self.lib, st, np.int32, n.value)}
+
+    def fold_status(self):
+        return self.fold_summary()["status"]
+
+    def write_fold_text(self, fasta_path, out_path):
+        self._check(self.lib.mirp_write_fold_text(self.h, str(fasta_path).encode(), str(out_path).encode()), "mirp_write_fold_text")
 
     def get_fold(self):
         vp = C.c_void_p

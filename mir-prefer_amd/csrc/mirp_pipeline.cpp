@@ -313,6 +313,60 @@ extern "C" int mirp_get_fold(mirp_ctx* c, MirpFoldLine** lines, char** ss, int32
     return 0;
 }
 
+extern "C" int mirp_get_fold_summary(mirp_ctx* c, int32_t** n_lines, int32_t** mfe, int32_t** status, int64_t* n_windows) {
+    if (!c) return -1;
+    if (!n_lines || !mfe || !status || !n_windows) return fail(c, -1, "mirp_get_fold_summary: null argument");
+    if (!c->have_fold) return fail(c, -1, "mirp_get_fold_summary: run mirp_fold first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nw = (size_t)c->n_windows;
+    int32_t* hn = host_copy<int32_t>(c, c->nlines.p, nw);
+    int32_t* hm = host_copy<int32_t>(c, c->mfe.p, nw);
+    int32_t* ht = host_copy<int32_t>(c, c->status.p, nw);
+    if (!hn || !hm || !ht) { std::free(hn); std::free(hm); std::free(ht); return fail(c, -2, "D2H failed"); }
+    *n_lines = hn; *mfe = hm; *status = ht; *n_windows = c->n_windows;
+    return 0;
+}
+
+extern "C" int mirp_write_fold_text(mirp_ctx* c, const char* fasta_path, const char* out_path) {
+    if (!c) return -1;
+    if (!fasta_path || !out_path) return fail(c, -1, "mirp_write_fold_text: null argument");
+    if (!c->have_fold) return fail(c, -1, "mirp_write_fold_text: run mirp_fold first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nw = (size_t)c->n_windows, ml = (size_t)c->fold_max_lines, stride = (size_t)c->fold_stride;
+    MirpFoldLine* hl = host_copy<MirpFoldLine>(c, c->lines.p, nw * ml);
+    char* hs = host_copy<char>(c, c->ss.p, nw * ml * stride);
+    int32_t* hn = host_copy<int32_t>(c, c->nlines.p, nw);
+    int32_t* hm = host_copy<int32_t>(c, c->mfe.p, nw);
+    auto done = [&](int rc, const char* msg) { std::free(hl); std::free(hs); std::free(hn); std::free(hm); return rc ? fail(c, rc, msg) : 0; };
+    if (!hl || !hs || !hn || !hm) return done(-2, "D2H failed");
+    FILE* fin = std::fopen(fasta_path, "r");
+    if (!fin) return done(-8, "mirp_write_fold_text: cannot open the FASTA file");
+    FILE* fo = std::fopen(out_path, "w");
+    if (!fo) { std::fclose(fin); return done(-8, "mirp_write_fold_text: cannot open the output file"); }
+    std::vector<char> head(1 << 16), seq(1 << 16);
+    int rc = 0;
+    for (size_t w = 0; w < nw; w++) {
+        if (!std::fgets(head.data(), (int)head.size(), fin) || !std::fgets(seq.data(), (int)seq.size(), fin)) { rc = -8; break; }
+        std::fputs(head.data(), fo);
+        for (int k = 0; k < hn[w]; k++) {
+            const MirpFoldLine& ln = hl[w * ml + k];
+            if (!ln.printed) continue;
+            std::fwrite(hs + (w * ml + k) * stride, 1, (size_t)ln.len, fo);
+            std::fprintf(fo, " (%6.2f) %4d\n", ln.energy / 100., ln.start);
+        }
+        for (char* p = seq.data(); *p && *p != '\n' && *p != '\r'; p++) {
+            char ch = *p;
+            if (ch >= 'a' && ch <= 'z') ch -= 32;
+            if (ch == 'T') ch = 'U';
+            std::fputc(ch, fo);
+        }
+        std::fprintf(fo, "\n (%6.2f)\n", hm[w] / 100.);
+    }
+    std::fclose(fin);
+    if (std::fclose(fo) != 0) rc = -8;
+    return done(rc, "mirp_write_fold_text: I/O error or FASTA shorter than the window list");
+}
+
 extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride,
                             int32_t** n_passed, int64_t* n_windows) {
     if (!c) return -1;

@@ -156,23 +156,14 @@ class Pipeline:
         self.state = "fold"
         prefix = self.opt["NAME_PREFIX"]
         foldname = self._p(prefix + "_rnalfoldoutput_0")
-        raw = self.ctx.get_fold()
-        bad = np.nonzero(raw["status"] != 0)[0]
+        status = self.ctx.fold_status()
+        bad = np.nonzero(status != 0)[0]
         if len(bad):
-            sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (bad[0], raw["status"][bad[0]]))
+            sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (bad[0], status[bad[0]]))
             sys.exit(-1)
         if write_text:
             d = load_recover_file(self.recovername)
-            with open(d["finished_stages"]["candidate"]["fasta"][0]) as fin, open(foldname, "w") as f:
-                for k in range(len(raw["n_lines"])):
-                    head = fin.readline().rstrip("\n")
-                    seq = fin.readline().rstrip("\n")
-                    f.write(head + "\n")
-                    for j in range(raw["n_lines"][k]):
-                        ln = raw["lines"][k, j]
-                        if ln["printed"]:
-                            f.write("%s (%6.2f) %4d\n" % (raw["ss"][k, j, :ln["len"]].tobytes().decode(), ln["energy"] / 100., ln["start"]))
-                    f.write(seq.upper().replace("T", "U") + "\n (%6.2f)\n" % (raw["mfe"][k] / 100.))
+            self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][0], foldname)
         else:
             open(foldname, "w").close()
         d = load_recover_file(self.recovername)

@@ -21,7 +21,12 @@ TAG = "0LR"
 
 def depth_text(depth, contig_names):
     """bam.depth.cut<CUT> text: `chr\\tpos\\td+\\td-` (miR_PREFeR.py:937-949)."""
-    return "".join("%s\t%d\t%d\t%d\n" % (contig_names[r["tid"]], r["pos"], r["dp"], r["dm"]) for r in depth)
+    if len(depth) == 0:
+        return ""
+    names = np.array(contig_names, dtype=object)[depth["tid"]]
+    cols = [names, depth["pos"].astype(str).astype(object), depth["dp"].astype(str).astype(object), depth["dm"].astype(str).astype(object)]
+    lines = cols[0] + "\t" + cols[1] + "\t" + cols[2] + "\t" + cols[3]
+    return "\n".join(lines.tolist()) + "\n"
 
 
 def peaks_to_dict(peaks, contig_names):
