@@ -152,10 +152,14 @@ def main():
         cells = np.where(D > 3, (D - 3) * lens - (D * (D + 1) // 2 - 6), 0)
         b_fold = float((lens + 64 + 4 * cells + 6000).sum())
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
+        valu_util = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_b_hbm_traffic_pmc.json")))["kernels"]["mirp::fold_lds_kernel"]
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_c_hbm_traffic_and_sq_pmc.json")))["kernels"]["mirp::fold_lds_kernel"]
             if a.genome == CHR1_LEN and a.loci == N_LOCI:
                 traffic = prof["fetch_bytes_corrected"] + prof["write_bytes"]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_c_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
+            # wave64 integer VALU ops occupy a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles); 1024 SIMDs
+            valu_util = sq["SQ_INSTS_VALU"] * 4.0 / (sq["SQ_WAVE_CYCLES"] * 4.0 / 4.0) if a.genome == CHR1_LEN and a.loci == N_LOCI else None
         except Exception:
             traffic = None
         # relaxations per window (ML splits + interior candidates on paired cells are data dependent; use the fixed accounting figure)
@@ -173,7 +177,7 @@ def main():
                          "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": fold_s * 1e3,
                          "note": "integer min-plus DP: LDS/VALU-bound by design, HBM fraction << 1 is expected (DESIGN.md)"},
             "roofline_fold_valu": {"relaxations_per_s": relax / fold_s, "peak_lane_ops_per_s": 256 * 64 * 2.4e9,
-                                   "frac_at_3_ops_per_relaxation": 3.0 * relax / fold_s / (256 * 64 * 2.4e9)},
+                                   "frac_at_3_ops_per_relaxation": 3.0 * relax / fold_s / (256 * 64 * 2.4e9), "valu_issue_util_profiled": valu_util},
             "roofline_coverage": {"kernel": "memset + cov_scatter_kernel + cov_scan_kernel", "bound": "hbm", "achieved": b_cov / cov_s / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cov / cov_s / 1e9 / HBM_PEAK_GBS, "avg_ms": cov_s * 1e3},
             "stage_ms": {"coverage": cov_s * 1e3, "candidate_rest": float(np.mean(rest_ms)), "fold": fold_s * 1e3, "predict": float(np.mean(pred_ms))},

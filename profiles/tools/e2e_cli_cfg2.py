@@ -1,6 +1,6 @@
 """Dev tool: end-to-end wall-clock of the CLI `pipeline` verb on a BASELINE config[1]-sized synthetic dataset (files in, gff3 out)."""
 import os, sys, time, tempfile, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mir_prefer_amd import synth, cli
 t = time.time()
 ds = synth.make_dataset([30427671], 12000, n_samples=1, seed=2, contig_names=["Chr1"])
