@@ -43,7 +43,7 @@ struct LdsTables {          // int16 copies of the hot parameter tables
 #define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
 
 struct LTab {               // table accessors for the shared epilogue/backtrack
-    const short* fml;       // LDS
+    const short* fml;       // triangular fML (per-window global slab in the epilogue kernel)
     const int* off;         // LDS: triangular offset of diagonal d (valid for d >= 4)
     const short* carch;     // global archive of c, triangular like fML: (d,i) -> off[d] + i (keeps a workgroup's slab ~88 KB, L2-friendly)
     __device__ __forceinline__ int C(int d, int i) const { int v = carch[off[d] + i]; return v == I16_INF ? INF : v; }
@@ -122,7 +122,8 @@ __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
 
 __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
-    int n_work, int span, short* __restrict__ carch_all, unsigned int* __restrict__ work_counter, int* __restrict__ fallback_list,
+    int n_work, int win_base, int span, short* __restrict__ slabs, size_t slab_shorts, int* __restrict__ win_state,
+    unsigned int* __restrict__ work_counter, int* __restrict__ fallback_list,
     unsigned int* __restrict__ fallback_count, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
     int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags, long long* __restrict__ dbg_cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -148,7 +149,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     int* lens = (int*)(smem + LY.lens);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nc = LCAP + 8;
-    short* carch = carch_all + (size_t)blockIdx.x * (size_t)(LDMAX + 1) * LCAP;   // slab capacity; only the triangle of the window is touched
 
     // ---- one-time: hot parameter tables into LDS
     for (int x = tid; x < 64; x += LNT) T.stack[x] = (short)min(P->stack[x >> 3][x & 7], (int)I16_INF);
@@ -190,11 +190,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (win >= n_work) break;
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
+        short* carch = slabs + (size_t)win * 2 * slab_shorts;      // per-window slab: c triangle, then fML triangle (read by fold_lds_epilogue_kernel)
+        short* fml_out = carch + slab_shorts;
         if (dbg_cycles && tid == 0) t0 = clock64();
         if (n < 1 || n > LCAP - 2) {   // wave-uniform: empty window, or too long for this kernel (-> generic kernel)
             if (tid == 0) {
-                out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0;
-                if (n >= 1) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win; }
+                out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0;
+                if (n >= 1) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; }
             }
         } else {
         const int D = (span - 1 < n - 1) ? span - 1 : n - 1;
@@ -524,21 +526,17 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         }
         const int overflow = misc[1];
         __syncthreads();
-        if (dbg_flags & 16) {
-        } else if (overflow) {   // int16 range exceeded: hand the window to the generic kernel
-            if (tid == 0) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win; out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; }
+        if (dbg_cycles && tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; }
+        if (overflow) {   // int16 range exceeded: hand the window to the generic kernel
+            if (tid == 0) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0; }
         } else {
-            __threadfence_block();
-            // small parameter tables for the backtracks, built in the tail of the (now free) fill scratch
-            EpiTables* EP = reinterpret_cast<EpiTables*>(smem + LY.aux + ((((size_t)LNW * (LCAP + 8) + 15) & ~(size_t)15) + (size_t)LNW * 3 * BT_STACK * 4));
-            fill_epi_tables(EP, P, tid, LNT);
-            __syncthreads();
-            X.E = EP;
-            LTab TB;
-            TB.fml = fml; TB.off = off; TB.carch = carch;
-            fold_epilogue<LTab, LNT>(X, TB, span, f3, starts, lens, btbuf, LCAP + 8, btstk, misc + 8, win, max_lines, ss_stride, out_lines, out_ss,
-                                     out_nlines, out_mfe, out_status);
-            if (dbg_cycles && tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; }
+            // hand the tables to the epilogue kernel: c was archived on the fly, fML is copied out now (coalesced dwords)
+            int tri = 0;
+            if (D >= 4) tri = off[D] + (n - D) + 1;
+            const unsigned int* src = reinterpret_cast<const unsigned int*>(fml);
+            unsigned int* dst = reinterpret_cast<unsigned int*>(fml_out);
+            for (int x = tid; x < (tri + 1) / 2; x += LNT) dst[x] = src[x];
+            if (tid == 0) win_state[win] = 1;
         }
         }   // window fits this kernel
         __syncthreads();
@@ -549,21 +547,104 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Epilogue kernel: exterior sweep, enumeration, backtracks, output.  Latency-bound pointer chasing with global
+// (L2) table reads, so it runs as many small workgroups (256 threads, ~16 KB LDS) per CU instead of sharing the
+// fill kernel's one-workgroup-per-CU geometry.
+// ------------------------------------------------------------------------------------------
+#define ENT 256
+__global__ void __launch_bounds__(ENT, 6) fold_lds_epilogue_kernel(
+    const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
+    int n_work, int span, const short* __restrict__ slabs, size_t slab_shorts, const int* __restrict__ win_state, unsigned int* __restrict__ work_counter,
+    int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss, int* __restrict__ out_nlines,
+    int* __restrict__ out_mfe, int* __restrict__ out_status) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nc = LCAP + 8;
+    int* f3 = (int*)smem;                                            // nc
+    int* starts = f3 + nc;                                           // max_lines
+    int* lens = starts + max_lines;                                  // max_lines
+    int* btstk = lens + max_lines;                                   // (ENT/64)*3*BT_STACK
+    int* misc = btstk + (ENT / 64) * 3 * BT_STACK;                   // 16
+    int* off = misc + 16;                                            // LDMAX + 2
+    short* spec = (short*)(off + LDMAX + 2);                         // 3*nc
+    unsigned char* S = (unsigned char*)(spec + 3 * nc);              // nc
+    unsigned char* seq = S + nc;                                     // nc
+    char* btbuf = (char*)(seq + nc);                                 // (ENT/64)*nc
+    EpiTables* EP = (EpiTables*)(smem + ((((size_t)(btbuf - (char*)smem) + (ENT / 64) * nc) + 15) & ~(size_t)15));
+    const int tid = threadIdx.x;
+    fill_epi_tables(EP, P, tid, ENT);
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) misc[0] = (int)atomicAdd(work_counter, 1u);
+        __syncthreads();
+        const int win = misc[0];
+        __syncthreads();
+        if (win >= n_work) break;
+        if (win_state[win] == 1) {
+            const long long o0 = offs[win];
+            const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
+            const int D = (span - 1 < n - 1) ? span - 1 : n - 1;
+            for (int x = tid; x <= n + 1; x += ENT) {
+                unsigned char ch = 0;
+                if (x >= 1 && x <= n) {
+                    ch = seqs[o0 + x - 1];
+                    if (ch >= 'a' && ch <= 'z') ch -= 32;
+                    if (ch == 'T') ch = 'U';
+                }
+                seq[x] = ch;
+                S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
+            }
+            if (tid == 0) {
+                int o = 0;
+                for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
+            }
+            __syncthreads();
+            if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
+            special_hairpins(P, seq, n, spec, nc, tid, ENT);
+            __syncthreads();
+            WinCtx X;
+            X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D; X.E = EP;
+            LTab TB;
+            TB.carch = slabs + (size_t)win * 2 * slab_shorts; TB.fml = TB.carch + slab_shorts; TB.off = off;
+            fold_epilogue<LTab, ENT>(X, TB, span, f3, starts, lens, btbuf, nc, btstk, misc + 8, win, max_lines, ss_stride, out_lines, out_ss, out_nlines,
+                                    out_mfe, out_status);
+        }
+        __syncthreads();
+    }
+}
+
+size_t fold_lds_epilogue_bytes(int max_lines) {
+    const int nc = LCAP + 8;
+    size_t b = sizeof(int) * (nc + 2 * (size_t)max_lines + (ENT / 64) * 3 * BT_STACK + 16 + LDMAX + 2) + sizeof(short) * 3 * nc + 2 * (size_t)nc + (ENT / 64) * (size_t)nc;
+    b = (b + 15) & ~(size_t)15;
+    return b + sizeof(EpiTables) + 16;
+}
+
 size_t fold_lds_bytes(int max_lines) { return lds_layout(max_lines).total; }
-size_t fold_lds_carch_shorts_per_wg() { return (size_t)(LDMAX + 1) * LCAP; }
 int fold_lds_max_n() { return LCAP - 2; }
 int fold_lds_max_span() { return LDMAX + 1; }
 
-hipError_t launch_fold_lds(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
-                           int n_work, int span, short* carch, unsigned int* work_counter, int* fallback_list, unsigned int* fallback_count,
-                           int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status,
-                           int dbg_flags, long long* dbg_cycles) {
+hipError_t launch_fold_lds(hipStream_t stream, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
+                           int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
+                           unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
+                           int* out_status, int dbg_flags, long long* dbg_cycles) {
     size_t lds = fold_lds_bytes(max_lines);
     hipError_t e = hipFuncSetAttribute((const void*)fold_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fold_lds_kernel, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, span, carch, work_counter, fallback_list,
-                       fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+    hipLaunchKernelGGL(fold_lds_kernel, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                       fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (!(dbg_flags & 16))
+        hipLaunchKernelGGL(fold_lds_epilogue_kernel, dim3(grid_epi), dim3(ENT), fold_lds_epilogue_bytes(max_lines), stream, P, seqs, offs, lens, n_work, span,
+                           slabs, slab_shorts, win_state, work_counter + 1, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
     return hipGetLastError();
+}
+
+size_t fold_lds_slab_shorts(int n_cap) {   // triangle of d = 4..LDMAX for windows up to n_cap (+ slack for the dword copy)
+    size_t tri = 0;
+    for (int d = 4; d <= LDMAX; d++) tri += (size_t)(n_cap - d > 0 ? n_cap - d : 0);
+    return (tri + 8 + 7) & ~(size_t)7;
 }
 
 }  // namespace mirp

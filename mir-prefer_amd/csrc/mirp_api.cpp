@@ -48,7 +48,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
-    c->nlines.release(); c->mfe.release(); c->status.release(); c->carch.release(); c->fctl.release(); c->flist.release();
+    c->nlines.release(); c->mfe.release(); c->status.release(); c->carch.release(); c->fctl.release(); c->flist.release(); c->wstate.release();
     for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,
                       &c->keep, &c->kscan, &c->csq, &c->cdest, &c->peaks_sq, &c->peaks_sorted, &c->head, &c->hscan, &c->rfirst, &c->nent,
                       &c->isloc, &c->nslots, &c->escan, &c->lscan, &c->sscan, &c->windows, &c->roles, &c->loci, &c->wpeaks, &c->matures,
@@ -191,18 +191,29 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
     int n_generic = n_work;
     c->last_fallback = 0;
     if (span <= mirp::fold_lds_max_span() && mirp::fold_lds_bytes(max_lines) <= 160 * 1024) {
-        const int grid = std::min(n_work, c->n_cu);
-        if (c->carch.ensure(2 * mirp::fold_lds_carch_shorts_per_wg() * (size_t)c->n_cu) || c->fctl.ensure(64) || c->flist.ensure(4 * (size_t)n_work))
+        // fill kernel (one 1024-thread workgroup per CU, tables in LDS) + epilogue kernel (many small workgroups) per sub-batch;
+        // the two exchange the c / fML triangles of every window through per-window slabs in HBM
+        const size_t slab = mirp::fold_lds_slab_shorts(std::min(n_cap, mirp::fold_lds_max_n() + 2));
+        const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_work, ((size_t)8 << 30) / (slab * 4)));
+        if (c->carch.ensure((size_t)sub * slab * 4) || c->fctl.ensure(256) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub))
             return fail(c, -6, "device allocation failed (fold LDS kernel)");
-        HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 64, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 256, c->stream));
         unsigned int* ctl = (unsigned int*)c->fctl.p;
         // diagnostics (never set in production): MIRP_FOLD_DEBUG=<flags> ablates phases (results then wrong), MIRP_FOLD_CLOCKS=1 prints phase clocks
         const char* dbg_env = std::getenv("MIRP_FOLD_DEBUG");
         const int dbg_flags = dbg_env ? std::atoi(dbg_env) : 0;
         long long* dbg_cycles = std::getenv("MIRP_FOLD_CLOCKS") ? (long long*)(ctl + 8) : nullptr;
-        hipError_t e = mirp::launch_fold_lds(c->stream, grid, c->d_params, d_seqs, d_offs, d_lens, n_work, span, (short*)c->carch.p, ctl, (int*)c->flist.p,
-                                             ctl + 4, max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status, dbg_flags, dbg_cycles);
-        if (e != hipSuccess) return fail(c, -2, std::string("fold LDS kernel launch failed: ") + hipGetErrorString(e));
+        for (int b0 = 0; b0 < n_work; b0 += sub) {
+            const int nb = std::min(sub, n_work - b0);
+            if (b0 > 0) HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 8, c->stream));   // the two work counters; the fallback count keeps accumulating
+            const int grid = std::min(nb, c->n_cu);
+            const int grid_epi = std::min(nb, c->n_cu * 8);
+            hipError_t e = mirp::launch_fold_lds(c->stream, grid, grid_epi, c->d_params, d_seqs, d_offs + b0, d_lens ? d_lens + b0 : nullptr, nb, b0, span,
+                                                 (short*)c->carch.p, slab, (int*)c->wstate.p, ctl, (int*)c->flist.p, ctl + 4, max_lines, stride,
+                                                 d_lines + (size_t)b0 * max_lines, d_ss + (size_t)b0 * max_lines * stride, d_nlines + b0, d_mfe + b0,
+                                                 d_status + b0, dbg_flags, dbg_cycles);
+            if (e != hipSuccess) return fail(c, -2, std::string("fold LDS kernel launch failed: ") + hipGetErrorString(e));
+        }
         unsigned int nfb = 0;
         HIPCHK(c, hipMemcpyAsync(&nfb, ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -210,8 +221,8 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         if (dbg_cycles) {
             long long cyc[4];
             HIPCHK(c, hipMemcpy(cyc, dbg_cycles, sizeof(cyc), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "[mirp fold clocks] windows=%d grid=%d setup=%lld fillA=%lld fillB=%lld epilogue=%lld (sum over workgroups, s_memtime ticks)\n", n_work,
-                         grid, cyc[0], cyc[1], cyc[2], cyc[3]);
+            std::fprintf(stderr, "[mirp fold clocks] windows=%d setup=%lld fillA=%lld fillB=%lld writeout=%lld (sum over workgroups, s_memtime ticks)\n", n_work,
+                         cyc[0], cyc[1], cyc[2], cyc[3]);
         }
         if (nfb == 0) return 0;
         work_list = (const int*)c->flist.p;

@@ -39,7 +39,7 @@ struct mirp_ctx {
     std::string err;
     int n_cu = 256;
     FoldParams* d_params = nullptr;
-    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist;
+    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist, wstate;
     long long last_fallback = 0;
     // ---- device-resident pipeline state (mirp_pipeline.cpp)
     int n_contigs = 0;

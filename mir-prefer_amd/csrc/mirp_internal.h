@@ -21,13 +21,14 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
 
 // fold_lds_kernel.hip
 size_t fold_lds_bytes(int max_lines);
-size_t fold_lds_carch_shorts_per_wg();
+size_t fold_lds_epilogue_bytes(int max_lines);
+size_t fold_lds_slab_shorts(int n_cap);
 int fold_lds_max_n();
 int fold_lds_max_span();
-hipError_t launch_fold_lds(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
-                           int n_work, int span, short* carch, unsigned int* work_counter, int* fallback_list, unsigned int* fallback_count,
-                           int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status,
-                           int dbg_flags, long long* dbg_cycles);
+hipError_t launch_fold_lds(hipStream_t stream, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
+                           int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
+                           unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
+                           int* out_status, int dbg_flags, long long* dbg_cycles);
 
 // candidate_kernels.hip
 void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m);
