@@ -28,6 +28,8 @@ namespace mirp {
 #define LDMAX 299           // max pair distance (span 300)
 #define I16_INF 0x7fff
 #define FIN_LIMIT 32000
+#define FML_BIAS 32000       // fML is kept in LDS as uint16 (value + FML_BIAS), 65535 = INF; finite fML must stay in [-32000, 767] so that the sum of
+#define FML_MAX 767          // two finite entries (<= 65534) can never be mistaken for a sum that involves INF (>= 65535)
 
 struct LdsTables {          // int16 copies of the hot parameter tables
     short stack[64];
@@ -49,8 +51,8 @@ struct LTab {               // table accessors for the shared epilogue/backtrack
     __device__ __forceinline__ int C(int d, int i) const { int v = carch[off[d] + i]; return v == I16_INF ? INF : v; }
     __device__ __forceinline__ int M(int d, int i) const {
         if (d < 4) return INF;
-        int v = fml[off[d] + i];
-        return v == I16_INF ? INF : v;
+        const int v = (unsigned short)fml[off[d] + i];
+        return v == 65535 ? INF : v - FML_BIAS;
     }
 };
 
@@ -90,7 +92,7 @@ __device__ __forceinline__ int lds_intloop(const LdsTables& T, const FoldParams*
 }
 
 struct LdsLayout {
-    size_t fml, aux, f3, rowfin, colfin, S, seq, spec, list, off, tabs, misc, starts, lens, total;
+    size_t fml, aux, f3, S, seq, spec, list, off, tabs, misc, starts, lens, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     LdsLayout L;
@@ -105,8 +107,6 @@ __host__ __device__ inline LdsLayout lds_layout(int max_lines) {
     size_t bt_aux = (size_t)LNW * (LCAP + 8) + (size_t)LNW * 3 * BT_STACK * 4;
     L.aux = take(fill_aux > bt_aux ? fill_aux : bt_aux);
     L.f3 = take((LCAP + 8) * 4);
-    L.rowfin = take((LCAP + 8) * 2);
-    L.colfin = take((LCAP + 8) * 2);
     L.S = take(LCAP + 8);
     L.seq = L.f3;   // staged characters are only needed while the special-hairpin table is built; f3 is epilogue-only
     L.spec = take((size_t)3 * (LCAP + 8) * 2);
@@ -129,15 +129,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsLayout LY = lds_layout(max_lines);
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
-    short* fml = (short*)(smem + LY.fml);
+    unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
     unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
     short* dmlring = (short*)(cring + 32 * CSTR);                             // [3][LCAP] int16
     int* acc = (int*)(dmlring + 3 * LCAP);                          // [2 (diagonal parity)][2 (cpart, mdec)][LCAP]
     char* btbuf = (char*)(smem + LY.aux);                           // epilogue alias
     int* btstk = (int*)(smem + LY.aux + (((size_t)LNW * (LCAP + 8) + 15) & ~(size_t)15));
     int* f3 = (int*)(smem + LY.f3);
-    short* rowfin = (short*)(smem + LY.rowfin);
-    short* colfin = (short*)(smem + LY.colfin);
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
     short* spec = (short*)(smem + LY.spec);
@@ -211,7 +209,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             seq[x] = ch;
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
-        for (int x = tid; x < LCAP + 8; x += LNT) { rowfin[x] = 20000; colfin[x] = 20000; }
         for (int x = tid; x < 3 * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
         for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = INF;
         if (tid == 0) {
@@ -386,68 +383,45 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
                 if (sub < nsub && !(dbg_flags & 2)) {
                     const int i = cell + 1, j = i + d;
-                    // per-lane finite split range [tlo, thi]; lanes without one (no cell, or a row/column that is still all-INF) are "don't care"
-                    int tlo = 4, thi = d - 5;
-                    bool live = false;
-                    if (cell < ncell) {
-                        int a = rowfin[i]; if (a < 4) a = 4;
-                        int b = d - 1 - colfin[j]; if (b > d - 5) b = d - 5;
-                        if (b >= a) { tlo = a; thi = b; live = true; }
-                    }
-                    // wave-wide common range: inside [TLO, THI] every live lane is valid, so the loop body needs no predicate
-                    int TLO = live ? tlo : 4, THI = live ? thi : d - 5;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { int x = __shfl_xor(TLO, o); TLO = x > TLO ? x : TLO; int y = __shfl_xor(THI, o); THI = y < THI ? y : THI; }
-                    TLO = __builtin_amdgcn_readfirstlane(TLO); THI = __builtin_amdgcn_readfirstlane(THI);
-                    const int rng = thi - tlo;
-                    int best = INF;
-                    // offsets of the two operand diagonals advance by second-order recurrences (scalar unit):
+                    // every split t in [4, d-5] is relaxed unconditionally: with the biased uint16 encoding a sum that involves an INF entry
+                    // is >= 65535 and any sum of two finite entries is <= 65534, so no per-lane range bookkeeping is needed.
+                    // The byte offsets of the two operand diagonals live in SGPRs and advance by second-order recurrences:
                     //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1,  off(x) = (x-4) n - (x(x-1)/2 - 6)
-                    const int s1 = nsub, ss = nsub * nsub;
+                    const int s1 = nsub;
                     int t = 4 + sub;
-                    int o1 = __builtin_amdgcn_readfirstlane((t - 4) * n - ((t * (t - 1)) / 2 - 6));
-                    int uu = d - t - 1;
-                    int o2 = __builtin_amdgcn_readfirstlane((uu - 4) * n - ((uu * (uu - 1)) / 2 - 6) + t + 1);
-                    int inc1 = __builtin_amdgcn_readfirstlane(s1 * n - s1 * t - (s1 * (s1 - 1)) / 2);           // off(t+s) - off(t)
-                    int inc2 = __builtin_amdgcn_readfirstlane(-(s1 * n) + s1 * uu - (s1 * (s1 + 1)) / 2 + s1);  // off(uu-s) - off(uu) + s
-                    const short* fi = fml + i;
-                    // leading edge: t < TLO (predicated)
-                    for (; t <= d - 5 && t < TLO; t += s1) {
-                        const int e = (int)fi[o1] + (int)fi[o2];
-                        if (live && (unsigned)(t - tlo) <= (unsigned)rng) best = e < best ? e : best;
-                        o1 += inc1; inc1 -= ss; o2 += inc2; inc2 -= ss;
-                    }
-                    // interior: four splits per trip, eight LDS reads in flight, no predicate; the byte offsets of the two operand
-                    // diagonals are kept in SGPRs (scalar adds), so a relaxation costs two address adds, one add and one min on the VALU
-                    {
-                        const char* fb = reinterpret_cast<const char*>(fml + i);
-                        int so1 = __builtin_amdgcn_readfirstlane(o1 * 2), so2 = __builtin_amdgcn_readfirstlane(o2 * 2);
-                        int si1 = __builtin_amdgcn_readfirstlane(inc1 * 2), si2 = __builtin_amdgcn_readfirstlane(inc2 * 2);
-                        const int sss = __builtin_amdgcn_readfirstlane(ss * 2);
+                    const int uu = d - t - 1;
+                    int so1 = __builtin_amdgcn_readfirstlane(2 * ((t - 4) * n - ((t * (t - 1)) / 2 - 6)));
+                    int so2 = __builtin_amdgcn_readfirstlane(2 * ((uu - 4) * n - ((uu * (uu - 1)) / 2 - 6) + t + 1));
+                    int si1 = __builtin_amdgcn_readfirstlane(2 * (s1 * n - s1 * t - (s1 * (s1 - 1)) / 2));           // off(t+s) - off(t)
+                    int si2 = __builtin_amdgcn_readfirstlane(2 * (-(s1 * n) + s1 * uu - (s1 * (s1 + 1)) / 2 + s1));  // off(uu-s) - off(uu) + s
+                    const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
+                    const char* fb = reinterpret_cast<const char*>(fml + i);
+                    unsigned bu = 65535u;
 #define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss))
-                        for (; t + 3 * s1 <= THI; t += 4 * s1) {
-                            const int a0 = *reinterpret_cast<const short*>(fb + so1), b0 = *reinterpret_cast<const short*>(fb + so2);
-                            MIRP_SSTEP();
-                            const int a1 = *reinterpret_cast<const short*>(fb + so1), b1 = *reinterpret_cast<const short*>(fb + so2);
-                            MIRP_SSTEP();
-                            const int a2 = *reinterpret_cast<const short*>(fb + so1), b2 = *reinterpret_cast<const short*>(fb + so2);
-                            MIRP_SSTEP();
-                            const int a3 = *reinterpret_cast<const short*>(fb + so1), b3 = *reinterpret_cast<const short*>(fb + so2);
-                            MIRP_SSTEP();
-                            int e0 = a0 + b0, e1 = a1 + b1, e2 = a2 + b2, e3 = a3 + b3;
-                            e0 = e0 < e1 ? e0 : e1; e2 = e2 < e3 ? e2 : e3; e0 = e0 < e2 ? e0 : e2;
-                            best = e0 < best ? e0 : best;
-                        }
-#undef MIRP_SSTEP
-                        o1 = so1 / 2; o2 = so2 / 2; inc1 = si1 / 2; inc2 = si2 / 2;
+#define MIRP_LD(o) ((unsigned)*reinterpret_cast<const unsigned short*>(fb + (o)))
+                    for (; t + 3 * s1 <= d - 5; t += 4 * s1) {
+                        const unsigned a0 = MIRP_LD(so1), b0 = MIRP_LD(so2);
+                        MIRP_SSTEP();
+                        const unsigned a1 = MIRP_LD(so1), b1 = MIRP_LD(so2);
+                        MIRP_SSTEP();
+                        const unsigned a2 = MIRP_LD(so1), b2 = MIRP_LD(so2);
+                        MIRP_SSTEP();
+                        const unsigned a3 = MIRP_LD(so1), b3 = MIRP_LD(so2);
+                        MIRP_SSTEP();
+                        unsigned e0 = a0 + b0, e1 = a1 + b1, e2 = a2 + b2, e3 = a3 + b3;
+                        e0 = e0 < e1 ? e0 : e1; e2 = e2 < e3 ? e2 : e3; e0 = e0 < e2 ? e0 : e2;
+                        bu = e0 < bu ? e0 : bu;
                     }
-                    // trailing edge (predicated)
+                    so1 = __builtin_amdgcn_readfirstlane(so1); so2 = __builtin_amdgcn_readfirstlane(so2);
+                    si1 = __builtin_amdgcn_readfirstlane(si1); si2 = __builtin_amdgcn_readfirstlane(si2);
                     for (; t <= d - 5; t += s1) {
-                        const int e = (int)fi[o1] + (int)fi[o2];
-                        if (live && (unsigned)(t - tlo) <= (unsigned)rng) best = e < best ? e : best;
-                        o1 += inc1; inc1 -= ss; o2 += inc2; inc2 -= ss;
+                        const unsigned e = MIRP_LD(so1) + MIRP_LD(so2);
+                        MIRP_SSTEP();
+                        bu = e < bu ? e : bu;
                     }
-                    if (!live) best = INF;
+#undef MIRP_SSTEP
+#undef MIRP_LD
+                    const int best = (cell < ncell && bu < 65535u) ? (int)bu - 2 * FML_BIAS : INF;
                     if (best < INF) atomicMin(&mdec[i], best);
                 }
             }
@@ -489,15 +463,15 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 int m = INF;
                 if (d > 4) {
                     int a = fml[off[d - 1] + i], b = fml[off[d - 1] + i + 1];
-                    a = a == I16_INF ? INF : a; b = b == I16_INF ? INF : b;
+                    a = a == 65535 ? INF : a - FML_BIAS; b = b == 65535 ? INF : b - FML_BIAS;
                     m = a < b ? a : b;
                 }
                 if (type) { int e = cv + lds_mlstem(T, P, type, i > 1 ? (int)S[i - 1] : -1, j < n ? (int)S[j + 1] : -1); m = e < m ? e : m; }
                 m = md < m ? md : m;
-                if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FIN_LIMIT || m < -FIN_LIMIT)) ||
+                if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
                     (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
                 const short c16 = cv >= INF ? (short)I16_INF : (short)cv;
-                const short m16 = m >= INF ? (short)I16_INF : (short)m;
+                const unsigned short m16 = m >= INF ? (unsigned short)65535 : (unsigned short)(m + FML_BIAS);
                 {   // G0 = c + mismatchI of (i,j) seen as the inner pair of a generic interior loop
                     unsigned short g16 = 65535;
                     if (cv < INF) g16 = (unsigned short)(cv + T.mismatchI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] + 32768);
@@ -506,7 +480,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 carch[off[d] + i] = c16;
                 fml[off[d] + i] = m16;
                 dmlring[(d % 3) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
-                if (m < INF) { if (rowfin[i] > d) rowfin[i] = (short)d; if (colfin[j] > d) colfin[j] = (short)d; }
                 cpart[i] = INF; mdec[i] = INF;
                 if (d + 2 <= D && i + d + 2 <= n && pair_type(S[i], S[i + d + 2])) {   // paired list of diagonal d+2
                     int k = atomicAdd(&misc[2 + (d + 2) % 3], 1);
