@@ -108,9 +108,12 @@ def main():
         dist.broadcast(n_all, src=0)
         return int(n_all.item())
 
+    fb = [0]
+
     def step():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)
         ctx.fold(L)
+        fb[0] = ctx.last_fold_fallbacks()
         out = ctx.predict(1, 18, 23, False, True)
         total = gather_loci(out)
         return nwin, total, ctx.last_timings()
@@ -172,7 +175,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: A. thaliana chr1-sized contig per GPU (%d bp), 1 sample, L=300, %d synthetic loci -> %d windows/GPU; "
                                    "candidate+fold+predict, inputs resident in HBM" % (a.genome, a.loci, nwin),
-                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)), "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)"},
+                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)), "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)",
+                       "fold_generic_fallback_windows": int(fb[0])},
             "roofline": {"kernel": "fold_lds_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": fold_s * 1e3,
                          "note": "integer min-plus DP: LDS/VALU-bound by design, HBM fraction << 1 is expected (DESIGN.md)"},

@@ -143,6 +143,9 @@ int mirp_predict(mirp_ctx* ctx, const MirpPredictParams* params, MirpMirna** res
 /* Per-stage device time of the last mirp_candidate / mirp_fold / mirp_predict calls, measured with HIP events on the
  * context's stream: ms[0]=coverage scatter+scan, ms[1]=rest of candidate, ms[2]=fold kernel, ms[3]=predict kernel. */
 int mirp_last_timings(mirp_ctx* ctx, double ms[4]);
+/* Number of windows of the last fold call that the LDS-resident kernel handed to the generic kernel (window longer than 350 nt,
+ * or energies outside the fast path's 16-bit ranges); purely informational -- results are identical either way. */
+int64_t mirp_last_fold_fallbacks(mirp_ctx* ctx);
 
 #ifdef __cplusplus
 }

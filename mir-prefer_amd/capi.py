@@ -62,6 +62,8 @@ def load_library():
     lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
     lib.mirp_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.mirp_last_fold_fallbacks.argtypes = [vp]
+    lib.mirp_last_fold_fallbacks.restype = C.c_int64
     lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mirp_write_fold_text.restype = C.c_int
     lib.mirp_get_fold_summary.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
@@ -215,6 +217,9 @@ class Context:
 
     def fold(self, span, max_lines=96):
         self._check(self.lib.mirp_fold(self.h, int(span), int(max_lines)), "mirp_fold")
+
+    def last_fold_fallbacks(self):
+        return int(self.lib.mirp_last_fold_fallbacks(self.h))
 
     def fold_summary(self):
         vp = C.c_void_p

@@ -350,11 +350,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             const int n1 = on1[r4], n2 = on2[r4], u = n1 + n2;
                             bool ok = okc[r4] != 0;
                             const int p = i + 1 + n1, q = j - 1 - n2;
-                            const int g0u = ok ? (int)cring[((q - p) & 31) * CSTR + p] : 65535;
+                            // reads are unconditional: for an inadmissible slot p, q stay inside [i, i+31] x [j-31, j], i.e. inside the LDS
+                            // arrays (S has slack, the ring is followed by the DML ring), and the result is discarded
+                            const int g0u = (int)cring[((q - p) & 31) * CSTR + p];
                             ok = ok && g0u != 65535;
                             const int g0 = g0u - 32768;
-                            const int t2 = T.rt2[S[ok ? p : i] * 5 + S[ok ? q : j]];
-                            const int code = t2 * 25 + S[(ok ? q : j) + 1] * 5 + S[(ok ? p : i) - 1];
+                            const int t2 = T.rt2[S[p] * 5 + S[q]];
+                            const int code = t2 * 25 + S[q + 1] * 5 + S[p - 1];
                             const int cpq = g0 - (int)T.mismatchI[code];
                             int e;
                             if (r4 <= 1) {

@@ -421,3 +421,5 @@ extern "C" int mirp_last_timings(mirp_ctx* c, double ms[4]) {
     for (int i = 0; i < 4; i++) ms[i] = c->ms[i];
     return 0;
 }
+
+extern "C" int64_t mirp_last_fold_fallbacks(mirp_ctx* c) { return c ? (int64_t)c->last_fallback : -1; }
