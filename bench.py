@@ -147,20 +147,20 @@ def main():
     if rank == 0:
         fold_s = float(np.mean(fold_ms)) / 1e3
         cov_s = float(np.mean(cov_ms)) / 1e3
-        # algorithmic HBM bytes of the dominant kernel (fold_lds_kernel: fML stays in LDS, c is archived once as int16 and read
-        # once by the exterior sweep): n + 64 + 4*cells + ~6 KB of structure lines per window, cells(300,300) = 43,956
+        # algorithmic HBM bytes of the fold (fill + epilogue kernels): the c and fML triangles are written once as 16-bit values and
+        # read once: n + 64 + 8*cells + ~6 KB of structure lines per window, cells(300,300) = 43,956
         w = ctx.get_windows()["windows"]
         lens = w["seq_len"].astype(np.int64)
         D = np.minimum(L - 1, lens - 1)
         cells = np.where(D > 3, (D - 3) * lens - (D * (D + 1) // 2 - 6), 0)
-        b_fold = float((lens + 64 + 4 * cells + 6000).sum())
+        b_fold = float((lens + 64 + 8 * cells + 6000).sum())
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
         valu_util = None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r1_c_hbm_traffic_and_sq_pmc.json")))["kernels"]["mirp::fold_lds_kernel"]
-            if a.genome == CHR1_LEN and a.loci == N_LOCI:
-                traffic = prof["fetch_bytes_corrected"] + prof["write_bytes"]
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_c_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
+            profk = json.load(open(os.path.join(ROOT, "profiles", "r1_d_hbm_traffic_and_sq_pmc.json")))["kernels"]
+            if a.genome == CHR1_LEN and a.loci == N_LOCI:   # fill + epilogue kernels of the fold
+                traffic = sum(profk[k]["fetch_bytes_corrected"] + profk[k]["write_bytes"] for k in ("mirp::fold_lds_kernel", "mirp::fold_lds_epilogue_kernel"))
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_d_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
             # wave64 integer VALU ops occupy a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles); 1024 SIMDs
             valu_util = sq["SQ_INSTS_VALU"] * 4.0 / (sq["SQ_WAVE_CYCLES"] * 4.0 / 4.0) if a.genome == CHR1_LEN and a.loci == N_LOCI else None
         except Exception:
@@ -177,7 +177,7 @@ def main():
                                    "candidate+fold+predict, inputs resident in HBM" % (a.genome, a.loci, nwin),
                        "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)), "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)",
                        "fold_generic_fallback_windows": int(fb[0])},
-            "roofline": {"kernel": "fold_lds_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": fold_s * 1e3,
                          "note": "integer min-plus DP: LDS/VALU-bound by design, HBM fraction << 1 is expected (DESIGN.md)"},
             "roofline_fold_valu": {"relaxations_per_s": relax / fold_s, "peak_lane_ops_per_s": 256 * 64 * 2.4e9,
@@ -186,7 +186,7 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cov / cov_s / 1e9 / HBM_PEAK_GBS, "avg_ms": cov_s * 1e3},
             "stage_ms": {"coverage": cov_s * 1e3, "candidate_rest": float(np.mean(rest_ms)), "fold": fold_s * 1e3, "predict": float(np.mean(pred_ms))},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             wins = ctx.get_windows()
             seqs = [wins["seq"][x["seq_off"]:x["seq_off"] + x["seq_len"]].tobytes() for x in wins["windows"][:4096]]
             line["cpu_baseline"] = cpu_baseline(seqs)

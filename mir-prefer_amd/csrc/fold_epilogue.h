@@ -309,18 +309,21 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = X.n, D = X.D;
     // ---- f3 (exterior) sweep.  f3[i] = min(f3[i+1], min_j c(i,j) + ext(i,j) + f3[j+1]) is sequential in i, but only through f3:
-    // rows are processed in blocks of NW = NT/64.  Step 1 (one wave per row, all in parallel): the partners j whose f3[j+1] is already
+    // rows are processed in blocks of RB.  Step 1 (waves take the rows of the block round-robin, all in parallel): the partners j whose f3[j+1] is already
     // final (j+1 above the block) are reduced to one partial minimum per row, and the few partners inside the block (span < NW)
     // are fetched to LDS.  Step 2 (wave 0): the short sequential chain through the block touches LDS only.  The backtrack stacks
     // are idle here and serve as scratch: part[NW], inner[NW][NW].
     constexpr int NW = NT / 64;
+    constexpr int RB = 32;   // rows per block: 32 consecutive i share their cache lines of every archived diagonal
+    static_assert((RB + RB * RB) * 4 <= NW * 3 * BT_STACK * 4, "f3 scratch must fit the backtrack stacks");
     int* part = btstk;
-    int* inner = btstk + NW;
+    int* inner = btstk + RB;
     for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
     __syncthreads();
-    for (int i_hi = n - TURN - 1; i_hi >= 1; i_hi -= NW) {
-        const int i = i_hi - wave;
-        if (i >= 1) {
+    for (int i_hi = n - TURN - 1; i_hi >= 1; i_hi -= RB) {
+        for (int r = wave; r < RB; r += NW) {
+            const int i = i_hi - r;
+            if (i < 1) break;
             int best = INF;
             const int jmax = (i + D < n) ? i + D : n;
             const int j0 = (i + TURN + 1 > i_hi) ? i + TURN + 1 : i_hi;    // f3[j+1] final for j >= i_hi
@@ -332,27 +335,27 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
                 }
             }
             best = wave_min(best);
-            if (lane == 0) part[wave] = best;
-            if (lane < NW) {                                             // partners inside the block: j = i+TURN+1+lane <= i_hi-1
+            if (lane == 0) part[r] = best;
+            if (lane < RB) {                                             // partners inside the block: j = i+TURN+1+lane <= i_hi-1
                 const int j = i + TURN + 1 + lane;
                 int e = INF;
                 if (j <= i_hi - 1 && j <= jmax) {
                     int type = pair_type(X.S[i], X.S[j]);
                     if (type) e = T.C(j - i, i) + ext_term(X, i, j, type);
                 }
-                inner[wave * NW + lane] = e;
+                inner[r * RB + lane] = e;
             }
         }
         __syncthreads();
         if (wave == 0) {
-            const int i_lo = (i_hi - NW + 1 > 1) ? i_hi - NW + 1 : 1;
+            const int i_lo = (i_hi - RB + 1 > 1) ? i_hi - RB + 1 : 1;
             for (int r = i_hi; r >= i_lo; r--) {
                 const int w = i_hi - r;
                 int best = f3[r + 1];
                 const int p = part[w];
                 best = p < best ? p : best;
-                if (lane < NW) {
-                    const int e = inner[w * NW + lane];
+                if (lane < RB) {
+                    const int e = inner[w * RB + lane];
                     if (e < INF) { const int c = e + f3[r + TURN + 1 + lane + 1]; best = c < best ? c : best; }
                 }
                 best = wave_min(best);
