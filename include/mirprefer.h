@@ -147,6 +147,21 @@ int mirp_last_timings(mirp_ctx* ctx, double ms[4]);
  * or energies outside the fast path's 16-bit ranges); purely informational -- results are identical either way. */
 int64_t mirp_last_fold_fallbacks(mirp_ctx* ctx);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host-side native ingest (no device involved).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_contigs; char* contig_names;   /* n_contigs NUL-terminated names back to back, @SQ order of the first file (MP:500-509) */
+    int64_t* contig_len;
+    int32_t n_samples; char* sample_names;   /* one per SAM file (MP:3300-3308) */
+    MirpAln* alns; int64_t n_alns;           /* stably sorted by (tid, pos) over the sample-ordered concatenation */
+} MirpSamData;
+/* Replaces sam2bam / samtools cat / sort / expand_bamfile / strand split of prepare_data (MP:656-746, 772-874): parses the
+ * sample SAM files (ungapped `<len>M` alignments, read ids `sample_rA_xN`) with n_threads threads (0 = all cores).
+ * Returns 0 or -1 with a message in errbuf; release with mirp_free_sam_data. */
+int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32_t n_threads, MirpSamData* out, char* errbuf, size_t errbuf_len);
+void mirp_free_sam_data(MirpSamData* data);
+
 #ifdef __cplusplus
 }
 #endif

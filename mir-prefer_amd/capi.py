@@ -18,6 +18,37 @@ class FoldLine(C.Structure):
     _fields_ = [("start", C.c_int32), ("len", C.c_int32), ("energy", C.c_int32), ("printed", C.c_int32)]
 
 
+class SamData(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("contig_names", C.c_void_p), ("contig_len", C.POINTER(C.c_int64)), ("n_samples", C.c_int32),
+                ("sample_names", C.c_void_p), ("alns", C.c_void_p), ("n_alns", C.c_int64)]
+
+
+def ingest_sams(paths, n_threads=0):
+    """Native multi-threaded SAM ingest (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns)."""
+    from .synth import ALN_DTYPE
+    lib = load_library()
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    d = SamData()
+    err = C.create_string_buffer(512)
+    if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
+        raise ValueError(err.value.decode())
+    try:
+        def names(ptr, n):
+            out, off = [], 0
+            for _ in range(n):
+                s = C.string_at(ptr + off)
+                out.append(s.decode()); off += len(s) + 1
+            return out
+        cn = names(d.contig_names, d.n_contigs)
+        sn = names(d.sample_names, d.n_samples)
+        lens = np.array([d.contig_len[k] for k in range(d.n_contigs)], dtype=np.int64)
+        n = d.n_alns
+        alns = np.frombuffer((C.c_char * (n * 16)).from_address(d.alns), dtype=ALN_DTYPE, count=n).copy() if n else np.zeros(0, dtype=ALN_DTYPE)
+    finally:
+        lib.mirp_free_sam_data(C.byref(d))
+    return cn, lens, sn, alns
+
+
 FOLD_LINE_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("energy", "<i4"), ("printed", "<i4")])
 
 _lib = None
@@ -71,6 +102,10 @@ def load_library():
     for f in ("mirp_load_genome", "mirp_load_alignments", "mirp_candidate", "mirp_get_depth", "mirp_get_peaks", "mirp_get_loci",
               "mirp_get_windows", "mirp_fold", "mirp_get_fold", "mirp_predict", "mirp_last_timings"):
         getattr(lib, f).restype = C.c_int
+    lib.mirp_ingest_sams.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(SamData), C.c_char_p, C.c_size_t]
+    lib.mirp_ingest_sams.restype = C.c_int
+    lib.mirp_free_sam_data.argtypes = [C.POINTER(SamData)]
+    lib.mirp_free_sam_data.restype = None
     _lib = lib
     return lib
 

@@ -49,10 +49,16 @@ def read_sam_header(path):
     return names, lens
 
 
-def read_sams(paths):
-    """-> (contig_names, contig_lens, sample_names, alns) with alns stably sorted by (tid, pos) over
+def read_sams(paths, native=True):
+    """Uses the native multi-threaded parser of libmirprefer.so for plain-text SAM files; gzip-compressed files (test fixtures)
+    go through the Python parser below, which implements the same rules.
+
+    -> (contig_names, contig_lens, sample_names, alns) with alns stably sorted by (tid, pos) over
     the sample-ordered concatenation (what `samtools cat` + `samtools sort` produce for the reference).
     Only ungapped alignments (`<len>M`, as bowtie -v 0 emits) are accepted; unmapped reads are skipped."""
+    if native and not any(str(p).endswith(".gz") for p in paths):
+        from . import capi
+        return capi.ingest_sams(paths)
     names, lens = read_sam_header(paths[0])
     tid_of = {n: i for i, n in enumerate(names)}
     sample_names = []

@@ -84,6 +84,22 @@ def test_ingest_matches_generator_and_sort_is_stable(tmp_path):
     assert (np.diff(key) >= 0).all()
 
 
+def test_native_sam_ingest_matches_python_parser(tmp_path):
+    ds = synth.make_dataset([200000, 120000, 90000], 400, n_samples=3, seed=8, contig_names=["z", "a", "m"], edge_cases=True)
+    sams = ds.write_sams(str(tmp_path), sq_order=[2, 0, 1])
+    a = ingest.read_sams(sams, native=True)
+    b = ingest.read_sams(sams, native=False)
+    assert a[0] == b[0] == ["m", "z", "a"] and list(a[1]) == list(b[1]) and a[2] == b[2] == ["S1", "S2", "S3"]
+    assert len(a[3]) == len(b[3]) > 3000 and np.array_equal(a[3], b[3])
+    from mir_prefer_amd import capi
+    for nt in (1, 3):
+        assert np.array_equal(capi.ingest_sams(sams, n_threads=nt)[3], b[3])
+    bad = tmp_path / "bad.sam"
+    bad.write_text("@SQ\tSN:c\tLN:100\nS_r0_x5\t0\tc\t5\t255\t10M2D9M\t*\t0\t0\t" + "A" * 19 + "\t" + "I" * 19 + "\n")
+    with pytest.raises(ValueError):
+        ingest.read_sams([str(bad)])
+
+
 def test_partition_contigs_lpt():
     parts = dist.partition_contigs([43, 36, 36, 35, 30, 31, 30, 28, 23, 23, 29, 27], 8)
     assert sorted(t for p in parts for t in p) == list(range(12))
