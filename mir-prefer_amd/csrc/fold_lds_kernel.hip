@@ -1,21 +1,25 @@
-// LDS-resident batched L-bounded Zuker local fold for precursor windows (n <= 352, span <= 300):
+// LDS-resident batched L-bounded Zuker local fold for precursor windows (n <= 350, span <= 300):
 // the production case PRECURSOR_LEN = 300 (/root/reference/miR_PREFeR.py:90, RNALfold -L at :3053).
 //
 // One window per workgroup (1024 threads = 16 wavefronts), one workgroup per CU:
-//   * fML lives entirely in LDS as a triangular int16 table, diagonal-major: (d,i) -> off(d)+i, so
+//   * fML lives entirely in LDS as a triangular biased-uint16 table, diagonal-major: (d,i) -> off(d)+i, so
 //     the two operands of a multiloop split are read at consecutive addresses by consecutive lanes;
 //   * c keeps its last 32 anti-diagonals in an LDS ring (interior loops reach back MAXLOOP+2) and is
-//     archived once, coalesced, as int16 to a per-workgroup global slab for the exterior (f3) sweep
-//     and the backtracks;
-//   * per anti-diagonal: phase A = interior-loop candidates (32 lanes per paired cell; the ring stores
-//     G0 = c + inner mismatch, so a generic candidate is one LDS read; stack/bulge/1xn/2x3 in four
-//     class-homogeneous rounds; the four small loops that need the big int11/21/22 tables are issued
-//     first and consumed last) and multiloop splits (lane = cell, wave-uniform split point, scalar
-//     offsets), reduced with shuffles + LDS atomic min; phase B = one thread per cell finalises
-//     c, fML, DML and runs in the same barrier interval as phase A of the next diagonal;
-//   * INF is never read inside the split loop: fML is monotone (ML_BASE = 0), so each row/column
-//     has a first-finite distance and the split range is clipped to it;
-//   * windows whose energies leave the int16 range are flagged and re-run by the generic kernel.
+//     archived once, coalesced, as int16 to a per-window global slab for the exterior (f3) sweep
+//     and the backtracks (fold_lds_epilogue_kernel);
+//   * per anti-diagonal, phase A1 = interior-loop candidates with LANE = PAIRED CELL and WAVE = CANDIDATE GROUP:
+//     every wave walks its own fixed share of the 496 (n1, n2) shapes for up to 64 paired cells at once, so the
+//     loop shape is wave-uniform -- ring rows are scalar offsets, candidates are immediate offsets, size penalties
+//     are scalar loads -- and one candidate costs one LDS read + add + min (generic shapes, ring stores
+//     G0 = c + inner mismatch) or three LDS reads + four VALU ops (bulges and 1xn loops, through combined
+//     per-window pair-code arrays).  Waves 0-7: generic rows (47 shapes each), 8-13: bulges / 1xn (18-19 each),
+//     14: stack, 1-bulges, 2x3, 15: the 1x1/1x2/2x2 loops that read the big tables from global memory;
+//   * phase A2 = multiloop splits (lane = cell, wave-uniform split point, scalar offsets); phase B = one thread per
+//     cell finalises c, fML, DML, builds the ordered paired-cell list of diagonal d+2 (ballot compaction) and runs
+//     in the same barrier interval as phase A of the next diagonal;
+//   * INF needs no predicates: tables are biased unsigned 16-bit with INF = 65535, so any sum that involves
+//     INF is >= 65535 and can never beat the 65535 start value of a running minimum;
+//   * windows whose energies leave the 16-bit ranges are flagged and re-run by the generic kernel.
 // No MFMA: integer min-plus DP with irregular table lookups.
 #include <hip/hip_runtime.h>
 #include "fold_epilogue.h"
@@ -27,19 +31,21 @@ namespace mirp {
 #define LCAP 352            // window length capacity
 #define LDMAX 299           // max pair distance (span 300)
 #define I16_INF 0x7fff
-#define FIN_LIMIT 32000
+#define FIN_LIMIT 28000      // finite c must stay in [-28000, 28000]: G0 + 32768 + any loop term then stays below 65535
 #define FML_BIAS 32000       // fML is kept in LDS as uint16 (value + FML_BIAS), 65535 = INF; finite fML must stay in [-32000, 767] so that the sum of
 #define FML_MAX 767          // two finite entries (<= 65534) can never be mistaken for a sum that involves INF (>= 65535)
+#define LSEG 384             // paired-cell list: 6 producer waves x 64 entries
+#define OTH_BIAS 2048        // keeps (table delta + size term) of a bulge / 1xn candidate non-negative (FoldParams::k_bulge, k_1n carry it)
 
 struct LdsTables {          // int16 copies of the hot parameter tables
     short stack[64];
     short bulge[32];
     short internal_loop[32];
     short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200];
-    unsigned short penK[25 * 34];       // generic interior loops: [u-6][n1] = il[u] + min(MAX_NINIO, |2 n1 - u| ninio) for 2 <= n1 <= u-2, else 65535
-    unsigned short ocombo[120];         // the other classes: n1 | n2 << 5 | class << 10
-    short n_gcombo, n_ocombo;
-    unsigned char rt2[28];              // rtype(pair_type(a, b)) at [a*5+b]
+    // inner-pair terms by combined pair code idx = PA(p)*25 + QB(q), PA = S[p]*5 + S[p-1], QB = S[q]*5 + S[q+1]; relative to G0:
+    short XB[628];          // TerminalAU(inner) - mismatchI(inner)           (bulges of size >= 2)
+    short X1[628];          // mismatch1nI(inner) - mismatchI(inner)          (1 x n loops, n >= 3)
+    unsigned char rt2[28];  // rtype(pair_type(a, b)) at [a*5+b]
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
 };
 #define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
@@ -92,32 +98,173 @@ __device__ __forceinline__ int lds_intloop(const LdsTables& T, const FoldParams*
 }
 
 struct LdsLayout {
-    size_t fml, aux, f3, S, seq, spec, list, off, tabs, misc, starts, lens, total;
+    unsigned fml, aux, S, seq, pax, qb2, spec, list, off, tabs, misc, total;
 };
-__host__ __device__ inline LdsLayout lds_layout(int max_lines) {
-    LdsLayout L;
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
-    // fML triangle for d = 4..LDMAX at n = LCAP
-    size_t tri = 0;
-    for (int d = 4; d <= LDMAX; d++) tri += (size_t)(LCAP - d);
-    L.fml = take(tri * 2);
-    // fill-phase scratch (c ring 32 diagonals, DML ring 3, accumulators), re-used by the epilogue for backtrack buffers/stacks
-    size_t fill_aux = (size_t)32 * CSTR * 2 + (size_t)3 * LCAP * 2 + (size_t)4 * LCAP * 4;   // c ring, DML ring (int16), 2 x {cpart, mdec}
-    size_t bt_aux = (size_t)LNW * (LCAP + 8) + (size_t)LNW * 3 * BT_STACK * 4;
-    L.aux = take(fill_aux > bt_aux ? fill_aux : bt_aux);
-    L.f3 = take((LCAP + 8) * 4);
-    L.S = take(LCAP + 8);
-    L.seq = L.f3;   // staged characters are only needed while the special-hairpin table is built; f3 is epilogue-only
-    L.spec = take((size_t)3 * (LCAP + 8) * 2);
-    L.list = take((size_t)3 * LCAP * 2 + 16);
-    L.off = take((LDMAX + 2) * 4);
-    L.tabs = take(sizeof(LdsTables));
-    L.misc = take(16 * 4);
-    L.starts = take((size_t)max_lines * 4);
-    L.lens = take((size_t)max_lines * 4);
+__host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
+__host__ __device__ constexpr LdsLayout lds_layout() {
+    LdsLayout L{};
+    unsigned o = 0;
+    L.fml = o; o += lds_al(((LDMAX - 3) * LCAP - (LDMAX * (LDMAX + 1) / 2 - 6)) * 2);   // fML triangle, d = 4..LDMAX at n = LCAP
+    L.aux = o; o += lds_al(32 * CSTR * 2 + 3 * LCAP * 2 + 4 * LCAP * 4);                // c ring (32 diagonals), DML ring (3), 2 x {cpart, mdec}
+    L.S = o; o += lds_al(LCAP + 8);
+    L.seq = o; o += lds_al(LCAP + 8);
+    L.pax = o; o += lds_al((LCAP + 8) * 2);
+    L.qb2 = o; o += lds_al(LCAP + 8);
+    L.spec = o; o += lds_al(3 * (LCAP + 8) * 2);
+    L.list = o; o += lds_al(3 * LSEG * 2);
+    L.off = o; o += lds_al((LDMAX + 2) * 4);
+    L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
+    L.misc = o; o += lds_al(48 * 4);
     L.total = o;
     return L;
+}
+static_assert(lds_layout().total <= 160 * 1024, "fill kernel LDS budget");
+
+// ---- phase A1 building blocks.  All take the lane's paired cell (i, j = i + d) and wave-uniform d; r0 = d - 2 (ring row of the
+// stacked pair), um = largest admissible n1 + n2 (inner pair keeps q - p >= TURN + 1).  Running minima are biased uint (65535 = none).
+typedef const volatile __attribute__((address_space(3))) unsigned short* lds_vu16;   // LDS reads that must stay narrow (see a1_gen_row)
+typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8;
+struct A1 {
+    const FoldParams* __restrict__ P;
+    const LdsTables* T;
+    const unsigned char* S;
+    const unsigned short* cring;
+    const unsigned short* pax;     // PA(x) * 50: byte offset of row PA in XB / X1
+    const unsigned char* qbr;      // QB(n + 1 - y) * 2 at y: the q side is walked downwards, so it is stored reversed (ascending immediates)
+    int r0, um, n;
+};
+
+// generic loops (n1, n2 >= 2) of size U: one contiguous run of ring row r0 - U.  The reads stay 16-bit on purpose (volatile keeps the
+// compiler from fusing neighbours into b64/b128 reads): a lane's run starts at an arbitrary 2-byte boundary, and a wide DS read off its
+// natural alignment is replayed at 64 cycles per wave-instruction on gfx950, against 2 cycles for a 16-bit read.
+template <bool CHECK, int U>
+__device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb, unsigned& bg) {
+    if (!CHECK || U <= a.um) {
+        lds_vu16 rp = (lds_vu16)(rb + ((a.r0 - U) & 31) * CSTR);
+        unsigned v[U - 3];      // all reads of the run in flight before the first use
+#pragma unroll
+        for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = rp[n1];
+#pragma unroll
+        for (int n1 = 2; n1 <= U - 2; n1++) {
+            const unsigned e = v[n1 - 2] + (unsigned)a.P->gen_pen[U - 6][n1];
+            bg = e < bg ? e : bg;
+        }
+    }
+}
+template <bool CHECK, int... Us>
+__device__ __forceinline__ int a1_generic(const A1& a, int i, int j, int type) {
+    unsigned bg = 65535u;
+    const unsigned short* rb = a.cring + i + 1;
+    (a1_gen_row<CHECK, Us>(a, rb, bg), ...);
+    if (bg >= 65535u) return INF;
+    return (int)bg - 32768 + (int)a.T->mismatchI[type * 25 + a.S[i + 1] * 5 + a.S[j - 1]];
+}
+
+// bulges, n1 = 0, n2 = U in [LO, HI]: p = i+1, q = j-1-U
+template <bool CHECK, int LO, int HI>
+__device__ __forceinline__ void a1_b0(const A1& a, int i, int j, unsigned& best) {
+    const unsigned idxp = a.pax[i + 1];
+    lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
+    const unsigned short* rb = a.cring + i + 1;
+    const char* xb = reinterpret_cast<const char*>(a.T->XB);
+#pragma unroll
+    for (int U = LO; U <= HI; U++) {
+        if (!CHECK || U <= a.um) {
+            const unsigned idx2 = idxp + ql[U];
+            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const unsigned g = rb[((a.r0 - U) & 31) * CSTR];
+            const unsigned e = g + (unsigned)(x + a.P->k_bulge[U]);
+            best = e < best ? e : best;
+        }
+    }
+}
+// bulges, n2 = 0, n1 = U: p = i+1+U, q = j-1
+template <bool CHECK, int LO, int HI>
+__device__ __forceinline__ void a1_b1(const A1& a, int i, int j, unsigned& best) {
+    const unsigned idxq = a.qbr[a.n + 2 - j];
+    lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+    const unsigned short* rb = a.cring + i + 1;
+    const char* xb = reinterpret_cast<const char*>(a.T->XB);
+#pragma unroll
+    for (int U = LO; U <= HI; U++) {
+        if (!CHECK || U <= a.um) {
+            const unsigned idx2 = idxq + pl[U];
+            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const unsigned g = rb[((a.r0 - U) & 31) * CSTR + U];
+            const unsigned e = g + (unsigned)(x + a.P->k_bulge[U]);
+            best = e < best ? e : best;
+        }
+    }
+}
+// 1 x K loops, n1 = 1, n2 = K in [LO, HI]: p = i+2, q = j-1-K
+template <bool CHECK, int LO, int HI>
+__device__ __forceinline__ void a1_i0(const A1& a, int i, int j, unsigned& best) {
+    const unsigned idxp = a.pax[i + 2];
+    lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
+    const unsigned short* rb = a.cring + i + 2;
+    const char* xb = reinterpret_cast<const char*>(a.T->X1);
+#pragma unroll
+    for (int K = LO; K <= HI; K++) {
+        if (!CHECK || K + 1 <= a.um) {
+            const unsigned idx2 = idxp + ql[K];
+            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR];
+            const unsigned e = g + (unsigned)(x + a.P->k_1n[K]);
+            best = e < best ? e : best;
+        }
+    }
+}
+// K x 1 loops, n2 = 1, n1 = K: p = i+1+K, q = j-2
+template <bool CHECK, int LO, int HI>
+__device__ __forceinline__ void a1_i1(const A1& a, int i, int j, unsigned& best) {
+    const unsigned idxq = a.qbr[a.n + 3 - j];
+    lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+    const unsigned short* rb = a.cring + i + 1;
+    const char* xb = reinterpret_cast<const char*>(a.T->X1);
+#pragma unroll
+    for (int K = LO; K <= HI; K++) {
+        if (!CHECK || K + 1 <= a.um) {
+            const unsigned idx2 = idxq + pl[K];
+            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR + K];
+            const unsigned e = g + (unsigned)(x + a.P->k_1n[K]);
+            best = e < best ? e : best;
+        }
+    }
+}
+__device__ __forceinline__ int a1_fin(unsigned best, int klane) { return best >= 65535u ? INF : (int)best - 32768 - OTH_BIAS + klane; }
+
+// the nine small shapes: full energy function, branch-free so the global table loads of one wave are issued together
+template <int N1, int N2>
+__device__ __forceinline__ void a1_small(const A1& a, int i, int j, int type, int si1, int sj1, int& best) {
+    if (N1 + N2 <= a.um) {
+        const int p = i + 1 + N1, q = j - 1 - N2;
+        const unsigned g = a.cring[((a.r0 - N1 - N2) & 31) * CSTR + p];
+        const int sp1 = a.S[p - 1], sq1 = a.S[q + 1];
+        const int t2 = a.T->rt2[a.S[p] * 5 + a.S[q]];
+        const int c = (int)g - 32768 - (int)a.T->mismatchI[t2 * 25 + sq1 * 5 + sp1];
+        int e = lds_intloop(*a.T, a.P, N1, N2, type, t2, si1, sj1, sp1, sq1) + c;
+        e = g == 65535u ? INF : e;
+        best = e < best ? e : best;
+    }
+}
+
+// the four shapes whose energies come from the big int11 / int21 / int22 tables in global memory: the load is issued here and consumed
+// by the caller after its LDS-only shapes, so the L2 latency is covered
+template <int N1, int N2>
+__device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, int si1, int sj1, int& raw, int& cc) {
+    raw = 0; cc = INF;
+    if (N1 + N2 <= a.um) {
+        const int p = i + 1 + N1, q = j - 1 - N2;
+        const unsigned g = a.cring[((a.r0 - N1 - N2) & 31) * CSTR + p];
+        const int sp1 = a.S[p - 1], sq1 = a.S[q + 1];
+        const int t2 = a.T->rt2[a.S[p] * 5 + a.S[q]];
+        cc = g == 65535u ? INF : (int)g - 32768 - (int)a.T->mismatchI[t2 * 25 + sq1 * 5 + sp1];
+        if (N1 == 1 && N2 == 1) raw = a.P->int11[type][t2][si1][sj1];
+        else if (N1 == 1 && N2 == 2) raw = a.P->int21[type][t2][si1][sq1][sj1];
+        else if (N1 == 2 && N2 == 1) raw = a.P->int21[t2][type][sq1][si1][sp1];
+        else raw = a.P->int22[type][t2][si1][sp1][sq1][sj1];
+    }
 }
 
 __global__ void __launch_bounds__(LNT) fold_lds_kernel(
@@ -127,25 +274,24 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     unsigned int* __restrict__ fallback_count, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
     int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags, long long* __restrict__ dbg_cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const LdsLayout LY = lds_layout(max_lines);
+    constexpr LdsLayout LY = lds_layout();
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
     unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
-    short* dmlring = (short*)(cring + 32 * CSTR);                             // [3][LCAP] int16
+    short* dmlring = (short*)(cring + 32 * CSTR);                   // [3][LCAP] int16
     int* acc = (int*)(dmlring + 3 * LCAP);                          // [2 (diagonal parity)][2 (cpart, mdec)][LCAP]
-    char* btbuf = (char*)(smem + LY.aux);                           // epilogue alias
-    int* btstk = (int*)(smem + LY.aux + (((size_t)LNW * (LCAP + 8) + 15) & ~(size_t)15));
-    int* f3 = (int*)(smem + LY.f3);
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
+    unsigned short* pax = (unsigned short*)(smem + LY.pax);
+    unsigned char* qbr = smem + LY.qb2;
     short* spec = (short*)(smem + LY.spec);
-    unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LCAP], list of diagonal d in buffer d % 3
+    unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LSEG]: i | type << 9, list of diagonal d in buffer d % 3, segment w = producer wave w
     int* off = (int*)(smem + LY.off);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
-    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 2..4: list counts, 8..: epilogue sh_misc
-    int* starts = (int*)(smem + LY.starts);
-    int* lens = (int*)(smem + LY.lens);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16 + 8 b + w: entries in segment w of list buffer b
+    int* lcnt = misc + 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nc = LCAP + 8;
 
     // ---- one-time: hot parameter tables into LDS
@@ -157,26 +303,18 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         T.mismatchM[x] = (short)P->mismatchM[t][a][b]; T.mismatch1nI[x] = (short)min(P->mismatch1nI[t][a][b], (int)I16_INF);
         T.mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], (int)I16_INF);
     }
-    if (tid == 0) {
-        // combination tables of the interior-loop search window (n1 + n2 <= MAXLOOP)
-        int g = 0, o = 0;
-        for (int u = 6; u <= MAXLOOP; u++)
-            for (int n1 = 0; n1 < 32; n1++) {
-                int v = 65535;   // inadmissible slot: biased-unsigned ring value (>= 768) + 65535 can never beat the 65535 start value
-                if (n1 >= 2 && n1 <= u - 2) { int n2 = u - n1, y = (n1 > n2 ? n1 - n2 : n2 - n1) * P->ninio; v = P->internal_loop[u] + (y < P->MAX_NINIO ? y : P->MAX_NINIO); }
-                T.penK[(u - 6) * 34 + n1] = (unsigned short)v;
-            }
-        g = 375;
-        T.ocombo[o++] = 0;                                                                    // class 0: stack
-        for (int k = 1; k <= MAXLOOP; k++) T.ocombo[o++] = (unsigned short)(0 | (k << 5) | (1 << 10));   // class 1: bulge, n1 = 0
-        for (int k = 1; k <= MAXLOOP; k++) T.ocombo[o++] = (unsigned short)(k | (0 << 5) | (1 << 10));   //          bulge, n2 = 0
-        for (int k = 3; k <= MAXLOOP - 1; k++) T.ocombo[o++] = (unsigned short)(1 | (k << 5) | (2 << 10)); // class 2: 1 x n
-        for (int k = 3; k <= MAXLOOP - 1; k++) T.ocombo[o++] = (unsigned short)(k | (1 << 5) | (2 << 10)); //          n x 1
-        T.ocombo[o++] = (unsigned short)(2 | (3 << 5) | (3 << 10));                           // class 3: 2 x 3
-        T.ocombo[o++] = (unsigned short)(3 | (2 << 5) | (3 << 10));                           //          3 x 2
-        T.n_gcombo = (short)g; T.n_ocombo = (short)o;
-        for (int x = 0; x < 25; x++) T.rt2[x] = (unsigned char)rtype_of(pair_type(x / 5, x % 5));
+    for (int x = tid; x < 625; x += LNT) {
+        const int pa = x / 25, qb = x % 25, sp = pa / 5, sp1 = pa % 5, sq = qb / 5, sq1 = qb % 5;
+        const int t2 = rtype_of(pair_type(sp, sq));
+        int xb = 0, x1 = 0;
+        if (t2) {
+            const int mi = P->mismatchI[t2][sq1][sp1];
+            xb = (t2 > 2 ? P->TerminalAU : 0) - mi;
+            x1 = P->mismatch1nI[t2][sq1][sp1] - mi;
+        }
+        T.XB[x] = (short)xb; T.X1[x] = (short)x1;
     }
+    if (tid < 25) T.rt2[tid] = (unsigned char)rtype_of(pair_type(tid / 5, tid % 5));
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
     __syncthreads();
 
@@ -198,7 +336,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             }
         } else {
         const int D = (span - 1 < n - 1) ? span - 1 : n - 1;
-        // ---- stage sequence, codes, special hairpins, partner masks, triangular offsets
+        // ---- stage sequence, codes, special hairpins, pair-code arrays, triangular offsets
         for (int x = tid; x <= n + 1; x += LNT) {
             unsigned char ch = 0;
             if (x >= 1 && x <= n) {
@@ -214,7 +352,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (tid == 0) {
             int o = 0;
             for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
-            misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0;
+            misc[1] = 0;
         }
         __syncthreads();
         if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
@@ -229,151 +367,106 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     for (int k = 0; k < 4; k++) { bool m = true; for (int t = 0; t < 8; t++) m = m && (seq[x + t] == (unsigned char)P->hexa[k][t]); if (m && s6 == -32768) s6 = (short)P->hexaE[k]; }
             }
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
-        }
-        // paired-cell lists of the first two diagonals (list of diagonal d lives in buffer d % 3)
-        for (int dd = 4; dd <= 5 && dd <= D; dd++)
-            for (int x = tid; x < n - dd; x += LNT) {
-                int i = x + 1;
-                if (pair_type(S[i], S[i + dd])) { int k = atomicAdd(&misc[2 + dd % 3], 1); list[(dd % 3) * LCAP + k] = (unsigned short)i; }
+            // combined pair codes (only interior positions are ever read: p - 1 >= 1, q + 1 <= n)
+            if (x >= 1) {
+                pax[x] = (unsigned short)((S[x] * 5 + (x > 1 ? S[x - 1] : 0)) * 50);
+                qbr[n + 1 - x] = (unsigned char)((S[x] * 5 + (x < n ? S[x + 1] : 0)) * 2);
             }
+        }
+        // ordered paired-cell lists of the first two diagonals (ballot compaction; list of diagonal d lives in buffer d % 3)
+        for (int dd = 4; dd <= 5 && dd <= D; dd++) {
+            const int i = tid + 1;
+            int t = 0;
+            if (tid < n - dd) t = pair_type(S[i], S[i + dd]);
+            const unsigned long long bal = __ballot(t != 0);
+            if (t) list[(dd % 3) * LSEG + wave * 64 + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(i | (t << 9));
+            if (lane == 0 && wave < 6) lcnt[(dd % 3) * 8 + wave] = __popcll(bal);
+        }
         __syncthreads();
-        WinCtx X;
-        X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D;
 
         if (dbg_cycles && tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; }
         // ---- anti-diagonal wavefront, software-pipelined: phase B of diagonal d (one thread per cell) runs in the same barrier
         // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
-            const unsigned short* clist = list + (d % 3) * LCAP;
-            const int ncp = misc[2 + d % 3];
             int* cpart = acc + (d & 1) * 2 * LCAP;
             int* mdec = cpart + LCAP;
-            // The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]]: the inner-pair part of a generic interior loop
-            // is folded in when the cell is finalised, so a generic candidate costs one LDS read.  Plain c = G0 - mismatchI[code].
-            // phase A0: the four small interior loops of each paired cell (1x1, 1x2, 2x1, 2x2) read the big int11/int21/int22
-            // tables from global memory; their loads are issued here and consumed after A1/A2 so the latency is covered.
-            int sp_e[4] = {INF, INF, INF, INF};
-            int sp_i = 0;
-            if (tid < ncp && !(dbg_flags & 1)) {
-                const int i = clist[tid], j = i + d;
-                sp_i = i;
-                const int type = pair_type(S[i], S[j]);
-                const int si1 = S[i + 1], sj1 = S[j - 1];
-#pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) {
-                    const int a = 1 + (c4 >> 1), b = 1 + (c4 & 1);       // n1 = a, n2 = b
-                    const int p = i + 1 + a, q = j - 1 - b;
-                    if (q - p >= TURN + 1) {
-                        int t2 = pair_type(S[p], S[q]);
-                        if (t2) {
-                            t2 = rtype_of(t2);
-                            const int sp1 = S[p - 1], sq1 = S[q + 1];
-                            int e;
-                            if (a == 1 && b == 1) e = P->int11[type][t2][si1][sj1];
-                            else if (a == 1 && b == 2) e = P->int21[type][t2][si1][sq1][sj1];
-                            else if (a == 2 && b == 1) e = P->int21[t2][type][sq1][si1][sp1];
-                            else e = P->int22[type][t2][si1][sp1][sq1][sj1];
-                            sp_e[c4] = e + (int)cring[((q - p) & 31) * CSTR + p] - 32768 - (int)T.mismatchI[t2 * 25 + sq1 * 5 + sp1];
+            // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
+            if (!(dbg_flags & (1 | 64)) && d >= 6) {
+                const unsigned short* clist = list + (d % 3) * LSEG;
+                const int* lc = lcnt + (d % 3) * 8;
+                const int p1 = __builtin_amdgcn_readfirstlane(lc[0]), p2 = p1 + __builtin_amdgcn_readfirstlane(lc[1]),
+                          p3 = p2 + __builtin_amdgcn_readfirstlane(lc[2]), p4 = p3 + __builtin_amdgcn_readfirstlane(lc[3]),
+                          p5 = p4 + __builtin_amdgcn_readfirstlane(lc[4]), ncp = p5 + __builtin_amdgcn_readfirstlane(lc[5]);
+                A1 a;
+                a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
+                for (int blk = 0; blk * 64 < ncp; blk++) {
+                    {   // re-materialise the wave-uniform loop parameters per block: keeps the admissibility tests and row offsets as plain
+                        // scalar compares inside the block instead of dozens of hoisted masks (SGPR spills)
+                        int r0 = d - 2, um = d - 2 - (TURN + 1) < MAXLOOP ? d - 2 - (TURN + 1) : MAXLOOP;
+                        asm volatile("" : "+s"(r0), "+s"(um));
+                        a.r0 = r0; a.um = um;
+                    }
+                    const int k = blk * 64 + lane;
+                    const bool act = k < ncp;
+                    int pre = 0, seg = 0;
+                    if (k >= p1) { pre = p1; seg = 64; }
+                    if (k >= p2) { pre = p2; seg = 128; }
+                    if (k >= p3) { pre = p3; seg = 192; }
+                    if (k >= p4) { pre = p4; seg = 256; }
+                    if (k >= p5) { pre = p5; seg = 320; }
+                    const unsigned ent = act ? (unsigned)clist[seg + k - pre] : (1u | (1u << 9));   // idle lanes: harmless dummy cell
+                    const int i = ent & 511, type = ent >> 9, j = i + d;
+                    int res = INF;
+                    const int au1 = type > 2 ? (int)T.TerminalAU : 0;
+                    if (wave < 8) {
+                        if (!(dbg_flags & 4)) {
+#define MIRP_GEN(CK)                                                                      \
+    switch (wave) {                                                                       \
+    case 0: res = a1_generic<CK, 30, 23>(a, i, j, type); break;                           \
+    case 1: res = a1_generic<CK, 29, 24>(a, i, j, type); break;                           \
+    case 2: res = a1_generic<CK, 28, 25>(a, i, j, type); break;                           \
+    case 3: res = a1_generic<CK, 27, 26>(a, i, j, type); break;                           \
+    case 4: res = a1_generic<CK, 22, 21, 13>(a, i, j, type); break;                       \
+    case 5: res = a1_generic<CK, 20, 19, 17>(a, i, j, type); break;                       \
+    case 6: res = a1_generic<CK, 18, 16, 15, 10>(a, i, j, type); break;                   \
+    default: res = a1_generic<CK, 14, 12, 11, 9, 8, 7, 6>(a, i, j, type); break;          \
+    }
+                            if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
+#undef MIRP_GEN
                         }
-                    }
-                }
-            }
-            // phase A1: 32 lanes per paired cell
-            if (!(dbg_flags & 1)) {
-                const int sub = tid & 31;
-                // the lane's loop size u = 6 + sub is fixed across cells: its 27 penalty taps are loaded once per diagonal (packed pairs)
-                unsigned pk2[14];
-                {
-                    const unsigned* pkp = reinterpret_cast<const unsigned*>(T.penK + (sub < 25 ? sub : 24) * 34 + 2);
-#pragma unroll
-                    for (int k = 0; k < 14; k++) pk2[k] = pkp[k];
-                }
-                // lane constants of the four non-generic rounds (the lane's (n1, n2) per round do not depend on the cell)
-                const int umax = d - 2 - (TURN + 1);             // n1 + n2 <= umax keeps q - p >= TURN + 1
-                int on1[4], on2[4], okc[4], kc[4];
-                {
-                    const int nin = T.ninio, mxn = T.MAX_NINIO;
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        int n1, n2;
-                        if (r4 == 0) { n1 = 0; n2 = sub; }                                   // stack + 3'-side bulges
-                        else if (r4 == 1) { n1 = sub + 1; n2 = 0; }                          // 5'-side bulges
-                        else if (r4 == 2) { n1 = 1; n2 = sub + 3; }                          // 1 x n
-                        else { n1 = sub < 27 ? sub + 3 : sub - 25; n2 = sub < 27 ? 1 : 30 - sub; }   // n x 1, then 2x3 (lane 27), 3x2 (lane 28)
-                        const int u = n1 + n2;
-                        bool ok = u <= umax && u <= MAXLOOP;
-                        if (r4 == 1) ok = ok && sub < 30;
-                        if (r4 == 2) ok = ok && sub < 27;
-                        if (r4 == 3) ok = ok && sub < 29;
-                        on1[r4] = n1; on2[r4] = n2; okc[r4] = ok ? 1 : 0;
-                        const int uu = ok ? u : 0;
-                        int k;
-                        if (r4 <= 1) k = uu == 0 ? 0 : (int)T.bulge[uu];
-                        else if (r4 == 2 || sub < 27) { int y = (uu - 2) * nin; y = y < mxn ? y : mxn; k = (int)T.internal_loop[uu] + y; }
-                        else k = (int)T.internal_loop[5] + nin;
-                        kc[r4] = k;
-                    }
-                }
-                for (int cidx = tid >> 5; cidx < ncp; cidx += LNT / 32) {
-                    const int i = clist[cidx], j = i + d;
-                    const int type = pair_type(S[i], S[j]);
-                    const int o_out = type * 25 + S[i + 1] * 5 + S[j - 1];
-                    int best = INF;
-                    // generic loops (n1, n2 >= 2, u = n1 + n2 >= 6): il[u] + min(MAX_NINIO, |n1-n2| ninio) + mismatchI(outer) + G0.
-                    // The candidates of one size u are a contiguous run of ring row d-2-u; each lane takes the sizes u = 6 + sub, 38 + ... and
-                    // walks the run with immediate offsets (straight-line: one LDS read pair + add + min per slot, no index arithmetic).
-                    {
-                        const int mo = T.mismatchI[o_out];
-                        unsigned bg = 65535u;
-                        const int um = umax < MAXLOOP ? umax : MAXLOOP;
-                        const int u = 6 + sub;
-                        if (u <= um && !(dbg_flags & 4)) {
-                            const unsigned short* row = cring + ((d - 2 - u) & 31) * CSTR + i + 1;
-#pragma unroll
-                            for (int n1 = 2; n1 <= 28; n1++) {
-                                const unsigned pen = (n1 & 1) ? (pk2[(n1 - 2) >> 1] >> 16) : (pk2[(n1 - 2) >> 1] & 0xffffu);
-                                const unsigned e = (unsigned)row[n1] + pen;
-                                bg = e < bg ? e : bg;
-                            }
+                    } else if (wave < 14) {
+                        if (!(dbg_flags & 8)) {
+                            unsigned bb = 65535u, bi = 65535u;
+#define MIRP_OTH(CK)                                                                      \
+    switch (wave) {                                                                       \
+    case 8: a1_b0<CK, 2, 20>(a, i, j, bb); break;                                         \
+    case 9: a1_b0<CK, 21, 30>(a, i, j, bb); a1_b1<CK, 2, 10>(a, i, j, bb); break;         \
+    case 10: a1_b1<CK, 11, 29>(a, i, j, bb); break;                                       \
+    case 11: a1_b1<CK, 30, 30>(a, i, j, bb); a1_i0<CK, 3, 20>(a, i, j, bi); break;        \
+    case 12: a1_i0<CK, 21, 29>(a, i, j, bi); a1_i1<CK, 3, 11>(a, i, j, bi); break;        \
+    default: a1_i1<CK, 12, 29>(a, i, j, bi); break;                                       \
+    }
+                            if (a.um >= MAXLOOP) { MIRP_OTH(false) } else { MIRP_OTH(true) }
+#undef MIRP_OTH
+                            const int rb = a1_fin(bb, au1);
+                            const int ri = a1_fin(bi, (int)T.mismatch1nI[type * 25 + S[i + 1] * 5 + S[j - 1]]);
+                            res = rb < ri ? rb : ri;
                         }
-                        if (bg < 65535u) { const int r = (int)bg - 32768 + mo; best = r < best ? r : best; }
-                    }
-                    // stack, bulges, 1xn, 2x3: four class-homogeneous rounds over the 32 lanes of the cell
-                    {
-                        const int au1 = type > 2 ? T.TerminalAU : 0;
-                        const int m1 = T.mismatch1nI[o_out], m2 = T.mismatch23I[o_out];
-                        const int tau = T.TerminalAU;
-                        const short* strow = T.stack + type * 8;
-#pragma unroll
-                        for (int r4 = 0; r4 < ((dbg_flags & 8) ? 0 : 4); r4++) {
-                            const int n1 = on1[r4], n2 = on2[r4], u = n1 + n2;
-                            bool ok = okc[r4] != 0;
-                            const int p = i + 1 + n1, q = j - 1 - n2;
-                            // reads are unconditional: for an inadmissible slot p, q stay inside [i, i+31] x [j-31, j], i.e. inside the LDS
-                            // arrays (S has slack, the ring is followed by the DML ring), and the result is discarded
-                            const int g0u = (int)cring[((q - p) & 31) * CSTR + p];
-                            ok = ok && g0u != 65535;
-                            const int g0 = g0u - 32768;
-                            const int t2 = T.rt2[S[p] * 5 + S[q]];
-                            const int code = t2 * 25 + S[q + 1] * 5 + S[p - 1];
-                            const int cpq = g0 - (int)T.mismatchI[code];
-                            int e;
-                            if (r4 <= 1) {
-                                const int st = strow[t2];
-                                e = u == 0 ? st : kc[r4] + (u == 1 ? st : au1 + (t2 > 2 ? tau : 0));
-                            } else if (r4 == 2 || sub < 27) {
-                                e = kc[r4] + m1 + (int)T.mismatch1nI[code];
-                            } else {
-                                e = kc[r4] + m2 + (int)T.mismatch23I[code];
-                            }
-                            e += cpq;
-                            if (ok && e < best) best = e;
+                    } else if (!(dbg_flags & 32)) {
+                        const int si1 = S[i + 1], sj1 = S[j - 1];
+                        int ra, ca, rb2, cb2;
+                        if (wave == 14) {
+                            a1_small_g<1, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<1, 2>(a, i, j, type, si1, sj1, rb2, cb2);
+                            a1_small<0, 0>(a, i, j, type, si1, sj1, res); a1_small<0, 1>(a, i, j, type, si1, sj1, res); a1_small<1, 0>(a, i, j, type, si1, sj1, res);
+                        } else {
+                            a1_small_g<2, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<2, 2>(a, i, j, type, si1, sj1, rb2, cb2);
+                            a1_small<2, 3>(a, i, j, type, si1, sj1, res); a1_small<3, 2>(a, i, j, type, si1, sj1, res);
                         }
+                        if (ca < INF && ra + ca < res) res = ra + ca;
+                        if (cb2 < INF && rb2 + cb2 < res) res = rb2 + cb2;
                     }
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) { int t = __shfl_xor(best, o); best = t < best ? t : best; }
-                    if (sub == 0 && best < INF) atomicMin(&cpart[i], best);
+                    if (act && res < INF) atomicMin(&cpart[i], res);
                 }
             }
             // phase A2: multiloop splits DML(i,j) over the finite range of row i / column j.
@@ -399,7 +492,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
                     const char* fb = reinterpret_cast<const char*>(fml + i);
                     unsigned bu = 65535u;
-#define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss))
+#define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
 #define MIRP_LD(o) ((unsigned)*reinterpret_cast<const unsigned short*>(fb + (o)))
                     for (; t + 3 * s1 <= d - 5; t += 4 * s1) {
                         const unsigned a0 = MIRP_LD(so1), b0 = MIRP_LD(so2);
@@ -427,19 +520,15 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (best < INF) atomicMin(&mdec[i], best);
                 }
             }
-            {
-                int e = sp_e[0] < sp_e[1] ? sp_e[0] : sp_e[1];
-                int f = sp_e[2] < sp_e[3] ? sp_e[2] : sp_e[3];
-                e = e < f ? e : f;
-                if (e < INF) atomicMin(&cpart[sp_i], e);
-            }
         };
         auto phaseB = [&](const int d) {
             const int ncell = n - d;
             int* cpart = acc + (d & 1) * 2 * LCAP;
             int* mdec = cpart + LCAP;
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
-            for (int x = tid; x < ncell; x += LNT) {
+            int lt = 0;          // pair type of this thread's cell on diagonal d+2 (0: not in the list)
+            const int x = tid;
+            if (x < ncell) {
                 const int i = x + 1, j = i + d;
                 const int type = pair_type(S[i], S[j]);
                 int cv = INF;
@@ -483,17 +572,18 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 fml[off[d] + i] = m16;
                 dmlring[(d % 3) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 cpart[i] = INF; mdec[i] = INF;
-                if (d + 2 <= D && i + d + 2 <= n && pair_type(S[i], S[i + d + 2])) {   // paired list of diagonal d+2
-                    int k = atomicAdd(&misc[2 + (d + 2) % 3], 1);
-                    list[((d + 2) % 3) * LCAP + k] = (unsigned short)i;
-                }
+                if (d + 2 <= D && i + d + 2 <= n) lt = pair_type(S[i], S[i + d + 2]);
+            }
+            if (d + 2 <= D) {   // ordered paired-cell list of diagonal d+2: ballot compaction per producer wave
+                const unsigned long long bal = __ballot(lt != 0);
+                if (lt) list[((d + 2) % 3) * LSEG + wave * 64 + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
+                if (lane == 0 && wave < 6) lcnt[((d + 2) % 3) * 8 + wave] = __popcll(bal);
             }
         };
         if (D >= 4) phaseA(4);
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
         for (int d = 4; d <= D; d++) {
-            if (tid == 0) misc[2 + d % 3] = 0;   // list(d) was consumed in the previous interval; the buffer is refilled as list(d+3) in the next one
             phaseB(d);
             if (d + 1 <= D) phaseA(d + 1);
             __syncthreads();
@@ -595,7 +685,7 @@ size_t fold_lds_epilogue_bytes(int max_lines) {
     return b + sizeof(EpiTables) + 16;
 }
 
-size_t fold_lds_bytes(int max_lines) { return lds_layout(max_lines).total; }
+size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout().total; }
 int fold_lds_max_n() { return LCAP - 2; }
 int fold_lds_max_span() { return LDMAX + 1; }
 

@@ -30,6 +30,10 @@ struct FoldParams {
     char tri[2][8];
     char hexa[4][12];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
+    // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes):
+    int gen_pen[25][28];          // generic interior loop [u-6][n1], 2 <= n1 <= u-2: internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)
+    int k_bulge[31];              // bulge[u] + 2048
+    int k_1n[31];                 // 1 x k loops: internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048
 };
 
 // Fills *p from the generated Turner-2004 tables (host side, mirp_params.cpp).

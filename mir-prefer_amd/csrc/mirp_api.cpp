@@ -218,6 +218,11 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         HIPCHK(c, hipMemcpyAsync(&nfb, ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->last_fallback = nfb;
+        if (const char* dump = std::getenv("MIRP_FOLD_DUMP")) {   // diagnostics: c / fML slabs of the first window of the last sub-batch
+            std::vector<short> h(2 * slab);
+            HIPCHK(c, hipMemcpy(h.data(), c->carch.p, 4 * slab, hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 2, h.size(), f); std::fclose(f); }
+        }
         if (dbg_cycles) {
             long long cyc[4];
             HIPCHK(c, hipMemcpy(cyc, dbg_cycles, sizeof(cyc), hipMemcpyDeviceToHost));

@@ -2,6 +2,7 @@
 #include "fold_params.h"
 #include "energy_params_t2004.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static inline int clamp0(int v) { return v > 0 ? 0 : v; }
@@ -37,4 +38,15 @@ void mirp_fill_fold_params(FoldParams* p) {
     p->TerminalAU = T04_TerminalAU;
     p->ninio = T04_ninio;
     p->MAX_NINIO = T04_MAX_NINIO;
+    for (int u = 6; u <= MIRP_MAXLOOP; u++)
+        for (int n1 = 0; n1 < 28; n1++) {
+            int v = 65535;
+            if (n1 >= 2 && n1 <= u - 2) { int y = std::abs(2 * n1 - u) * p->ninio; v = p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO); }
+            p->gen_pen[u - 6][n1] = v;
+        }
+    for (int u = 0; u <= MIRP_MAXLOOP; u++) {
+        p->k_bulge[u] = p->bulge[u] + 2048;
+        int y = (u - 1) * p->ninio;
+        p->k_1n[u] = (u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048;
+    }
 }
