@@ -398,6 +398,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int p1 = __builtin_amdgcn_readfirstlane(lc[0]), p2 = p1 + __builtin_amdgcn_readfirstlane(lc[1]),
                           p3 = p2 + __builtin_amdgcn_readfirstlane(lc[2]), p4 = p3 + __builtin_amdgcn_readfirstlane(lc[3]),
                           p5 = p4 + __builtin_amdgcn_readfirstlane(lc[4]), ncp = p5 + __builtin_amdgcn_readfirstlane(lc[5]);
+                // roles: phase B of the previous diagonal runs on waves 0-5 (one thread per cell), so those waves take the lighter candidate groups
+                const int role = (wave + 8) & 15;   // role 0-7: generic rows, 8-13: bulges / 1xn, 14-15: small shapes
                 A1 a;
                 a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
                 for (int blk = 0; blk * 64 < ncp; blk++) {
@@ -419,10 +421,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int i = ent & 511, type = ent >> 9, j = i + d;
                     int res = INF;
                     const int au1 = type > 2 ? (int)T.TerminalAU : 0;
-                    if (wave < 8) {
+                    if (role < 8) {
                         if (!(dbg_flags & 4)) {
 #define MIRP_GEN(CK)                                                                      \
-    switch (wave) {                                                                       \
+    switch (role) {                                                                       \
     case 0: res = a1_generic<CK, 30, 23>(a, i, j, type); break;                           \
     case 1: res = a1_generic<CK, 29, 24>(a, i, j, type); break;                           \
     case 2: res = a1_generic<CK, 28, 25>(a, i, j, type); break;                           \
@@ -435,11 +437,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
 #undef MIRP_GEN
                         }
-                    } else if (wave < 14) {
+                    } else if (role < 14) {
                         if (!(dbg_flags & 8)) {
                             unsigned bb = 65535u, bi = 65535u;
 #define MIRP_OTH(CK)                                                                      \
-    switch (wave) {                                                                       \
+    switch (role) {                                                                       \
     case 8: a1_b0<CK, 2, 20>(a, i, j, bb); break;                                         \
     case 9: a1_b0<CK, 21, 30>(a, i, j, bb); a1_b1<CK, 2, 10>(a, i, j, bb); break;         \
     case 10: a1_b1<CK, 11, 29>(a, i, j, bb); break;                                       \
@@ -456,7 +458,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     } else if (!(dbg_flags & 32)) {
                         const int si1 = S[i + 1], sj1 = S[j - 1];
                         int ra, ca, rb2, cb2;
-                        if (wave == 14) {
+                        if (role == 14) {
                             a1_small_g<1, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<1, 2>(a, i, j, type, si1, sj1, rb2, cb2);
                             a1_small<0, 0>(a, i, j, type, si1, sj1, res); a1_small<0, 1>(a, i, j, type, si1, sj1, res); a1_small<1, 0>(a, i, j, type, si1, sj1, res);
                         } else {
