@@ -496,6 +496,18 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     unsigned bu = 65535u;
 #define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
 #define MIRP_LD(o) ((unsigned)*reinterpret_cast<const unsigned short*>(fb + (o)))
+                    for (; t + 7 * s1 <= d - 5; t += 8 * s1) {     // 16 reads in flight
+                        unsigned a[8], b[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { a[k] = MIRP_LD(so1); b[k] = MIRP_LD(so2); MIRP_SSTEP(); }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) a[k] += b[k];
+                        a[0] = a[0] < a[1] ? a[0] : a[1]; a[2] = a[2] < a[3] ? a[2] : a[3]; a[4] = a[4] < a[5] ? a[4] : a[5]; a[6] = a[6] < a[7] ? a[6] : a[7];
+                        a[0] = a[0] < a[2] ? a[0] : a[2]; a[4] = a[4] < a[6] ? a[4] : a[6]; a[0] = a[0] < a[4] ? a[0] : a[4];
+                        bu = a[0] < bu ? a[0] : bu;
+                    }
+                    so1 = __builtin_amdgcn_readfirstlane(so1); so2 = __builtin_amdgcn_readfirstlane(so2);
+                    si1 = __builtin_amdgcn_readfirstlane(si1); si2 = __builtin_amdgcn_readfirstlane(si2);
                     for (; t + 3 * s1 <= d - 5; t += 4 * s1) {
                         const unsigned a0 = MIRP_LD(so1), b0 = MIRP_LD(so2);
                         MIRP_SSTEP();
