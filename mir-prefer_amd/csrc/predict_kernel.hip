@@ -15,13 +15,27 @@ namespace mirp {
 #define PW_MAX_STRUCTS 192   // structures per window (lines * pieces)
 #define PW_MAX_PIECES 6
 #define PW_MAX_MATURES 40
-#define EVW 10
 
-struct PStruct { double ne; int start; int line; int off; int len; int type; };
+// One structure piece of a window: line index, offset and length inside the line, kind (0 stem-loop, 1 good bifurcation).
+// start and normalised energy are recomputed from the line record.
+struct PStruct { unsigned short line, off, len, type; };
 
-__device__ __forceinline__ int d_find(const char* s, char c, int a, int b) { for (int i = a; i < b; i++) if (s[i] == c) return i; return -1; }
-__device__ __forceinline__ int d_rfind(const char* s, char c, int a, int b) { for (int i = b - 1; i >= a; i--) if (s[i] == c) return i; return -1; }
-__device__ __forceinline__ int d_count(const char* s, char c, int a, int b) { int n = 0; for (int i = a; i < b; i++) n += (s[i] == c); return n; }
+// Dot-bracket text staged in LDS at 2 bits per character (16 characters per word): a window's lines then take <= 9 KB instead of
+// 34 KB, which is what bounds the number of resident windows per CU.  0 '.', 1 '(', 2 ')'.
+struct SS {
+    const unsigned* w;
+    int o;
+    __device__ __forceinline__ char operator[](int i) const {
+        const int k = o + i;
+        const unsigned c = (w[k >> 4] >> ((k & 15) * 2)) & 3u;
+        return c == 0 ? '.' : (c == 1 ? '(' : ')');
+    }
+    __device__ __forceinline__ SS operator+(int d) const { SS r; r.w = w; r.o = o + d; return r; }
+};
+
+__device__ __forceinline__ int d_find(SS s, char c, int a, int b) { for (int i = a; i < b; i++) if (s[i] == c) return i; return -1; }
+__device__ __forceinline__ int d_rfind(SS s, char c, int a, int b) { for (int i = b - 1; i >= a; i--) if (s[i] == c) return i; return -1; }
+__device__ __forceinline__ int d_count(SS s, char c, int a, int b) { int n = 0; for (int i = a; i < b; i++) n += (s[i] == c); return n; }
 __device__ __forceinline__ void d_clip(int len, int& a, int& b) {   // Python slice bounds
     if (a < 0) { a += len; if (a < 0) a = 0; }
     if (b < 0) { b += len; if (b < 0) b = 0; }
@@ -30,7 +44,7 @@ __device__ __forceinline__ void d_clip(int len, int& a, int& b) {   // Python sl
 }
 
 // partner of bracket at x inside s[0,len); -1 if unmatched
-__device__ int d_partner(const char* s, int len, int x) {
+__device__ int d_partner(SS s, int len, int x) {
     int depth = 0;
     if (s[x] == '(') {
         for (int i = x; i < len; i++) { if (s[i] == '(') depth++; else if (s[i] == ')') { if (--depth == 0) return i; } }
@@ -40,13 +54,13 @@ __device__ int d_partner(const char* s, int len, int x) {
     return -1;
 }
 
-__device__ bool d_is_stem_loop(const char* s, int len) {   // MP:1602-1608, minloop 3
+__device__ bool d_is_stem_loop(SS s, int len) {   // MP:1602-1608, minloop 3
     int lo = d_rfind(s, '(', 0, len), fc = d_find(s, ')', 0, len);
     return fc - lo - 1 >= 3;
 }
 
 // MP:1611-1659
-__device__ bool d_good_bifurcation(const char* s, int len) {
+__device__ bool d_good_bifurcation(SS s, int len) {
     int depth = 0, bif = 0, last_pop = 0, first_bi_last = 0, second_bi_first = 0, last_pos = 0;
     for (int idx = 0; idx < len; idx++) {
         char ch = s[idx];
@@ -74,7 +88,7 @@ __device__ bool d_good_bifurcation(const char* s, int len) {
 }
 
 // stat_duplex + pass_stat_duplex (MP:1815-1873) on mature_duplex = s[m0,m1), star_duplex = s[s0,s1). Returns MS code.
-__device__ int d_duplex_code(const char* s, int m0, int m1, int s0, int s1) {
+__device__ int d_duplex_code(SS s, int m0, int m1, int s0, int s1) {
     const int ml = m1 - m0, L = ml + (s1 - s0);
 #define DCH(i) ((i) < ml ? s[m0 + (i)] : s[s0 + (i) - ml])
     int openpos = -1, closepos = -1;
@@ -119,7 +133,7 @@ __device__ int d_duplex_code(const char* s, int m0, int m1, int s0, int s1) {
 struct MStar { int code, star_s, star_e, fold_s, fold_e; };
 
 // get_maturestar_info (MP:1876-1999). strand 0 '+', 1 '-'.
-__device__ void d_maturestar(const char* ss, int len, int m0, int m1, int foldstart, int rs, int re, int strand, MStar& o) {
+__device__ void d_maturestar(SS ss, int len, int m0, int m1, int foldstart, int rs, int re, int strand, MStar& o) {
     o.code = 0; o.star_s = o.star_e = 0;
     { int depth = 0; for (int i = 0; i < len; i++) { if (ss[i] == '(') depth++; else if (ss[i] == ')') { if (depth == 0) { o.code = 1; return; } depth--; } } }
     int l0, l1, fg0, fg1;
@@ -240,22 +254,37 @@ __global__ void __launch_bounds__(64) predict_kernel(
     int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
     MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status) {
     extern __shared__ __align__(16) unsigned char smem[];
-    char* text = (char*)smem;                                           // max_lines * ss_stride
-    PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * ss_stride + 15) & ~(size_t)15)); // PW_MAX_STRUCTS
+    const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
+    unsigned* textw = (unsigned*)smem;                                   // max_lines * wpl
+    PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * wpl * 4 + 15) & ~(size_t)15)); // PW_MAX_STRUCTS
     PStruct* slot = sts + PW_MAX_STRUCTS;                                // 64 * PW_MAX_PIECES
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
-    int* ev = cnts + 64;                                                 // PW_MAX_STRUCTS * EVW (per-structure evaluation of the current mature)
     const int lane = threadIdx.x;
     for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
         const MirpWindow W = windows[w];
         const int nl = n_lines[w] < max_lines ? n_lines[w] : max_lines;
+        const MirpFoldLine* wl = lines + (size_t)w * max_lines;
         int st_flag = 0;
-        // stage the window's structure text (coalesced 4-byte copies)
+        // stage the window's structure text, 2 bits per character (lane = one packed word = 16 characters)
         {
-            const unsigned int* src = (const unsigned int*)(ss + (size_t)w * max_lines * ss_stride);
-            unsigned int* dst = (unsigned int*)text;
-            int nwords = (nl * ss_stride) / 4;
-            for (int x = lane; x < nwords; x += 64) dst[x] = src[x];
+            const char* src = ss + (size_t)w * max_lines * ss_stride;
+            for (int x = lane; x < nl * wpl; x += 64) {
+                const int ln = x / wpl, wi = x - ln * wpl;
+                const char* p = src + (size_t)ln * ss_stride + wi * 16;
+                const int lim = ss_stride - wi * 16;       // bytes of this line left
+                unsigned v = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned four = 0;
+                    if (q * 4 + 4 <= lim) four = *reinterpret_cast<const unsigned*>(p + q * 4);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const unsigned ch = (four >> (8 * b)) & 0xffu;
+                        v |= (ch == '(' ? 1u : (ch == ')' ? 2u : 0u)) << ((q * 4 + b) * 2);
+                    }
+                }
+                textw[x] = v;
+            }
         }
         __syncthreads();
         // ---- phase 1: structures (lane per line, chunks of 64 lines)
@@ -263,12 +292,11 @@ __global__ void __launch_bounds__(64) predict_kernel(
         for (int lb = 0; lb < nl; lb += 64) {
             int k = lb + lane, cnt = 0;
             if (k < nl) {
-                MirpFoldLine ln = lines[(size_t)w * max_lines + k];
-                const char* s = text + (size_t)k * ss_stride;
+                MirpFoldLine ln = wl[k];
+                SS s; s.w = textw + (size_t)k * wpl; s.o = 0;
                 if (ln.printed && ln.len >= pp.minlen) {
-                    double ne = ((double)ln.energy / 100.0) / (double)ln.len;
                     if (d_is_stem_loop(s, ln.len)) {
-                        PStruct p; p.ne = ne; p.start = ln.start; p.line = k; p.off = 0; p.len = ln.len; p.type = 0;
+                        PStruct p; p.line = (unsigned short)k; p.off = 0; p.len = (unsigned short)ln.len; p.type = 0;
                         slot[lane * PW_MAX_PIECES + cnt++] = p;
                     } else {
                         // filter_ss (MP:1685-1724): one piece per top-level stem, [previous gap start, next stem start)
@@ -287,7 +315,7 @@ __global__ void __launch_bounds__(64) predict_kernel(
                                     else if (d_good_bifurcation(s + ps, pl)) type = 1;
                                     if (type >= 0) {
                                         if (cnt < PW_MAX_PIECES) {
-                                            PStruct p; p.ne = ne; p.start = ln.start + ps; p.line = k; p.off = ps; p.len = pl; p.type = type;
+                                            PStruct p; p.line = (unsigned short)k; p.off = (unsigned short)ps; p.len = (unsigned short)pl; p.type = (unsigned short)type;
                                             slot[lane * PW_MAX_PIECES + cnt++] = p;
                                         } else st_flag = 2;
                                     }
@@ -329,13 +357,20 @@ __global__ void __launch_bounds__(64) predict_kernel(
                 MirpMature m = matures[W.mature_off + mi];
                 int ml = m.end - m.start;
                 if (ml < pp.min_mature_len || ml > pp.max_mature_len) continue;
+                // Each lane evaluates its structures and keeps its own winner of the sequential rule of MP:2246-2343
+                // ("for s in order: skip if ne > lowest; if it passes: best = s, lowest = ne", lowest starting at 0.0), which selects the
+                // passing structure with the smallest normalised energy <= 0 and, among equals, the LAST one in order.
+                double b_ne = 0.0;
+                int b_s = -1, b_has_star = 0, b_star_s = 0, b_star_e = 0, b_fold_s = 0, b_fold_e = 0, b_tm = 0, b_ts = 0, b_imp = 0;
                 for (int sb = 0; sb < nst; sb += 64) {
                     int s = sb + lane;
                     if (s < nst) {
-                        PStruct p = sts[s];
-                        const char* str = text + (size_t)p.line * ss_stride + p.off;
+                        const PStruct p = sts[s];
+                        const MirpFoldLine ln = wl[p.line];
+                        const double ne = ((double)ln.energy / 100.0) / (double)ln.len;
+                        SS str; str.w = textw + (size_t)p.line * wpl; str.o = p.off;
                         MStar ms;
-                        d_maturestar(str, p.len, m.start, m.end, p.start, W.ws, W.we, m.strand, ms);
+                        d_maturestar(str, p.len, m.start, m.end, ln.start + p.off, W.ws, W.we, m.strand, ms);
                         int pass = 0, has_star = 0, star_s = ms.star_s, star_e = ms.star_e, impf = 0;
                         long long tm = 0, ts = 0;
                         if (ms.code == 0) {
@@ -356,32 +391,33 @@ __global__ void __launch_bounds__(64) predict_kernel(
                                 }
                             }
                         }
-                        int* e = ev + s * EVW;
-                        e[0] = pass; e[1] = has_star; e[2] = star_s; e[3] = star_e; e[4] = ms.fold_s; e[5] = ms.fold_e;
-                        e[6] = (int)(tm > 0x7fffffffLL ? 0x7fffffffLL : tm); e[7] = (int)(ts > 0x7fffffffLL ? 0x7fffffffLL : ts); e[8] = impf;
+                        if (pass && ne <= b_ne) {   // later structures win ties (this lane's s only grows)
+                            b_ne = ne; b_s = s; b_has_star = has_star; b_star_s = star_s; b_star_e = star_e; b_fold_s = ms.fold_s; b_fold_e = ms.fold_e;
+                            b_tm = (int)(tm > 0x7fffffffLL ? 0x7fffffffLL : tm); b_ts = (int)(ts > 0x7fffffffLL ? 0x7fffffffLL : ts); b_imp = impf;
+                        }
                     }
                 }
-                __syncthreads();
-                if (lane == 0) {
-                    double lowest = 0.0;
-                    int best = -1;
-                    for (int s = 0; s < nst; s++) {
-                        if (sts[s].ne > lowest) continue;       // MP:2251
-                        if (ev[s * EVW]) { best = s; lowest = sts[s].ne; }
-                    }
-                    if (best >= 0 && nout < MIRP_MAX_MIRNA_PER_WINDOW) {
-                        const int* e = ev + best * EVW;
+                // wave arg-min over (ne ascending, s descending) among lanes that have a candidate
+                double r_ne = b_ne;
+                int r_s = b_s;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double t_ne = __shfl_xor(r_ne, o);
+                    const int t_s = __shfl_xor(r_s, o);
+                    const bool take = t_s >= 0 && (r_s < 0 || t_ne < r_ne || (t_ne == r_ne && t_s > r_s));
+                    if (take) { r_ne = t_ne; r_s = t_s; }
+                }
+                if (r_s >= 0 && nout < MIRP_MAX_MIRNA_PER_WINDOW) {
+                    if (b_s == r_s) {   // exactly one lane owns the winner
+                        const PStruct bp = sts[r_s];
                         MirpMirna r;
-                        r.window = w; r.tid = W.tid; r.fold_s = e[4]; r.fold_e = e[5]; r.mat_s = m.start; r.mat_e = m.end;
-                        r.star_s = e[2]; r.star_e = e[3]; r.strand = m.strand; r.has_star = e[1];
-                        r.line = sts[best].line; r.ss_off = sts[best].off; r.ss_len = sts[best].len; r.reserved = e[8];
-                        r.total_depth_mature = e[6]; r.total_depth_star = e[7];
+                        r.window = w; r.tid = W.tid; r.fold_s = b_fold_s; r.fold_e = b_fold_e; r.mat_s = m.start; r.mat_e = m.end;
+                        r.star_s = b_star_s; r.star_e = b_star_e; r.strand = m.strand; r.has_star = b_has_star;
+                        r.line = bp.line; r.ss_off = bp.off; r.ss_len = bp.len; r.reserved = b_imp;
+                        r.total_depth_mature = b_tm; r.total_depth_star = b_ts;
                         out[(size_t)w * MIRP_MAX_MIRNA_PER_WINDOW + nout] = r;
-                        nout++;
                     }
+                    nout++;
                 }
-                nout = __shfl(nout, 0);
-                __syncthreads();
             }
         }
         if (lane == 0) { n_out[w] = nout; }
@@ -396,10 +432,9 @@ __global__ void __launch_bounds__(64) predict_kernel(
 }
 
 size_t predict_lds_bytes(int max_lines, int ss_stride) {
-    size_t b = (((size_t)max_lines * ss_stride + 15) & ~(size_t)15);
+    size_t b = (((size_t)max_lines * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15);
     b += sizeof(PStruct) * (PW_MAX_STRUCTS + 64 * PW_MAX_PIECES);
     b += sizeof(int) * 64;
-    b += sizeof(int) * PW_MAX_STRUCTS * EVW;
     return (b + 15) & ~(size_t)15;
 }
 
