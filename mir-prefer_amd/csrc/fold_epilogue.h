@@ -238,6 +238,11 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             if (cij == e_hairpin(X, i, j, type)) break;
             int pmax = (j - 2 - TURN < i + MAXLOOP + 1) ? j - 2 - TURN : i + MAXLOOP + 1;
             int fp = -1, fq = -1;
+            // Trace-back code of the fill kernel (T.TB >= 0): 1 + (n1 << 5 | n2) names the interior loop this search would find first,
+            // 0 says that none realises c(i,j) (multiloop).  Tables without codes (TB < 0) are searched: p ascending, q descending.
+            const int code = __builtin_amdgcn_readfirstlane(T.TB(j - i, i));
+            if (code > 0) { fp = i + 1 + ((code - 1) >> 5); fq = j - 1 - ((code - 1) & 31); }
+            if (code < 0)
             for (int pb = i + 1; pb <= pmax && fp < 0; pb += 2) {
                 int p = pb + (lane >> 5), q = j - 1 - (lane & 31);
                 int minq = j - i + p - MAXLOOP - 2;

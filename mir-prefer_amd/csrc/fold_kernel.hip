@@ -22,6 +22,7 @@ struct GTab {
     int ld;
     __device__ __forceinline__ int C(int d, int i) const { return c[(size_t)d * ld + i]; }
     __device__ __forceinline__ int M(int d, int i) const { return m[(size_t)d * ld + i]; }
+    __device__ __forceinline__ int TB(int, int) const { return -1; }   // no trace-back codes: the backtrack searches
 };
 
 // ------------------------------------------------------------------------------------------

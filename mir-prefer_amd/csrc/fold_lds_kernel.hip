@@ -35,7 +35,10 @@ namespace mirp {
 #define FML_BIAS 32000       // fML is kept in LDS as uint16 (value + FML_BIAS), 65535 = INF; finite fML must stay in [-32000, 767] so that the sum of
 #define FML_MAX 767          // two finite entries (<= 65534) can never be mistaken for a sum that involves INF (>= 65535)
 #define LSEG 384             // paired-cell list: 6 producer waves x 64 entries
-#define OTH_BIAS 2048        // keeps (table delta + size term) of a bulge / 1xn candidate non-negative (FoldParams::k_bulge, k_1n carry it)
+#define KEY_BIAS 40000        // candidate keys: (energy + KEY_BIAS) << 10 | n1 << 5 | n2, 0xffffffff = none
+#define KEY_NONE 0xffffffffu
+#define KEY_INF (65535u << 10) // running-minimum start inside a job: any key that involves an INF ring entry is >= this
+#define OTH_BIAS 2048        // keeps (table delta + size term) of a bulge / 1xn candidate non-negative (the FoldParams key tables carry it)
 
 struct LdsTables {          // int16 copies of the hot parameter tables
     short stack[64];
@@ -54,6 +57,8 @@ struct LTab {               // table accessors for the shared epilogue/backtrack
     const short* fml;       // triangular fML (per-window global slab in the epilogue kernel)
     const int* off;         // LDS: triangular offset of diagonal d (valid for d >= 4)
     const short* carch;     // global archive of c, triangular like fML: (d,i) -> off[d] + i (keeps a workgroup's slab ~88 KB, L2-friendly)
+    const unsigned short* tb;   // trace-back codes written by the fill kernel, same triangle
+    __device__ __forceinline__ int TB(int d, int i) const { return tb[off[d] + i]; }
     __device__ __forceinline__ int C(int d, int i) const { int v = carch[off[d] + i]; return v == I16_INF ? INF : v; }
     __device__ __forceinline__ int M(int d, int i) const {
         if (d < 4) return INF;
@@ -146,18 +151,21 @@ __device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb
         for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = rp[n1];
 #pragma unroll
         for (int n1 = 2; n1 <= U - 2; n1++) {
-            const unsigned e = v[n1 - 2] + (unsigned)a.P->gen_pen[U - 6][n1];
+            const unsigned e = (v[n1 - 2] << 10) + a.P->gen_key[U - 6][n1];
             bg = e < bg ? e : bg;
         }
     }
 }
+// job-local key (term << 10 | code) -> cell key ((energy + KEY_BIAS) << 10 | code); `adj` turns the job's term into the loop energy
+__device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
+    return b >= KEY_INF ? KEY_NONE : ((unsigned)((int)(b >> 10) + adj + KEY_BIAS) << 10) | (b & 1023u);
+}
 template <bool CHECK, int... Us>
-__device__ __forceinline__ int a1_generic(const A1& a, int i, int j, int type) {
-    unsigned bg = 65535u;
+__device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int type) {
+    unsigned bg = KEY_INF;
     const unsigned short* rb = a.cring + i + 1;
     (a1_gen_row<CHECK, Us>(a, rb, bg), ...);
-    if (bg >= 65535u) return INF;
-    return (int)bg - 32768 + (int)a.T->mismatchI[type * 25 + a.S[i + 1] * 5 + a.S[j - 1]];
+    return a1_key(bg, -32768 + (int)a.T->mismatchI[type * 25 + a.S[i + 1] * 5 + a.S[j - 1]]);
 }
 
 // bulges, n1 = 0, n2 = U in [LO, HI]: p = i+1, q = j-1-U
@@ -173,7 +181,7 @@ __device__ __forceinline__ void a1_b0(const A1& a, int i, int j, unsigned& best)
             const unsigned idx2 = idxp + ql[U];
             const int x = *reinterpret_cast<const short*>(xb + idx2);
             const unsigned g = rb[((a.r0 - U) & 31) * CSTR];
-            const unsigned e = g + (unsigned)(x + a.P->k_bulge[U]);
+            const unsigned e = ((g + (unsigned)x) << 10) + a.P->kb0_key[U];
             best = e < best ? e : best;
         }
     }
@@ -191,7 +199,7 @@ __device__ __forceinline__ void a1_b1(const A1& a, int i, int j, unsigned& best)
             const unsigned idx2 = idxq + pl[U];
             const int x = *reinterpret_cast<const short*>(xb + idx2);
             const unsigned g = rb[((a.r0 - U) & 31) * CSTR + U];
-            const unsigned e = g + (unsigned)(x + a.P->k_bulge[U]);
+            const unsigned e = ((g + (unsigned)x) << 10) + a.P->kb1_key[U];
             best = e < best ? e : best;
         }
     }
@@ -209,7 +217,7 @@ __device__ __forceinline__ void a1_i0(const A1& a, int i, int j, unsigned& best)
             const unsigned idx2 = idxp + ql[K];
             const int x = *reinterpret_cast<const short*>(xb + idx2);
             const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR];
-            const unsigned e = g + (unsigned)(x + a.P->k_1n[K]);
+            const unsigned e = ((g + (unsigned)x) << 10) + a.P->k1n0_key[K];
             best = e < best ? e : best;
         }
     }
@@ -227,25 +235,24 @@ __device__ __forceinline__ void a1_i1(const A1& a, int i, int j, unsigned& best)
             const unsigned idx2 = idxq + pl[K];
             const int x = *reinterpret_cast<const short*>(xb + idx2);
             const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR + K];
-            const unsigned e = g + (unsigned)(x + a.P->k_1n[K]);
+            const unsigned e = ((g + (unsigned)x) << 10) + a.P->k1n1_key[K];
             best = e < best ? e : best;
         }
     }
 }
-__device__ __forceinline__ int a1_fin(unsigned best, int klane) { return best >= 65535u ? INF : (int)best - 32768 - OTH_BIAS + klane; }
 
 // the nine small shapes: full energy function, branch-free so the global table loads of one wave are issued together
 template <int N1, int N2>
-__device__ __forceinline__ void a1_small(const A1& a, int i, int j, int type, int si1, int sj1, int& best) {
+__device__ __forceinline__ void a1_small(const A1& a, int i, int j, int type, int si1, int sj1, unsigned& best) {
     if (N1 + N2 <= a.um) {
         const int p = i + 1 + N1, q = j - 1 - N2;
         const unsigned g = a.cring[((a.r0 - N1 - N2) & 31) * CSTR + p];
         const int sp1 = a.S[p - 1], sq1 = a.S[q + 1];
         const int t2 = a.T->rt2[a.S[p] * 5 + a.S[q]];
         const int c = (int)g - 32768 - (int)a.T->mismatchI[t2 * 25 + sq1 * 5 + sp1];
-        int e = lds_intloop(*a.T, a.P, N1, N2, type, t2, si1, sj1, sp1, sq1) + c;
-        e = g == 65535u ? INF : e;
-        best = e < best ? e : best;
+        const int e = lds_intloop(*a.T, a.P, N1, N2, type, t2, si1, sj1, sp1, sq1) + c;
+        const unsigned k = g == 65535u ? KEY_NONE : ((unsigned)(e + KEY_BIAS) << 10) | (unsigned)(N1 << 5 | N2);
+        best = k < best ? k : best;
     }
 }
 
@@ -326,8 +333,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (win >= n_work) break;
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
-        short* carch = slabs + (size_t)win * 2 * slab_shorts;      // per-window slab: c triangle, then fML triangle (read by fold_lds_epilogue_kernel)
+        short* carch = slabs + (size_t)win * 3 * slab_shorts;      // per-window slab: c, fML and trace-back triangles (read by fold_lds_epilogue_kernel)
         short* fml_out = carch + slab_shorts;
+        unsigned short* tb_out = reinterpret_cast<unsigned short*>(carch + 2 * slab_shorts);
         if (dbg_cycles && tid == 0) t0 = clock64();
         if (n < 1 || n > LCAP - 2) {   // wave-uniform: empty window, or too long for this kernel (-> generic kernel)
             if (tid == 0) {
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
         for (int x = tid; x < 3 * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
-        for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = INF;
+        for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = ((x / LCAP) & 1) ? INF : (int)KEY_NONE;   // [parity][ckey | mdec]
         if (tid == 0) {
             int o = 0;
             for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
@@ -389,8 +397,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
-            int* cpart = acc + (d & 1) * 2 * LCAP;
-            int* mdec = cpart + LCAP;
+            unsigned* ckey = reinterpret_cast<unsigned*>(acc + (d & 1) * 2 * LCAP);   // best interior-loop candidate key per cell
+            int* mdec = acc + (d & 1) * 2 * LCAP + LCAP;
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
             if (!(dbg_flags & (1 | 64)) && d >= 6) {
                 const unsigned short* clist = list + (d % 3) * LSEG;
@@ -419,7 +427,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (k >= p5) { pre = p5; seg = 320; }
                     const unsigned ent = act ? (unsigned)clist[seg + k - pre] : (1u | (1u << 9));   // idle lanes: harmless dummy cell
                     const int i = ent & 511, type = ent >> 9, j = i + d;
-                    int res = INF;
+                    unsigned res = KEY_NONE;
                     const int au1 = type > 2 ? (int)T.TerminalAU : 0;
                     if (role < 8) {
                         if (!(dbg_flags & 4)) {
@@ -439,7 +447,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         }
                     } else if (role < 14) {
                         if (!(dbg_flags & 8)) {
-                            unsigned bb = 65535u, bi = 65535u;
+                            unsigned bb = KEY_INF, bi = KEY_INF;
 #define MIRP_OTH(CK)                                                                      \
     switch (role) {                                                                       \
     case 8: a1_b0<CK, 2, 20>(a, i, j, bb); break;                                         \
@@ -451,24 +459,27 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     }
                             if (a.um >= MAXLOOP) { MIRP_OTH(false) } else { MIRP_OTH(true) }
 #undef MIRP_OTH
-                            const int rb = a1_fin(bb, au1);
-                            const int ri = a1_fin(bi, (int)T.mismatch1nI[type * 25 + S[i + 1] * 5 + S[j - 1]]);
+                            const unsigned rb = a1_key(bb, -32768 - OTH_BIAS + au1);
+                            const unsigned ri = a1_key(bi, -32768 - OTH_BIAS + (int)T.mismatch1nI[type * 25 + S[i + 1] * 5 + S[j - 1]]);
                             res = rb < ri ? rb : ri;
                         }
                     } else if (!(dbg_flags & 32)) {
                         const int si1 = S[i + 1], sj1 = S[j - 1];
                         int ra, ca, rb2, cb2;
+                        unsigned ka, kb2;
                         if (role == 14) {
                             a1_small_g<1, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<1, 2>(a, i, j, type, si1, sj1, rb2, cb2);
                             a1_small<0, 0>(a, i, j, type, si1, sj1, res); a1_small<0, 1>(a, i, j, type, si1, sj1, res); a1_small<1, 0>(a, i, j, type, si1, sj1, res);
+                            ka = 1 << 5 | 1; kb2 = 1 << 5 | 2;
                         } else {
                             a1_small_g<2, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<2, 2>(a, i, j, type, si1, sj1, rb2, cb2);
                             a1_small<2, 3>(a, i, j, type, si1, sj1, res); a1_small<3, 2>(a, i, j, type, si1, sj1, res);
+                            ka = 2 << 5 | 1; kb2 = 2 << 5 | 2;
                         }
-                        if (ca < INF && ra + ca < res) res = ra + ca;
-                        if (cb2 < INF && rb2 + cb2 < res) res = rb2 + cb2;
+                        if (ca < INF) { const unsigned k = ((unsigned)(ra + ca + KEY_BIAS) << 10) | ka; res = k < res ? k : res; }
+                        if (cb2 < INF) { const unsigned k = ((unsigned)(rb2 + cb2 + KEY_BIAS) << 10) | kb2; res = k < res ? k : res; }
                     }
-                    if (act && res < INF) atomicMin(&cpart[i], res);
+                    if (act && res != KEY_NONE) atomicMin(&ckey[i], res);
                 }
             }
             // phase A2: multiloop splits DML(i,j) over the finite range of row i / column j.
@@ -537,8 +548,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         };
         auto phaseB = [&](const int d) {
             const int ncell = n - d;
-            int* cpart = acc + (d & 1) * 2 * LCAP;
-            int* mdec = cpart + LCAP;
+            unsigned* ckey = reinterpret_cast<unsigned*>(acc + (d & 1) * 2 * LCAP);
+            int* mdec = acc + (d & 1) * 2 * LCAP + LCAP;
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             int lt = 0;          // pair type of this thread's cell on diagonal d+2 (0: not in the list)
             const int x = tid;
@@ -547,8 +558,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int type = pair_type(S[i], S[j]);
                 int cv = INF;
                 const int md = mdec[i];
+                int tb = 0;          // trace-back code: 0 = hairpin / multiloop / unpaired, else 1 + (n1 << 5 | n2) of the interior loop the backtrack takes
                 if (type) {
-                    cv = cpart[i];
+                    const unsigned kk = ckey[i];
+                    const int cint = kk == KEY_NONE ? INF : (int)(kk >> 10) - KEY_BIAS;
+                    cv = cint;
                     int h;
                     {
                         const int u = d - 1;
@@ -564,6 +578,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         int e = dml + T.ML_closing + lds_mlstem(T, P, rtype_of(type), S[j - 1], S[i + 1]);
                         cv = e < cv ? e : cv;
                     }
+                    // the backtrack tests the hairpin first, then the interior loops in key order, then the multiloop
+                    if (cint < INF && cint == cv && h != cv) tb = (int)(kk & 1023u) + 1;
                 }
                 int m = INF;
                 if (d > 4) {
@@ -583,9 +599,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     cring[(d & 31) * CSTR + i] = g16;
                 }
                 carch[off[d] + i] = c16;
+                tb_out[off[d] + i] = (unsigned short)tb;
                 fml[off[d] + i] = m16;
                 dmlring[(d % 3) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
-                cpart[i] = INF; mdec[i] = INF;
+                ckey[i] = KEY_NONE; mdec[i] = INF;
                 if (d + 2 <= D && i + d + 2 <= n) lt = pair_type(S[i], S[i + d + 2]);
             }
             if (d + 2 <= D) {   // ordered paired-cell list of diagonal d+2: ballot compaction per producer wave
@@ -632,7 +649,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 // fill kernel's one-workgroup-per-CU geometry.
 // ------------------------------------------------------------------------------------------
 #define ENT 256
-__global__ void __launch_bounds__(ENT, 6) fold_lds_epilogue_kernel(
+__global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int span, const short* __restrict__ slabs, size_t slab_shorts, const int* __restrict__ win_state, unsigned int* __restrict__ work_counter,
     int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss, int* __restrict__ out_nlines,
@@ -684,7 +701,8 @@ __global__ void __launch_bounds__(ENT, 6) fold_lds_epilogue_kernel(
             WinCtx X;
             X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D; X.E = EP;
             LTab TB;
-            TB.carch = slabs + (size_t)win * 2 * slab_shorts; TB.fml = TB.carch + slab_shorts; TB.off = off;
+            TB.carch = slabs + (size_t)win * 3 * slab_shorts; TB.fml = TB.carch + slab_shorts; TB.off = off;
+            TB.tb = reinterpret_cast<const unsigned short*>(TB.carch + 2 * slab_shorts);
             fold_epilogue<LTab, ENT>(X, TB, span, f3, starts, lens, btbuf, nc, btstk, misc + 8, win, max_lines, ss_stride, out_lines, out_ss, out_nlines,
                                     out_mfe, out_status);
         }

@@ -194,8 +194,8 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         // fill kernel (one 1024-thread workgroup per CU, tables in LDS) + epilogue kernel (many small workgroups) per sub-batch;
         // the two exchange the c / fML triangles of every window through per-window slabs in HBM
         const size_t slab = mirp::fold_lds_slab_shorts(std::min(n_cap, mirp::fold_lds_max_n() + 2));
-        const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_work, ((size_t)8 << 30) / (slab * 4)));
-        if (c->carch.ensure((size_t)sub * slab * 4) || c->fctl.ensure(256) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub))
+        const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_work, ((size_t)8 << 30) / (slab * 6)));   // three 16-bit triangles per window: c, fML, trace-back codes
+        if (c->carch.ensure((size_t)sub * slab * 6) || c->fctl.ensure(256) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub))
             return fail(c, -6, "device allocation failed (fold LDS kernel)");
         HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 256, c->stream));
         unsigned int* ctl = (unsigned int*)c->fctl.p;
@@ -219,8 +219,8 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->last_fallback = nfb;
         if (const char* dump = std::getenv("MIRP_FOLD_DUMP")) {   // diagnostics: c / fML slabs of the first window of the last sub-batch
-            std::vector<short> h(2 * slab);
-            HIPCHK(c, hipMemcpy(h.data(), c->carch.p, 4 * slab, hipMemcpyDeviceToHost));
+            std::vector<short> h(3 * slab);
+            HIPCHK(c, hipMemcpy(h.data(), c->carch.p, 6 * slab, hipMemcpyDeviceToHost));
             if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 2, h.size(), f); std::fclose(f); }
         }
         if (dbg_cycles) {

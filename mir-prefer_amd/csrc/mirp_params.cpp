@@ -40,13 +40,20 @@ void mirp_fill_fold_params(FoldParams* p) {
     p->MAX_NINIO = T04_MAX_NINIO;
     for (int u = 6; u <= MIRP_MAXLOOP; u++)
         for (int n1 = 0; n1 < 28; n1++) {
-            int v = 65535;
-            if (n1 >= 2 && n1 <= u - 2) { int y = std::abs(2 * n1 - u) * p->ninio; v = p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO); }
-            p->gen_pen[u - 6][n1] = v;
+            unsigned v = 65535u << 10;
+            if (n1 >= 2 && n1 <= u - 2) {
+                int y = std::abs(2 * n1 - u) * p->ninio;
+                v = ((unsigned)(p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO)) << 10) | (unsigned)(n1 << 5 | (u - n1));
+            }
+            p->gen_key[u - 6][n1] = v;
         }
     for (int u = 0; u <= MIRP_MAXLOOP; u++) {
-        p->k_bulge[u] = p->bulge[u] + 2048;
+        const unsigned kb = (unsigned)(p->bulge[u] + 2048) << 10;
+        p->kb0_key[u] = kb | (unsigned)u;
+        p->kb1_key[u] = kb | (unsigned)(u << 5);
         int y = (u - 1) * p->ninio;
-        p->k_1n[u] = (u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048;
+        const unsigned k1 = (unsigned)((u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048) << 10;
+        p->k1n0_key[u] = k1 | (unsigned)(1 << 5 | u);
+        p->k1n1_key[u] = k1 | (unsigned)(u << 5 | 1);
     }
 }
