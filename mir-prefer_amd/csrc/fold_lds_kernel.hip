@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr LdsLayout LY = lds_layout();
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
+    long long wB = 0, wA1 = 0, wA2 = 0, wW = 0, wt = 0; // per-wave: phase B, interior loops, multiloop splits, barrier wait (lane 0 of each wave)
     unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
     unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
     short* dmlring = (short*)(cring + 32 * CSTR);                   // [3][LCAP] int16
@@ -399,6 +400,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + (d & 1) * 2 * LCAP);   // best interior-loop candidate key per cell
             int* mdec = acc + (d & 1) * 2 * LCAP + LCAP;
+            if (dbg_cycles && lane == 0) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
             if (!(dbg_flags & (1 | 64)) && d >= 6) {
                 const unsigned short* clist = list + (d % 3) * LSEG;
@@ -406,8 +408,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int p1 = __builtin_amdgcn_readfirstlane(lc[0]), p2 = p1 + __builtin_amdgcn_readfirstlane(lc[1]),
                           p3 = p2 + __builtin_amdgcn_readfirstlane(lc[2]), p4 = p3 + __builtin_amdgcn_readfirstlane(lc[3]),
                           p5 = p4 + __builtin_amdgcn_readfirstlane(lc[4]), ncp = p5 + __builtin_amdgcn_readfirstlane(lc[5]);
-                // roles: phase B of the previous diagonal runs on waves 0-5 (one thread per cell), so those waves take the lighter candidate groups
-                const int role = (wave + 8) & 15;   // role 0-7: generic rows, 8-13: bulges / 1xn, 14-15: small shapes
+                // roles (0-7: generic rows, 8-13: bulges / 1xn, 14-15: small shapes), measured job costs (MIRP_FOLD_CLOCKS): generic 2-row < small
+                // shapes < generic 4-row < bulges / 1xn.  Phase B of the previous diagonal runs on waves 0-5 (one thread per cell, wave 0 always,
+                // wave 5 rarely), so those waves take the cheapest jobs.
+                const int role = wave < 4 ? wave : wave < 6 ? wave + 10 : wave < 12 ? wave + 2 : wave - 8;
                 A1 a;
                 a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
                 for (int blk = 0; blk * 64 < ncp; blk++) {
@@ -437,10 +441,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     case 1: res = a1_generic<CK, 29, 24>(a, i, j, type); break;                           \
     case 2: res = a1_generic<CK, 28, 25>(a, i, j, type); break;                           \
     case 3: res = a1_generic<CK, 27, 26>(a, i, j, type); break;                           \
-    case 4: res = a1_generic<CK, 22, 21, 13>(a, i, j, type); break;                       \
-    case 5: res = a1_generic<CK, 20, 19, 17>(a, i, j, type); break;                       \
-    case 6: res = a1_generic<CK, 18, 16, 15, 10>(a, i, j, type); break;                   \
-    default: res = a1_generic<CK, 14, 12, 11, 9, 8, 7, 6>(a, i, j, type); break;          \
+    case 4: res = a1_generic<CK, 22, 17, 12, 7>(a, i, j, type); break;                    \
+    case 5: res = a1_generic<CK, 21, 18, 11, 8>(a, i, j, type); break;                    \
+    case 6: res = a1_generic<CK, 20, 16, 13, 9>(a, i, j, type); break;                    \
+    default: res = a1_generic<CK, 19, 15, 14, 10, 6>(a, i, j, type); break;               \
     }
                             if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
 #undef MIRP_GEN
@@ -482,6 +486,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (act && res != KEY_NONE) atomicMin(&ckey[i], res);
                 }
             }
+            if (dbg_cycles && lane == 0) { const long long t = clock64(); wA1 += t - wt; wt = t; }
             // phase A2: multiloop splits DML(i,j) over the finite range of row i / column j.
             // The split point t is wave-uniform (scalar address arithmetic); lanes = consecutive cells.
             {
@@ -615,9 +620,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
         for (int d = 4; d <= D; d++) {
+            if (dbg_cycles && lane == 0) wt = clock64();
             phaseB(d);
+            if (dbg_cycles && lane == 0) { const long long t = clock64(); wB += t - wt; wt = t; }
             if (d + 1 <= D) phaseA(d + 1);
+            if (dbg_cycles && lane == 0) { const long long t = clock64(); wA2 += t - wt; wt = t; }
             __syncthreads();
+            if (dbg_cycles && lane == 0) { const long long t = clock64(); wW += t - wt; wt = t; }
             if (dbg_cycles && tid == 0) { long long t = clock64(); tB += t - t0; t0 = t; }
         }
         const int overflow = misc[1];
@@ -636,6 +645,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         }
         }   // window fits this kernel
         __syncthreads();
+    }
+    if (dbg_cycles && lane == 0) {
+        atomicAdd((unsigned long long*)&dbg_cycles[4 + wave * 4 + 0], (unsigned long long)wB); atomicAdd((unsigned long long*)&dbg_cycles[4 + wave * 4 + 1], (unsigned long long)wA1);
+        atomicAdd((unsigned long long*)&dbg_cycles[4 + wave * 4 + 2], (unsigned long long)wA2); atomicAdd((unsigned long long*)&dbg_cycles[4 + wave * 4 + 3], (unsigned long long)wW);
     }
     if (dbg_cycles && tid == 0) {
         atomicAdd((unsigned long long*)&dbg_cycles[0], (unsigned long long)tS); atomicAdd((unsigned long long*)&dbg_cycles[1], (unsigned long long)tA);

@@ -195,9 +195,9 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         // the two exchange the c / fML triangles of every window through per-window slabs in HBM
         const size_t slab = mirp::fold_lds_slab_shorts(std::min(n_cap, mirp::fold_lds_max_n() + 2));
         const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_work, ((size_t)8 << 30) / (slab * 6)));   // three 16-bit triangles per window: c, fML, trace-back codes
-        if (c->carch.ensure((size_t)sub * slab * 6) || c->fctl.ensure(256) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub))
+        if (c->carch.ensure((size_t)sub * slab * 6) || c->fctl.ensure(1024) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub))
             return fail(c, -6, "device allocation failed (fold LDS kernel)");
-        HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 256, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 1024, c->stream));
         unsigned int* ctl = (unsigned int*)c->fctl.p;
         // diagnostics (never set in production): MIRP_FOLD_DEBUG=<flags> ablates phases (results then wrong), MIRP_FOLD_CLOCKS=1 prints phase clocks
         const char* dbg_env = std::getenv("MIRP_FOLD_DEBUG");
@@ -224,10 +224,13 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 2, h.size(), f); std::fclose(f); }
         }
         if (dbg_cycles) {
-            long long cyc[4];
+            long long cyc[4 + 64];
             HIPCHK(c, hipMemcpy(cyc, dbg_cycles, sizeof(cyc), hipMemcpyDeviceToHost));
             std::fprintf(stderr, "[mirp fold clocks] windows=%d setup=%lld fillA=%lld fillB=%lld writeout=%lld (sum over workgroups, s_memtime ticks)\n", n_work,
                          cyc[0], cyc[1], cyc[2], cyc[3]);
+            for (int w = 0; w < 16; w++)
+                std::fprintf(stderr, "[mirp fold clocks] wave %2d: phaseB=%lld interior=%lld splits=%lld barrier=%lld\n", w, cyc[4 + 4 * w], cyc[5 + 4 * w], cyc[6 + 4 * w],
+                             cyc[7 + 4 * w]);
         }
         if (nfb == 0) return 0;
         work_list = (const int*)c->flist.p;
