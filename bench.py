@@ -147,20 +147,20 @@ def main():
     if rank == 0:
         fold_s = float(np.mean(fold_ms)) / 1e3
         cov_s = float(np.mean(cov_ms)) / 1e3
-        # algorithmic HBM bytes of the fold (fill + epilogue kernels): the c and fML triangles are written once as 16-bit values and
-        # read once: n + 64 + 8*cells + ~6 KB of structure lines per window, cells(300,300) = 43,956
+        # algorithmic HBM bytes of the fold (fill + epilogue kernels): the c, fML and trace-back triangles are written once as 16-bit values,
+        # c and fML are read once: n + 64 + 10*cells + ~6 KB of structure lines per window, cells(300,300) = 43,956
         w = ctx.get_windows()["windows"]
         lens = w["seq_len"].astype(np.int64)
         D = np.minimum(L - 1, lens - 1)
         cells = np.where(D > 3, (D - 3) * lens - (D * (D + 1) // 2 - 6), 0)
-        b_fold = float((lens + 64 + 8 * cells + 6000).sum())
+        b_fold = float((lens + 64 + 10 * cells + 6000).sum())
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
         valu_util = None
         try:
-            profk = json.load(open(os.path.join(ROOT, "profiles", "r1_e_hbm_traffic_and_sq_pmc.json")))["kernels"]
+            profk = json.load(open(os.path.join(ROOT, "profiles", "r1_f_hbm_traffic_and_sq_pmc.json")))["kernels"]
             if a.genome == CHR1_LEN and a.loci == N_LOCI:   # fill + epilogue kernels of the fold
                 traffic = sum(profk[k]["fetch_bytes_corrected"] + profk[k]["write_bytes"] for k in ("mirp::fold_lds_kernel", "mirp::fold_lds_epilogue_kernel"))
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_e_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_f_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
             # wave64 integer VALU ops occupy a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles); 1024 SIMDs
             valu_util = sq["SQ_INSTS_VALU"] * 4.0 / (sq["SQ_WAVE_CYCLES"] * 4.0 / 4.0) if a.genome == CHR1_LEN and a.loci == N_LOCI else None
         except Exception:
