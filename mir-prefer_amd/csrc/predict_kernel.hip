@@ -12,7 +12,7 @@
 
 namespace mirp {
 
-#define PW_MAX_STRUCTS 192   // structures per window (lines * pieces)
+#define PW_MIN_STRUCTS 192   // structures per window (lines * pieces): capacity = max(PW_MIN_STRUCTS, 2 * max_lines)
 #define PW_MAX_PIECES 6
 #define PW_MAX_MATURES 40
 
@@ -256,8 +256,9 @@ __global__ void __launch_bounds__(64) predict_kernel(
     extern __shared__ __align__(16) unsigned char smem[];
     const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
     unsigned* textw = (unsigned*)smem;                                   // max_lines * wpl
-    PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * wpl * 4 + 15) & ~(size_t)15)); // PW_MAX_STRUCTS
-    PStruct* slot = sts + PW_MAX_STRUCTS;                                // 64 * PW_MAX_PIECES
+    const int max_structs = 2 * max_lines > PW_MIN_STRUCTS ? 2 * max_lines : PW_MIN_STRUCTS;
+    PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * wpl * 4 + 15) & ~(size_t)15)); // max_structs
+    PStruct* slot = sts + max_structs;                                // 64 * PW_MAX_PIECES
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
     const int lane = threadIdx.x;
     for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
@@ -332,13 +333,13 @@ __global__ void __launch_bounds__(64) predict_kernel(
             // ordered compaction (line order, piece order)
             int base = nst;
             for (int l = 0; l < 64; l++) { if (l < lane) base += cnts[l]; }
-            for (int c = 0; c < cnt; c++) { if (base + c < PW_MAX_STRUCTS) sts[base + c] = slot[lane * PW_MAX_PIECES + c]; else st_flag = 2; }
+            for (int c = 0; c < cnt; c++) { if (base + c < max_structs) sts[base + c] = slot[lane * PW_MAX_PIECES + c]; else st_flag = 2; }
             int tot = 0;
             for (int l = 0; l < 64; l++) tot += cnts[l];
             nst += tot;
             __syncthreads();
         }
-        if (nst > PW_MAX_STRUCTS) nst = PW_MAX_STRUCTS;
+        if (nst > max_structs) nst = max_structs;
         // ---- phases 2+3 per mature, depth-descending stable order (MP:2241)
         int nm = W.n_matures < PW_MAX_MATURES ? W.n_matures : PW_MAX_MATURES;
         if (W.n_matures > PW_MAX_MATURES) st_flag = 3;
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(64) predict_kernel(
 
 size_t predict_lds_bytes(int max_lines, int ss_stride) {
     size_t b = (((size_t)max_lines * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15);
-    b += sizeof(PStruct) * (PW_MAX_STRUCTS + 64 * PW_MAX_PIECES);
+    b += sizeof(PStruct) * ((size_t)(2 * max_lines > PW_MIN_STRUCTS ? 2 * max_lines : PW_MIN_STRUCTS) + 64 * PW_MAX_PIECES);
     b += sizeof(int) * 64;
     return (b + 15) & ~(size_t)15;
 }

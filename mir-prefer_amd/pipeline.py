@@ -146,17 +146,27 @@ class Pipeline:
         sys.stdout.write("%d candidate loci generated, %d regions to fold.\n" % (self.counts[1], self.counts[2]))
         _msg("Done (candidate stage)\n")
 
+    def _fold_device(self):
+        """Fold every window on the device; returns the per-window status array.  A window can produce more structure lines than the
+        default capacity of 96 (tandem repeats do: one line per start position is possible); RNALfold has no such limit, so the stage is
+        repeated once with the capacity no window can exceed."""
+        self.ctx.fold(self.opt["PRECURSOR_LEN"])
+        status = self.ctx.fold_status()
+        if np.any(status == 1):
+            self.ctx.fold(self.opt["PRECURSOR_LEN"], max_lines=self.opt["PRECURSOR_LEN"] + 52)
+            status = self.ctx.fold_status()
+        return status
+
     # ---- fold (MP:3441-3495)
     def run_fold(self, write_text=True):
         if not previous_stage_saved(self.recovername, "candidate"):
             self._fail_stage()
         _msg("Starting folding candidate sequences.")
         self._ensure_candidate()
-        self.ctx.fold(self.opt["PRECURSOR_LEN"])
+        status = self._fold_device()
         self.state = "fold"
         prefix = self.opt["NAME_PREFIX"]
         foldname = self._p(prefix + "_rnalfoldoutput_0")
-        status = self.ctx.fold_status()
         bad = np.nonzero(status != 0)[0]
         if len(bad):
             sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (bad[0], status[bad[0]]))
@@ -180,7 +190,7 @@ class Pipeline:
         _msg("Starting predicting miRNAs.")
         if self.state != "fold":
             self._ensure_candidate()
-            self.ctx.fold(self.opt["PRECURSOR_LEN"])
+            self._fold_device()
             self.state = "fold"
         out = self.ctx.predict(len(self.data["samples"]), self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"],
                                self.opt["ALLOW_NO_STAR_EXPRESSION"])

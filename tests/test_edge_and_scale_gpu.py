@@ -134,3 +134,58 @@ def test_full_size_config1_properties(gpu_ctx, oracle):
         found[m["fold_s"]:m["fold_e"]] = True
     hit = sum(found[(a + b) // 2] for _, a, b, _ in ds.planted)
     assert hit > 0.6 * len(ds.planted)
+
+
+def _repeat_dataset():
+    """A 60 kb contig with a 700-nt (GTGG)n tandem repeat under a read peak: its window folds into > 96 structure lines."""
+    ds = synth.make_dataset([60000], 30, n_samples=1, seed=5, contig_names=["c1"])
+    name, seq = ds.contigs[0]
+    seq = seq.copy()
+    seq[19800:20500] = np.frombuffer(("GTGG" * 175).encode(), dtype=np.uint8)
+    ds.contigs[0] = (name, seq)
+    extra = np.zeros(4, dtype=synth.ALN_DTYPE)      # a read contributes min(depth, cutoff) to the coverage: stack three isomiRs
+    extra[0] = (0, 20101, 60, 21, 0, 0)
+    extra[1] = (0, 20101, 20, 22, 0, 0)
+    extra[2] = (0, 20102, 15, 21, 0, 0)
+    extra[3] = (0, 20160, 8, 21, 0, 0)
+    ds.alns = np.concatenate([ds.alns, extra])
+    return ds
+
+
+def test_fold_line_capacity_flag_and_large_capacity(gpu_ctx, oracle):
+    s = "GUGG" * 59
+    want = oracle.lfold(s, 300)
+    assert len(want["lines"]) > 96
+    assert gpu_ctx.fold_batch([s], 300)[0]["status"] == 1           # default capacity of 96 lines: flagged, never silently truncated
+    got = gpu_ctx.fold_batch([s], 300, max_lines=352)[0]
+    assert got["status"] == 0 and got["mfe"] == want["mfe"] and got["lines"] == want["lines"]
+
+
+def test_pipeline_with_a_window_over_the_default_line_capacity(gpu_ctx, oracle):
+    from tests.test_oracle_golden import mirna_record, run_predict
+    ds = _repeat_dataset()
+    names, alns = ds.contig_names, ds.sorted_alns()
+    cut, gap, L = 10, 100, 300
+    order = np.zeros(1, dtype=np.int32)
+    depth, peaks = oracle.coverage_peaks(alns, ds.contig_lens, cut)
+    win = oracle.make_windows(peaks, alns, ds.contigs, order, gap, L, cut * 0.5)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    npk, nloci, nwin = gpu_ctx.candidate(cut, gap, L, order)
+    assert nwin == len(win["windows"])
+    gpu_ctx.fold(L)
+    assert (gpu_ctx.fold_status() == 1).any()                       # the repeat window overflows 96 lines ...
+    gpu_ctx.fold(L, max_lines=L + 52)                               # ... and the host's retry (pipeline.Pipeline._fold_device) clears it
+    assert (gpu_ctx.fold_status() == 0).all()
+    out = gpu_ctx.predict(1, 18, 23, False, True)
+    structs = []
+    for b in win["windows"]:
+        r = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+        structs.append(oracle.structures_from_lines(r["lines"], 55))
+    case = {"cfg": {"MIN_MATURE_LEN": 18, "MAX_MATURE_LEN": 23, "ALLOW_3NT_OVERHANG": "N", "ALLOW_NO_STAR_EXPRESSION": "Y"}, "win": win,
+            "sample_names": ds.sample_names, "alns": alns}
+    _, result = run_predict(case, oracle, structs)
+    want = [mirna_record(m, names) for _, m in result]
+    got = [[names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
+            records.STRAND[m["strand"]], bool(m["has_star"])] for m, ss in zip(out["result"], out["ss"])]
+    assert got == want

@@ -132,3 +132,25 @@ def test_stage_checkpoint_rules(tmp_path):
     assert pipeline.previous_stage_saved(rec, "prepare") and pipeline.detect_stage_last_finished(rec) == "prepare"
     f1.unlink()
     assert not pipeline.previous_stage_saved(rec, "prepare") and pipeline.detect_stage_last_finished(rec) is None
+
+
+def test_fold_stage_retries_with_full_line_capacity():
+    """pipeline.Pipeline._fold_device: a window flagged 'more than max_lines structure lines' makes the stage fold again with the
+    capacity no window can exceed (RNALfold itself has no limit)."""
+    import numpy as np
+    from mir_prefer_amd import pipeline
+
+    class StubCtx:
+        def __init__(self):
+            self.calls = []
+
+        def fold(self, span, max_lines=96):
+            self.calls.append((span, max_lines))
+
+        def fold_status(self):
+            return np.array([0, 1, 0], dtype=np.int32) if self.calls[-1][1] == 96 else np.zeros(3, dtype=np.int32)
+
+    p = pipeline.Pipeline.__new__(pipeline.Pipeline)
+    p.ctx, p.opt = StubCtx(), {"PRECURSOR_LEN": 300}
+    st = p._fold_device()
+    assert p.ctx.calls == [(300, 96), (300, 352)] and (st == 0).all()
