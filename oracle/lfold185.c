@@ -1,0 +1,348 @@
+/*
+ * oracle/lfold185.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the observable behaviour of `RNALfold -L <span>` in the "vienna-1.8.5" flavour: the RNALfold the
+ * reference bundles for Linux (dependency/Linux/x64/RNALfold: ViennaRNA 1.8.5, Turner-1999 tables, default dangles = 1, full
+ * backtrack enumeration with multi-component structure strings).  Call site: /root/reference/miR_PREFeR.py:3053-3064, consumer
+ * :1541-1599.  The ViennaRNA source is not in the reference tree; this file follows the behavioural specification of
+ * SURVEY.md Appendix B (d1 column), which was verified against that binary.
+ *
+ * Parity pinning: byte-for-byte against the outputs of the bundled 1.8.5 binary run in the build container
+ * (tests/golden/tools/gen_fold_golden.py -> tests/golden/fold_rnalfold185.json.gz).
+ *
+ * Only tests/ may use this file.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <ctype.h>
+#include "energy_params_t1999.h"
+#include "oracle.h"
+
+#define TURN 3
+#define MAXLOOP 30
+#define INF 1000000
+
+static const int PAIR[5][5] = {
+    {0, 0, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, 1, 0}, {0, 0, 2, 0, 3}, {0, 6, 0, 4, 0}};
+static const int RTYPE[8] = {0, 2, 1, 4, 3, 6, 5, 7};
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int clamp0(int v) { return v > 0 ? 0 : v; }
+static inline int AU(int t) { return t > 2 ? T99_TerminalAU : 0; }
+static inline int MLintern(int t) { return T99_ML_intern + AU(t); }
+static inline int d5(int t, int b) { return clamp0(T99_dangle5[t][b]); }
+static inline int d3(int t, int b) { return clamp0(T99_dangle3[t][b]); }
+
+typedef struct {
+    int n, M;
+    char *seq;
+    int *S;
+    int *c, *fML;
+    int *f3;
+    unsigned char *pt;
+} Fold;
+
+#define IDX(F, i, j) ((size_t)(i) * ((F)->M + 2) + ((j) - (i)))
+
+static int ptype(const Fold *F, int i, int j) {
+    int d = j - i;
+    if (d <= TURN || d > F->M - 1 || i < 1 || j > F->n) return 0;
+    return F->pt[IDX(F, i, j)];
+}
+static int cget(const Fold *F, int i, int j) {
+    int d = j - i;
+    if (d <= TURN || d > F->M || i < 1 || j > F->n) return INF;
+    return F->c[IDX(F, i, j)];
+}
+static int mget(const Fold *F, int i, int j) {
+    int d = j - i;
+    if (d <= TURN || d > F->M || i < 1 || j > F->n) return INF;
+    return F->fML[IDX(F, i, j)];
+}
+
+static int extrap(int base30, int size) { return base30 + (int)(T99_LXC * log((double)size / 30.)); }
+
+static int E_hairpin(const Fold *F, int i, int j, int type) {
+    int u = j - i - 1;
+    int e = (u <= 30) ? T99_hairpin[u] : extrap(T99_hairpin[30], u);
+    if (u == 4) {
+        for (int k = 0; k < T99_N_TETRALOOPS; k++)
+            if (!strncmp(F->seq + i, T99_Tetraloops[k], 6)) { e += T99_Tetraloop_E[k]; break; }
+    }
+    if (u == 3) e += AU(type);
+    else e += T99_mismatchH[type][F->S[i + 1]][F->S[j - 1]];
+    return e;
+}
+
+static int E_loop(int n1, int n2, int type, int type2, int si1, int sj1, int sp1, int sq1) {
+    int nl = imax(n1, n2), ns = imin(n1, n2), e;
+    if (nl == 0) return T99_stack[type][type2];
+    if (ns == 0) {
+        e = (nl <= MAXLOOP) ? T99_bulge[nl] : extrap(T99_bulge[30], nl);
+        if (nl == 1) e += T99_stack[type][type2];
+        else e += AU(type) + AU(type2);
+        return e;
+    }
+    if (ns == 1 && nl == 1) return T99_int11[type][type2][si1][sj1];
+    if (ns == 1 && nl == 2) return n1 == 1 ? T99_int21[type][type2][si1][sq1][sj1] : T99_int21[type2][type][sq1][si1][sp1];
+    if (ns == 2 && nl == 2) return T99_int22[type][type2][si1][sp1][sq1][sj1];
+    e = (n1 + n2 <= MAXLOOP) ? T99_internal_loop[n1 + n2] : extrap(T99_internal_loop[30], n1 + n2);
+    e += imin(T99_MAX_NINIO, (nl - ns) * T99_ninio);
+    e += T99_mismatchI[type][si1][sj1] + T99_mismatchI[type2][sq1][sp1];
+    return e;
+}
+
+static int DML(const Fold *F, int a, int b) {
+    int dec = INF;
+    for (int k = a + TURN + 1; k <= b - TURN - 2; k++) dec = imin(dec, mget(F, a, k) + mget(F, k + 1, b));
+    return dec;
+}
+
+static void fill(Fold *F) {
+    const int n = F->n, M = F->M;
+    const int *S = F->S;
+    for (int i = n - TURN - 1; i >= 1; i--) {
+        for (int j = i + TURN + 1; j <= n && j <= i + M; j++) {
+            int type = ptype(F, i, j), newc = INF;
+            if (type) {
+                newc = E_hairpin(F, i, j, type);
+                int pmax = imin(j - 2 - TURN, i + MAXLOOP + 1);
+                for (int p = i + 1; p <= pmax; p++) {
+                    int minq = j - i + p - MAXLOOP - 2;
+                    if (minq < p + 1 + TURN) minq = p + 1 + TURN;
+                    for (int q = minq; q < j; q++) {
+                        int t2 = ptype(F, p, q);
+                        if (!t2) continue;
+                        t2 = RTYPE[t2];
+                        newc = imin(newc, E_loop(p - i - 1, j - q - 1, type, t2, S[i + 1], S[j - 1], S[p - 1], S[q + 1]) + cget(F, p, q));
+                    }
+                }
+                int tt = RTYPE[type];
+                int e3 = d3(tt, S[i + 1]), e5 = d5(tt, S[j - 1]);
+                int X = DML(F, i + 1, j - 1);
+                X = imin(X, DML(F, i + 2, j - 1) + e3 + T99_ML_BASE);
+                X = imin(X, DML(F, i + 1, j - 2) + e5 + T99_ML_BASE);
+                X = imin(X, DML(F, i + 2, j - 2) + e3 + e5 + 2 * T99_ML_BASE);
+                newc = imin(newc, T99_ML_closing + MLintern(type) + X);
+            }
+            F->c[IDX(F, i, j)] = newc;
+            int m = imin(mget(F, i + 1, j) + T99_ML_BASE, mget(F, i, j - 1) + T99_ML_BASE);
+            m = imin(m, newc + MLintern(type));
+            { int t = ptype(F, i + 1, j);     m = imin(m, cget(F, i + 1, j) + d5(t, S[i]) + MLintern(t) + T99_ML_BASE); }
+            { int t = ptype(F, i, j - 1);     m = imin(m, cget(F, i, j - 1) + d3(t, S[j]) + MLintern(t) + T99_ML_BASE); }
+            { int t = ptype(F, i + 1, j - 1); m = imin(m, cget(F, i + 1, j - 1) + d5(t, S[i]) + d3(t, S[j]) + MLintern(t) + 2 * T99_ML_BASE); }
+            m = imin(m, DML(F, i, j));
+            F->fML[IDX(F, i, j)] = m;
+        }
+        int best = F->f3[i + 1];
+        for (int j = i + TURN + 1; j <= n && j <= i + M; j++) {
+            int t = ptype(F, i, j);
+            if (t) {
+                int e = cget(F, i, j) + AU(t);
+                if (j < n) {
+                    best = imin(best, F->f3[j + 1] + e);
+                    best = imin(best, F->f3[j + 2] + e + d3(t, S[j + 1]));
+                } else best = imin(best, e);
+            }
+            t = ptype(F, i + 1, j);
+            if (t) {
+                int e = cget(F, i + 1, j) + d5(t, S[i]) + AU(t);
+                if (j < n) {
+                    best = imin(best, F->f3[j + 1] + e);
+                    best = imin(best, F->f3[j + 2] + e + d3(t, S[j + 1]));
+                } else best = imin(best, e);
+            }
+        }
+        F->f3[i] = best;
+    }
+}
+
+typedef struct { int i, j, ml; } Sector;
+
+static int backtrack(const Fold *F, int start, int maxdist, char *out, int cap) {
+    const int n = F->n;
+    const int *S = F->S;
+    int len0 = imin(n - start, maxdist) + 1;
+    if (len0 + 3 > cap) return -9;
+    memset(out, '-', len0);
+    memset(out + len0, 0, 3);   /* the 3' dangle dot of the last helix may land one cell behind the nominal buffer (probed on the binary) */
+    Sector st[2048];
+    int s = 0;
+    st[++s] = (Sector){start, imin(n, start + maxdist + 1), 0};
+    while (s > 0) {
+        int i = st[s].i, j = st[s].j, ml = st[s].ml;
+        s--;
+        if (j < i + TURN + 1) continue;
+        if (s > 2000) return -8;
+        int k;
+        if (ml == 0) {
+            int fij = F->f3[i];
+            if (fij == F->f3[i + 1]) { st[++s] = (Sector){i + 1, j, 0}; continue; }
+            int traced = 0, jj = 0;
+            for (k = i + TURN + 1; k <= j; k++) {
+                jj = k + 1;
+                int t = ptype(F, i + 1, k);
+                if (t) {
+                    int cc = cget(F, i + 1, k) + d5(t, S[i]) + AU(t);
+                    if (fij == cc + F->f3[k + 1]) traced = i + 1;
+                    if (k < n && fij == cc + F->f3[k + 2] + d3(t, S[k + 1])) { traced = i + 1; jj = k + 2; }
+                }
+                t = ptype(F, i, k);
+                if (t) {
+                    int cc = cget(F, i, k) + AU(t);
+                    if (fij == cc + F->f3[k + 1]) traced = i;
+                    if (k < n && fij == cc + F->f3[k + 2] + d3(t, S[k + 1])) { traced = i; jj = k + 2; }
+                }
+                if (traced) break;
+            }
+            if (!traced) return -1;
+            if (j == n) st[++s] = (Sector){jj, j, 0};
+            i = traced; j = k;
+            out[i - start] = '(';
+            out[j - start] = ')';
+            if (jj == k + 2) out[k + 1 - start] = '.';
+        } else {
+            int fij = mget(F, i, j);
+            if (mget(F, i, j - 1) + T99_ML_BASE == fij) { st[++s] = (Sector){i, j - 1, 1}; continue; }
+            if (mget(F, i + 1, j) + T99_ML_BASE == fij) { st[++s] = (Sector){i + 1, j, 1}; continue; }
+            int t = ptype(F, i, j);
+            int cij = cget(F, i, j) + MLintern(t);
+            t = ptype(F, i + 1, j);
+            int ci1j = cget(F, i + 1, j) + d5(t, S[i]) + MLintern(t) + T99_ML_BASE;
+            t = ptype(F, i, j - 1);
+            int cij1 = cget(F, i, j - 1) + d3(t, S[j]) + MLintern(t) + T99_ML_BASE;
+            t = ptype(F, i + 1, j - 1);
+            int ci1j1 = cget(F, i + 1, j - 1) + d5(t, S[i]) + d3(t, S[j]) + MLintern(t) + 2 * T99_ML_BASE;
+            if (fij == cij || fij == ci1j || fij == cij1 || fij == ci1j1) {
+                if (fij == ci1j) i++;
+                else if (fij == cij1) j--;
+                else if (fij == ci1j1) { i++; j--; }
+                out[i - start] = '(';
+                out[j - start] = ')';
+            } else {
+                for (k = i + 1 + TURN; k <= j - 2 - TURN; k++)
+                    if (fij == mget(F, i, k) + mget(F, k + 1, j)) break;
+                if (k > j - 2 - TURN) return -2;
+                st[++s] = (Sector){i, k, 1};
+                st[++s] = (Sector){k + 1, j, 1};
+                continue;
+            }
+        }
+        for (;;) {   /* (i,j) is a pair */
+            int type = ptype(F, i, j);
+            int cij = cget(F, i, j);
+            if (cij == E_hairpin(F, i, j, type)) break;
+            int found = 0;
+            int pmax = imin(j - 2 - TURN, i + MAXLOOP + 1);
+            for (int p = i + 1; p <= pmax && !found; p++) {
+                int minq = j - i + p - MAXLOOP - 2;
+                if (minq < p + 1 + TURN) minq = p + 1 + TURN;
+                for (int q = j - 1; q >= minq; q--) {
+                    int t2 = ptype(F, p, q);
+                    if (!t2) continue;
+                    t2 = RTYPE[t2];
+                    if (cij == E_loop(p - i - 1, j - q - 1, type, t2, S[i + 1], S[j - 1], S[p - 1], S[q + 1]) + cget(F, p, q)) {
+                        out[p - start] = '(';
+                        out[q - start] = ')';
+                        i = p; j = q; found = 1;
+                        break;
+                    }
+                }
+            }
+            if (found) continue;
+            int tt = RTYPE[type];
+            int mm = T99_ML_closing + MLintern(tt);
+            int e5 = d5(tt, S[j - 1]), e3 = d3(tt, S[i + 1]);
+            int i1 = i + 1, j1 = j - 1;
+            for (k = i + 2 + TURN; k <= j - 3 - TURN; k++) {
+                if (cij == mget(F, i + 1, k) + mget(F, k + 1, j - 1) + mm) break;
+                if (cij == mget(F, i + 2, k) + mget(F, k + 1, j - 1) + mm + e3 + T99_ML_BASE) { i1 = i + 2; break; }
+                if (cij == mget(F, i + 1, k) + mget(F, k + 1, j - 2) + mm + e5 + T99_ML_BASE) { j1 = j - 2; break; }
+                if (cij == mget(F, i + 2, k) + mget(F, k + 1, j - 2) + mm + e3 + e5 + 2 * T99_ML_BASE) { i1 = i + 2; j1 = j - 2; break; }
+            }
+            if (k > j - 3 - TURN) return -3;
+            st[++s] = (Sector){i1, k, 1};
+            st[++s] = (Sector){k + 1, j1, 1};
+            break;
+        }
+    }
+    int L = (int)strlen(out);
+    while (L > 1 && out[L - 1] == '-') L--;
+    out[L] = 0;
+    for (int x = 0; x < L; x++) if (out[x] == '-') out[x] = '.';
+    return L;
+}
+
+static void emit(OracleFoldResult *R, const char *body, int energy, int start) {
+    if (R->n_lines >= ORACLE_MAX_LINES) { R->overflow = 1; return; }
+    OracleFoldLine *l = &R->lines[R->n_lines++];
+    strncpy(l->ss, body, ORACLE_MAX_SS - 1);
+    l->ss[ORACLE_MAX_SS - 1] = 0;
+    l->len = (int)strlen(l->ss);
+    l->energy = energy;
+    l->start = start;
+}
+
+int oracle_lfold185(const char *seq_in, int n, int span, OracleFoldResult *R) {
+    Fold F;
+    memset(R, 0, sizeof(*R));
+    if (n < 1) return 0;
+    F.n = n; F.M = span;
+    F.seq = (char *)calloc(n + 16, 1);
+    F.S = (int *)calloc(n + 2, sizeof(int));
+    for (int i = 1; i <= n; i++) {
+        char ch = (char)toupper((unsigned char)seq_in[i - 1]);
+        if (ch == 'T') ch = 'U';
+        F.seq[i] = ch;
+        F.S[i] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
+    }
+    F.S[0] = F.S[n]; F.S[n + 1] = F.S[1];
+    size_t cells = (size_t)(n + 3) * (span + 2);
+    F.c = (int *)malloc(cells * sizeof(int));
+    F.fML = (int *)malloc(cells * sizeof(int));
+    F.pt = (unsigned char *)calloc(cells, 1);
+    F.f3 = (int *)calloc(n + span + 8, sizeof(int));
+    for (size_t x = 0; x < cells; x++) F.c[x] = F.fML[x] = INF;
+    for (int i = 1; i <= n; i++)
+        for (int j = i + TURN + 1; j <= n && j - i <= span - 1; j++) F.pt[IDX(&F, i, j)] = (unsigned char)PAIR[F.S[i]][F.S[j]];
+    fill(&F);
+
+    char *prev = (char *)malloc(n + span + 16), *cur = (char *)malloc(n + span + 16);
+    int have_prev = 0, prev_i = 0, do_bt = 0, rc = 0;
+    for (int i = n - TURN - 1; i >= 1; i--) {
+        if (F.f3[i] != F.f3[i + 1]) do_bt = 1;
+        else if (do_bt) {
+            int L = backtrack(&F, i + 1, span + 1, cur, n + span + 16);
+            if (L < 0) { rc = L; break; }
+            if (have_prev) {
+                int lp = (int)strlen(prev);
+                int off = prev_i - i;
+                int differ = (off > L) ? 1 : (strncmp(cur + off, prev, lp) != 0);
+                if (i + L < prev_i + lp || differ) emit(R, prev, F.f3[prev_i] - F.f3[prev_i + lp], prev_i);
+            }
+            char *t = prev; prev = cur; cur = t;
+            have_prev = 1; prev_i = i + 1; do_bt = 0;
+        }
+        if (i == 1) {
+            const int had_prev = have_prev;
+            if (have_prev) {
+                int lp = (int)strlen(prev);
+                emit(R, prev, F.f3[prev_i] - F.f3[prev_i + lp], prev_i);
+                have_prev = 0;
+            }
+            /* probed on the binary: a window without any structure still prints the start-1 backtrack ("." with energy 0.00) */
+            if (do_bt || !had_prev) {
+                int L = backtrack(&F, 1, span, cur, n + span + 16);
+                if (L < 0) { rc = L; break; }
+                emit(R, cur, F.f3[1] - F.f3[1 + L], 1);
+            }
+        }
+    }
+    R->mfe = F.f3[1];
+    free(prev); free(cur);
+    free(F.seq); free(F.S); free(F.c); free(F.fML); free(F.pt); free(F.f3);
+    return rc;
+}

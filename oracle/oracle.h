@@ -6,7 +6,7 @@
 extern "C" {
 #endif
 
-#define ORACLE_MAX_LINES 256
+#define ORACLE_MAX_LINES 384
 #define ORACLE_MAX_SS 512
 
 typedef struct {
@@ -25,6 +25,8 @@ typedef struct {
 
 /* RNALfold -L span on one sequence (vienna-2.1.2 flavour: Turner-2004, dangles=2). 0 = ok. */
 int oracle_lfold(const char *seq, int n, int span, OracleFoldResult *out);
+/* the same for the vienna-1.8.5 flavour (Turner-1999, dangles=1, multi-component structure strings). 0 = ok. */
+int oracle_lfold185(const char *seq, int n, int span, OracleFoldResult *out);
 
 
 /* ---- candidate stage (oracle/candidate.c) ---- */

@@ -45,31 +45,48 @@ def dump_gz(obj, path):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def _run_rnalfold(binary, seqs, span):
+    fa = "".join(">w%d\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    out = subprocess.run([binary, "-L", str(span)], input=fa, capture_output=True, text=True, cwd="/tmp").stdout
+    res = []
+    cur = None
+    for line in out.splitlines():
+        if line.startswith(">"):
+            cur = {"lines": [], "mfe": None}
+            res.append(cur)
+            continue
+        sp = line.split()
+        if line.startswith(" ("):
+            cur["mfe"] = int(round(float(line.strip().strip("()")) * 100))
+        elif len(sp) >= 3 and line[:1] in ".(":
+            e = line[line.index(" (") + 2:line.rindex(")")]
+            cur["lines"].append([sp[0], int(round(float(e) * 100)), int(sp[-1])])
+    assert len(res) == len(seqs)
+    return res
+
+
 def gen_fold_golden():
     """RNALfold 2.1.2 -L outputs on seeded windows (structure lines + final MFE)."""
     cases = []
     for seed, cnt, lo, hi, span in [(101, 160, 5, 120, 300), (102, 60, 60, 200, 40), (103, 40, 300, 350, 300),
                                     (104, 40, 120, 350, 100), (105, 30, 30, 90, 20)]:
         seqs = seqgen.windows(seed, cnt, lo, hi)
-        fa = "".join(">w%d\n%s\n" % (i, s) for i, s in enumerate(seqs))
-        out = subprocess.run([os.path.join(ORA_BIN, "RNALfold212"), "-L", str(span)], input=fa, capture_output=True, text=True).stdout
-        res = []
-        cur = None
-        for line in out.splitlines():
-            if line.startswith(">"):
-                cur = {"lines": [], "mfe": None}
-                res.append(cur)
-                continue
-            sp = line.split()
-            if len(sp) >= 3:
-                e = line[line.index(" (") + 2:line.rindex(")")]
-                cur["lines"].append([sp[0], int(round(float(e) * 100)), int(sp[-1])])
-            elif line.startswith(" ("):
-                cur["mfe"] = int(round(float(line.strip().strip("()")) * 100))
-        assert len(res) == len(seqs)
-        cases.append({"seed": seed, "span": span, "seqs": seqs, "expected": res})
+        cases.append({"seed": seed, "span": span, "seqs": seqs, "expected": _run_rnalfold(os.path.join(ORA_BIN, "RNALfold212"), seqs, span)})
     dump_gz({"generator": "RNALfold 2.1.2 (reference dependency/Mac/osx-10.9/RNALfold-2.1.2) -L span, default dangles",
              "cases": cases}, os.path.join(GOLD, "fold_rnalfold212.json.gz"))
+
+
+def gen_fold_golden_185():
+    """RNALfold 1.8.5 -L outputs (the Linux binary the reference bundles: Turner-1999, default dangles = 1) on seeded windows."""
+    cases = []
+    for seed, cnt, lo, hi, span in [(201, 160, 5, 120, 300), (202, 60, 60, 200, 40), (203, 40, 300, 350, 300),
+                                    (204, 40, 120, 350, 100), (205, 30, 30, 90, 20)]:
+        seqs = seqgen.windows(seed, cnt, lo, hi)
+        cases.append({"seed": seed, "span": span, "seqs": seqs, "expected": _run_rnalfold(os.path.join(ORA_BIN, "RNALfold185"), seqs, span)})
+    extra = ["AUCACUUCUUCGUAAUGUUGUUCGUAUAUAU", "AAAAAAAAAA", "GGGAAAACCC", "ACGU", "A", "GUGG" * 59, "GC" * 100, "N" * 30]
+    cases.append({"seed": 0, "span": 300, "seqs": extra, "expected": _run_rnalfold(os.path.join(ORA_BIN, "RNALfold185"), extra, 300)})
+    dump_gz({"generator": "RNALfold 1.8.5 (reference dependency/Linux/x64/RNALfold) -L span, default dangles (d1)",
+             "cases": cases}, os.path.join(GOLD, "fold_rnalfold185.json.gz"))
 
 
 def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_order, config_extra):
@@ -177,6 +194,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["fold", "mini"]
     if "fold" in what:
         gen_fold_golden()
+    if "fold185" in what:
+        gen_fold_golden_185()
     if "mini" in what:
         # 3 contigs, @SQ order deliberately non-lexicographic, 2 samples, edge cases planted
         gen_pipeline_golden("mini", [120000, 60000, 90000], ["Chr2", "Chr10", "Chr1"], 130, 2, 5, None, {})

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
-MAX_LINES = 256
+MAX_LINES = 384
 MAX_SS = 512
 
 
@@ -84,6 +84,8 @@ class Oracle:
         self.lib = lib
         lib.oracle_lfold.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FoldResult)]
         lib.oracle_lfold.restype = C.c_int
+        lib.oracle_lfold185.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FoldResult)]
+        lib.oracle_lfold185.restype = C.c_int
         lib.oracle_free.argtypes = [C.c_void_p]
         lib.oracle_free.restype = None
         vp, sz = C.c_void_p, C.c_size_t
@@ -178,13 +180,17 @@ class Oracle:
         n = self.lib.oracle_check_loci(st, len(structs), mat.ctypes.data, len(mat), w.ctypes.data, alns.ctypes.data, len(alns), C.byref(pp), out, 64)
         return [out[k] for k in range(n)]
 
-    def lfold(self, seq, span):
-        """Returns {'lines': [(ss, energy_dcal, start)], 'mfe': int} exactly as RNALfold -L prints."""
+    def lfold(self, seq, span, model="vienna-2.1.2"):
+        """Returns {'lines': [(ss, energy_dcal, start)], 'mfe': int} exactly as RNALfold -L prints (RNALfold 2.1.2 by default,
+        model="vienna-1.8.5" for the Turner-1999 / dangles-1 flavour)."""
         b = seq.encode() if isinstance(seq, str) else bytes(seq)
         r = FoldResult()
-        rc = self.lib.oracle_lfold(b, len(b), int(span), C.byref(r))
+        fn = self.lib.oracle_lfold185 if model == "vienna-1.8.5" else self.lib.oracle_lfold
+        rc = fn(b, len(b), int(span), C.byref(r))
         if rc != 0:
             raise RuntimeError("oracle_lfold rc=%d" % rc)
+        if r.overflow:
+            raise RuntimeError("oracle_lfold: more than ORACLE_MAX_LINES structure lines")
         lines = [(r.lines[k].ss.decode(), r.lines[k].energy, r.lines[k].start) for k in range(r.n_lines)]
         return {"lines": lines, "mfe": r.mfe}
 

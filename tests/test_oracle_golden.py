@@ -21,6 +21,19 @@ def test_lfold_matches_rnalfold212(oracle):
     assert n >= 300
 
 
+def test_lfold185_matches_rnalfold185(oracle):
+    """vienna-1.8.5 flavour (Turner-1999, dangles 1, multi-component strings) against the Linux binary the reference bundles."""
+    gold = gu.load_json("fold_rnalfold185.json.gz")
+    n = 0
+    for case in gold["cases"]:
+        for seq, exp in zip(case["seqs"], case["expected"]):
+            got = oracle.lfold(seq, case["span"], model="vienna-1.8.5")
+            assert got["mfe"] == exp["mfe"], seq
+            assert [list(l) for l in got["lines"]] == exp["lines"], seq
+            n += 1
+    assert n >= 330
+
+
 @pytest.fixture(scope="module", params=CASES)
 def case(request, oracle):
     c = gu.load_pipeline_case(request.param)
