@@ -73,6 +73,16 @@ void mirp_free(void* p);
 int mirp_abi_version(void);
 
 /*
+ * Which RNALfold the fold entry points reproduce.  The reference runs whatever `RNALfold` is on PATH (MP:3053) and bundles two:
+ * dependency/Mac/osx-10.9/RNALfold-2.1.2 (Turner-2004 parameters, dangles = 2: the default here, LDS-resident fast path) and
+ * dependency/Linux/x64/RNALfold = ViennaRNA 1.8.5 (Turner-1999 parameters, dangles = 1, multi-component structure strings:
+ * compatibility mode, one generic kernel).  Both are bit-exact against the respective binary.  Sticky per context.
+ */
+#define MIRP_FOLD_MODEL_VIENNA_212 0
+#define MIRP_FOLD_MODEL_VIENNA_185 1
+int mirp_set_fold_model(mirp_ctx* ctx, int32_t model);
+
+/*
  * Replaces: `RNALfold -L <span>` on a FASTA chunk (MP:3047-3119, command MP:3053, consumer MP:1541-1599).
  * seqs: concatenated sequence bytes (any case, T or U); offsets[n_seqs+1]: byte offsets into seqs.
  * Out (library-owned): lines[n_seqs*max_lines], ss[n_seqs*max_lines*ss_stride] (NUL-terminated texts),

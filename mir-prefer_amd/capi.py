@@ -90,6 +90,8 @@ def load_library():
     lib.mirp_get_loci.argtypes = [vp, C.POINTER(vp), i64p, C.POINTER(vp), i64p]
     lib.mirp_get_windows.argtypes = [vp, C.POINTER(vp), i64p, C.POINTER(vp), i64p, C.POINTER(vp), i64p, C.POINTER(vp), i64p]
     lib.mirp_fold.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.mirp_set_fold_model.argtypes = [vp, C.c_int32]
+    lib.mirp_set_fold_model.restype = C.c_int
     lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
     lib.mirp_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
@@ -249,6 +251,15 @@ class Context:
                                               C.byref(sq), C.byref(nsq)), "mirp_get_windows")
         return {"windows": _copy_out(self.lib, w, records.WINDOW_DTYPE, nw.value), "wpeaks": _copy_out(self.lib, pk, records.PEAK_DTYPE, npk.value),
                 "matures": _copy_out(self.lib, mt, records.MATURE_DTYPE, nmt.value), "seq": _copy_out(self.lib, sq, np.uint8, nsq.value)}
+
+    FOLD_MODELS = {"vienna-2.1.2": 0, "vienna-1.8.5": 1}
+
+    def set_fold_model(self, model):
+        """Which RNALfold the fold entry points reproduce: "vienna-2.1.2" (Turner-2004, dangles 2; default) or "vienna-1.8.5"
+        (Turner-1999, dangles 1: the Linux binary the reference bundles)."""
+        if model not in self.FOLD_MODELS:
+            raise MirpError("unknown fold model %r (expected one of %s)" % (model, ", ".join(sorted(self.FOLD_MODELS))))
+        self._check(self.lib.mirp_set_fold_model(self.h, self.FOLD_MODELS[model]), "mirp_set_fold_model")
 
     def fold(self, span, max_lines=96):
         self._check(self.lib.mirp_fold(self.h, int(span), int(max_lines)), "mirp_fold")

@@ -40,5 +40,25 @@ struct FoldParams {
     unsigned k1n1_key[31];        // k x 1 loop (n1 = k, n2 = 1): ... | k << 5 | 1
 };
 
+// Energy model of the "vienna-1.8.5" compatibility mode (Turner-1999 parameters as shipped in ViennaRNA 1.8.5, dangles = 1).
+struct FoldParams185 {
+    int stack[8][8];
+    int bulge[31];
+    int internal_loop[31];
+    int mismatchI[8][5][5];
+    int mismatchH[8][5][5];
+    int dangle5[8][5];            // clamped <= 0
+    int dangle3[8][5];            // clamped <= 0
+    int int11[8][8][5][5];
+    int int21[8][8][5][5][5];
+    int int22[8][8][5][5][5][5];
+    int hairpinE[MIRP_HP_MAX];    // size table, log-extrapolated above 30 on the host
+    int n_tetra;
+    int tetraE[32];               // bonus added to the hairpin energy (not a total, unlike Turner-2004)
+    char tetra[32][8];
+    int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
+};
+void mirp_fill_fold_params185(FoldParams185* p);
+
 // Fills *p from the generated Turner-2004 tables (host side, mirp_params.cpp).
 void mirp_fill_fold_params(FoldParams* p);

@@ -44,6 +44,26 @@ extern "C" int mirp_create(int device, mirp_ctx** out) {
     return 0;
 }
 
+extern "C" int mirp_set_fold_model(mirp_ctx* c, int32_t model) {
+    if (!c) return -1;
+    if (model != MIRP_FOLD_MODEL_VIENNA_212 && model != MIRP_FOLD_MODEL_VIENNA_185) return fail(c, -1, "mirp_set_fold_model: unknown model");
+    (void)hipSetDevice(c->device);
+    if (model == MIRP_FOLD_MODEL_VIENNA_185 && !c->d_params185) {
+        FoldParams185* hp = new FoldParams185();
+        mirp_fill_fold_params185(hp);
+        if (hipMalloc((void**)&c->d_params185, sizeof(FoldParams185)) != hipSuccess ||
+            hipMemcpy(c->d_params185, hp, sizeof(FoldParams185), hipMemcpyHostToDevice) != hipSuccess) {
+            delete hp;
+            if (c->d_params185) { (void)hipFree(c->d_params185); c->d_params185 = nullptr; }
+            return fail(c, -6, "mirp_set_fold_model: device allocation failed");
+        }
+        delete hp;
+    }
+    c->fold_model = model;
+    c->have_fold = false;
+    return 0;
+}
+
 extern "C" void mirp_destroy(mirp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -56,6 +76,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
         b->release();
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_params185) (void)hipFree(c->d_params185);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -185,11 +206,23 @@ extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_
 int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,
                   int max_lines, int stride, MirpFoldLine* d_lines, char* d_ss, int* d_nlines, int* d_mfe, int* d_status) {
     if (n_work <= 0) return 0;
+    c->last_fallback = 0;
+    if (c->fold_model == MIRP_FOLD_MODEL_VIENNA_185) {
+        // compatibility mode: one kernel, tables in a global workspace (3 int32 tables per resident window)
+        if (mirp::fold185_lds_bytes(n_cap, max_lines) > 160 * 1024) return fail(c, -5, "LDS budget exceeded (vienna-1.8.5 kernel: window or max_lines too large)");
+        const size_t slot = mirp::fold185_ws_slot_ints(n_cap, span);
+        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot * 4)));
+        slots = std::min(slots, n_work);
+        if (c->ws.ensure((size_t)slots * slot * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
+        hipError_t e = mirp::launch_fold185(c->stream, slots, c->d_params185, d_seqs, d_offs, d_lens, n_work, span, n_cap, (int*)c->ws.p, slot, max_lines, stride,
+                                            d_lines, d_ss, d_nlines, d_mfe, d_status);
+        if (e != hipSuccess) return fail(c, -2, std::string("fold (vienna-1.8.5) kernel launch failed: ") + hipGetErrorString(e));
+        return 0;
+    }
     if (mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
     const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);
     const int* work_list = nullptr;
     int n_generic = n_work;
-    c->last_fallback = 0;
     if (span <= mirp::fold_lds_max_span() && mirp::fold_lds_bytes(max_lines) <= 160 * 1024) {
         // fill kernel (one 1024-thread workgroup per CU, tables in LDS) + epilogue kernel (many small workgroups) per sub-batch;
         // the two exchange the c / fML triangles of every window through per-window slabs in HBM

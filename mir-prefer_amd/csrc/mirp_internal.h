@@ -14,6 +14,13 @@ void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, cons
                          const int* lens, const int* work_list, int n_work, int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines,
                          int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status);
 
+// fold185_kernel.hip: vienna-1.8.5 compatibility mode
+size_t fold185_lds_bytes(int n_cap, int max_lines);
+size_t fold185_ws_slot_ints(int n_cap, int span);
+hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens, int n_work,
+                          int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss,
+                          int* out_nlines, int* out_mfe, int* out_status);
+
 size_t predict_lds_bytes(int max_lines, int ss_stride);
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,

@@ -1,6 +1,7 @@
 // Host-side construction of the device energy model from the generated Turner-2004 tables.
 #include "fold_params.h"
 #include "energy_params_t2004.h"
+#include "energy_params_t1999.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -56,4 +57,27 @@ void mirp_fill_fold_params(FoldParams* p) {
         p->k1n0_key[u] = k1 | (unsigned)(1 << 5 | u);
         p->k1n1_key[u] = k1 | (unsigned)(u << 5 | 1);
     }
+}
+
+void mirp_fill_fold_params185(FoldParams185* p) {
+    std::memset(p, 0, sizeof(*p));
+    std::memcpy(p->stack, T99_stack, sizeof(p->stack));
+    std::memcpy(p->bulge, T99_bulge, sizeof(p->bulge));
+    std::memcpy(p->internal_loop, T99_internal_loop, sizeof(p->internal_loop));
+    std::memcpy(p->mismatchI, T99_mismatchI, sizeof(p->mismatchI));
+    std::memcpy(p->mismatchH, T99_mismatchH, sizeof(p->mismatchH));
+    for (int t = 0; t < 8; t++)
+        for (int a = 0; a < 5; a++) { p->dangle5[t][a] = clamp0(T99_dangle5[t][a]); p->dangle3[t][a] = clamp0(T99_dangle3[t][a]); }
+    std::memcpy(p->int11, T99_int11, sizeof(p->int11));
+    std::memcpy(p->int21, T99_int21, sizeof(p->int21));
+    std::memcpy(p->int22, T99_int22, sizeof(p->int22));
+    for (int u = 0; u < MIRP_HP_MAX; u++)
+        p->hairpinE[u] = (u <= 30) ? T99_hairpin[u] : T99_hairpin[30] + (int)(T99_LXC * std::log((double)u / 30.));
+    p->n_tetra = T99_N_TETRALOOPS;
+    for (int k = 0; k < T99_N_TETRALOOPS; k++) { std::strncpy(p->tetra[k], T99_Tetraloops[k], 7); p->tetraE[k] = T99_Tetraloop_E[k]; }
+    p->ML_closing = T99_ML_closing;
+    p->ML_intern = T99_ML_intern;
+    p->TerminalAU = T99_TerminalAU;
+    p->ninio = T99_ninio;
+    p->MAX_NINIO = T99_MAX_NINIO;
 }

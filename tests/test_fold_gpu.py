@@ -32,3 +32,42 @@ def test_fold_edge_cases(gpu_ctx, oracle):
     seqs = ["A", "ACGU", "GGGGAAAACCCC", "A" * 24, "N" * 30, "GGGAAAUCCCGGGAAAUCCCAAAAGGGGGGAUUUCCCCCCUUUUGGGAUUUCCCGGAUUUCCC",
             "GC" * 150, "G" * 150 + "C" * 150, ""]
     _compare(gpu_ctx, oracle, seqs, 300)
+
+
+def _compare185(gpu_ctx, oracle, seqs, span, max_lines=96):
+    gpu_ctx.set_fold_model("vienna-1.8.5")
+    try:
+        got = gpu_ctx.fold_batch(seqs, span, max_lines=max_lines)
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
+    for s, g in zip(seqs, got):
+        want = oracle.lfold(s, span, model="vienna-1.8.5")
+        assert g["status"] == 0, (s, g["status"])
+        assert g["mfe"] == want["mfe"], s
+        assert g["lines"] == want["lines"], s
+
+
+def test_fold_vienna185_mode_matches_oracle(gpu_ctx, oracle):
+    """Compatibility mode: the RNALfold 1.8.5 the reference bundles for Linux (Turner-1999, dangles 1, multi-component strings)."""
+    _compare185(gpu_ctx, oracle, seqgen.windows(31, 150, 5, 120), 300)
+    _compare185(gpu_ctx, oracle, seqgen.windows(32, 60, 60, 200), 40)
+    _compare185(gpu_ctx, oracle, seqgen.windows(33, 40, 300, 350), 300)
+    _compare185(gpu_ctx, oracle, ["A", "ACGU", "AAAAAAAAAA", "GGGAAAACCC", "N" * 30, "GC" * 100, "G" * 150 + "C" * 150, ""], 300)
+    _compare185(gpu_ctx, oracle, ["GUGG" * 59], 300, max_lines=352)
+
+
+def test_fold_vienna185_mode_matches_the_bundled_binary(gpu_ctx):
+    from tests import golden_util as gu
+    gold = gu.load_json("fold_rnalfold185.json.gz")
+    gpu_ctx.set_fold_model("vienna-1.8.5")
+    try:
+        n = 0
+        for case in gold["cases"]:
+            got = gpu_ctx.fold_batch(case["seqs"], case["span"], max_lines=352)
+            for g, exp, seq in zip(got, case["expected"], case["seqs"]):
+                assert g["status"] == 0 and g["mfe"] == exp["mfe"], seq
+                assert [list(l) for l in g["lines"]] == exp["lines"], seq
+                n += 1
+        assert n >= 330
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
