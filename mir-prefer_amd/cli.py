@@ -1,7 +1,8 @@
 """Command line of the MI355X host: same verbs, flags and config file as the reference
 (/root/reference/miR_PREFeR.py:44-78 parse_option_optparse, verbs dispatched at :3728-3774).
 
-    python -m mir_prefer_amd.cli [-L] [-k] [-d] {check|prepare|candidate|fold|predict|pipeline|recover} configfile
+    python -m mir_prefer_amd.cli [-L] [-k] [-d] [--device N] [--fold-model vienna-2.1.2|vienna-1.8.5]
+                                 {check|prepare|candidate|fold|predict|pipeline|recover} configfile
 """
 import logging
 import optparse
@@ -19,13 +20,16 @@ def parse_option_optparse(argv=None):
     parser.add_option("-k", "--keep-tmp", action="store_true", dest="keeptmp", help="After finish the whole pipeline, do not remove the temporary folder.")
     parser.add_option("-d", "--output-detail-for-debug", action="store_true", dest="debug", help="Output detailed information for debug.")
     parser.add_option("--device", type="int", default=0, help="GPU index (default 0).")
+    parser.add_option("--fold-model", dest="fold_model", default="vienna-2.1.2", choices=["vienna-2.1.2", "vienna-1.8.5"],
+                      help="Which RNALfold the fold stage reproduces: the reference runs whatever RNALfold is on PATH and bundles 2.1.2 "
+                           "(Turner-2004, dangles 2; default) and 1.8.5 (Turner-1999, dangles 1).")
     options, args = parser.parse_args(argv)
     if len(args) != 2:
         parser.error("incorrect number of arguments. Run the script with -h option to see help.")
     if args[0] not in ACTIONS:
         parser.error("unknow command. Run the script with -h option to see help.")
     return {"action": args[0], "config": args[1], "log": bool(options.log), "keeptmp": bool(options.keeptmp), "debug": bool(options.debug),
-            "device": options.device}
+            "device": options.device, "fold_model": options.fold_model}
 
 
 def main(argv=None):
@@ -54,7 +58,7 @@ def main(argv=None):
         print("Last finished stage: %s" % last)
         return 0
     try:
-        p = pipeline.Pipeline(opt, o["device"])
+        p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"])
         if o["action"] == "pipeline":
             p.run_pipeline()
             if not o["keeptmp"] and opt["DELETE_IF_SUCCESS"].upper().startswith("Y"):

@@ -61,13 +61,14 @@ class Pipeline:
     """One device context + the option dict; the stage methods can run in one process (pipeline verb) or one per process
     (stage verbs): a stage that finds no device-resident state re-creates it from the previous stages' artefacts."""
 
-    def __init__(self, dict_option, device=0):
+    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2"):
         self.opt = dict_option
         self.tmp = dict_option["TMPFOLDER"] or os.path.join(dict_option["OUTFOLDER"], dict_option["NAME_PREFIX"] + "_tmp")
         os.makedirs(dict_option["OUTFOLDER"], exist_ok=True)
         os.makedirs(self.tmp, exist_ok=True)
         self.recovername = os.path.join(self.tmp, dict_option["NAME_PREFIX"] + "_recover")
         self.ctx = capi.Context(device)
+        self.ctx.set_fold_model(fold_model)
         self.state = None  # None / "candidate" / "fold"
         self.data = None
 

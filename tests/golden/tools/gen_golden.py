@@ -89,7 +89,7 @@ def gen_fold_golden_185():
              "cases": cases}, os.path.join(GOLD, "fold_rnalfold185.json.gz"))
 
 
-def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_order, config_extra):
+def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_order, config_extra, rnalfold="RNALfold212"):
     work = os.path.join("/tmp", "golden_" + name)
     shutil.rmtree(work, ignore_errors=True)
     os.makedirs(work)
@@ -106,12 +106,13 @@ def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_or
     with open(cfg, "w") as f:
         for k, v in opts.items():
             f.write("%s = %s\n" % (k, v))
-    ref_shim.run_pipeline(["-L", "-k", "-d", "pipeline", cfg])
-    g = ref_shim.load_reference()
+    ref_shim.run_pipeline(["-L", "-k", "-d", "pipeline", cfg], rnalfold)
+    g = ref_shim.load_reference(rnalfold)
     out = opts["OUTFOLDER"]
     tmp = os.path.join(out, name + "_tmp")
     exp = {"config": {k: v for k, v in opts.items() if k not in ("PIPELINE_PATH", "FASTA_FILE", "ALIGNMENT_FILE", "OUTFOLDER")},
-           "sample_names": ds.sample_names, "sq_order": [names[t] for t in (sq_order or range(len(names)))]}
+           "sample_names": ds.sample_names, "sq_order": [names[t] for t in (sq_order or range(len(names)))],
+           "fold_model": "vienna-1.8.5" if rnalfold == "RNALfold185" else "vienna-2.1.2"}
     exp["depth_cut"] = open(os.path.join(tmp, "bam.depth.cut%d" % opts["READS_DEPTH_CUTOFF"])).read()
     dict_option = {"READS_DEPTH_CUTOFF": opts["READS_DEPTH_CUTOFF"]}
     _, dict_contigs = g["gen_contig_typeA"](os.path.join(tmp, "expanded.plus.bam"), os.path.join(tmp, "expanded.minus.bam"),
@@ -199,6 +200,9 @@ if __name__ == "__main__":
     if "mini" in what:
         # 3 contigs, @SQ order deliberately non-lexicographic, 2 samples, edge cases planted
         gen_pipeline_golden("mini", [120000, 60000, 90000], ["Chr2", "Chr10", "Chr1"], 130, 2, 5, None, {})
+    if "mini185" in what:
+        # the "mini" dataset with the RNALfold the reference bundles for Linux (1.8.5) on PATH instead of 2.1.2
+        gen_pipeline_golden("mini185", [120000, 60000, 90000], ["Chr2", "Chr10", "Chr1"], 130, 2, 5, None, {}, rnalfold="RNALfold185")
     if "mini3" in what:
         gen_pipeline_golden("mini3", [80000, 50000], ["ctgB", "ctgA"], 70, 3, 9, [1, 0],
                             {"ALLOW_3NT_OVERHANG": "Y", "ALLOW_NO_STAR_EXPRESSION": "N", "MAX_MATURE_LEN": 24})

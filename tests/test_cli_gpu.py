@@ -31,10 +31,10 @@ def _setup(name, tmp_path):
     return exp, str(cfg), tmp_path / "out"
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
 def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     exp, cfg, out = _setup(name, tmp_path)
-    assert cli.main(["-k", "pipeline", cfg]) == 0
+    assert cli.main(["-k", "--fold-model", exp.get("fold_model", "vienna-2.1.2"), "pipeline", cfg]) == 0
     prefix = exp["config"]["NAME_PREFIX"]
     tmp = out / (prefix + "_tmp")
     assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"]

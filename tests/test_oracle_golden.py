@@ -6,7 +6,7 @@ import pytest
 from mir_prefer_amd import records
 from tests import golden_util as gu
 
-CASES = ["mini", "mini3"]
+CASES = ["mini", "mini3", "mini185"]   # mini185: the "mini" dataset run with the bundled RNALfold 1.8.5 on PATH
 
 
 def test_lfold_matches_rnalfold212(oracle):
@@ -107,7 +107,7 @@ def test_fold_of_pipeline_windows(case, oracle):
     assert len(ref) == len(w["windows"])
     for win, exp in zip(w["windows"], ref):
         seq = w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes()
-        got = oracle.lfold(seq, case["cfg"]["PRECURSOR_LEN"])
+        got = oracle.lfold(seq, case["cfg"]["PRECURSOR_LEN"], model=case["exp"].get("fold_model", "vienna-2.1.2"))
         assert got["lines"] == exp
 
 

@@ -19,9 +19,17 @@ def _gpu_record(m, ss, names):
             records.STRAND[m["strand"]], bool(m["has_star"])]
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
 def test_pipeline_matches_reference_fixture(name, gpu_ctx):
     c = gu.load_pipeline_case(name)
+    gpu_ctx.set_fold_model(c["exp"].get("fold_model", "vienna-2.1.2"))
+    try:
+        _check_pipeline_fixture(c, gpu_ctx)
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
+
+
+def _check_pipeline_fixture(c, gpu_ctx):
     cfg, exp, names = c["exp"]["config"], c["exp"], c["contig_names"]
     gpu_ctx.load_genome(c["contigs"])
     gpu_ctx.load_alignments(c["alns"])
@@ -40,7 +48,7 @@ def test_pipeline_matches_reference_fixture(name, gpu_ctx):
     for win, (hdr, seq) in zip(w["windows"], entries):
         assert records.fasta_header(win, w["wpeaks"], w["matures"], names) == hdr
         assert w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes().decode() == seq
-    # a7: fold output of every window == RNALfold 2.1.2 text
+    # a7: fold output of every window == the RNALfold text of the reference run
     gpu_ctx.fold(cfg["PRECURSOR_LEN"])
     raw = gpu_ctx.get_fold()
     assert (raw["status"] == 0).all()
