@@ -1,6 +1,6 @@
 """Dev tool: large differential stress of the HIP fold against the CPU oracle (structure lines bit-exact), with sequence families that
 provoke energy ties (repeats, low complexity, GC-only, long N runs).  Oracle runs in a process pool.
-usage: python profiles/tools/stress_fold.py [n_windows] [seed]"""
+usage: python profiles/tools/stress_fold.py [n_windows] [seed] [vienna-2.1.2|vienna-1.8.5]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -30,20 +30,22 @@ def family(r, k):
     return s
 
 def oracle_chunk(args):
-    seqs, span = args
+    seqs, span, model = args
     from tests import oracle_binding
     o = oracle_binding.load()
-    return [o.lfold(s, span) for s in seqs]
+    return [o.lfold(s, span, model=model) for s in seqs]
 
 def main():
     nw = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    model = sys.argv[3] if len(sys.argv) > 3 else "vienna-2.1.2"
     r = random.Random(seed)
     seqs = [family(r, i % 5) for i in range(nw)]
     from tests import oracle_binding
     oracle_binding.load()
     from mir_prefer_amd import capi
     ctx = capi.Context(0)
+    ctx.set_fold_model(model)
     bad = 0
     for span in (300, 150):
         t = time.time()
@@ -52,7 +54,7 @@ def main():
         ncpu = min(64, os.cpu_count() or 1)
         chunks = [seqs[i::ncpu] for i in range(ncpu)]
         with cf.ProcessPoolExecutor(ncpu) as ex:
-            res = list(ex.map(oracle_chunk, [(c, span) for c in chunks]))
+            res = list(ex.map(oracle_chunk, [(c, span, model) for c in chunks]))
         want = [None] * nw
         for ci, c in enumerate(res):
             for k, w in enumerate(c): want[ci + k * ncpu] = w
