@@ -6,243 +6,14 @@
 // against oracle/lfold185.c, which is pinned to the bundled binary.  Arithmetic is deliberately uncapped (INF = 1,000,000 plus
 // small terms, exactly as the original): equality tests in the backtrack see the same numbers.
 #include <hip/hip_runtime.h>
-#include "fold_device.h"
-#include "mirp_internal.h"
+#include "fold185_device.h"
 
 namespace mirp {
 namespace v185 {
 
-#define V_TURN 3
-#define V_MAXLOOP 30
-#define V_INF 1000000
-#define V_NT 256
-#define V_G 8
-#define V_BT_STACK 192
-
-struct Tab {
-    int* __restrict__ c;
-    int* __restrict__ m;
-    int* __restrict__ dm;
-    int ld, n, M;
-    __device__ __forceinline__ int C(int i, int j) const { const int d = j - i; return (d <= V_TURN || d > M || i < 1 || j > n) ? V_INF : c[(size_t)d * ld + i]; }
-    __device__ __forceinline__ int Mm(int i, int j) const { const int d = j - i; return (d <= V_TURN || d > M || i < 1 || j > n) ? V_INF : m[(size_t)d * ld + i]; }
-    __device__ __forceinline__ int DM(int i, int j) const { const int d = j - i; return (d <= V_TURN || d > M || i < 1 || j > n) ? V_INF : dm[(size_t)d * ld + i]; }
-};
-
-struct Ctx {
-    const FoldParams185* __restrict__ P;
-    const unsigned char* S;     // LDS 0..n+1
-    const short* tetra;         // LDS: tetraloop bonus of the hairpin closed at i (0 = none)
-    const int* f3;              // LDS
-    int n, M;
-};
-
-__device__ __forceinline__ int ptype(const Ctx& X, int i, int j) {
-    const int d = j - i;
-    if (d <= V_TURN || d > X.M - 1 || i < 1 || j > X.n) return 0;
-    return pair_type(X.S[i], X.S[j]);
-}
-__device__ __forceinline__ int AU(const Ctx& X, int t) { return t > 2 ? X.P->TerminalAU : 0; }
-__device__ __forceinline__ int MLi(const Ctx& X, int t) { return X.P->ML_intern + AU(X, t); }
-
-__device__ __forceinline__ int hairpin(const Ctx& X, int i, int j, int type) {
-    const int u = j - i - 1;
-    int e = X.P->hairpinE[u < MIRP_HP_MAX ? u : MIRP_HP_MAX - 1];
-    if (u == 4) e += X.tetra[i];
-    if (u == 3) e += AU(X, type);
-    else e += X.P->mismatchH[type][X.S[i + 1]][X.S[j - 1]];
-    return e;
-}
-
-__device__ __forceinline__ int loopE(const Ctx& X, int n1, int n2, int type, int type2, int si1, int sj1, int sp1, int sq1) {
-    const FoldParams185* __restrict__ P = X.P;
-    const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;
-    if (nl == 0) return P->stack[type][type2];
-    if (ns == 0) {
-        int e = P->bulge[nl];
-        if (nl == 1) e += P->stack[type][type2];
-        else e += AU(X, type) + AU(X, type2);
-        return e;
-    }
-    if (ns == 1 && nl == 1) return P->int11[type][type2][si1][sj1];
-    if (ns == 1 && nl == 2) return n1 == 1 ? P->int21[type][type2][si1][sq1][sj1] : P->int21[type2][type][sq1][si1][sp1];
-    if (ns == 2 && nl == 2) return P->int22[type][type2][si1][sp1][sq1][sj1];
-    int x = (nl - ns) * P->ninio;
-    return P->internal_loop[n1 + n2] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + P->mismatchI[type][si1][sj1] + P->mismatchI[type2][sq1][sp1];
-}
-
-__device__ __forceinline__ int first_lane(unsigned long long mask) { return mask ? (__ffsll((long long)mask) - 1) : -1; }
-
-// Wave-cooperative backtrack (all 64 lanes, wave-uniform arguments).  Returns the string length or a negative error code.
-__device__ int backtrack(const Ctx& X, const Tab& T, int start, int maxdist, char* buf, int bufcap, int* stk) {
-    const int lane = threadIdx.x & 63;
-    const int n = X.n;
-    const FoldParams185* __restrict__ P = X.P;
-    const int len0 = (n - start < maxdist ? n - start : maxdist) + 1;
-    if (len0 + 3 > bufcap) return -9;
-    for (int x = lane; x < len0 + 3; x += 64) buf[x] = x < len0 ? '-' : (char)0;
-    int sp = 0;
-    if (lane == 0) { stk[0] = start; stk[1] = (n < start + maxdist + 1 ? n : start + maxdist + 1); stk[2] = 0; }
-    sp = 1;
-    __builtin_amdgcn_wave_barrier();
-    while (sp > 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        sp--;
-        int i = __builtin_amdgcn_readfirstlane(stk[3 * sp]), j = __builtin_amdgcn_readfirstlane(stk[3 * sp + 1]), ml = __builtin_amdgcn_readfirstlane(stk[3 * sp + 2]);
-        if (j < i + V_TURN + 1) continue;
-        if (sp + 3 >= V_BT_STACK) return -20;
-        if (ml == 0) {
-            const int fij = X.f3[i];
-            if (fij == X.f3[i + 1]) {
-                if (lane == 0) { stk[3 * sp] = i + 1; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 0; }
-                sp++;
-                continue;
-            }
-            // ascending scan over the partner k; inside one k the four tests run in the original order and later hits overwrite earlier ones
-            int fk = -1, ftr = 0, fjj = 0;
-            for (int kb = i + V_TURN + 1; kb <= j && fk < 0; kb += 64) {
-                const int k = kb + lane;
-                int traced = 0, jj = k + 1;
-                if (k <= j) {
-                    int t = ptype(X, i + 1, k);
-                    if (t) {
-                        const int cc = T.C(i + 1, k) + P->dangle5[t][X.S[i]] + AU(X, t);
-                        if (fij == cc + X.f3[k + 1]) traced = i + 1;
-                        if (k < n && fij == cc + X.f3[k + 2] + P->dangle3[t][X.S[k + 1]]) { traced = i + 1; jj = k + 2; }
-                    }
-                    t = ptype(X, i, k);
-                    if (t) {
-                        const int cc = T.C(i, k) + AU(X, t);
-                        if (fij == cc + X.f3[k + 1]) traced = i;
-                        if (k < n && fij == cc + X.f3[k + 2] + P->dangle3[t][X.S[k + 1]]) { traced = i; jj = k + 2; }
-                    }
-                }
-                const int fl = first_lane(__ballot(traced != 0));
-                if (fl >= 0) { fk = kb + fl; ftr = __shfl(traced, fl); fjj = __shfl(jj, fl); }
-            }
-            if (fk < 0) return -21;
-            if (j == n) {
-                if (lane == 0) { stk[3 * sp] = fjj; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 0; }
-                sp++;
-            }
-            i = ftr; j = fk;
-            if (lane == 0) {
-                buf[i - start] = '(';
-                buf[j - start] = ')';
-                if (fjj == fk + 2) buf[fk + 1 - start] = '.';
-            }
-        } else {
-            const int fij = T.Mm(i, j);
-            if (T.Mm(i, j - 1) + 0 == fij) {
-                if (lane == 0) { stk[3 * sp] = i; stk[3 * sp + 1] = j - 1; stk[3 * sp + 2] = 1; }
-                sp++;
-                continue;
-            }
-            if (T.Mm(i + 1, j) + 0 == fij) {
-                if (lane == 0) { stk[3 * sp] = i + 1; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 1; }
-                sp++;
-                continue;
-            }
-            int t = ptype(X, i, j);
-            const int cij = T.C(i, j) + MLi(X, t);
-            t = ptype(X, i + 1, j);
-            const int ci1j = T.C(i + 1, j) + P->dangle5[t][X.S[i]] + MLi(X, t);
-            t = ptype(X, i, j - 1);
-            const int cij1 = T.C(i, j - 1) + P->dangle3[t][X.S[j]] + MLi(X, t);
-            t = ptype(X, i + 1, j - 1);
-            const int ci1j1 = T.C(i + 1, j - 1) + P->dangle5[t][X.S[i]] + P->dangle3[t][X.S[j]] + MLi(X, t);
-            if (fij == cij || fij == ci1j || fij == cij1 || fij == ci1j1) {
-                if (fij == ci1j) i++;
-                else if (fij == cij1) j--;
-                else if (fij == ci1j1) { i++; j--; }
-                if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
-            } else {
-                int found = -1;
-                for (int kb = i + 1 + V_TURN; kb <= j - 2 - V_TURN && found < 0; kb += 64) {
-                    const int k = kb + lane;
-                    bool hit = false;
-                    if (k <= j - 2 - V_TURN) hit = (fij == T.Mm(i, k) + T.Mm(k + 1, j));
-                    const int fl = first_lane(__ballot(hit));
-                    if (fl >= 0) found = kb + fl;
-                }
-                if (found < 0) return -22;
-                if (lane == 0) {
-                    stk[3 * sp] = i; stk[3 * sp + 1] = found; stk[3 * sp + 2] = 1;
-                    stk[3 * sp + 3] = found + 1; stk[3 * sp + 4] = j; stk[3 * sp + 5] = 1;
-                }
-                sp += 2;
-                continue;
-            }
-        }
-        // (i,j) is a traced pair: follow stacks / interior loops until a hairpin or a multiloop
-        for (;;) {
-            const int type = ptype(X, i, j);
-            const int cij = T.C(i, j);
-            if (cij == hairpin(X, i, j, type)) break;
-            const int pmax = (j - 2 - V_TURN < i + V_MAXLOOP + 1) ? j - 2 - V_TURN : i + V_MAXLOOP + 1;
-            int fp = -1, fq = -1;
-            for (int pb = i + 1; pb <= pmax && fp < 0; pb += 2) {
-                const int p = pb + (lane >> 5), q = j - 1 - (lane & 31);
-                int minq = j - i + p - V_MAXLOOP - 2;
-                if (minq < p + 1 + V_TURN) minq = p + 1 + V_TURN;
-                bool hit = false;
-                if (p <= pmax && q >= minq) {
-                    int t2 = ptype(X, p, q);
-                    if (t2) {
-                        t2 = rtype_of(t2);
-                        hit = (cij == loopE(X, p - i - 1, j - q - 1, type, t2, X.S[i + 1], X.S[j - 1], X.S[p - 1], X.S[q + 1]) + T.C(p, q));
-                    }
-                }
-                const int fl = first_lane(__ballot(hit));
-                if (fl >= 0) { fp = pb + (fl >> 5); fq = j - 1 - (fl & 31); }
-            }
-            if (fp >= 0) {
-                i = fp; j = fq;
-                if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
-                continue;
-            }
-            const int tt = rtype_of(type);
-            const int mm = P->ML_closing + MLi(X, tt);
-            const int e5 = P->dangle5[tt][X.S[j - 1]], e3 = P->dangle3[tt][X.S[i + 1]];
-            int fk = -1, fv = 0;
-            for (int kb = i + 2 + V_TURN; kb <= j - 3 - V_TURN && fk < 0; kb += 64) {
-                const int k = kb + lane;
-                int v = 0;      // 1: plain, 2: i1 = i+2, 3: j1 = j-2, 4: both (first in this order)
-                if (k <= j - 3 - V_TURN) {
-                    if (cij == T.Mm(i + 1, k) + T.Mm(k + 1, j - 1) + mm) v = 1;
-                    else if (cij == T.Mm(i + 2, k) + T.Mm(k + 1, j - 1) + mm + e3) v = 2;
-                    else if (cij == T.Mm(i + 1, k) + T.Mm(k + 1, j - 2) + mm + e5) v = 3;
-                    else if (cij == T.Mm(i + 2, k) + T.Mm(k + 1, j - 2) + mm + e3 + e5) v = 4;
-                }
-                const int fl = first_lane(__ballot(v != 0));
-                if (fl >= 0) { fk = kb + fl; fv = __shfl(v, fl); }
-            }
-            if (fk < 0) return -23;
-            const int i1 = (fv == 2 || fv == 4) ? i + 2 : i + 1, j1 = (fv == 3 || fv == 4) ? j - 2 : j - 1;
-            if (lane == 0) {
-                stk[3 * sp] = i1; stk[3 * sp + 1] = fk; stk[3 * sp + 2] = 1;
-                stk[3 * sp + 3] = fk + 1; stk[3 * sp + 4] = j1; stk[3 * sp + 5] = 1;
-            }
-            sp += 2;
-            break;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // length = C string length (the 3' dangle dot of the last helix may sit one cell behind the nominal buffer), trailing '-' stripped
-    int L = len0;
-    while (L < len0 + 2 && buf[L] != 0) L++;
-    while (L > 1 && buf[L - 1] == '-') L--;
-    for (int x = lane; x < L; x += 64)
-        if (buf[x] == '-') buf[x] = '.';
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    return L;
-}
-
 __global__ void __launch_bounds__(V_NT) fold185_kernel(
     const FoldParams185* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
-    int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
+    const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
     char* __restrict__ out_ss, int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int nc = n_cap + 8;
@@ -257,7 +28,8 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
     char* btbuf = (char*)(seq + nc);                       // (NT/64) * (nc + 8)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = span;
-    for (int win = blockIdx.x; win < n_work; win += gridDim.x) {
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const int win = work_list ? work_list[w] : w;
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
         if (n < 1 || n > n_cap) {
@@ -287,13 +59,13 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                 }
             tetra[x] = b;
         }
-        Tab T;
+        GTab185 T;
         T.ld = n_cap + 2; T.n = n; T.M = M;
         T.c = ws + (size_t)blockIdx.x * ws_slot_ints;
         T.m = T.c + ws_slot_ints / 3;
         T.dm = T.m + ws_slot_ints / 3;
         __syncthreads();
-        Ctx X;
+        Ctx<FoldParams185> X;
         X.P = P; X.S = S; X.tetra = tetra; X.f3 = f3; X.n = n; X.M = M;
 
         // ---- anti-diagonal wavefront fill; cells at distance M hold c = INF but a finite fML
@@ -364,104 +136,8 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
             __syncthreads();
         }
 
-        // ---- exterior sweep, sequential in i, partners j reduced in parallel
-        for (int i = n - V_TURN - 1; i >= 1; i--) {
-            int best = V_INF;
-            const int jmax = (i + M < n) ? i + M : n;
-            for (int j = i + V_TURN + 1 + tid; j <= jmax; j += V_NT) {
-                int t = ptype(X, i, j);
-                if (t) {
-                    const int e = T.C(i, j) + AU(X, t);
-                    if (j < n) {
-                        int v = f3[j + 1] + e; best = v < best ? v : best;
-                        v = f3[j + 2] + e + P->dangle3[t][S[j + 1]]; best = v < best ? v : best;
-                    } else best = e < best ? e : best;
-                }
-                t = ptype(X, i + 1, j);
-                if (t) {
-                    const int e = T.C(i + 1, j) + P->dangle5[t][S[i]] + AU(X, t);
-                    if (j < n) {
-                        int v = f3[j + 1] + e; best = v < best ? v : best;
-                        v = f3[j + 2] + e + P->dangle3[t][S[j + 1]]; best = v < best ? v : best;
-                    } else best = e < best ? e : best;
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(best, o); best = t < best ? t : best; }
-            if (lane == 0) red[wave] = best;
-            __syncthreads();
-            if (tid == 0) {
-                int b = f3[i + 1];
-                for (int w = 0; w < V_NT / 64; w++) b = red[w] < b ? red[w] : b;
-                f3[i] = b;
-            }
-            __syncthreads();
-        }
-
-        // ---- structure starts, descending: l >= 2 with f3[l] != f3[l+1] && f3[l-1] == f3[l]; l == 1 with f3[1] != f3[2], or when there is
-        // no other start at all (probed on the binary: a structure-free window still prints the start-1 backtrack ".")
-        if (wave == 0) {
-            int cnt = 0;
-            for (int base = n - V_TURN - 1; base >= 2; base -= 64) {
-                const int l = base - lane;
-                bool is = false;
-                if (l >= 2) is = (f3[l] != f3[l + 1]) && (f3[l - 1] == f3[l]);
-                const unsigned long long mask = __ballot(is);
-                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                if (is && cnt + rank < max_lines) starts[cnt + rank] = l;
-                cnt += __popcll(mask);
-            }
-            if (n >= V_TURN + 2 && (f3[1] != f3[2] || cnt == 0)) {
-                if (lane == 0 && cnt < max_lines) starts[cnt] = 1;
-                cnt++;
-            }
-            if (lane == 0) { red[8] = cnt < max_lines ? cnt : max_lines; red[9] = cnt > max_lines ? 1 : 0; red[10] = 0; }
-        }
-        __syncthreads();
-        const int nst = red[8];
-        char* mybuf = btbuf + wave * (nc + 8);
-        int* mystk = btstk + wave * 3 * V_BT_STACK;
-        for (int k = wave; k < nst; k += V_NT / 64) {
-            const int lind = starts[k];
-            const int L = backtrack(X, T, lind, lind == 1 ? M : M + 1, mybuf, nc + 8, mystk);
-            if (L < 0) { if (lane == 0) { red[10] = L; lens[k] = 0; } continue; }
-            if (L + 1 > ss_stride) { if (lane == 0) { red[10] = -30; lens[k] = 0; } continue; }
-            char* dst = out_ss + ((size_t)win * max_lines + k) * ss_stride;
-            for (int x = lane; x < L; x += 64) dst[x] = mybuf[x];
-            if (lane == 0) {
-                dst[L] = 0;
-                lens[k] = L;
-                MirpFoldLine ln;
-                ln.start = lind; ln.len = L; ln.energy = f3[lind] - f3[lind + L]; ln.printed = 1;
-                out_lines[(size_t)win * max_lines + k] = ln;
-            }
-        }
-        __syncthreads();
-        // ---- RNALfold prints `prev` unless it is contained in `new` (the next start); the start-1 structure never takes part as `new`
-        for (int k = wave; k + 1 < nst; k += V_NT / 64) {
-            const int prev_i = starts[k], new_i = starts[k + 1];
-            if (new_i < 2) continue;
-            const int lp = lens[k], Ln = lens[k + 1];
-            if (lp <= 0 || Ln <= 0) continue;
-            const int i = new_i - 1;
-            const int off = prev_i - i;
-            const char* prev = out_ss + ((size_t)win * max_lines + k) * ss_stride;
-            const char* nw = out_ss + ((size_t)win * max_lines + k + 1) * ss_stride;
-            bool differ = false;
-            for (int t = lane; t < lp; t += 64) {
-                const char a = (off + t < Ln) ? nw[off + t] : (char)0;
-                if (a != prev[t]) differ = true;
-            }
-            const bool anyd = __ballot(differ) != 0ull;
-            const bool print = (i + Ln < prev_i + lp) || anyd;
-            if (lane == 0 && !print) out_lines[(size_t)win * max_lines + k].printed = 0;
-        }
-        if (tid == 0) {
-            out_nlines[win] = nst;
-            out_mfe[win] = f3[1];
-            out_status[win] = red[10] ? red[10] : (red[9] ? 1 : 0);
-        }
-        __syncthreads();
+        epilogue<FoldParams185, GTab185, V_NT>(X, T, f3, starts, lens, btstk, red, btbuf, nc, win, max_lines, ss_stride, out_lines, out_ss, out_nlines,
+                                                out_mfe, out_status);
     }
 }
 
@@ -479,7 +155,8 @@ size_t fold185_ws_slot_ints(int n_cap, int span) {
     return 3 * ((per + 3) & ~(size_t)3);
 }
 
-hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens, int n_work,
+hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens,
+                          const int* work_list, int n_work,
                           int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss,
                           int* out_nlines, int* out_mfe, int* out_status) {
     const size_t lds = fold185_lds_bytes(n_cap, max_lines);
@@ -487,7 +164,7 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
         hipError_t e = hipFuncSetAttribute((const void*)v185::fold185_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(v185::fold185_kernel, dim3(grid), dim3(V_NT), lds, stream, P, seqs, offs, lens, n_work, span, n_cap, ws, ws_slot_ints, max_lines,
+    hipLaunchKernelGGL(v185::fold185_kernel, dim3(grid), dim3(V_NT), lds, stream, P, seqs, offs, lens, work_list, n_work, span, n_cap, ws, ws_slot_ints, max_lines,
                        ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
     return hipGetLastError();
 }

@@ -77,19 +77,19 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
             short s3 = -32768, s4 = -32768, s6 = -32768;
             if (x >= 1) {
                 if (x + 4 <= n)
-                    for (int k = 0; k < 2; k++) {
+                    for (int k = 0; k < P->n_tri; k++) {
                         bool m = true;
                         for (int t = 0; t < 5; t++) m = m && (seq[x + t] == (unsigned char)P->tri[k][t]);
                         if (m && s3 == -32768) s3 = (short)P->triE[k];
                     }
                 if (x + 5 <= n)
-                    for (int k = 0; k < 16; k++) {
+                    for (int k = 0; k < P->n_tetra; k++) {
                         bool m = true;
                         for (int t = 0; t < 6; t++) m = m && (seq[x + t] == (unsigned char)P->tetra[k][t]);
                         if (m && s4 == -32768) s4 = (short)P->tetraE[k];
                     }
                 if (x + 7 <= n)
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < P->n_hexa; k++) {
                         bool m = true;
                         for (int t = 0; t < 8; t++) m = m && (seq[x + t] == (unsigned char)P->hexa[k][t]);
                         if (m && s6 == -32768) s6 = (short)P->hexaE[k];

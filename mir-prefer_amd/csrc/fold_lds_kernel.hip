@@ -23,17 +23,19 @@
 // No MFMA: integer min-plus DP with irregular table lookups.
 #include <hip/hip_runtime.h>
 #include "fold_epilogue.h"
+#include "fold185_device.h"
 
 namespace mirp {
 
 #define LNT 1024
 #define LNW (LNT / 64)
 #define LCAP 352            // window length capacity
-#define LDMAX 299           // max pair distance (span 300)
+#define LDMAX 300           // diagonals 4..LDMAX are allocated: pair distances up to span-1 = 299, plus the fML-only diagonal d = span of the vienna-1.8.5 model
+#define LSPAN 300           // largest span (-L) this kernel supports
 #define I16_INF 0x7fff
 #define FIN_LIMIT 28000      // finite c must stay in [-28000, 28000]: G0 + 32768 + any loop term then stays below 65535
-#define FML_BIAS 32000       // fML is kept in LDS as uint16 (value + FML_BIAS), 65535 = INF; finite fML must stay in [-32000, 767] so that the sum of
-#define FML_MAX 767          // two finite entries (<= 65534) can never be mistaken for a sum that involves INF (>= 65535)
+#define FML_BIAS 31500       // fML is kept in LDS as uint16 (value + FML_BIAS), 65535 = INF; finite fML must stay in [-31500, 1267] so that the sum of
+#define FML_MAX 1267         // two finite entries (<= 65534) can never be mistaken for a sum that involves INF (>= 65535)
 #define LSEG 384             // paired-cell list: 6 producer waves x 64 entries
 #define KEY_BIAS 40000        // candidate keys: (energy + KEY_BIAS) << 10 | n1 << 5 | n2, 0xffffffff = none
 #define KEY_NONE 0xffffffffu
@@ -48,6 +50,7 @@ struct LdsTables {          // int16 copies of the hot parameter tables
     // inner-pair terms by combined pair code idx = PA(p)*25 + QB(q), PA = S[p]*5 + S[p-1], QB = S[q]*5 + S[q+1]; relative to G0:
     short XB[628];          // TerminalAU(inner) - mismatchI(inner)           (bulges of size >= 2)
     short X1[628];          // mismatch1nI(inner) - mismatchI(inner)          (1 x n loops, n >= 3)
+    short dangle5[40], dangle3[40];   // [type*5 + base], clamped <= 0 (vienna-1.8.5 model)
     unsigned char rt2[28];  // rtype(pair_type(a, b)) at [a*5+b]
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
 };
@@ -106,11 +109,12 @@ struct LdsLayout {
     unsigned fml, aux, S, seq, pax, qb2, spec, list, off, tabs, misc, total;
 };
 __host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
+template <int MODEL>
 __host__ __device__ constexpr LdsLayout lds_layout() {
     LdsLayout L{};
     unsigned o = 0;
     L.fml = o; o += lds_al(((LDMAX - 3) * LCAP - (LDMAX * (LDMAX + 1) / 2 - 6)) * 2);   // fML triangle, d = 4..LDMAX at n = LCAP
-    L.aux = o; o += lds_al(32 * CSTR * 2 + 3 * LCAP * 2 + 4 * LCAP * 4);                // c ring (32 diagonals), DML ring (3), 2 x {cpart, mdec}
+    L.aux = o; o += lds_al(32 * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + 4 * LCAP * 4);   // c ring (32 diagonals), DML ring (3; 5 in the vienna-1.8.5 model), 2 x {ckey, mdec}
     L.S = o; o += lds_al(LCAP + 8);
     L.seq = o; o += lds_al(LCAP + 8);
     L.pax = o; o += lds_al((LCAP + 8) * 2);
@@ -123,7 +127,7 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.total = o;
     return L;
 }
-static_assert(lds_layout().total <= 160 * 1024, "fill kernel LDS budget");
+static_assert(lds_layout<0>().total <= 160 * 1024 && lds_layout<1>().total <= 160 * 1024, "fill kernel LDS budget");
 
 // ---- phase A1 building blocks.  All take the lane's paired cell (i, j = i + d) and wave-uniform d; r0 = d - 2 (ring row of the
 // stacked pair), um = largest admissible n1 + n2 (inner pair keeps q - p >= TURN + 1).  Running minima are biased uint (65535 = none).
@@ -274,6 +278,9 @@ __device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, 
     }
 }
 
+// MODEL 0: vienna-2.1.2 (Turner-2004, dangles 2).  MODEL 1: vienna-1.8.5 (Turner-1999 values in the same parameter layout, dangles 1: four-way
+// dangle minima in the multiloop closing and the fML pair terms, fML also on the diagonal d = span; SURVEY.md Appendix B, d1 column).
+template <int MODEL>
 __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int win_base, int span, short* __restrict__ slabs, size_t slab_shorts, int* __restrict__ win_state,
@@ -281,13 +288,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     unsigned int* __restrict__ fallback_count, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
     int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags, long long* __restrict__ dbg_cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr LdsLayout LY = lds_layout();
+    constexpr LdsLayout LY = lds_layout<MODEL>();
+    constexpr int DMLR = MODEL ? 5 : 3;      // depth of the DML ring
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     long long wB = 0, wA1 = 0, wA2 = 0, wW = 0, wt = 0; // per-wave: phase B, interior loops, multiloop splits, barrier wait (lane 0 of each wave)
     unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
     unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
-    short* dmlring = (short*)(cring + 32 * CSTR);                   // [3][LCAP] int16
-    int* acc = (int*)(dmlring + 3 * LCAP);                          // [2 (diagonal parity)][2 (cpart, mdec)][LCAP]
+    short* dmlring = (short*)(cring + 32 * CSTR);                   // [DMLR][LCAP] int16
+    int* acc = (int*)(dmlring + DMLR * LCAP);                          // [2 (diagonal parity)][2 (cpart, mdec)][LCAP]
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
     unsigned short* pax = (unsigned short*)(smem + LY.pax);
@@ -322,6 +330,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         }
         T.XB[x] = (short)xb; T.X1[x] = (short)x1;
     }
+    if (tid < 40) { T.dangle5[tid] = (short)P->dangle5[tid / 5][tid % 5]; T.dangle3[tid] = (short)P->dangle3[tid / 5][tid % 5]; }
     if (tid < 25) T.rt2[tid] = (unsigned char)rtype_of(pair_type(tid / 5, tid % 5));
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
     __syncthreads();
@@ -344,7 +353,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 if (n >= 1) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; }
             }
         } else {
-        const int D = (span - 1 < n - 1) ? span - 1 : n - 1;
+        const int D = (span - 1 < n - 1) ? span - 1 : n - 1;      // largest pair distance
+        const int Dm = MODEL ? ((span < n - 1) ? span : n - 1) : D;   // last diagonal of the fill (vienna-1.8.5: fML exists at distance span, c does not)
         // ---- stage sequence, codes, special hairpins, pair-code arrays, triangular offsets
         for (int x = tid; x <= n + 1; x += LNT) {
             unsigned char ch = 0;
@@ -356,7 +366,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             seq[x] = ch;
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
-        for (int x = tid; x < 3 * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
+        for (int x = tid; x < DMLR * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
         for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = ((x / LCAP) & 1) ? INF : (int)KEY_NONE;   // [parity][ckey | mdec]
         if (tid == 0) {
             int o = 0;
@@ -369,12 +379,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             short s3 = -32768, s4 = -32768, s6 = -32768;
             if (x >= 1) {
                 if (x + 4 <= n)
-                    for (int k = 0; k < 2; k++) { bool m = true; for (int t = 0; t < 5; t++) m = m && (seq[x + t] == (unsigned char)P->tri[k][t]); if (m && s3 == -32768) s3 = (short)P->triE[k]; }
+                    for (int k = 0; k < P->n_tri; k++) { bool m = true; for (int t = 0; t < 5; t++) m = m && (seq[x + t] == (unsigned char)P->tri[k][t]); if (m && s3 == -32768) s3 = (short)P->triE[k]; }
                 if (x + 5 <= n)
-                    for (int k = 0; k < 16; k++) { bool m = true; for (int t = 0; t < 6; t++) m = m && (seq[x + t] == (unsigned char)P->tetra[k][t]); if (m && s4 == -32768) s4 = (short)P->tetraE[k]; }
+                    for (int k = 0; k < P->n_tetra; k++) { bool m = true; for (int t = 0; t < 6; t++) m = m && (seq[x + t] == (unsigned char)P->tetra[k][t]); if (m && s4 == -32768) s4 = (short)P->tetraE[k]; }
                 if (x + 7 <= n)
-                    for (int k = 0; k < 4; k++) { bool m = true; for (int t = 0; t < 8; t++) m = m && (seq[x + t] == (unsigned char)P->hexa[k][t]); if (m && s6 == -32768) s6 = (short)P->hexaE[k]; }
+                    for (int k = 0; k < P->n_hexa; k++) { bool m = true; for (int t = 0; t < 8; t++) m = m && (seq[x + t] == (unsigned char)P->hexa[k][t]); if (m && s6 == -32768) s6 = (short)P->hexaE[k]; }
             }
+            if (MODEL) s4 = s4 == -32768 ? (short)0 : s4;     // vienna-1.8.5: a bonus added to the hairpin energy, not a total
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
             // combined pair codes (only interior positions are ever read: p - 1 >= 1, q + 1 <= n)
             if (x >= 1) {
@@ -402,7 +413,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             int* mdec = acc + (d & 1) * 2 * LCAP + LCAP;
             if (dbg_cycles && lane == 0) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
-            if (!(dbg_flags & (1 | 64)) && d >= 6) {
+            if (!(dbg_flags & (1 | 64)) && d >= 6 && d <= D) {
                 const unsigned short* clist = list + (d % 3) * LSEG;
                 const int* lc = lcnt + (d % 3) * 8;
                 const int p1 = __builtin_amdgcn_readfirstlane(lc[0]), p2 = p1 + __builtin_amdgcn_readfirstlane(lc[1]),
@@ -560,7 +571,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int x = tid;
             if (x < ncell) {
                 const int i = x + 1, j = i + d;
-                const int type = pair_type(S[i], S[j]);
+                const int type = (MODEL && d > D) ? 0 : pair_type(S[i], S[j]);
                 int cv = INF;
                 const int md = mdec[i];
                 int tb = 0;          // trace-back code: 0 = hairpin / multiloop / unpaired, else 1 + (n1 << 5 | n2) of the interior loop the backtrack takes
@@ -569,8 +580,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int cint = kk == KEY_NONE ? INF : (int)(kk >> 10) - KEY_BIAS;
                     cv = cint;
                     int h;
-                    {
-                        const int u = d - 1;
+                    const int u = d - 1;
+                    if (MODEL) {
+                        h = hp_u + (u == 3 ? (type > 2 ? (int)T.TerminalAU : 0) : (int)T.mismatchH[type * 25 + S[i + 1] * 5 + S[j - 1]]);
+                        if (u == 4) h += spec[nc + i];
+                    } else {
                         int sv = -32768;
                         if (u == 4) sv = spec[nc + i]; else if (u == 6) sv = spec[2 * nc + i]; else if (u == 3) sv = spec[i];
                         if (sv != -32768) h = sv;
@@ -578,10 +592,25 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         else h = hp_u + T.mismatchH[type * 25 + S[i + 1] * 5 + S[j - 1]];
                     }
                     cv = h < cv ? h : cv;
-                    int dml = dmlring[((d + 1) % 3) * LCAP + i + 1];     // (d-2) mod 3
-                    if (dml != I16_INF) {
-                        int e = dml + T.ML_closing + lds_mlstem(T, P, rtype_of(type), S[j - 1], S[i + 1]);
-                        cv = e < cv ? e : cv;
+                    if (MODEL) {
+                        // multiloop closed by (i,j), dangles 1: min over { DML(i+1,j-1), DML(i+2,j-1)+d3, DML(i+1,j-2)+d5, DML(i+2,j-2)+d3+d5 }
+                        const int tt = rtype_of(type);
+                        const int e3 = T.dangle3[tt * 5 + S[i + 1]], e5 = T.dangle5[tt * 5 + S[j - 1]];
+                        int X = INF, v;
+                        v = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1]; if (v != I16_INF) X = v;
+                        v = dmlring[((d + DMLR - 3) % DMLR) * LCAP + i + 2]; if (v != I16_INF && v + e3 < X) X = v + e3;
+                        v = dmlring[((d + DMLR - 3) % DMLR) * LCAP + i + 1]; if (v != I16_INF && v + e5 < X) X = v + e5;
+                        v = dmlring[((d + DMLR - 4) % DMLR) * LCAP + i + 2]; if (v != I16_INF && v + e3 + e5 < X) X = v + e3 + e5;
+                        if (X < INF) {
+                            const int e = X + T.ML_closing + T.ML_intern + (type > 2 ? (int)T.TerminalAU : 0);
+                            cv = e < cv ? e : cv;
+                        }
+                    } else {
+                        int dml = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1];
+                        if (dml != I16_INF) {
+                            int e = dml + T.ML_closing + lds_mlstem(T, P, rtype_of(type), S[j - 1], S[i + 1]);
+                            cv = e < cv ? e : cv;
+                        }
                     }
                     // the backtrack tests the hairpin first, then the interior loops in key order, then the multiloop
                     if (cint < INF && cint == cv && h != cv) tb = (int)(kk & 1023u) + 1;
@@ -592,7 +621,29 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     a = a == 65535 ? INF : a - FML_BIAS; b = b == 65535 ? INF : b - FML_BIAS;
                     m = a < b ? a : b;
                 }
-                if (type) { int e = cv + lds_mlstem(T, P, type, i > 1 ? (int)S[i - 1] : -1, j < n ? (int)S[j + 1] : -1); m = e < m ? e : m; }
+                if (MODEL) {
+                    // fML pair terms, dangles 1: (i,j) plain, (i+1,j) with a 5' dangle, (i,j-1) with a 3' dangle, (i+1,j-1) with both.  Plain c of the
+                    // neighbouring cells comes out of the G0 ring (G0 = c + mismatchI of the pair seen as an inner pair).
+                    const int mli = T.ML_intern, tau = T.TerminalAU;
+                    if (type) { const int e = cv + mli + (type > 2 ? tau : 0); m = e < m ? e : m; }
+                    auto plain = [&](int dd, int ii, int& tp) -> int {
+                        tp = 0;
+                        if (dd < 4) return INF;
+                        const unsigned g = cring[(dd & 31) * CSTR + ii];
+                        if (g == 65535u) return INF;
+                        tp = pair_type(S[ii], S[ii + dd]);
+                        return (int)g - 32768 - (int)T.mismatchI[rtype_of(tp) * 25 + S[ii + dd + 1] * 5 + S[ii - 1]];
+                    };
+                    int tp;
+                    int cc = plain(d - 1, i + 1, tp);
+                    if (cc < INF) { const int e = cc + T.dangle5[tp * 5 + S[i]] + mli + (tp > 2 ? tau : 0); m = e < m ? e : m; }
+                    cc = plain(d - 1, i, tp);
+                    if (cc < INF) { const int e = cc + T.dangle3[tp * 5 + S[j]] + mli + (tp > 2 ? tau : 0); m = e < m ? e : m; }
+                    cc = plain(d - 2, i + 1, tp);
+                    if (cc < INF) { const int e = cc + T.dangle5[tp * 5 + S[i]] + T.dangle3[tp * 5 + S[j]] + mli + (tp > 2 ? tau : 0); m = e < m ? e : m; }
+                } else if (type) {
+                    int e = cv + lds_mlstem(T, P, type, i > 1 ? (int)S[i - 1] : -1, j < n ? (int)S[j + 1] : -1); m = e < m ? e : m;
+                }
                 m = md < m ? md : m;
                 if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
                     (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
@@ -606,7 +657,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 carch[off[d] + i] = c16;
                 tb_out[off[d] + i] = (unsigned short)tb;
                 fml[off[d] + i] = m16;
-                dmlring[(d % 3) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
+                dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 ckey[i] = KEY_NONE; mdec[i] = INF;
                 if (d + 2 <= D && i + d + 2 <= n) lt = pair_type(S[i], S[i + d + 2]);
             }
@@ -616,14 +667,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 if (lane == 0 && wave < 6) lcnt[((d + 2) % 3) * 8 + wave] = __popcll(bal);
             }
         };
-        if (D >= 4) phaseA(4);
+        if (Dm >= 4) phaseA(4);
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
-        for (int d = 4; d <= D; d++) {
+        for (int d = 4; d <= Dm; d++) {
             if (dbg_cycles && lane == 0) wt = clock64();
             phaseB(d);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wB += t - wt; wt = t; }
-            if (d + 1 <= D) phaseA(d + 1);
+            if (d + 1 <= Dm) phaseA(d + 1);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA2 += t - wt; wt = t; }
             __syncthreads();
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wW += t - wt; wt = t; }
@@ -637,7 +688,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         } else {
             // hand the tables to the epilogue kernel: c was archived on the fly, fML is copied out now (coalesced dwords)
             int tri = 0;
-            if (D >= 4) tri = off[D] + (n - D) + 1;
+            if (Dm >= 4) tri = off[Dm] + (n - Dm) + 1;
             const unsigned int* src = reinterpret_cast<const unsigned int*>(fml);
             unsigned int* dst = reinterpret_cast<unsigned int*>(fml_out);
             for (int x = tid; x < (tri + 1) / 2; x += LNT) dst[x] = src[x];
@@ -723,6 +774,105 @@ __global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
     }
 }
 
+// Epilogue of the vienna-1.8.5 model on the slabs of fold_lds_kernel<1>: exterior sweep, enumeration, full backtracks (interior loops follow the
+// trace-back codes), output.  Shares its device code with the generic vienna-1.8.5 kernel (fold185_device.h).
+struct LTab185 {
+    const short* carch;
+    const short* fml;
+    const unsigned short* tb;
+    const int* off;
+    int n, D, Dm;
+    __device__ __forceinline__ int C(int i, int j) const {
+        const int d = j - i;
+        if (d <= TURN || d > D || i < 1 || j > n) return V_INF;
+        const int v = carch[off[d] + i];
+        return v == I16_INF ? V_INF : v;
+    }
+    __device__ __forceinline__ int Mm(int i, int j) const {
+        const int d = j - i;
+        if (d <= TURN || d > Dm || i < 1 || j > n) return V_INF;
+        const int v = (unsigned short)fml[off[d] + i];
+        return v == 65535 ? V_INF : v - FML_BIAS;
+    }
+    __device__ __forceinline__ int TB(int i, int j) const { return tb[off[j - i] + i]; }
+};
+
+__global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
+    const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
+    int n_work, int span, const short* __restrict__ slabs, size_t slab_shorts, const int* __restrict__ win_state, unsigned int* __restrict__ work_counter,
+    int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss, int* __restrict__ out_nlines,
+    int* __restrict__ out_mfe, int* __restrict__ out_status) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nc = LCAP + 8;
+    int* f3 = (int*)smem;                                            // nc + 8
+    int* starts = f3 + nc + 8;                                       // max_lines
+    int* lens = starts + max_lines;                                  // max_lines
+    int* btstk = lens + max_lines;                                   // (ENT/64) * 3 * V_BT_STACK
+    int* red = btstk + (ENT / 64) * 3 * V_BT_STACK;                  // ENT/64 + 8
+    int* misc = red + ENT / 64 + 8;                                  // 4
+    int* off = misc + 4;                                             // LDMAX + 2
+    short* tetra = (short*)(off + LDMAX + 2);                        // nc
+    unsigned char* S = (unsigned char*)(tetra + nc);                 // nc
+    unsigned char* seq = S + nc;                                     // nc
+    char* btbuf = (char*)(seq + nc);                                 // (ENT/64) * (nc + 8)
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) misc[0] = (int)atomicAdd(work_counter, 1u);
+        __syncthreads();
+        const int win = misc[0];
+        __syncthreads();
+        if (win >= n_work) break;
+        if (win_state[win] == 1) {
+            const long long o0 = offs[win];
+            const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
+            for (int x = tid; x <= n + 1; x += ENT) {
+                unsigned char ch = 0;
+                if (x >= 1 && x <= n) {
+                    ch = seqs[o0 + x - 1];
+                    if (ch >= 'a' && ch <= 'z') ch -= 32;
+                    if (ch == 'T') ch = 'U';
+                }
+                seq[x] = ch;
+                S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
+            }
+            for (int x = tid; x < nc + 8; x += ENT) f3[x] = 0;
+            if (tid == 0) {
+                int o = 0;
+                for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
+            }
+            __syncthreads();
+            if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
+            for (int x = tid; x <= n; x += ENT) {
+                short b = 0;
+                if (x >= 1 && x + 5 <= n)
+                    for (int k = 0; k < P->n_tetra; k++) {
+                        bool m = true;
+                        for (int t = 0; t < 6; t++) m = m && (seq[x + t] == (unsigned char)P->tetra[k][t]);
+                        if (m) { b = (short)P->tetraE[k]; break; }
+                    }
+                tetra[x] = b;
+            }
+            __syncthreads();
+            v185::Ctx<FoldParams> X;
+            X.P = P; X.S = S; X.tetra = tetra; X.f3 = f3; X.n = n; X.M = span;
+            LTab185 T;
+            T.carch = slabs + (size_t)win * 3 * slab_shorts; T.fml = T.carch + slab_shorts;
+            T.tb = reinterpret_cast<const unsigned short*>(T.carch + 2 * slab_shorts);
+            T.off = off; T.n = n; T.D = (span - 1 < n - 1) ? span - 1 : n - 1; T.Dm = (span < n - 1) ? span : n - 1;
+            v185::epilogue<FoldParams, LTab185, ENT>(X, T, f3, starts, lens, btstk, red, btbuf, nc, win, max_lines, ss_stride, out_lines, out_ss, out_nlines,
+                                                     out_mfe, out_status);
+        }
+        __syncthreads();
+    }
+}
+
+size_t fold185_lds_epilogue_bytes(int max_lines) {
+    const size_t nc = LCAP + 8;
+    size_t b = sizeof(int) * (nc + 8 + 2 * (size_t)max_lines + (ENT / 64) * 3 * V_BT_STACK + ENT / 64 + 8 + 4 + LDMAX + 2);
+    b += sizeof(short) * nc + 2 * nc + (ENT / 64) * (nc + 8);
+    return (b + 15) & ~(size_t)15;
+}
+
 size_t fold_lds_epilogue_bytes(int max_lines) {
     const int nc = LCAP + 8;
     size_t b = sizeof(int) * (nc + 2 * (size_t)max_lines + (ENT / 64) * 3 * BT_STACK + 16 + LDMAX + 2) + sizeof(short) * 3 * nc + 2 * (size_t)nc + (ENT / 64) * (size_t)nc;
@@ -730,24 +880,40 @@ size_t fold_lds_epilogue_bytes(int max_lines) {
     return b + sizeof(EpiTables) + 16;
 }
 
-size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout().total; }
+size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout<1>().total; }
 int fold_lds_max_n() { return LCAP - 2; }
-int fold_lds_max_span() { return LDMAX + 1; }
+int fold_lds_max_span() { return LSPAN; }
 
-hipError_t launch_fold_lds(hipStream_t stream, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
+hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
                            int* out_status, int dbg_flags, long long* dbg_cycles) {
-    size_t lds = fold_lds_bytes(max_lines);
-    hipError_t e = hipFuncSetAttribute((const void*)fold_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = model ? lds_layout<1>().total : lds_layout<0>().total;
+    const void* fn = model ? (const void*)fold_lds_kernel<1> : (const void*)fold_lds_kernel<0>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fold_lds_kernel, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
-                       fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+    if (model)
+        hipLaunchKernelGGL(fold_lds_kernel<1>, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                           fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+    else
+        hipLaunchKernelGGL(fold_lds_kernel<0>, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                           fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (!(dbg_flags & 16))
-        hipLaunchKernelGGL(fold_lds_epilogue_kernel, dim3(grid_epi), dim3(ENT), fold_lds_epilogue_bytes(max_lines), stream, P, seqs, offs, lens, n_work, span,
-                           slabs, slab_shorts, win_state, work_counter + 1, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
+    if (!(dbg_flags & 16)) {
+        if (model) {
+            const size_t el = fold185_lds_epilogue_bytes(max_lines);
+            if (el > 64 * 1024) {
+                e = hipFuncSetAttribute((const void*)fold185_lds_epilogue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)el);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(fold185_lds_epilogue_kernel, dim3(grid_epi), dim3(ENT), el, stream, P, seqs, offs, lens, n_work, span, slabs, slab_shorts, win_state,
+                               work_counter + 1, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
+        } else {
+            hipLaunchKernelGGL(fold_lds_epilogue_kernel, dim3(grid_epi), dim3(ENT), fold_lds_epilogue_bytes(max_lines), stream, P, seqs, offs, lens, n_work, span,
+                               slabs, slab_shorts, win_state, work_counter + 1, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
+        }
+    }
     return hipGetLastError();
 }
 

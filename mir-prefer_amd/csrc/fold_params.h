@@ -25,11 +25,12 @@ struct FoldParams {
     int int21[8][8][5][5][5];
     int int22[8][8][5][5][5][5];
     int hairpinE[MIRP_HP_MAX];
-    int tetraE[16], triE[2], hexaE[4];
-    char tetra[16][8];
+    int tetraE[32], triE[2], hexaE[4];
+    char tetra[32][8];
     char tri[2][8];
     char hexa[4][12];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
+    int n_tri, n_tetra, n_hexa;   // motifs in use
     // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes).  An interior-loop candidate is ranked by the key
     // (energy term << 10) | (n1 << 5 | n2): the minimum key is the minimum energy and, among equal energies, the first shape in the
     // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
@@ -62,3 +63,6 @@ void mirp_fill_fold_params185(FoldParams185* p);
 
 // Fills *p from the generated Turner-2004 tables (host side, mirp_params.cpp).
 void mirp_fill_fold_params(FoldParams* p);
+// Turner-1999 (ViennaRNA 1.8.5) values in the same layout for the LDS-resident kernels of the vienna-1.8.5 model: the 1 x n and 2 x 3
+// loops of that model use the generic formula, i.e. mismatch1nI = mismatch23I = mismatchI; tetraE holds bonuses; mismatchM / mismatchExt unused.
+void mirp_fill_fold_params_t1999(FoldParams* p);

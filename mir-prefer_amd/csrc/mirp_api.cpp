@@ -48,6 +48,17 @@ extern "C" int mirp_set_fold_model(mirp_ctx* c, int32_t model) {
     if (!c) return -1;
     if (model != MIRP_FOLD_MODEL_VIENNA_212 && model != MIRP_FOLD_MODEL_VIENNA_185) return fail(c, -1, "mirp_set_fold_model: unknown model");
     (void)hipSetDevice(c->device);
+    if (model == MIRP_FOLD_MODEL_VIENNA_185 && !c->d_params185l) {
+        FoldParams* hl = new FoldParams();
+        mirp_fill_fold_params_t1999(hl);
+        if (hipMalloc((void**)&c->d_params185l, sizeof(FoldParams)) != hipSuccess ||
+            hipMemcpy(c->d_params185l, hl, sizeof(FoldParams), hipMemcpyHostToDevice) != hipSuccess) {
+            delete hl;
+            if (c->d_params185l) { (void)hipFree(c->d_params185l); c->d_params185l = nullptr; }
+            return fail(c, -6, "mirp_set_fold_model: device allocation failed");
+        }
+        delete hl;
+    }
     if (model == MIRP_FOLD_MODEL_VIENNA_185 && !c->d_params185) {
         FoldParams185* hp = new FoldParams185();
         mirp_fill_fold_params185(hp);
@@ -77,6 +88,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_params185) (void)hipFree(c->d_params185);
+    if (c->d_params185l) (void)hipFree(c->d_params185l);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -207,20 +219,30 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
                   int max_lines, int stride, MirpFoldLine* d_lines, char* d_ss, int* d_nlines, int* d_mfe, int* d_status) {
     if (n_work <= 0) return 0;
     c->last_fallback = 0;
-    if (c->fold_model == MIRP_FOLD_MODEL_VIENNA_185) {
-        // compatibility mode: one kernel, tables in a global workspace (3 int32 tables per resident window)
-        if (mirp::fold185_lds_bytes(n_cap, max_lines) > 160 * 1024) return fail(c, -5, "LDS budget exceeded (vienna-1.8.5 kernel: window or max_lines too large)");
-        const size_t slot = mirp::fold185_ws_slot_ints(n_cap, span);
-        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot * 4)));
-        slots = std::min(slots, n_work);
-        if (c->ws.ensure((size_t)slots * slot * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
-        hipError_t e = mirp::launch_fold185(c->stream, slots, c->d_params185, d_seqs, d_offs, d_lens, n_work, span, n_cap, (int*)c->ws.p, slot, max_lines, stride,
-                                            d_lines, d_ss, d_nlines, d_mfe, d_status);
-        if (e != hipSuccess) return fail(c, -2, std::string("fold (vienna-1.8.5) kernel launch failed: ") + hipGetErrorString(e));
+    const bool m185 = c->fold_model == MIRP_FOLD_MODEL_VIENNA_185;
+    // generic kernels (tables in a global workspace): every window when the LDS-resident path does not apply, else its flagged windows
+    auto run_generic = [&](const int* work_list, int n_generic) -> int {
+        if (m185) {
+            if (mirp::fold185_lds_bytes(n_cap, max_lines) > 160 * 1024) return fail(c, -5, "LDS budget exceeded (vienna-1.8.5 kernel: window or max_lines too large)");
+            const size_t slot = mirp::fold185_ws_slot_ints(n_cap, span);
+            int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot * 4)));
+            slots = std::min(slots, n_generic);
+            if (c->ws.ensure((size_t)slots * slot * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
+            hipError_t e = mirp::launch_fold185(c->stream, slots, c->d_params185, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot,
+                                                max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
+            if (e != hipSuccess) return fail(c, -2, std::string("fold (vienna-1.8.5) kernel launch failed: ") + hipGetErrorString(e));
+            return 0;
+        }
+        const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);
+        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
+        slots = std::min(slots, n_generic);
+        if (c->ws.ensure((size_t)slots * slot_ints * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
+        mirp::launch_fold_generic(c->stream, slots, c->d_params, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot_ints,
+                                  max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
+        HIPCHK(c, hipGetLastError());
         return 0;
-    }
-    if (mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
-    const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);
+    };
+    if (!m185 && mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
     const int* work_list = nullptr;
     int n_generic = n_work;
     if (span <= mirp::fold_lds_max_span() && mirp::fold_lds_bytes(max_lines) <= 160 * 1024) {
@@ -241,7 +263,7 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             if (b0 > 0) HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 8, c->stream));   // the two work counters; the fallback count keeps accumulating
             const int grid = std::min(nb, c->n_cu);
             const int grid_epi = std::min(nb, c->n_cu * 8);
-            hipError_t e = mirp::launch_fold_lds(c->stream, grid, grid_epi, c->d_params, d_seqs, d_offs + b0, d_lens ? d_lens + b0 : nullptr, nb, b0, span,
+            hipError_t e = mirp::launch_fold_lds(c->stream, m185 ? 1 : 0, grid, grid_epi, m185 ? c->d_params185l : c->d_params, d_seqs, d_offs + b0, d_lens ? d_lens + b0 : nullptr, nb, b0, span,
                                                  (short*)c->carch.p, slab, (int*)c->wstate.p, ctl, (int*)c->flist.p, ctl + 4, max_lines, stride,
                                                  d_lines + (size_t)b0 * max_lines, d_ss + (size_t)b0 * max_lines * stride, d_nlines + b0, d_mfe + b0,
                                                  d_status + b0, dbg_flags, dbg_cycles);
@@ -269,11 +291,5 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         work_list = (const int*)c->flist.p;
         n_generic = (int)nfb;
     }
-    int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 4, ((size_t)8 << 30) / (slot_ints * 4)));
-    slots = std::min(slots, n_generic);
-    if (c->ws.ensure((size_t)slots * slot_ints * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
-    mirp::launch_fold_generic(c->stream, slots, c->d_params, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot_ints,
-                              max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    return run_generic(work_list, n_generic);
 }

@@ -39,7 +39,8 @@ struct mirp_ctx {
     std::string err;
     int n_cu = 256;
     FoldParams* d_params = nullptr;
-    FoldParams185* d_params185 = nullptr;   // created on the first use of the vienna-1.8.5 model
+    FoldParams185* d_params185 = nullptr;   // created on the first use of the vienna-1.8.5 model (generic kernel)
+    FoldParams* d_params185l = nullptr;     // Turner-1999 values in the layout of the LDS-resident kernels
     int fold_model = MIRP_FOLD_MODEL_VIENNA_212;
     DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist, wstate;
     long long last_fallback = 0;

@@ -17,7 +17,8 @@ void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, cons
 // fold185_kernel.hip: vienna-1.8.5 compatibility mode
 size_t fold185_lds_bytes(int n_cap, int max_lines);
 size_t fold185_ws_slot_ints(int n_cap, int span);
-hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens, int n_work,
+hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens,
+                          const int* work_list, int n_work,
                           int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss,
                           int* out_nlines, int* out_mfe, int* out_status);
 
@@ -32,7 +33,7 @@ size_t fold_lds_epilogue_bytes(int max_lines);
 size_t fold_lds_slab_shorts(int n_cap);
 int fold_lds_max_n();
 int fold_lds_max_span();
-hipError_t launch_fold_lds(hipStream_t stream, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
+hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
                            int* out_status, int dbg_flags, long long* dbg_cycles);

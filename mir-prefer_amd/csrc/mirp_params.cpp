@@ -8,6 +8,27 @@
 
 static inline int clamp0(int v) { return v > 0 ? 0 : v; }
 
+static void fill_derived(FoldParams* p) {
+    for (int u = 6; u <= MIRP_MAXLOOP; u++)
+        for (int n1 = 0; n1 < 28; n1++) {
+            unsigned v = 65535u << 10;
+            if (n1 >= 2 && n1 <= u - 2) {
+                int y = std::abs(2 * n1 - u) * p->ninio;
+                v = ((unsigned)(p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO)) << 10) | (unsigned)(n1 << 5 | (u - n1));
+            }
+            p->gen_key[u - 6][n1] = v;
+        }
+    for (int u = 0; u <= MIRP_MAXLOOP; u++) {
+        const unsigned kb = (unsigned)(p->bulge[u] + 2048) << 10;
+        p->kb0_key[u] = kb | (unsigned)u;
+        p->kb1_key[u] = kb | (unsigned)(u << 5);
+        int y = (u - 1) * p->ninio;
+        const unsigned k1 = (unsigned)((u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048) << 10;
+        p->k1n0_key[u] = k1 | (unsigned)(1 << 5 | u);
+        p->k1n1_key[u] = k1 | (unsigned)(u << 5 | 1);
+    }
+}
+
 void mirp_fill_fold_params(FoldParams* p) {
     std::memset(p, 0, sizeof(*p));
     std::memcpy(p->stack, T04_stack, sizeof(p->stack));
@@ -39,24 +60,8 @@ void mirp_fill_fold_params(FoldParams* p) {
     p->TerminalAU = T04_TerminalAU;
     p->ninio = T04_ninio;
     p->MAX_NINIO = T04_MAX_NINIO;
-    for (int u = 6; u <= MIRP_MAXLOOP; u++)
-        for (int n1 = 0; n1 < 28; n1++) {
-            unsigned v = 65535u << 10;
-            if (n1 >= 2 && n1 <= u - 2) {
-                int y = std::abs(2 * n1 - u) * p->ninio;
-                v = ((unsigned)(p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO)) << 10) | (unsigned)(n1 << 5 | (u - n1));
-            }
-            p->gen_key[u - 6][n1] = v;
-        }
-    for (int u = 0; u <= MIRP_MAXLOOP; u++) {
-        const unsigned kb = (unsigned)(p->bulge[u] + 2048) << 10;
-        p->kb0_key[u] = kb | (unsigned)u;
-        p->kb1_key[u] = kb | (unsigned)(u << 5);
-        int y = (u - 1) * p->ninio;
-        const unsigned k1 = (unsigned)((u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048) << 10;
-        p->k1n0_key[u] = k1 | (unsigned)(1 << 5 | u);
-        p->k1n1_key[u] = k1 | (unsigned)(u << 5 | 1);
-    }
+    p->n_tri = T04_N_TRILOOPS; p->n_tetra = T04_N_TETRALOOPS; p->n_hexa = T04_N_HEXALOOPS;
+    fill_derived(p);
 }
 
 void mirp_fill_fold_params185(FoldParams185* p) {
@@ -80,4 +85,30 @@ void mirp_fill_fold_params185(FoldParams185* p) {
     p->TerminalAU = T99_TerminalAU;
     p->ninio = T99_ninio;
     p->MAX_NINIO = T99_MAX_NINIO;
+}
+
+void mirp_fill_fold_params_t1999(FoldParams* p) {
+    std::memset(p, 0, sizeof(*p));
+    std::memcpy(p->stack, T99_stack, sizeof(p->stack));
+    std::memcpy(p->bulge, T99_bulge, sizeof(p->bulge));
+    std::memcpy(p->internal_loop, T99_internal_loop, sizeof(p->internal_loop));
+    std::memcpy(p->mismatchI, T99_mismatchI, sizeof(p->mismatchI));
+    std::memcpy(p->mismatch1nI, T99_mismatchI, sizeof(p->mismatch1nI));
+    std::memcpy(p->mismatch23I, T99_mismatchI, sizeof(p->mismatch23I));
+    std::memcpy(p->mismatchH, T99_mismatchH, sizeof(p->mismatchH));
+    for (int t = 0; t < 8; t++)
+        for (int a = 0; a < 5; a++) { p->dangle5[t][a] = clamp0(T99_dangle5[t][a]); p->dangle3[t][a] = clamp0(T99_dangle3[t][a]); }
+    std::memcpy(p->int11, T99_int11, sizeof(p->int11));
+    std::memcpy(p->int21, T99_int21, sizeof(p->int21));
+    std::memcpy(p->int22, T99_int22, sizeof(p->int22));
+    for (int u = 0; u < MIRP_HP_MAX; u++)
+        p->hairpinE[u] = (u <= 30) ? T99_hairpin[u] : T99_hairpin[30] + (int)(T99_LXC * std::log((double)u / 30.));
+    p->n_tri = 0; p->n_hexa = 0; p->n_tetra = T99_N_TETRALOOPS;
+    for (int k = 0; k < T99_N_TETRALOOPS; k++) { std::strncpy(p->tetra[k], T99_Tetraloops[k], 7); p->tetraE[k] = T99_Tetraloop_E[k]; }
+    p->ML_closing = T99_ML_closing;
+    p->ML_intern = T99_ML_intern;
+    p->TerminalAU = T99_TerminalAU;
+    p->ninio = T99_ninio;
+    p->MAX_NINIO = T99_MAX_NINIO;
+    fill_derived(p);
 }
