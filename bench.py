@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--loci", type=int, default=N_LOCI)
     ap.add_argument("--genome", type=int, default=CHR1_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fold-model", default="vienna-2.1.2", choices=["vienna-2.1.2", "vienna-1.8.5"],
+                    help="RNALfold flavour to reproduce (the headline metric is quoted on the default, Turner-2004)")
     a = ap.parse_args()
 
     import torch
@@ -93,6 +95,7 @@ def main():
     alns = ds.sorted_alns()
     order = np.zeros(1, dtype=np.int32)
     ctx = capi.Context(local_rank)
+    ctx.set_fold_model(a.fold_model)
     ctx.load_genome(ds.contigs)
     ctx.load_alignments(alns)
 
@@ -175,7 +178,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: A. thaliana chr1-sized contig per GPU (%d bp), 1 sample, L=300, %d synthetic loci -> %d windows/GPU; "
                                    "candidate+fold+predict, inputs resident in HBM" % (a.genome, a.loci, nwin),
-                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)), "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)",
+                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)), "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)" if a.fold_model == "vienna-2.1.2" else "vienna-1.8.5 (Turner-1999, d1)",
                        "fold_generic_fallback_windows": int(fb[0])},
             "roofline": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": fold_s * 1e3,
