@@ -206,7 +206,11 @@ class Pipeline:
         maturename = os.path.join(outdir, prefix + "_miRNA.mature.fa")
         stemloopname = os.path.join(outdir, prefix + "_miRNA.precursor.fa")
         ssname = os.path.join(outdir, prefix + "_miRNA.precursor.ss")
-        write_fasta_ss(result, dict(self.data["contigs"]), maturename, stemloopname, ssname)
+        contigs = dict(self.data["contigs"])
+        write_fasta_ss(result, contigs, maturename, stemloopname, ssname)
+        counts = mirna_read_counts(result, self.data["names"], self.data["alns"], len(self.data["samples"]))
+        write_csv_and_stat(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
+                           os.path.join(outdir, "miRNA.stat.txt"))
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         d = load_recover_file(self.recovername)
@@ -275,20 +279,87 @@ def write_gff(resultlist, gffname):
             f.write("\t".join([m[0], "miR-PREFeR", "miRNA", str(m[3]), str(m[4] - 1), ".", m[8], ".", "ID=%s;NAME=%s;Other=" % (mat, mat)]) + "\n")
 
 
-_RC = bytes.maketrans(b"ATGCU", b"UACGA")
+_RC = bytes.maketrans(b"ATGCU", b"UACGA")   # get_complement, MP:232-235
 
 
-def _region_seq(contigs, chrom, s, e, strand):
-    seq = contigs[chrom][s - 1:e - 1].tobytes()
-    return seq.translate(_RC)[::-1].decode() if strand == "-" else seq.decode()
+def _faidx(contigs, chrom, s, e_incl):
+    """`samtools faidx chr:s-e` (1-based, inclusive) as the report writers use it: upper case, T -> U (MP:2570-2590, 2659-2661)."""
+    return contigs[chrom][s - 1:e_incl].tobytes().decode().upper().replace("T", "U")
+
+
+def _revcomp(seq):
+    return seq.encode().translate(_RC)[::-1].decode()
 
 
 def write_fasta_ss(resultlist, contigs, maturename, stemloopname, ssname):
-    """Mature / precursor FASTA and structure file in the spirit of gen_mirna_fasta_ss_from_result (MP:2963-3019)."""
+    """gen_mirna_fasta_ss_from_result (MP:2963-3019): mature / precursor FASTA and the structure file with its M/S annotation line."""
     with open(maturename, "w") as fm, open(stemloopname, "w") as fp, open(ssname, "w") as fs:
         for idx, m in enumerate(resultlist):
-            pre = _region_seq(contigs, m[0], m[1], m[2], m[8])
-            mat = _region_seq(contigs, m[0], m[3], m[4], m[8])
-            fm.write(">miRNA_%d %s:%d-%d %s\n%s\n" % (idx, m[0], m[3], m[4] - 1, m[8], mat))
-            fp.write(">miRNA-precursor_%d %s:%d-%d %s\n%s\n" % (idx, m[0], m[1], m[2] - 1, m[8], pre))
-            fs.write(">miRNA-precursor_%d %s:%d-%d %s\n%s\n%s\n" % (idx, m[0], m[1], m[2] - 1, m[8], pre, m[7]))
+            mirname = "miRNA-precursor_%d" % idx
+            matureid = ">%s:%d-%d %s %s" % (m[0], m[3], m[4] - 1, m[8], mirname)
+            stemloopid = ">%s:%d-%d %s %s" % (m[0], m[1], m[2] - 1, m[8], mirname)
+            matureseq = _faidx(contigs, m[0], m[3], m[4] - 1)
+            stemloopseq = _faidx(contigs, m[0], m[1], m[2] - 1)
+            ms, me, ss_, se = m[3] - m[1], m[4] - m[1], m[5] - m[1], m[6] - m[1]
+            if ms < ss_:
+                seq_dot = "." * ms + "M" * (me - ms) + "." * (ss_ - me) + "S" * (se - ss_) + "." * (len(stemloopseq) - se)
+            else:
+                seq_dot = "." * ss_ + "S" * (se - ss_) + "." * (ms - se) + "M" * (me - ms) + "." * (len(stemloopseq) - me)
+            if m[8] == "-":
+                matureseq, stemloopseq, seq_dot = _revcomp(matureseq), _revcomp(stemloopseq), seq_dot[::-1]
+            fm.write(matureid + "\n" + matureseq + "\n")
+            fp.write(stemloopid + "\n" + stemloopseq + "\n")
+            fs.write(stemloopid + "\n" + stemloopseq + "\n" + m[7] + "\n" + seq_dot + "\n")
+
+
+def mirna_read_counts(resultlist, names, alns, n_samples):
+    """Per locus and sample: reads on the precursor / exactly the mature / exactly the star / antisense (gen_mirna_info, MP:2644-2728),
+    from the position-sorted alignment records instead of one `samtools view` per locus.  -> int64 array [n_loci, n_samples, 4]."""
+    tid_of = {n: t for t, n in enumerate(names)}
+    key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
+    out = np.zeros((len(resultlist), n_samples, 4), dtype=np.int64)
+    for k, m in enumerate(resultlist):
+        t = tid_of[m[0]]
+        lo = np.searchsorted(key, (t << 32) | m[1], side="left")
+        hi = np.searchsorted(key, (t << 32) | m[2], side="left")
+        a = alns[lo:hi]
+        a = a[a["pos"].astype(np.int64) + a["len"].astype(np.int64) <= m[2]]       # startpos >= locus_start and startpos + readlen <= locus_end
+        sense = a["strand"] == (1 if m[8] == "-" else 0)
+        depth = a["depth"].astype(np.int64)
+        for s in range(n_samples):
+            of = a["sample"] == s
+            out[k, s, 3] = depth[of & ~sense].sum()
+            on = of & sense
+            out[k, s, 0] = depth[on].sum()
+            out[k, s, 1] = depth[on & (a["pos"] == m[3]) & (a["len"] == m[4] - m[3])].sum()
+            out[k, s, 2] = depth[on & (a["pos"] == m[5]) & (a["len"] == m[6] - m[5])].sum()
+    return out
+
+
+def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
+    """gen_csv_table (MP:2744-2779) and the miRNA.stat.txt block of the predict stage (MP:3585-3593)."""
+    dict_len, dict_first = {}, {}
+    with open(csvname, "w") as f:
+        head = "miRNAID, Seqid(chromosome), start position, end position, strand, precursor sequence, secondary structure, mature sequence, star sequence, "
+        f.write(head + "".join(s + "," + s + "," + s + "," + s + "," for s in samples) + "\n")
+        f.write(head + "reads mapped to precursor, reads mapped to mature, reads mapped to star, reads mapped to antisense region," * len(samples) + "\n")
+        for idx, m in enumerate(resultlist):
+            pre = _faidx(contigs, m[0], m[1], m[2] - 1)
+            mat = _faidx(contigs, m[0], m[3], m[4] - 1)
+            star = _faidx(contigs, m[0], m[5], m[6] - 1)
+            dict_len[len(mat)] = dict_len.get(len(mat), 0) + 1                     # gen_miRNA_stat (MP:2731-2741) uses the forward-strand text
+            dict_first[mat[0]] = dict_first.get(mat[0], 0) + 1
+            if m[8] == "-":
+                pre, mat, star = _revcomp(pre), _revcomp(mat), _revcomp(star)
+            row = ["miRNA-precursor_%d" % idx, m[0], str(m[1]), str(m[2]), m[8], pre, m[7], mat, star]
+            for s in range(len(samples)):
+                row += [str(int(v)) for v in counts[idx, s]]
+            f.write(", ".join(row) + "\n")
+    with open(statname, "w") as f:
+        f.write("Total number of predicted miRNAs: %d\n" % len(resultlist))
+        f.write("Distribution of the length of the mature miRNAs:\n")
+        for k in sorted(dict_len):
+            f.write("%s: %d\n" % (k, dict_len[k]))
+        f.write("Distribution of the nucleotide of the first base of the mature miRNAs:\n")
+        for k in sorted(dict_first):
+            f.write("%s: %d\n" % (k, dict_first[k]))

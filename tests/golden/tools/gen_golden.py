@@ -181,6 +181,11 @@ def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_or
 
     exp["result_raw"] = jsonable([strip(m) for m in raw_result])
     exp["gff3"] = open(os.path.join(out, name + "_miRNA.gff3")).read()
+    exp["reports"] = {"mature_fa": open(os.path.join(out, name + "_miRNA.mature.fa")).read(),
+                      "precursor_fa": open(os.path.join(out, name + "_miRNA.precursor.fa")).read(),
+                      "precursor_ss": open(os.path.join(out, name + "_miRNA.precursor.ss")).read(),
+                      "detail_csv": open(os.path.join(out, name + "_miRNA.detail.csv")).read(),
+                      "stat_txt": open(os.path.join(out, "miRNA.stat.txt")).read()}
     d = os.path.join(GOLD, name)
     os.makedirs(d, exist_ok=True)
     for p in [fa] + sams:

@@ -38,6 +38,12 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     prefix = exp["config"]["NAME_PREFIX"]
     tmp = out / (prefix + "_tmp")
     assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"]
+    rep = exp["reports"]    # the report files of the predict stage (MP:2963-3019, 2644-2779, 3585-3593), byte for byte
+    assert open(out / (prefix + "_miRNA.mature.fa")).read() == rep["mature_fa"]
+    assert open(out / (prefix + "_miRNA.precursor.fa")).read() == rep["precursor_fa"]
+    assert open(out / (prefix + "_miRNA.precursor.ss")).read() == rep["precursor_ss"]
+    assert open(out / (prefix + "_miRNA.detail.csv")).read() == rep["detail_csv"]
+    assert open(out / "miRNA.stat.txt").read() == rep["stat_txt"]
     assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
     fasta = open(tmp / (prefix + ".rnalfold.in_0.fa")).read().splitlines()
     want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]

@@ -154,3 +154,30 @@ def test_fold_stage_retries_with_full_line_capacity():
     p.ctx, p.opt = StubCtx(), {"PRECURSOR_LEN": 300}
     st = p._fold_device()
     assert p.ctx.calls == [(300, 96), (300, 352)] and (st == 0).all()
+
+
+import pytest
+
+
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
+def test_report_writers_match_reference_files(name, tmp_path):
+    """mature.fa / precursor.fa / precursor.ss / detail.csv / miRNA.stat.txt of the predict stage, byte for byte, from the reference's own
+    result list (gen_mirna_fasta_ss_from_result MP:2963-3019, gen_mirna_info MP:2644-2728, gen_csv_table MP:2744-2779, MP:3585-3593)."""
+    from mir_prefer_amd import pipeline
+    from tests import golden_util as gu
+    c = gu.load_pipeline_case(name)
+    exp = c["exp"]
+    result = [list(m[:10]) + [dict(m[10])] for m in gu.unjson(exp["result_raw"])]
+    pipeline.adjust_mature_star(result)
+    pipeline.write_gff(result, str(tmp_path / "x.gff3"))           # sorts the list like gen_gff_from_result
+    assert open(tmp_path / "x.gff3").read() == exp["gff3"]
+    contigs = dict(c["contigs"])
+    pipeline.write_fasta_ss(result, contigs, str(tmp_path / "m.fa"), str(tmp_path / "p.fa"), str(tmp_path / "p.ss"))
+    counts = pipeline.mirna_read_counts(result, c["contig_names"], c["alns"], len(c["sample_names"]))
+    pipeline.write_csv_and_stat(result, contigs, c["sample_names"], counts, str(tmp_path / "d.csv"), str(tmp_path / "s.txt"))
+    rep = exp["reports"]
+    assert open(tmp_path / "m.fa").read() == rep["mature_fa"]
+    assert open(tmp_path / "p.fa").read() == rep["precursor_fa"]
+    assert open(tmp_path / "p.ss").read() == rep["precursor_ss"]
+    assert open(tmp_path / "d.csv").read() == rep["detail_csv"]
+    assert open(tmp_path / "s.txt").read() == rep["stat_txt"]
