@@ -10,7 +10,7 @@
 #include <vector>
 #include "mirp_internal.h"
 
-#define MIRP_ABI_VERSION 1
+#define MIRP_ABI_VERSION 2   // 2: mirp_set_fold_model, mirp_ingest_sams
 #define MIRP_NMAX 3096
 
 #include "mirp_ctx.h"
