@@ -68,8 +68,6 @@ def parse_configfile(configfile):
         sys.stderr.write("Error: CHECKPOINT_SIZE should >=10.\n"); ok = False
     if opt["GFF_FILE_INCLUDE"] and opt["GFF_FILE_EXCLUDE"]:
         sys.stderr.write("Error: GFF_FILE_EXCLUDE and GFF_FILE_INCLUDE are mutual exclusive, please remove one of them.\n"); ok = False
-    if opt["GFF_FILE_INCLUDE"] or opt["GFF_FILE_EXCLUDE"]:
-        sys.stderr.write("Error: GFF include/exclude masking is not implemented in this build (SURVEY.md 8f-4).\n"); ok = False
     if not ok:
         sys.exit(-1)
     return opt

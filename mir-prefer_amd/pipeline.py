@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from . import capi, ingest, records
+from . import capi, gffmask, ingest, records
 
 STAGES = ["prepare", "candidate", "fold", "predict"]
 
@@ -84,6 +84,23 @@ class Pipeline:
     def run_prepare(self):
         _msg("Starting preparing data for the 'candidate' stage.")
         names, lens, samples, alns = ingest.read_sams(self.opt["ALIGNMENT_FILE"])
+        # GFF masking (MP:817-859): keep regions as the reference's BED file, applied like `samtools view -L` on the combined records
+        gff_ex, gff_in = self.opt.get("GFF_FILE_EXCLUDE", ""), self.opt.get("GFF_FILE_INCLUDE", "")
+        regions = None
+        if gff_ex and os.path.exists(gff_ex):
+            _msg("Removing reads that are overlapped with features in the GFF file.")
+            regions = gffmask.keep_regions_exclude(gff_ex, {n: int(l) for n, l in zip(names, lens)}, 55)
+            if not regions:
+                _msg("!!! No regions need to analyze after excluding regions in the GFF file, stop analyze!")
+                sys.exit(-1)
+        elif gff_in and os.path.exists(gff_in):
+            _msg("GFF_FILE_INCLUDE specified, removing reads that are not overlap with features in the GFF file.")
+            regions = gffmask.keep_regions_include(gff_in, 55)
+            if not regions:
+                _msg("!!! No regions in the GFF_FILE_INCLUDE file or all regions are shorter than 55, stop analyze!")
+                sys.exit(-1)
+        if regions is not None:
+            alns = gffmask.apply_keep(alns, names, regions)
         prepared = self._p("prepared.npz")
         np.savez(prepared, contig_names=np.array(names, dtype=object), contig_lens=lens, sample_names=np.array(samples, dtype=object), alns=alns,
                  allow_pickle=True)

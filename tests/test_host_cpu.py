@@ -181,3 +181,59 @@ def test_report_writers_match_reference_files(name, tmp_path):
     assert open(tmp_path / "p.ss").read() == rep["precursor_ss"]
     assert open(tmp_path / "d.csv").read() == rep["detail_csv"]
     assert open(tmp_path / "s.txt").read() == rep["stat_txt"]
+
+
+def test_gff_keep_regions_match_the_reference_functions(tmp_path):
+    """Keep-region BED text of gen_keep_regions_from_exclude_gff / _include_gff (MP:543-652) on seeded GFF files (incl. comments, blank
+    lines, a ##FASTA section, features on unknown contigs, overlapping / nested / adjacent features)."""
+    from mir_prefer_amd import gffmask
+    from tests import golden_util as gu
+    gold = gu.load_json("gffmask.json.gz")
+    for k, c in enumerate(gold["bed_cases"]):
+        p = tmp_path / ("c%d.gff" % k)
+        p.write_text(c["gff"])
+        dict_len = {n: l for n, l in c["dict_len"]}
+        ex = "".join("%s\t%d\t%d\n" % r for r in gffmask.keep_regions_exclude(str(p), dict_len, 55))
+        inc = "".join("%s\t%d\t%d\n" % r for r in gffmask.keep_regions_include(str(p), 55))
+        assert ex == c["bed_exclude"], k
+        assert inc == c["bed_include"], k
+
+
+def test_gff_mask_keeps_what_samtools_view_L_keeps():
+    """apply_keep against `samtools view -L` of the bundled samtools 0.1.18 (names of the kept alignments, in order)."""
+    import numpy as np
+    from mir_prefer_amd import gffmask, synth
+    from tests import golden_util as gu
+    gold = gu.load_json("gffmask.json.gz")
+    for v in gold["view_cases"]:
+        names = [n for n, _ in v["contigs"]]
+        a = np.zeros(len(v["records"]), dtype=synth.ALN_DTYPE)
+        for k, (c, p, l) in enumerate(v["records"]):
+            a[k] = (names.index(c), p, 1, l, 0, 0)
+        a["depth"] = np.arange(len(a))                    # record identity
+        kept = gffmask.apply_keep(a, names, [tuple(x) for x in v["bed"]])
+        want = [int(nm.split("_r")[1].split("_x")[0]) for nm in v["kept_names"]]
+        assert [int(x) for x in kept["depth"]] == want
+        assert 0 < len(want) < len(a)
+
+
+def test_prepare_stage_applies_gff_exclude_mask(tmp_path):
+    """run_prepare with GFF_FILE_EXCLUDE: the prepared record array is the ingest output filtered by the reference's keep regions."""
+    import numpy as np
+    from mir_prefer_amd import gffmask, ingest, pipeline, synth
+    ds = synth.make_dataset([30000, 20000], 25, n_samples=2, seed=12, contig_names=["cB", "cA"])
+    ds.write_fasta(str(tmp_path / "g.fa"))
+    sams = ds.write_sams(str(tmp_path))
+    gff = tmp_path / "ex.gff"
+    gff.write_text("##gff-version 3\ncB\ts\tgene\t2000\t9000\t.\t+\t.\tID=a\ncB\ts\tgene\t8000\t12000\t.\t-\t.\tID=b\ncA\ts\tgene\t500\t700\t.\t+\t.\tID=c\n")
+    p = pipeline.Pipeline.__new__(pipeline.Pipeline)
+    p.opt = {"ALIGNMENT_FILE": sams, "GFF_FILE_EXCLUDE": str(gff), "GFF_FILE_INCLUDE": "", "NAME_PREFIX": "t", "OUTFOLDER": str(tmp_path)}
+    p.tmp = str(tmp_path)
+    p.recovername = str(tmp_path / "t_recover")
+    p.run_prepare()
+    z = np.load(tmp_path / "prepared.npz", allow_pickle=True)
+    names, lens, samples, alns = ingest.read_sams(sams)
+    want = gffmask.apply_keep(alns, names, gffmask.keep_regions_exclude(str(gff), dict(zip(names, [int(x) for x in lens])), 55))
+    assert np.array_equal(z["alns"], want) and 0 < len(want) < len(alns)
+    inside = (z["alns"]["tid"] == names.index("cB")) & (z["alns"]["pos"] > 2100) & (z["alns"]["pos"] + z["alns"]["len"] < 11900)
+    assert not inside.any()                               # nothing survives strictly inside the merged excluded block
