@@ -150,6 +150,17 @@ int mirp_write_fold_text(mirp_ctx* ctx, const char* fasta_path, const char* out_
  * ss_text[n_result*ss_stride] NUL-terminated structure strings, n_passed[n_windows] = len(miRNAs) per FASTA entry. */
 int mirp_predict(mirp_ctx* ctx, const MirpPredictParams* params, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride,
                  int32_t** n_passed, int64_t* n_windows);
+/*
+ * -d mode (OUTPUT_DETAILS_FOR_DEBUG): why a region is not reported, replaces the dict_why_not_miRNA_reasons bookkeeping of check_loci
+ * (MP:2206-2347) that convert_failure_reasons_list / write_dict_reasons (MP:2505-2567) print.  Returns int32 records of `stride` ints:
+ * one per window {window, -1, n_structures, any mature in [min,max], n_passed, 0...} and one per evaluated (mature, structure) pair
+ * {window, mature index, structure index, line, ss_off, ss_len, get_maturestar_info code (0 ok, 1..12 = MP:1876-1999's failures),
+ *  flags, fold_s, fold_e, star_s, star_e, depth on this strand, antisense, mature, isoform, star, imperfect star[3],
+ *  mature-star distance, mature depth per sample[n_samples]};  flags: 1 mature/star too close, 2 star but too few reads on the duplex,
+ *  4 no star and ALLOW_NO_STAR_EXPRESSION off, 8 too many start positions, 16 mature+iso ratio < 0.8, 32 mature depth <= 100,
+ *  64 not expressed in all samples, 128 passed, 256 no read on the precursor.  Record order is unspecified (sort by the first three fields).
+ */
+int mirp_predict_reasons(mirp_ctx* ctx, const MirpPredictParams* params, int32_t** records, int64_t* n_records, int32_t* stride);
 /* Per-stage device time of the last mirp_candidate / mirp_fold / mirp_predict calls, measured with HIP events on the
  * context's stream: ms[0]=coverage scatter+scan, ms[1]=rest of candidate, ms[2]=fold kernel, ms[3]=predict kernel. */
 int mirp_last_timings(mirp_ctx* ctx, double ms[4]);

@@ -94,6 +94,8 @@ def load_library():
     lib.mirp_set_fold_model.restype = C.c_int
     lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
+    lib.mirp_predict_reasons.argtypes = [vp, vp, C.POINTER(vp), i64p, i32p]
+    lib.mirp_predict_reasons.restype = C.c_int
     lib.mirp_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
     lib.mirp_last_fold_fallbacks.argtypes = [vp]
     lib.mirp_last_fold_fallbacks.restype = C.c_int64
@@ -303,6 +305,17 @@ class Context:
         t = _copy_out(self.lib, text, np.uint8, nres.value * stride.value).reshape(nres.value, stride.value)
         return {"result": r, "ss": [t[i, :r[i]["ss_len"]].tobytes().decode() for i in range(len(r))],
                 "n_passed": _copy_out(self.lib, npass, np.int32, nw.value)}
+
+    def predict_reasons(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
+        """-d mode: int32 records [n, stride] of mirp_predict_reasons (layout in include/mirprefer.h), sorted by (window, mature, structure);
+        the per-window records (mature index -1) come first within their window."""
+        pp = (C.c_int32 * 6)(int(n_samples), int(min_mature_len), int(max_mature_len), 1 if allow_3nt else 0, 1 if allow_no_star else 0, int(minlen))
+        rec, n, stride = C.c_void_p(), C.c_int64(), C.c_int32()
+        self._check(self.lib.mirp_predict_reasons(self.h, pp, C.byref(rec), C.byref(n), C.byref(stride)), "mirp_predict_reasons")
+        a = _copy_out(self.lib, rec, np.int32, n.value * stride.value).reshape(n.value, stride.value)
+        if len(a):
+            a = a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        return a
 
     def last_timings(self):
         ms = (C.c_double * 4)()

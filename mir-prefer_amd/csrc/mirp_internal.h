@@ -25,7 +25,8 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
 size_t predict_lds_bytes(int max_lines, int ss_stride);
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
-                          const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status);
+                          const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount = nullptr,
+                          int* rpool = nullptr, unsigned int rcap = 0, int rstride = 0);
 
 // fold_lds_kernel.hip
 size_t fold_lds_bytes(int max_lines);

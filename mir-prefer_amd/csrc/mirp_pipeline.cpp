@@ -416,6 +416,53 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
     return 0;
 }
 
+// -d mode of the reference (dict_why_not_miRNA_reasons of check_loci, MP:2206-2347): re-runs the filter kernel in its reasons mode and returns
+// one int32 record per window (field 1 == -1: {window, -1, n_structures, any mature in range, n_passed}) and per evaluated (mature, structure)
+// pair: {window, mature index, structure index, line, off, len, get_maturestar_info code, expression flags, fold_s, fold_e, star_s, star_e,
+// depth this strand, antisense, mature, isoform, star, imperfect star x3, mature-star distance, mature depth per sample...}; stride ints each.
+// Flags: 1 too close, 2 star but too few reads on the duplex, 4 no star and not allowed, 8 too many start positions, 16 ratio too small,
+// 32 mature depth <= 100, 64 not in all samples, 128 passed, 256 no read on the precursor (the reference divides by zero there).
+extern "C" int mirp_predict_reasons(mirp_ctx* c, const MirpPredictParams* pp, int32_t** records, int64_t* n_records, int32_t* stride) {
+    if (!c) return -1;
+    if (!pp || !records || !n_records || !stride) return fail(c, -1, "mirp_predict_reasons: null argument");
+    if (!c->have_fold) return fail(c, -1, "mirp_predict_reasons: run mirp_fold first");
+    if (pp->n_samples < 1 || pp->n_samples > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_predict_reasons: n_samples out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long nw = c->n_windows;
+    const int rstride = 21 + pp->n_samples;
+    *records = nullptr; *n_records = 0; *stride = rstride;
+    if (nw <= 0) return 0;
+    const size_t w1 = (size_t)nw;
+    if (c->p_out.ensure(sizeof(MirpMirna) * w1 * MIRP_MAX_MIRNA_PER_WINDOW) || c->p_nout.ensure(4 * w1) || c->p_status.ensure(4 * w1))
+        return fail(c, -6, "device allocation failed (predict)");
+    TmpDevice T;
+    unsigned int* d_cnt = (unsigned int*)T.get(16);
+    if (!d_cnt) return fail(c, -6, "device allocation failed (reasons)");
+    unsigned int cap = (unsigned int)std::min<unsigned long long>((unsigned long long)nw * 96ull + 1024ull, 0x7fffffffull / (unsigned)rstride);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int* d_pool = (int*)T.get((size_t)cap * rstride * 4);
+        if (!d_pool) return fail(c, -6, "device allocation failed (reasons pool)");
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+        int grid = (int)std::min<long long>(nw, (long long)c->n_cu * 16);
+        if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+                                 (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, *pp,
+                                 (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, d_cnt, d_pool, cap, rstride) != hipSuccess)
+            return fail(c, -2, "predict (reasons) kernel launch failed");
+        unsigned int n = 0;
+        HIPCHK(c, hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n <= cap) {
+            int32_t* h = host_copy<int32_t>(c, d_pool, (size_t)n * rstride);
+            if (!h) return fail(c, -2, "D2H failed");
+            *records = h; *n_records = n;
+            return 0;
+        }
+        if ((unsigned long long)n * rstride > 0x7fffffffull) return fail(c, -6, "mirp_predict_reasons: record pool too large");
+        cap = n;
+    }
+    return fail(c, -2, "mirp_predict_reasons: record pool overflow");
+}
+
 extern "C" int mirp_last_timings(mirp_ctx* c, double ms[4]) {
     if (!c || !ms) return -1;
     for (int i = 0; i < 4; i++) ms[i] = c->ms[i];

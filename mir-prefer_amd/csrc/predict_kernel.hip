@@ -190,12 +190,15 @@ __device__ __forceinline__ long long aln_lower_bound(const MirpAln* __restrict__
 
 struct ExprRes {
     long long total_this, total_mature, total_iso, total_star; // total_star = after max with imperfect (when key present)
+    long long raw_star, total_anti, imp[3];                    // reasons mode: star before the imperfect maximum, antisense depth, the three imperfect-star depths
+    int mature_each[MIRP_MAX_SAMPLES];                          // reasons mode: mature depth per sample
     int distance, has_imp_key, imp_start, imp_end, imp_which /* -1 none */;
     double ratio_total, ratio_iso;
     bool too_many_start, expressed_all, exception;
 };
 
 // check_expression_new (MP:2037-2163) on reads kept by gen_mapinfo_each_sample (MP:2021)
+template <bool REASONS>
 __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_samples, int tid, int ws, int we, int fold_s, int fold_e,
                              int m0, int m1, int star_s, int star_e, int strand, int allow_3nt, ExprRes& o) {
     const int mature_len = m1 - m0, star_len = star_e - star_s, pre_len = fold_e - fold_s;
@@ -205,14 +208,16 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
     int starts = 0;
     int last_pos[MIRP_MAX_SAMPLES];
     for (int s = 0; s < MIRP_MAX_SAMPLES; s++) last_pos[s] = -1;
+    long long tot_anti = 0;
+    if (REASONS) for (int s = 0; s < MIRP_MAX_SAMPLES; s++) o.mature_each[s] = 0;
     for (long long k = k0; k < k1; k++) {
         MirpAln r = a[k];
         if (r.pos < ws || r.pos + (int)r.len > we) continue;
-        if ((int)r.strand != strand) continue;   // antisense reads do not enter any rule used by check_loci
+        if ((int)r.strand != strand) { if (REASONS) tot_anti += (int)r.depth; continue; }   // antisense reads do not enter any rule used by check_loci
         int d = (int)r.depth, rl = r.len, sp = r.pos, sm = r.sample;
         if (last_pos[sm] != sp) { last_pos[sm] = sp; starts++; }
         tot_pre += d;
-        if (sp == m0 && rl == mature_len) { tot_mat += d; if (d > 0) mature_mask |= 1u << sm; }
+        if (sp == m0 && rl == mature_len) { tot_mat += d; if (d > 0) mature_mask |= 1u << sm; if (REASONS) o.mature_each[sm] += d; }
         if (sp == star_s && rl == star_len) tot_star += d;
         int dx = sp - m0, dl = rl - mature_len;
         if (dx >= -3 && dx <= 3 && dl >= -3 && dl <= 3) tot_iso += d;
@@ -223,6 +228,7 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
         }
     }
     o.total_this = tot_pre; o.total_mature = tot_mat; o.total_iso = tot_iso;
+    o.raw_star = tot_star; o.total_anti = tot_anti; o.imp[0] = imp[0]; o.imp[1] = imp[1]; o.imp[2] = imp[2];
     o.distance = (star_s > m1) ? star_s - m1 : m0 - star_e;
     long long max_imp = 0;
     o.has_imp_key = 0; o.imp_start = 0; o.imp_end = 0; o.imp_which = -1;
@@ -248,11 +254,15 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
     o.expressed_all = (mature_mask == ((n_samples >= 32) ? 0xffffffffu : ((1u << n_samples) - 1u)));
 }
 
+// REASONS: the -d mode of the reference (check_loci's dict_why_not_miRNA_reasons, MP:2206-2347): every evaluated (mature, structure) pair is
+// appended to a record pool (rstride ints per record, layout in mirp_pipeline.cpp) together with one record per window; nothing else changes.
+template <bool REASONS>
 __global__ void __launch_bounds__(64) predict_kernel(
     const MirpWindow* __restrict__ windows, int n_windows, const MirpMature* __restrict__ matures,
     const MirpAln* __restrict__ alns, long long n_alns, const MirpFoldLine* __restrict__ lines, const char* __restrict__ ss,
     int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
-    MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status) {
+    MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status,
+    unsigned int* __restrict__ rcount, int* __restrict__ rpool, unsigned int rcap, int rstride) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
     unsigned* textw = (unsigned*)smem;                                   // max_lines * wpl
@@ -374,9 +384,11 @@ __global__ void __launch_bounds__(64) predict_kernel(
                         d_maturestar(str, p.len, m.start, m.end, ln.start + p.off, W.ws, W.we, m.strand, ms);
                         int pass = 0, has_star = 0, star_s = ms.star_s, star_e = ms.star_e, impf = 0;
                         long long tm = 0, ts = 0;
+                        ExprRes rx;
+                        rx.exception = true;
                         if (ms.code == 0) {
-                            ExprRes ex;
-                            d_expression(alns, n_alns, pp.n_samples, W.tid, W.ws, W.we, ms.fold_s, ms.fold_e, m.start, m.end, ms.star_s, ms.star_e,
+                            ExprRes& ex = rx;
+                            d_expression<REASONS>(alns, n_alns, pp.n_samples, W.tid, W.ws, W.we, ms.fold_s, ms.fold_e, m.start, m.end, ms.star_s, ms.star_e,
                                          m.strand, pp.allow_3nt, ex);
                             tm = ex.total_mature; ts = ex.total_star;
                             // 'max_imperfect_star' in exprinfo (MP:2161, 2631-2635): bit0 key present, bits1-2 which+1, bit3 max > 0
@@ -390,6 +402,35 @@ __global__ void __launch_bounds__(64) predict_kernel(
                                 } else if (pp.allow_no_star && !ex.too_many_start) {
                                     if (ex.ratio_iso >= 0.8 && (ex.expressed_all || ex.total_mature >= 1000)) pass = 1;
                                 }
+                            }
+                        }
+                        if (REASONS) {
+                            int flags = 0;
+                            ExprRes* exp_ = nullptr;
+                            (void)exp_;
+                            const unsigned int ridx = atomicAdd(rcount, 1u);
+                            if (ridx < rcap) {
+                                int* r = rpool + (size_t)ridx * rstride;
+                                r[0] = w; r[1] = mi; r[2] = s; r[3] = p.line; r[4] = p.off; r[5] = p.len; r[6] = ms.code; r[8] = ms.fold_s; r[9] = ms.fold_e;
+                                r[10] = ms.star_s; r[11] = ms.star_e;
+                                for (int q = 12; q < rstride; q++) r[q] = 0;
+                                if (ms.code == 0) {
+                                    r[12] = (int)rx.total_this; r[13] = (int)rx.total_anti; r[14] = (int)rx.total_mature; r[15] = (int)rx.total_iso; r[16] = (int)rx.raw_star;
+                                    r[17] = (int)rx.imp[0]; r[18] = (int)rx.imp[1]; r[19] = (int)rx.imp[2]; r[20] = rx.distance;
+                                    for (int q = 0; q < pp.n_samples && 21 + q < rstride; q++) r[21 + q] = rx.mature_each[q];
+                                    if (rx.exception) flags |= 256;
+                                    else if (rx.distance <= 4) flags |= 1;
+                                    else if (rx.total_star > 0) { if (rx.ratio_total < 0.2) flags |= 2; else flags |= 128; }
+                                    else if (!pp.allow_no_star) flags |= 4;
+                                    else if (rx.too_many_start) flags |= 8;
+                                    else if (rx.ratio_iso >= 0.8 && (rx.expressed_all || rx.total_mature >= 1000)) flags |= 128;
+                                    else {
+                                        if (rx.ratio_iso < 0.8) flags |= 16;
+                                        if (rx.total_mature <= 100) flags |= 32;
+                                        if (!rx.expressed_all) flags |= 64;
+                                    }
+                                }
+                                r[7] = flags;
                             }
                         }
                         if (pass && ne <= b_ne) {   // later structures win ties (this lane's s only grows)
@@ -422,6 +463,14 @@ __global__ void __launch_bounds__(64) predict_kernel(
             }
         }
         if (lane == 0) { n_out[w] = nout; }
+        if (REASONS && lane == 0) {
+            const unsigned int ridx = atomicAdd(rcount, 1u);
+            if (ridx < rcap) {
+                int* r = rpool + (size_t)ridx * rstride;
+                for (int q = 0; q < rstride; q++) r[q] = 0;
+                r[0] = w; r[1] = -1; r[2] = nst; r[3] = any_in_range ? 1 : 0; r[4] = nout;
+            }
+        }
         // any lane may have raised a capacity flag
         {
             int f = st_flag;
@@ -441,14 +490,20 @@ size_t predict_lds_bytes(int max_lines, int ss_stride) {
 
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
-                          const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status) {
+                          const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount, int* rpool,
+                          unsigned int rcap, int rstride) {
     size_t lds = predict_lds_bytes(max_lines, ss_stride);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)predict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(rpool ? (const void*)predict_kernel<true> : (const void*)predict_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(predict_kernel, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                       max_lines, n_lines, pp, out, n_out, status);
+    if (rpool)
+        hipLaunchKernelGGL(predict_kernel<true>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
+                           max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride);
+    else
+        hipLaunchKernelGGL(predict_kernel<false>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
+                           max_lines, n_lines, pp, out, n_out, status, nullptr, nullptr, 0u, 0);
     return hipGetLastError();
 }
 

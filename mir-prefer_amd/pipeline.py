@@ -214,6 +214,12 @@ class Pipeline:
                                self.opt["ALLOW_NO_STAR_EXPRESSION"])
         result = result_records(out, self.data["names"])
         prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
+        if self.opt.get("OUTPUT_DETAILS_FOR_DEBUG"):          # -d: why the other regions are not miRNAs (MP:3532-3543)
+            rec = self.ctx.predict_reasons(len(self.data["samples"]), self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"],
+                                           self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
+            w = self.ctx.get_windows()
+            write_reasons(os.path.join(outdir, prefix + "_reason_why_not_miRNA.txt"), w, w["matures"], self.data["names"], rec, self.ctx.get_fold(),
+                          self.data["samples"], self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"])
         if not result:
             _msg("0 miRNA identified. No result files generated.")
             return result
@@ -380,3 +386,119 @@ def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
         f.write("Distribution of the nucleotide of the first base of the mature miRNAs:\n")
         for k in sorted(dict_first):
             f.write("%s: %d\n" % (k, dict_first[k]))
+
+
+# ---- -d artefact: <prefix>_reason_why_not_miRNA.txt (convert_failure_reasons_list MP:2505-2529, write_dict_reasons MP:2532-2567)
+MS_FAIL = {1: "FAIL_STRUCTURE_MATCHED_BASES", 2: "FAIL_STRUCTURE_MATURE_NOT_IN_FOLD_REGION", 3: "FAIL_STRUCTURE_MATURE_NOT_IN_ONE_ARM",
+           4: "FAIL_STRUCTURE_MATURE_MATCH_SMALL_THAN_14", 5: "FAIL_STRUCTURE_MATURE_STAR_OVERLAP", 6: "FAIL_STRUCTURE_STAR_OUT_OF_FOLD_REGION",
+           7: "FAIL_STRUCTURE_STAR_NOT_IN_ONE_ARM", 8: "FAIL_STRUCTURE_TOO_MANY_BULGE_OR_LOOP", 9: "FAIL_STRUCTURE_MAX_BULGE_LARGE_THAN_2",
+           10: "FAIL_STRUCTURE_TOTAL_LOOP_SIZE_LARGER_THAN_5", 11: "FAIL_STRUCTURE_NUM_BULGE_MORE_THAN_2"}
+
+
+def _expression_info_lines(r, samples, allow_3nt):
+    """The non-dict items of check_expression_new's result in insertion order (MP:2113-2163), `key\tstr(value)`."""
+    ns = len(samples)
+    this, anti, mature, iso, star = (int(r[k]) for k in (12, 13, 14, 15, 16))
+    imp = [int(r[17]), int(r[18]), int(r[19])]
+    out = [("samplenames", str(list(samples))), ("total_depth_just_this_strand", this), ("total_depth_anti", anti), ("total_depth_mature", mature),
+           ("total_depth_isoform", iso), ("total_depth_star", None), ("total_depth_imperfect_star", str(imp)),
+           ("mature_depth_each_sample", str([int(x) for x in r[21:21 + ns]])), ("mature_star_distance", int(r[20]))]
+    max_imp = 0
+    has_key = star == 0 and allow_3nt
+    if has_key:
+        max_imp = max(imp)
+        if max_imp == 0:
+            out += [("imperfect_star_start", 0), ("max_imperfect_star", 0)]
+        else:
+            which = imp.index(max_imp)
+            s0, s1 = int(r[10]), int(r[11])
+            st, en = [(s0, s1 + 1), (s0 + 1, s1), (s0 + 1, s1 + 1)][which]
+            out += [("imperfect_star_start", st), ("imperfect_star_end", en), ("max_imperfect_star", max_imp), ("imperfect_star_which", which)]
+    top = max(star, max_imp)
+    out += [("mature_star_ratio_total", float(mature + top) / this), ("mature_star_ratio_total_both_strand", float(mature + top) / (this + anti)),
+            ("mature_iso_star_ratio_total", float(iso + top) / this)]
+    final_star = top if has_key else star
+    return ["%s\t%s" % (k, final_star if k == "total_depth_star" else v) for k, v in out]
+
+
+def write_reasons(path, windows, matures, names, records_arr, fold_raw, samples, min_mature_len, max_mature_len, allow_3nt):
+    """Text of write_dict_reasons for the regions that produced no miRNA.  Block order: contig by first appearance, '+' before '-', regions
+    by first appearance (the order of Python dicts under the reference's py3 shim; the py2 original iterates in hash order)."""
+    win = windows["windows"]
+    mat = matures
+    per_window, pairs = {}, {}
+    for r in records_arr:
+        if r[1] < 0:
+            per_window[int(r[0])] = r
+        else:
+            pairs.setdefault(int(r[0]), []).append(r)
+    emitted = []          # (window index, which)
+    i, nw = 0, len(win)
+    while i < nw:
+        if win[i]["tag"] == 0:
+            if per_window[i][4] == 0:
+                emitted.append((i, "0"))
+            i += 1
+        else:                                        # (L, R) pair of FASTA entries, paired by position (MP:2394-2403)
+            if per_window[i][4] == 0:
+                emitted.append((i, "L"))
+                if i + 1 < nw and per_window[i + 1][4] == 0:
+                    emitted.append((i + 1, "R"))
+            i += 2
+    blocks = {}           # chrom -> strand -> region -> text lines
+    for w, which in emitted:
+        W = win[w]
+        chrom, strand = names[W["tid"]], records.STRAND[W["strand"]]
+        region = (int(W["ws"]), int(W["we"]))
+        peak = "%d-%d" % (W["loc_s"], W["loc_e"])
+        head = ["%s:%d-%d\t%s\tpeak-region:%s\t%s" % (chrom, region[0], region[1], strand, peak, which), "PEAK_PASS_DEPTH:PASSED"]
+        pw = per_window[w]
+        tail = []
+        if pw[2] == 0:
+            head.append("HAS_STEMLOOP_STRUCTURE:FAILED")
+        else:
+            head.append("HAS_STEMLOOP_STRUCTURE:PASSED")
+            head.append("HAS_MATURE_SIZE_IN_RANGE:" + ("PASSED" if pw[3] else "FAILED"))
+            if pw[3]:
+                ms = mat[W["mature_off"]:W["mature_off"] + W["n_matures"]]
+                order = sorted(range(len(ms)), key=lambda k: -int(ms[k]["depth"]))       # stable, depth descending (MP:2241)
+                by_pair = {(int(r[1]), int(r[2])): r for r in pairs.get(w, [])}
+                entries = {}                                                              # key1 -> lines (dict semantics: position of first insert, last value)
+                nst = int(pw[2])
+                for k in order:
+                    m0, m1 = int(ms[k]["start"]), int(ms[k]["end"])
+                    if m1 - m0 < min_mature_len or m1 - m0 > max_mature_len:
+                        continue
+                    for s in range(nst):
+                        r = by_pair.get((k, s))
+                        if r is None:
+                            continue
+                        ln = fold_raw["lines"][w, r[3]]
+                        if int(ln["energy"]) > 0:                                         # `if energy > lowest_energy: continue`, lowest stays 0 in a failing region
+                            continue
+                        ss = fold_raw["ss"][w, r[3], r[4]:r[4] + r[5]].tobytes().decode()
+                        lines = []
+                        if r[6] != 0:
+                            lines.append(MS_FAIL.get(int(r[6]), "FAIL_STRUCTURE_EXCEPTION") + "\tFAILED")
+                        else:
+                            f = int(r[7])
+                            if f & 1: lines.append("FAIL_EXPRESS_PATTERN_MATURE_STAR_TOO_CLOSE\tFAILED")
+                            if f & 2: lines.append("FAIL_EXPRESS_PATTERN_HAS_STAR_BUT_TOO_FEW_READS_MAPPED_TO_DUPLEX\tFAILED")
+                            if f & 4: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_EXPRESSION_DISALLOW_NO_STAR\tFAILED")
+                            if f & 8: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_EXPRESSION_TOO_MANY_START\tFAILED")
+                            if f & 16: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_MATURE_STAR_RATIO_TOO_SMALL\tFAILED")
+                            if f & 32: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_MATURE_DEPTH_TOO_SMALL\tFAILED")
+                            if f & 64: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_MATURE_NOT_IN_ALL_SAMPLE\tFAILED")
+                            if f & (4 | 8 | 16 | 32 | 64):
+                                lines += _expression_info_lines(r, samples, allow_3nt)
+                        entries[(m0, m1, strand, ss)] = ["MATURE region: %d-%d, SS: %s" % (m0, m1, ss)] + lines
+                for v in entries.values():
+                    tail += v
+        body = head + ["which:" + which, "peak:" + peak] + tail
+        blocks.setdefault(chrom, {"+": {}, "-": {}})[strand][region] = body
+    with open(path, "w") as f:
+        for chrom in blocks:
+            for strand in ("+", "-"):
+                for region, body in blocks[chrom][strand].items():
+                    f.write("===========================================================\n")
+                    f.write("\n".join(body) + "\n\n")
