@@ -234,6 +234,7 @@ class Pipeline:
         counts = mirna_read_counts(result, self.data["names"], self.data["alns"], len(self.data["samples"]))
         write_csv_and_stat(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
                            os.path.join(outdir, "miRNA.stat.txt"))
+        write_readmapping(result, contigs, self.data["names"], self.data["alns"], self.data["samples"], counts, os.path.join(outdir, "readmapping"))
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         d = load_recover_file(self.recovername)
@@ -357,6 +358,50 @@ def mirna_read_counts(resultlist, names, alns, n_samples):
             out[k, s, 1] = depth[on & (a["pos"] == m[3]) & (a["len"] == m[4] - m[3])].sum()
             out[k, s, 2] = depth[on & (a["pos"] == m[5]) & (a["len"] == m[6] - m[5])].sum()
     return out
+
+
+def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder):
+    """gen_map_result (MP:2907-2959): one <precursor id>.map.txt per locus with the reads of every sample laid out under the precursor.
+    The read text is the reference sequence under the alignment (upper case): exact for perfect-match alignments, which is what the
+    reference's own aligner script produces (bowtie -v 0); the ingest keeps coordinates, not read sequences."""
+    os.makedirs(folder, exist_ok=True)
+    tid_of = {n: t for t, n in enumerate(names)}
+    key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
+    for idx, m in enumerate(resultlist):
+        mirname = "miRNA-precursor_%d" % idx
+        pre = _faidx(contigs, m[0], m[1], m[2] - 1)
+        mlen, slen = m[4] - m[3], m[6] - m[5]
+        if m[8] == "-":
+            pre = _revcomp(pre)
+        out = [">%s %s:%d-%d %s" % (mirname, m[0], m[1], m[2], m[8])]
+        t = tid_of[m[0]]
+        lo = np.searchsorted(key, (t << 32) | m[1], side="left")
+        hi = np.searchsorted(key, (t << 32) | m[2], side="left")
+        a = alns[lo:hi]
+        a = a[(a["pos"].astype(np.int64) + a["len"].astype(np.int64) <= m[2]) & (a["strand"] == (1 if m[8] == "-" else 0))]
+        seq = contigs[m[0]]
+        for s, sample in enumerate(samples):
+            out += [">> Read mappings for sample: " + sample, "5'->3'", pre + "\ttotal_mapped_reads=" + str(int(counts[idx, s, 0])), m[7]]
+            rs = a[a["sample"] == s]
+            starts = sorted(set(int(p) for p in rs["pos"]), reverse=(m[8] == "-"))
+            for startpos in starts:
+                here = rs[rs["pos"] == startpos]
+                for r in sorted(here, key=lambda r: int(r["len"])):          # stable: alignment order among equal lengths
+                    rl = int(r["len"])
+                    read = seq[startpos - 1:startpos - 1 + rl].tobytes().decode().upper()
+                    pad = "m" if (startpos == m[3] and rl == mlen) else ("s" if (startpos == m[5] and rl == slen) else ".")
+                    line = pad * (startpos - m[1]) + read
+                    line += pad * (len(pre) - len(line))
+                    if m[8] == "-":
+                        line = _revcomp(line).replace("U", "T")
+                    line += "\tdepth=%d, length=%d" % (int(r["depth"]), rl)
+                    if pad == "m":
+                        line += " [mature]"
+                    if pad == "s":
+                        line += " [star]"
+                    out.append(line)
+        with open(os.path.join(folder, mirname + ".map.txt"), "w") as f:
+            f.write("\n".join(out) + "\n")
 
 
 def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):

@@ -181,6 +181,11 @@ def test_report_writers_match_reference_files(name, tmp_path):
     assert open(tmp_path / "p.ss").read() == rep["precursor_ss"]
     assert open(tmp_path / "d.csv").read() == rep["detail_csv"]
     assert open(tmp_path / "s.txt").read() == rep["stat_txt"]
+    # per-locus read layouts (gen_map_result MP:2907-2959); the synthetic reads are perfect matches, as bowtie -v 0 produces
+    pipeline.write_readmapping(result, contigs, c["contig_names"], c["alns"], c["sample_names"], counts, str(tmp_path / "rm"))
+    assert sorted(os.listdir(tmp_path / "rm")) == sorted(exp["readmapping"])
+    for fn, text in exp["readmapping"].items():
+        assert open(tmp_path / "rm" / fn).read() == text, fn
 
 
 def test_gff_keep_regions_match_the_reference_functions(tmp_path):
