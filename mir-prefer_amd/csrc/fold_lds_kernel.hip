@@ -22,6 +22,7 @@
 //   * windows whose energies leave the 16-bit ranges are flagged and re-run by the generic kernel.
 // No MFMA: integer min-plus DP with irregular table lookups.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "fold_epilogue.h"
 #include "fold185_device.h"
 
@@ -105,6 +106,16 @@ __device__ __forceinline__ int lds_intloop(const LdsTables& T, const FoldParams*
            T.mismatchI[type2 * 25 + sq1 * 5 + sp1];
 }
 
+// Diagonal-major triangle of fML / c / trace-back: cell (d, i), i = 1..n-d, lives at off(d) + i.  Every diagonal starts at an ODD offset and
+// is padded to an even length, so a pair of cells (i, i+1) with odd i is one naturally aligned 32-bit word (the split loop reads pairs; a
+// misaligned 32-bit DS read is replayed on gfx950).  off(d) = 1 + (d-4) n - (d(d-1)/2 - 6) + #{odd lengths among diagonals 4..d-1}.
+__host__ __device__ constexpr int tri_off(int d, int n) { return 1 + (d - 4) * n - (d * (d - 1) / 2 - 6) + (((d - 4) + (n & 1)) >> 1); }
+__host__ __device__ constexpr int tri_len(int d, int n) { return n - d > 0 ? (n - d) + ((n - d) & 1) : 0; }
+__device__ inline void fill_tri_off(int* off, int n) {
+    int o = 1;
+    for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += tri_len(d, n); }
+}
+
 struct LdsLayout {
     unsigned fml, aux, S, seq, pax, qb2, spec, list, off, tabs, misc, total;
 };
@@ -113,7 +124,7 @@ template <int MODEL>
 __host__ __device__ constexpr LdsLayout lds_layout() {
     LdsLayout L{};
     unsigned o = 0;
-    L.fml = o; o += lds_al(((LDMAX - 3) * LCAP - (LDMAX * (LDMAX + 1) / 2 - 6)) * 2);   // fML triangle, d = 4..LDMAX at n = LCAP
+    L.fml = o; o += lds_al((tri_off(LDMAX + 1, LCAP) + 2) * 2);                           // fML triangle, d = 4..LDMAX at n = LCAP
     L.aux = o; o += lds_al(32 * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + 4 * LCAP * 4);   // c ring (32 diagonals), DML ring (3; 5 in the vienna-1.8.5 model), 2 x {ckey, mdec}
     L.S = o; o += lds_al(LCAP + 8);
     L.seq = o; o += lds_al(LCAP + 8);
@@ -133,6 +144,7 @@ static_assert(lds_layout<0>().total <= 160 * 1024 && lds_layout<1>().total <= 16
 // stacked pair), um = largest admissible n1 + n2 (inner pair keeps q - p >= TURN + 1).  Running minima are biased uint (65535 = none).
 typedef const volatile __attribute__((address_space(3))) unsigned short* lds_vu16;   // LDS reads that must stay narrow (see a1_gen_row)
 typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 struct A1 {
     const FoldParams* __restrict__ P;
     const LdsTables* T;
@@ -369,8 +381,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         for (int x = tid; x < DMLR * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
         for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = ((x / LCAP) & 1) ? INF : (int)KEY_NONE;   // [parity][ckey | mdec]
         if (tid == 0) {
-            int o = 0;
-            for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
+            fill_tri_off(off, n);
             misc[1] = 0;
         }
         __syncthreads();
@@ -498,67 +509,77 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 }
             }
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA1 += t - wt; wt = t; }
-            // phase A2: multiloop splits DML(i,j) over the finite range of row i / column j.
-            // The split point t is wave-uniform (scalar address arithmetic); lanes = consecutive cells.
+            // phase A2: multiloop splits DML(i,j) = min_t fML(i, i+t) + fML(i+t+1, j).
+            // The split point t is wave-uniform (scalar address arithmetic); every lane owns TWO consecutive cells (i, i+1), i odd.  Operand a
+            // (diagonal t, cells i, i+1) is one aligned 32-bit word; operand b (diagonal d-t-1, cells i+t+1, i+t+2) is one aligned word for odd t
+            // and straddles two words for even t (one v_alignbit).  The step between the splits of a wave is even, so that parity is
+            // wave-uniform.  One packed saturating add and one packed min then relax both cells.
             {
-                const int ncpad = (ncell + 63) & ~63;
-                const int nsub = LNT / ncpad;            // >= 2 for ncell <= 512
-                const int cell = tid % ncpad;
+                const int npair = (ncell + 1) >> 1;
+                const int ncpad = (npair + 63) & ~63;
+                const int nsub = (LNT / ncpad) & ~1;     // even, >= 4 for ncell <= 384
+                const int pair = tid % ncpad;
                 const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
                 if (sub < nsub && !(dbg_flags & 2)) {
-                    const int i = cell + 1, j = i + d;
+                    const int i = 2 * pair + 1;
                     // every split t in [4, d-5] is relaxed unconditionally: with the biased uint16 encoding a sum that involves an INF entry
-                    // is >= 65535 and any sum of two finite entries is <= 65534, so no per-lane range bookkeeping is needed.
-                    // The byte offsets of the two operand diagonals live in SGPRs and advance by second-order recurrences:
-                    //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1,  off(x) = (x-4) n - (x(x-1)/2 - 6)
+                    // saturates at 65535 and any sum of two finite entries is <= 65534, so no per-lane range bookkeeping is needed.
+                    // The byte offsets of the two operand diagonals live in SGPRs and advance by second-order recurrences (tri_off above):
+                    //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1   (minus one short for even t: the aligned word below the pair)
                     const int s1 = nsub;
                     int t = 4 + sub;
                     const int uu = d - t - 1;
-                    int so1 = __builtin_amdgcn_readfirstlane(2 * ((t - 4) * n - ((t * (t - 1)) / 2 - 6)));
-                    int so2 = __builtin_amdgcn_readfirstlane(2 * ((uu - 4) * n - ((uu * (uu - 1)) / 2 - 6) + t + 1));
-                    int si1 = __builtin_amdgcn_readfirstlane(2 * (s1 * n - s1 * t - (s1 * (s1 - 1)) / 2));           // off(t+s) - off(t)
-                    int si2 = __builtin_amdgcn_readfirstlane(2 * (-(s1 * n) + s1 * uu - (s1 * (s1 + 1)) / 2 + s1));  // off(uu-s) - off(uu) + s
+                    const int odd = t & 1;
+                    int so1 = __builtin_amdgcn_readfirstlane(2 * tri_off(t, n));
+                    int so2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu, n) + t + 1 - (odd ? 0 : 1)));
+                    int si1 = __builtin_amdgcn_readfirstlane(2 * (tri_off(t + s1, n) - tri_off(t, n)));
+                    int si2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu - s1, n) - tri_off(uu, n) + s1));
                     const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
                     const char* fb = reinterpret_cast<const char*>(fml + i);
-                    unsigned bu = 65535u;
+                    us2 bu = {65535, 65535};
 #define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
-#define MIRP_LD(o) ((unsigned)*reinterpret_cast<const unsigned short*>(fb + (o)))
-                    for (; t + 7 * s1 <= d - 5; t += 8 * s1) {     // 16 reads in flight
-                        unsigned a[8], b[8];
+#define MIRP_LDW(o) (*reinterpret_cast<const unsigned*>(fb + (o)))
+                    auto relax = [&](auto ODD) {
+                        constexpr bool kOdd = decltype(ODD)::value;
+                        for (; t + 7 * s1 <= d - 5; t += 8 * s1) {     // 16 (24) reads in flight
+                            unsigned a[8], b[8], c[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) { a[k] = MIRP_LD(so1); b[k] = MIRP_LD(so2); MIRP_SSTEP(); }
+                            for (int k = 0; k < 8; k++) {
+                                a[k] = MIRP_LDW(so1); b[k] = MIRP_LDW(so2);
+                                if (!kOdd) c[k] = MIRP_LDW(so2 + 4);
+                                MIRP_SSTEP();
+                            }
+                            us2 e[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) a[k] += b[k];
-                        a[0] = a[0] < a[1] ? a[0] : a[1]; a[2] = a[2] < a[3] ? a[2] : a[3]; a[4] = a[4] < a[5] ? a[4] : a[5]; a[6] = a[6] < a[7] ? a[6] : a[7];
-                        a[0] = a[0] < a[2] ? a[0] : a[2]; a[4] = a[4] < a[6] ? a[4] : a[6]; a[0] = a[0] < a[4] ? a[0] : a[4];
-                        bu = a[0] < bu ? a[0] : bu;
-                    }
-                    so1 = __builtin_amdgcn_readfirstlane(so1); so2 = __builtin_amdgcn_readfirstlane(so2);
-                    si1 = __builtin_amdgcn_readfirstlane(si1); si2 = __builtin_amdgcn_readfirstlane(si2);
-                    for (; t + 3 * s1 <= d - 5; t += 4 * s1) {
-                        const unsigned a0 = MIRP_LD(so1), b0 = MIRP_LD(so2);
-                        MIRP_SSTEP();
-                        const unsigned a1 = MIRP_LD(so1), b1 = MIRP_LD(so2);
-                        MIRP_SSTEP();
-                        const unsigned a2 = MIRP_LD(so1), b2 = MIRP_LD(so2);
-                        MIRP_SSTEP();
-                        const unsigned a3 = MIRP_LD(so1), b3 = MIRP_LD(so2);
-                        MIRP_SSTEP();
-                        unsigned e0 = a0 + b0, e1 = a1 + b1, e2 = a2 + b2, e3 = a3 + b3;
-                        e0 = e0 < e1 ? e0 : e1; e2 = e2 < e3 ? e2 : e3; e0 = e0 < e2 ? e0 : e2;
-                        bu = e0 < bu ? e0 : bu;
-                    }
-                    so1 = __builtin_amdgcn_readfirstlane(so1); so2 = __builtin_amdgcn_readfirstlane(so2);
-                    si1 = __builtin_amdgcn_readfirstlane(si1); si2 = __builtin_amdgcn_readfirstlane(si2);
-                    for (; t <= d - 5; t += s1) {
-                        const unsigned e = MIRP_LD(so1) + MIRP_LD(so2);
-                        MIRP_SSTEP();
-                        bu = e < bu ? e : bu;
-                    }
+                            for (int k = 0; k < 8; k++) {
+                                const unsigned bw = kOdd ? b[k] : __builtin_amdgcn_alignbit(c[k], b[k], 16);
+                                us2 av, bv;
+                                __builtin_memcpy(&av, &a[k], 4); __builtin_memcpy(&bv, &bw, 4);
+                                e[k] = __builtin_elementwise_add_sat(av, bv);
+                            }
+                            e[0] = __builtin_elementwise_min(e[0], e[1]); e[2] = __builtin_elementwise_min(e[2], e[3]);
+                            e[4] = __builtin_elementwise_min(e[4], e[5]); e[6] = __builtin_elementwise_min(e[6], e[7]);
+                            e[0] = __builtin_elementwise_min(e[0], e[2]); e[4] = __builtin_elementwise_min(e[4], e[6]);
+                            bu = __builtin_elementwise_min(bu, __builtin_elementwise_min(e[0], e[4]));
+                        }
+                        so1 = __builtin_amdgcn_readfirstlane(so1); so2 = __builtin_amdgcn_readfirstlane(so2);
+                        si1 = __builtin_amdgcn_readfirstlane(si1); si2 = __builtin_amdgcn_readfirstlane(si2);
+                        for (; t <= d - 5; t += s1) {
+                            const unsigned aw = MIRP_LDW(so1), b0 = MIRP_LDW(so2);
+                            unsigned bw = b0;
+                            if (!kOdd) bw = __builtin_amdgcn_alignbit(MIRP_LDW(so2 + 4), b0, 16);
+                            MIRP_SSTEP();
+                            us2 av, bv;
+                            __builtin_memcpy(&av, &aw, 4); __builtin_memcpy(&bv, &bw, 4);
+                            bu = __builtin_elementwise_min(bu, __builtin_elementwise_add_sat(av, bv));
+                        }
+                    };
+                    if (odd) relax(std::true_type{}); else relax(std::false_type{});
 #undef MIRP_SSTEP
-#undef MIRP_LD
-                    const int best = (cell < ncell && bu < 65535u) ? (int)bu - 2 * FML_BIAS : INF;
-                    if (best < INF) atomicMin(&mdec[i], best);
+#undef MIRP_LDW
+                    const unsigned r0 = bu[0], r1 = bu[1];
+                    if (i <= ncell && r0 < 65535u) atomicMin(&mdec[i], (int)r0 - 2 * FML_BIAS);
+                    if (i + 1 <= ncell && r1 < 65535u) atomicMin(&mdec[i + 1], (int)r1 - 2 * FML_BIAS);
                 }
             }
         };
@@ -688,7 +709,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         } else {
             // hand the tables to the epilogue kernel: c was archived on the fly, fML is copied out now (coalesced dwords)
             int tri = 0;
-            if (Dm >= 4) tri = off[Dm] + (n - Dm) + 1;
+            if (Dm >= 4) tri = off[Dm + 1] + 1;
             const unsigned int* src = reinterpret_cast<const unsigned int*>(fml);
             unsigned int* dst = reinterpret_cast<unsigned int*>(fml_out);
             for (int x = tid; x < (tri + 1) / 2; x += LNT) dst[x] = src[x];
@@ -754,10 +775,7 @@ __global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
                 seq[x] = ch;
                 S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
             }
-            if (tid == 0) {
-                int o = 0;
-                for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
-            }
+            if (tid == 0) fill_tri_off(off, n);
             __syncthreads();
             if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
             special_hairpins(P, seq, n, spec, nc, tid, ENT);
@@ -836,10 +854,7 @@ __global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
                 S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
             }
             for (int x = tid; x < nc + 8; x += ENT) f3[x] = 0;
-            if (tid == 0) {
-                int o = 0;
-                for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += (n - d > 0 ? n - d : 0); }
-            }
+            if (tid == 0) fill_tri_off(off, n);
             __syncthreads();
             if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
             for (int x = tid; x <= n; x += ENT) {
@@ -919,7 +934,8 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
 
 size_t fold_lds_slab_shorts(int n_cap) {   // triangle of d = 4..LDMAX for windows up to n_cap (+ slack for the dword copy)
     size_t tri = 0;
-    for (int d = 4; d <= LDMAX; d++) tri += (size_t)(n_cap - d > 0 ? n_cap - d : 0);
+    tri = 1;
+    for (int d = 4; d <= LDMAX; d++) tri += (size_t)tri_len(d, n_cap);
     return (tri + 8 + 7) & ~(size_t)7;
 }
 

@@ -34,7 +34,7 @@ struct FoldParams {
     // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes).  An interior-loop candidate is ranked by the key
     // (energy term << 10) | (n1 << 5 | n2): the minimum key is the minimum energy and, among equal energies, the first shape in the
     // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
-    unsigned gen_key[25][28];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
+    unsigned gen_key[25][32];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
     unsigned kb0_key[31];         // bulge n1 = 0, n2 = u:   (bulge[u] + 2048) << 10 | u
     unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
     unsigned k1n0_key[31];        // 1 x k loop (n1 = 1, n2 = k): (internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048) << 10 | 1 << 5 | k

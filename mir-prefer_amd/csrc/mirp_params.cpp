@@ -10,7 +10,7 @@ static inline int clamp0(int v) { return v > 0 ? 0 : v; }
 
 static void fill_derived(FoldParams* p) {
     for (int u = 6; u <= MIRP_MAXLOOP; u++)
-        for (int n1 = 0; n1 < 28; n1++) {
+        for (int n1 = 0; n1 < 32; n1++) {          // n1 runs up to u - 2 = 28
             unsigned v = 65535u << 10;
             if (n1 >= 2 && n1 <= u - 2) {
                 int y = std::abs(2 * n1 - u) * p->ninio;

@@ -28,6 +28,16 @@ def test_fold_production_windows(gpu_ctx, oracle):
     _compare(gpu_ctx, oracle, seqgen.windows(13, 64, 300, 350), 300)
 
 
+def test_fold_maximal_asymmetric_interior_loop_tie(gpu_ctx, oracle):
+    """Regression (found by profiles/tools/stress_fold.py): a 28 x 2 interior loop -- the last admissible n1 of the largest loop size --
+    ties with a multiloop; RNALfold's backtrack takes the interior loop, so the fill kernel must rank that shape too."""
+    s = ("GUNUCGUAGCACGGGNCUACCCUACACCACAUUCCNNUNAUCANCGUCUUAGUANNCCAGCANNGAAANGGCGNGUAUUCAAGGCCUGCCUGUGAAUUUGCAGUCGNGUUAGUNGGCUUGCUCUUNAAGAAAUACCGCAAUCGAGCU"
+         "NCNGAUCAGGUANNUANGCUAAUCCCGCUGUACCNNUAUCNNAAANAGGUUCUGGACACAAACUCGCUAAAGUGUGAACUAUCNUGGUAACNGGAAAUUAACUUUUCGANAAAGUAUCUGCGCACCAGCGUGUAGCCGGGACAAUUAUGCC"
+         "UGGUUUCUUGCACUAGACCU")
+    _compare(gpu_ctx, oracle, [s], 150)
+    _compare(gpu_ctx, oracle, [s], 300)
+
+
 def test_fold_edge_cases(gpu_ctx, oracle):
     seqs = ["A", "ACGU", "GGGGAAAACCCC", "A" * 24, "N" * 30, "GGGAAAUCCCGGGAAAUCCCAAAAGGGGGGAUUUCCCCCCUUUUGGGAUUUCCCGGAUUUCCC",
             "GC" * 150, "G" * 150 + "C" * 150, ""]
