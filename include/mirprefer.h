@@ -120,6 +120,11 @@ typedef struct {
 int mirp_load_genome(mirp_ctx* ctx, int32_t n_contigs, const int64_t* contig_len, const uint8_t* seq_concat);
 /* Alignments sorted as described at MirpAln. Replaces the prepare-stage BAMs (MP:772-874) as device-resident records. */
 int mirp_load_alignments(mirp_ctx* ctx, const MirpAln* alns, int64_t n_alns);
+/* Contig sharding across GPUs (one context per shard, whole contigs per shard): the strand vote of the reference double-counts the first
+ * position of the first covered run of every contig except the very first run of the depth file (MP:905-906 + 926-929).  A shard whose first
+ * covered contig is preceded, in @SQ order, by a covered contig held by ANOTHER shard sets this to 1 so that its first run is double-counted
+ * as in the single-file run; default 0 (the context holds the whole genome). */
+int mirp_set_contig_shard(mirp_ctx* ctx, int32_t preceded_by_coverage_elsewhere);
 /* Replaces gen_contig_typeA + gen_candidate_region_typeA + dump_loci_seqs_and_alignment_multiprocess
  * (MP:877-962, 1246-1371, 1065-1244). contig_order = contig indices in the order sorted(dict_contigs) visits them (MP:1309). */
 int mirp_candidate(mirp_ctx* ctx, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks, int64_t* n_loci,

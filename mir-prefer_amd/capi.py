@@ -91,6 +91,8 @@ def load_library():
     lib.mirp_get_windows.argtypes = [vp, C.POINTER(vp), i64p, C.POINTER(vp), i64p, C.POINTER(vp), i64p, C.POINTER(vp), i64p]
     lib.mirp_fold.argtypes = [vp, C.c_int32, C.c_int32]
     lib.mirp_set_fold_model.argtypes = [vp, C.c_int32]
+    lib.mirp_set_contig_shard.argtypes = [vp, C.c_int32]
+    lib.mirp_set_contig_shard.restype = C.c_int
     lib.mirp_set_fold_model.restype = C.c_int
     lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
@@ -262,6 +264,10 @@ class Context:
         if model not in self.FOLD_MODELS:
             raise MirpError("unknown fold model %r (expected one of %s)" % (model, ", ".join(sorted(self.FOLD_MODELS))))
         self._check(self.lib.mirp_set_fold_model(self.h, self.FOLD_MODELS[model]), "mirp_set_fold_model")
+
+    def set_contig_shard(self, preceded_by_coverage_elsewhere):
+        """Contig sharding: see mirp_set_contig_shard in include/mirprefer.h."""
+        self._check(self.lib.mirp_set_contig_shard(self.h, 1 if preceded_by_coverage_elsewhere else 0), "mirp_set_contig_shard")
 
     def fold(self, span, max_lines=96):
         self._check(self.lib.mirp_fold(self.h, int(span), int(max_lines)), "mirp_fold")

@@ -57,8 +57,22 @@ def main(argv=None):
                                                                 opt["NAME_PREFIX"] + "_recover"))
         print("Last finished stage: %s" % last)
         return 0
+    # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m mir_prefer_amd.cli ...`): contigs are sharded over the ranks,
+    # only file names, counts and the final loci list are exchanged (RCCL / `nccl` by default, MIRP_DIST_BACKEND=gloo for CPU-side exchange)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch
+        import torch.distributed as tdist
+        backend = os.environ.get("MIRP_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            o["device"] = int(os.environ.get("LOCAL_RANK", str(rank)))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(o["device"])
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", o["device"]))
+        else:
+            tdist.init_process_group(backend)
     try:
-        p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"])
+        p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"], rank=rank, world=world)
         if o["action"] == "pipeline":
             p.run_pipeline()
             if not o["keeptmp"] and opt["DELETE_IF_SUCCESS"].upper().startswith("Y"):
@@ -70,6 +84,10 @@ def main(argv=None):
     except capi.MirpError as e:
         sys.stderr.write(str(e) + "\n")   # reference behaviour for a failed tool: message on stderr, exit status -1
         sys.exit(-1)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
     return 0
 
 

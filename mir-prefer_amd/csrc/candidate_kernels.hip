@@ -221,7 +221,7 @@ __device__ __forceinline__ int contig_of(const long long* __restrict__ goff, int
 __global__ void __launch_bounds__(256) run_walk_kernel(const RunStart* __restrict__ starts, long long n_runs, const int* __restrict__ diff_p,
                                                        const int* __restrict__ diff_m, long long gtot, int cutoff,
                                                        const long long* __restrict__ goff, int n_contigs, int min_len,
-                                                       MirpPeak* __restrict__ runs, int* __restrict__ keep) {
+                                                       MirpPeak* __restrict__ runs, int* __restrict__ keep, int first_run_double) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n_runs; k += (long long)gridDim.x * blockDim.x) {
         RunStart r = starts[k];
         int dp = r.dp, dm = r.dm;
@@ -234,6 +234,8 @@ __global__ void __launch_bounds__(256) run_walk_kernel(const RunStart* __restric
         if (k > 0) {
             int tprev = contig_of(goff, n_contigs, starts[k - 1].gx);
             if (tprev != t) { sum_p += r.dp; sum_m += r.dm; }
+        } else if (first_run_double) {   // contig shard: a contig of another shard precedes this run in the depth file of the whole genome
+            sum_p += r.dp; sum_m += r.dm;
         }
         MirpPeak p;
         p.tid = t; p.start = (int)(r.gx - goff[t] + 1); p.end = (int)(x - goff[t] + 1); p.strand = (sum_p > sum_m) ? 0 : 1;
@@ -506,10 +508,10 @@ void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long 
 }
 size_t run_start_bytes() { return sizeof(RunStart); }
 void launch_run_walk(hipStream_t st, const void* starts, long long n_runs, const int* diff_p, const int* diff_m, long long gtot, int cutoff,
-                     const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep) {
+                     const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep, int first_run_double) {
     if (n_runs <= 0) return;
     hipLaunchKernelGGL(run_walk_kernel, dim3(grid_for(n_runs, 256, 8192)), dim3(256), 0, st, (const RunStart*)starts, n_runs, diff_p, diff_m, gtot,
-                       cutoff, goff, n_contigs, min_len, runs, keep);
+                       cutoff, goff, n_contigs, min_len, runs, keep, first_run_double);
 }
 void launch_depth_fix(hipStream_t st, MirpDepthPos* d, const long long* gx, long long n, const long long* goff, int n_contigs) {
     if (n <= 0) return;

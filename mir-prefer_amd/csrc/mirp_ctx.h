@@ -56,6 +56,7 @@ struct mirp_ctx {
     long long n_runs = 0, n_above = 0, n_peaks = 0, n_regions = 0, n_loci = 0, n_windows = 0, n_slots = 0;
     int seq_stride = 0, fold_stride = 0, fold_max_lines = 0, fold_span = 0;
     bool have_candidate = false, have_fold = false;
+    int shard_first_run_double = 0;   // contig shard whose first covered contig is not the first covered contig of the whole genome
     double ms[4] = {0, 0, 0, 0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };

@@ -47,7 +47,7 @@ void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long 
                      unsigned long long* stat_c, unsigned int* ticket, void* starts, long long starts_cap, MirpDepthPos* depth_out,
                      long long depth_cap, long long* depth_gx, unsigned long long* totals);
 void launch_run_walk(hipStream_t st, const void* starts, long long n_runs, const int* diff_p, const int* diff_m, long long gtot, int cutoff,
-                     const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep);
+                     const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep, int first_run_double);
 void launch_depth_fix(hipStream_t st, MirpDepthPos* d, const long long* gx, long long n, const long long* goff, int n_contigs);
 void launch_excl_scan(hipStream_t st, const int* in, long long* out, long long n);
 void launch_peak_compact(hipStream_t st, const MirpPeak* runs, const int* keep, const long long* kscan, long long n_runs, int n_contigs,

@@ -115,6 +115,13 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     return 0;
 }
 
+extern "C" int mirp_set_contig_shard(mirp_ctx* c, int32_t preceded_by_coverage_elsewhere) {
+    if (!c) return -1;
+    c->shard_first_run_double = preceded_by_coverage_elsewhere ? 1 : 0;
+    c->have_candidate = false; c->have_fold = false;
+    return 0;
+}
+
 extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks_out,
                               int64_t* n_loci_out, int64_t* n_windows_out) {
     if (!c) return -1;
@@ -145,7 +152,7 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
         c->kscan.ensure(8 * (size_t)(nr + 1)) || c->csq.ensure(8 * (size_t)(nc + 2)) || c->cdest.ensure(8 * (size_t)(nc + 2)))
         return fail(c, -6, "device allocation failed (runs)");
     mirp::launch_run_walk(st, c->starts.p, nr, diff_p, diff_m, c->gtot, c->cand.cutoff, (const long long*)c->goff.p, nc, c->cand.min_peak_len,
-                          (MirpPeak*)c->runs.p, (int*)c->keep.p);
+                          (MirpPeak*)c->runs.p, (int*)c->keep.p, c->shard_first_run_double);
     mirp::launch_excl_scan(st, (const int*)c->keep.p, (long long*)c->kscan.p, nr);
     long long np = 0;
     if (read_ll(c, (const long long*)c->kscan.p + nr, &np)) return fail(c, -2, "D2H failed");

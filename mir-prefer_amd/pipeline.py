@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from . import capi, gffmask, ingest, records
+from . import capi, dist, gffmask, ingest, records
 
 STAGES = ["prepare", "candidate", "fold", "predict"]
 
@@ -61,7 +61,10 @@ class Pipeline:
     """One device context + the option dict; the stage methods can run in one process (pipeline verb) or one per process
     (stage verbs): a stage that finds no device-resident state re-creates it from the previous stages' artefacts."""
 
-    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2"):
+    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2", rank=0, world=1):
+        """rank / world: contig sharding over one process per GPU (`torch.distributed` initialised by the caller, see cli.py).  Every rank
+        runs the stages on its own contigs (dist.partition_contigs); rank 0 merges the artefacts and writes the result files."""
+        self.rank, self.world = rank, world
         self.opt = dict_option
         self.tmp = dict_option["TMPFOLDER"] or os.path.join(dict_option["OUTFOLDER"], dict_option["NAME_PREFIX"] + "_tmp")
         os.makedirs(dict_option["OUTFOLDER"], exist_ok=True)
@@ -75,6 +78,24 @@ class Pipeline:
     def _p(self, name):
         return os.path.join(self.tmp, name)
 
+    def _say(self, text):
+        if self.rank == 0:
+            _msg(text)
+
+    def _barrier(self):
+        if self.world > 1:
+            import torch.distributed as tdist
+            tdist.barrier()
+
+    def _all_gather(self, obj):
+        """Small python objects (file names, counts, the loci list) from every rank, in rank order."""
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as tdist
+        out = [None] * self.world
+        tdist.all_gather_object(out, obj)
+        return out
+
     def _fail_stage(self):
         _msg("Error: can not start the pipeline from this stage, the files needed are not generated or have been removed/moved. "
              "Please run previous stages first, or run the pipeline in the recover mode to automatically continue from where the job was ceased.")
@@ -82,6 +103,9 @@ class Pipeline:
 
     # ---- prepare (MP:3320-3358): SAM/FASTA ingest replaces sam2bam / cat / sort / expand / strand split
     def run_prepare(self):
+        if self.rank != 0:          # the ingest is one host job; the other ranks pick its output up in _load_inputs
+            self._barrier()
+            return
         _msg("Starting preparing data for the 'candidate' stage.")
         names, lens, samples, alns = ingest.read_sams(self.opt["ALIGNMENT_FILE"])
         # GFF masking (MP:817-859): keep regions as the reference's BED file, applied like `samtools view -L` on the combined records
@@ -107,6 +131,7 @@ class Pipeline:
         d = {"last_stage": "prepare", "finished_stages": {"prepare": {"preparedname": prepared}}, "files": {"prepare": [prepared]}}
         _save_recover(self.recovername, d)
         _msg("Done (prepare stage)\n")
+        self._barrier()
 
     def _load_inputs(self):
         if self.data is not None:
@@ -119,8 +144,13 @@ class Pipeline:
         if missing:
             sys.stderr.write("Error: sequence %s of the SAM header is not in the FASTA file\n" % missing[0])
             sys.exit(-1)
-        self.data = {"names": names, "lens": z["contig_lens"], "samples": [str(x) for x in z["sample_names"]], "alns": z["alns"],
+        alns = z["alns"]
+        self.data = {"names": names, "lens": z["contig_lens"], "samples": [str(x) for x in z["sample_names"]], "alns": alns, "alns_all": alns,
                      "contigs": [(n, fa[n]) for n in names]}
+        if self.world > 1:          # contig sharding: whole contigs per rank, balanced by length
+            mine = np.zeros(len(names), dtype=bool)
+            mine[dist.partition_contigs(self.data["lens"], self.world)[self.rank]] = True
+            self.data["alns"] = alns[mine[alns["tid"]]]
         self.ctx.load_genome(self.data["contigs"])
         self.ctx.load_alignments(self.data["alns"])
 
@@ -130,39 +160,75 @@ class Pipeline:
         self._load_inputs()
         order = np.argsort(np.array(self.data["names"], dtype=object), kind="stable").astype(np.int32)  # sorted(dict_contigs), MP:1309
         self.counts = self.ctx.candidate(self.opt["READS_DEPTH_CUTOFF"], self.opt["MAX_GAP"], self.opt["PRECURSOR_LEN"], order)
+        if self.world > 1:
+            # the strand vote double-counts the first position of every contig's first run except the first run of the whole depth file
+            # (MP:905-906, 926-929): a shard whose first covered contig is not the genome's first covered contig must do so for its first run too
+            depth = self.ctx.get_depth()
+            first = int(depth[0]["tid"]) if len(depth) else 1 << 30
+            firsts = self._all_gather(first)
+            if first != (1 << 30) and first != min(firsts):
+                self.ctx.set_contig_shard(True)
+                self.counts = self.ctx.candidate(self.opt["READS_DEPTH_CUTOFF"], self.opt["MAX_GAP"], self.opt["PRECURSOR_LEN"], order)
         self.state = "candidate"
 
     # ---- candidate (MP:3361-3438)
     def run_candidate(self):
         if not previous_stage_saved(self.recovername, "prepare"):
             self._fail_stage()
-        _msg("Starting identifying candidate regions")
+        self._say("Starting identifying candidate regions")
         self.state = None
         self._ensure_candidate()
-        names, prefix = self.data["names"], self.opt["NAME_PREFIX"]
+        names, prefix, r = self.data["names"], self.opt["NAME_PREFIX"], self.rank
         depthname = self._p("bam.depth.cut%d" % self.opt["READS_DEPTH_CUTOFF"])
-        with open(depthname, "w") as f:
-            f.write(records.depth_text(self.ctx.get_depth(), names))
+        depth = self.ctx.get_depth()
+        if self.world == 1:
+            with open(depthname, "w") as f:
+                f.write(records.depth_text(depth, names))
+        else:       # every rank writes the lines of its contigs; rank 0 stitches the parts back together in @SQ order
+            part = depthname + ".part%d" % r
+            spans = {}
+            with open(part, "w") as f:
+                for t in np.unique(depth["tid"]) if len(depth) else []:
+                    a = f.tell()
+                    f.write(records.depth_text(depth[depth["tid"] == t], names))
+                    spans[int(t)] = (a, f.tell())
+            all_spans = self._all_gather(spans)
+            if r == 0:
+                with open(depthname, "w") as fo:
+                    for t in range(len(names)):
+                        for rr, sp in enumerate(all_spans):
+                            if t in sp:
+                                with open(depthname + ".part%d" % rr) as fi:
+                                    fi.seek(sp[t][0])
+                                    fo.write(fi.read(sp[t][1] - sp[t][0]))
         loci, psorted = self.ctx.get_loci()
         lociname = self._p(prefix + "_loci_dump.dump")
-        with open(lociname, "wb") as f:
-            pickle.dump(records.loci_to_dict(loci, psorted, names, self.opt["PRECURSOR_LEN"]), f, protocol=2)
+        dict_loci = {}
+        for d_ in self._all_gather(records.loci_to_dict(loci, psorted, names, self.opt["PRECURSOR_LEN"])):
+            dict_loci.update(d_)
+        if r == 0:
+            with open(lociname, "wb") as f:
+                pickle.dump(dict_loci, f, protocol=2)
         w = self.ctx.get_windows()
-        fastaname = self._p(prefix + ".rnalfold.in_0.fa")
+        fastaname = self._p(prefix + ".rnalfold.in_%d.fa" % r)       # one piece per rank, like the reference's pieces per process
         with open(fastaname, "w") as f:
             for win in w["windows"]:
                 f.write(records.fasta_header(win, w["wpeaks"], w["matures"], names) + "\n")
                 f.write(w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes().decode() + "\n")
-        dumpname = self._p(prefix + ".alndump_0.npz")
+        dumpname = self._p(prefix + ".alndump_%d.npz" % r)
         np.savez(dumpname, windows=w["windows"], wpeaks=w["wpeaks"], matures=w["matures"])
-        d = load_recover_file(self.recovername)
-        d["last_stage"] = "candidate"
-        d["finished_stages"]["candidate"] = {"depthfilename": depthname, "loci_dump_name": lociname, "fasta": [fastaname], "infodump": [dumpname],
-                                             "num_loci": int(self.counts[1]), "num_fasta": int(self.counts[2])}
-        d["files"]["candidate"] = [fastaname, dumpname]
-        _save_recover(self.recovername, d)
-        sys.stdout.write("%d candidate loci generated, %d regions to fold.\n" % (self.counts[1], self.counts[2]))
-        _msg("Done (candidate stage)\n")
+        parts = self._all_gather((fastaname, dumpname, int(self.counts[1]), int(self.counts[2])))
+        nloci, nfasta = sum(x[2] for x in parts), sum(x[3] for x in parts)
+        if r == 0:
+            d = load_recover_file(self.recovername)
+            d["last_stage"] = "candidate"
+            d["finished_stages"]["candidate"] = {"depthfilename": depthname, "loci_dump_name": lociname, "fasta": [x[0] for x in parts],
+                                                 "infodump": [x[1] for x in parts], "num_loci": nloci, "num_fasta": nfasta}
+            d["files"]["candidate"] = [x[0] for x in parts] + [x[1] for x in parts]
+            _save_recover(self.recovername, d)
+            sys.stdout.write("%d candidate loci generated, %d regions to fold.\n" % (nloci, nfasta))
+        self._say("Done (candidate stage)\n")
+        self._barrier()
 
     def _fold_device(self):
         """Fold every window on the device; returns the per-window status array.  A window can produce more structure lines than the
@@ -179,49 +245,65 @@ class Pipeline:
     def run_fold(self, write_text=True):
         if not previous_stage_saved(self.recovername, "candidate"):
             self._fail_stage()
-        _msg("Starting folding candidate sequences.")
+        self._say("Starting folding candidate sequences.")
         self._ensure_candidate()
         status = self._fold_device()
         self.state = "fold"
         prefix = self.opt["NAME_PREFIX"]
-        foldname = self._p(prefix + "_rnalfoldoutput_0")
+        foldname = self._p(prefix + "_rnalfoldoutput_%d" % self.rank)
         bad = np.nonzero(status != 0)[0]
         if len(bad):
             sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (bad[0], status[bad[0]]))
             sys.exit(-1)
         if write_text:
             d = load_recover_file(self.recovername)
-            self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][0], foldname)
+            self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][self.rank], foldname)
         else:
             open(foldname, "w").close()
-        d = load_recover_file(self.recovername)
-        d["last_stage"] = "fold"
-        d["finished_stages"]["fold"] = {"foldnames": [foldname]}
-        d["files"]["fold"] = [foldname]
-        _save_recover(self.recovername, d)
-        _msg("Done (fold stage)\n")
+        foldnames = self._all_gather(foldname)
+        if self.rank == 0:
+            d = load_recover_file(self.recovername)
+            d["last_stage"] = "fold"
+            d["finished_stages"]["fold"] = {"foldnames": foldnames}
+            d["files"]["fold"] = foldnames
+            _save_recover(self.recovername, d)
+        self._say("Done (fold stage)\n")
+        self._barrier()
 
-    # ---- predict (MP:3498-3627); only the loci list, gff3 and fasta/ss outputs (report writers are out of scope)
+    # ---- predict (MP:3498-3627): the loci list, gff3, fasta / ss / csv / stat / readmapping files (the html table is out of scope)
     def run_predict(self):
         if not previous_stage_saved(self.recovername, "fold"):
             self._fail_stage()
-        _msg("Starting predicting miRNAs.")
+        self._say("Starting predicting miRNAs.")
         if self.state != "fold":
             self._ensure_candidate()
             self._fold_device()
             self.state = "fold"
-        out = self.ctx.predict(len(self.data["samples"]), self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"],
-                               self.opt["ALLOW_NO_STAR_EXPRESSION"])
-        result = result_records(out, self.data["names"])
+        ns = len(self.data["samples"])
+        out = self.ctx.predict(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
         prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
         if self.opt.get("OUTPUT_DETAILS_FOR_DEBUG"):          # -d: why the other regions are not miRNAs (MP:3532-3543)
-            rec = self.ctx.predict_reasons(len(self.data["samples"]), self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"],
-                                           self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
+            rec = self.ctx.predict_reasons(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"],
+                                           self.opt["ALLOW_NO_STAR_EXPRESSION"])
             w = self.ctx.get_windows()
-            write_reasons(os.path.join(outdir, prefix + "_reason_why_not_miRNA.txt"), w, w["matures"], self.data["names"], rec, self.ctx.get_fold(),
-                          self.data["samples"], self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"])
+            rname = os.path.join(outdir, prefix + "_reason_why_not_miRNA.txt")
+            mine = rname if self.world == 1 else rname + ".part%d" % self.rank
+            write_reasons(mine, w, w["matures"], self.data["names"], rec, self.ctx.get_fold(), self.data["samples"], self.opt["MIN_MATURE_LEN"],
+                          self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"])
+            if self.world > 1:
+                self._barrier()
+                if self.rank == 0:
+                    with open(rname, "w") as fo:
+                        for rr in range(self.world):
+                            with open(rname + ".part%d" % rr) as fi:
+                                fo.write(fi.read())
+        result = [m for part in self._all_gather(result_records(out, self.data["names"])) for m in part]   # rank order, as pieces in the reference
+        if self.rank != 0:
+            self._barrier()
+            return []
         if not result:
             _msg("0 miRNA identified. No result files generated.")
+            self._barrier()
             return result
         adjust_mature_star(result)
         gffname = os.path.join(outdir, prefix + "_miRNA.gff3")
@@ -231,10 +313,10 @@ class Pipeline:
         ssname = os.path.join(outdir, prefix + "_miRNA.precursor.ss")
         contigs = dict(self.data["contigs"])
         write_fasta_ss(result, contigs, maturename, stemloopname, ssname)
-        counts = mirna_read_counts(result, self.data["names"], self.data["alns"], len(self.data["samples"]))
+        counts = mirna_read_counts(result, self.data["names"], self.data["alns_all"], ns)
         write_csv_and_stat(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
                            os.path.join(outdir, "miRNA.stat.txt"))
-        write_readmapping(result, contigs, self.data["names"], self.data["alns"], self.data["samples"], counts, os.path.join(outdir, "readmapping"))
+        write_readmapping(result, contigs, self.data["names"], self.data["alns_all"], self.data["samples"], counts, os.path.join(outdir, "readmapping"))
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         d = load_recover_file(self.recovername)
@@ -245,6 +327,7 @@ class Pipeline:
         _msg("The output files are in " + outdir)
         sys.stdout.write("%d miRNAs identified.\n" % len(result))
         _msg("Done (predict stage)\n")
+        self._barrier()
         return result
 
     def run_pipeline(self):

@@ -78,3 +78,32 @@ def test_stage_verbs_and_recover(tmp_path):
         assert cli.main([verb, cfg]) == 0
     assert cli.main(["recover", cfg]) == 0    # continues with fold + predict
     assert open(out / "mini_miRNA.gff3").read() == exp["gff3"]
+
+
+def test_pipeline_verb_sharded_over_two_ranks(tmp_path):
+    """Contig sharding: two processes (one per rank; here both on GPU 0, exchanging the small host objects over gloo) must produce the
+    files of the single-process run -- including the strand-vote quirk at the first run of a shard (mirp_set_contig_shard)."""
+    import subprocess
+    import sys
+    exp, cfg, out = _setup("mini", tmp_path)
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", MIRP_DIST_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-m", "mir_prefer_amd.cli", "-k", "-d", "--device", "0", "pipeline", cfg], cwd=root,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    prefix = exp["config"]["NAME_PREFIX"]
+    tmp = out / (prefix + "_tmp")
+    assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"]
+    rep = exp["reports"]
+    assert open(out / (prefix + "_miRNA.detail.csv")).read() == rep["detail_csv"]
+    assert open(out / (prefix + "_miRNA.precursor.ss")).read() == rep["precursor_ss"]
+    assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
+    for fn, text in exp["readmapping"].items():
+        assert open(out / "readmapping" / fn).read() == text, fn
+    # both pieces exist and together hold every FASTA entry of the reference run
+    got = []
+    for r in range(2):
+        got += open(tmp / (prefix + ".rnalfold.in_%d.fa" % r)).read().splitlines()
+    want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]
+    assert sorted(got) == sorted(want) and len(got) == len(want)

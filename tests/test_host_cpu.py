@@ -151,6 +151,7 @@ def test_fold_stage_retries_with_full_line_capacity():
             return np.array([0, 1, 0], dtype=np.int32) if self.calls[-1][1] == 96 else np.zeros(3, dtype=np.int32)
 
     p = pipeline.Pipeline.__new__(pipeline.Pipeline)
+    p.rank, p.world = 0, 1
     p.ctx, p.opt = StubCtx(), {"PRECURSOR_LEN": 300}
     st = p._fold_device()
     assert p.ctx.calls == [(300, 96), (300, 352)] and (st == 0).all()
@@ -232,6 +233,7 @@ def test_prepare_stage_applies_gff_exclude_mask(tmp_path):
     gff = tmp_path / "ex.gff"
     gff.write_text("##gff-version 3\ncB\ts\tgene\t2000\t9000\t.\t+\t.\tID=a\ncB\ts\tgene\t8000\t12000\t.\t-\t.\tID=b\ncA\ts\tgene\t500\t700\t.\t+\t.\tID=c\n")
     p = pipeline.Pipeline.__new__(pipeline.Pipeline)
+    p.rank, p.world = 0, 1
     p.opt = {"ALIGNMENT_FILE": sams, "GFF_FILE_EXCLUDE": str(gff), "GFF_FILE_INCLUDE": "", "NAME_PREFIX": "t", "OUTFOLDER": str(tmp_path)}
     p.tmp = str(tmp_path)
     p.recovername = str(tmp_path / "t_recover")
