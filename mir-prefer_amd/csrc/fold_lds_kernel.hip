@@ -459,16 +459,24 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (!(dbg_flags & 4)) {
 #define MIRP_GEN(CK)                                                                      \
     switch (role) {                                                                       \
-    case 0: res = a1_generic<CK, 30, 23>(a, i, j, type); break;                           \
-    case 1: res = a1_generic<CK, 29, 24>(a, i, j, type); break;                           \
-    case 2: res = a1_generic<CK, 28, 25>(a, i, j, type); break;                           \
-    case 3: res = a1_generic<CK, 27, 26>(a, i, j, type); break;                           \
+    case 0: res = a1_generic<CK, 30, 23>(a, i, j, type); a1_i1<CK, 28, 29>(a, i, j, xi); break;      \
+    case 1: res = a1_generic<CK, 29, 24>(a, i, j, type); a1_i1<CK, 25, 27>(a, i, j, xi); break;      \
+    case 2: res = a1_generic<CK, 28, 25>(a, i, j, type); a1_i0<CK, 26, 29>(a, i, j, xi); break;      \
+    case 3: res = a1_generic<CK, 27, 26>(a, i, j, type); a1_b1<CK, 26, 30>(a, i, j, xb); break;      \
     case 4: res = a1_generic<CK, 22, 17, 12, 7>(a, i, j, type); break;                    \
     case 5: res = a1_generic<CK, 21, 18, 11, 8>(a, i, j, type); break;                    \
     case 6: res = a1_generic<CK, 20, 16, 13, 9>(a, i, j, type); break;                    \
     default: res = a1_generic<CK, 19, 15, 14, 10, 6>(a, i, j, type); break;               \
     }
+                            // the 2-row generic groups run on the phase-B waves, which have slack left: they also take a few bulge / 1xn shapes
+                            unsigned xb = KEY_INF, xi = KEY_INF;
                             if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
+                            if (role < 4) {
+                                const unsigned rb = a1_key(xb, -32768 - OTH_BIAS + au1);
+                                const unsigned ri = a1_key(xi, -32768 - OTH_BIAS + (int)T.mismatch1nI[type * 25 + S[i + 1] * 5 + S[j - 1]]);
+                                res = rb < res ? rb : res;
+                                res = ri < res ? ri : res;
+                            }
 #undef MIRP_GEN
                         }
                     } else if (role < 14) {
@@ -476,12 +484,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             unsigned bb = KEY_INF, bi = KEY_INF;
 #define MIRP_OTH(CK)                                                                      \
     switch (role) {                                                                       \
-    case 8: a1_b0<CK, 2, 20>(a, i, j, bb); break;                                         \
-    case 9: a1_b0<CK, 21, 30>(a, i, j, bb); a1_b1<CK, 2, 10>(a, i, j, bb); break;         \
-    case 10: a1_b1<CK, 11, 29>(a, i, j, bb); break;                                       \
-    case 11: a1_b1<CK, 30, 30>(a, i, j, bb); a1_i0<CK, 3, 20>(a, i, j, bi); break;        \
-    case 12: a1_i0<CK, 21, 29>(a, i, j, bi); a1_i1<CK, 3, 11>(a, i, j, bi); break;        \
-    default: a1_i1<CK, 12, 29>(a, i, j, bi); break;                                       \
+    case 8: a1_b0<CK, 2, 18>(a, i, j, bb); break;                                         \
+    case 9: a1_b0<CK, 19, 30>(a, i, j, bb); a1_b1<CK, 2, 6>(a, i, j, bb); break;          \
+    case 10: a1_b1<CK, 7, 22>(a, i, j, bb); break;                                        \
+    case 11: a1_b1<CK, 23, 25>(a, i, j, bb); a1_i0<CK, 3, 15>(a, i, j, bi); break;        \
+    case 12: a1_i0<CK, 16, 25>(a, i, j, bi); a1_i1<CK, 3, 8>(a, i, j, bi); break;         \
+    default: a1_i1<CK, 9, 24>(a, i, j, bi); break;                                        \
     }
                             if (a.um >= MAXLOOP) { MIRP_OTH(false) } else { MIRP_OTH(true) }
 #undef MIRP_OTH
