@@ -288,8 +288,8 @@ class Pipeline:
             w = self.ctx.get_windows()
             rname = os.path.join(outdir, prefix + "_reason_why_not_miRNA.txt")
             mine = rname if self.world == 1 else rname + ".part%d" % self.rank
-            write_reasons(mine, w, w["matures"], self.data["names"], rec, self.ctx.get_fold(), self.data["samples"], self.opt["MIN_MATURE_LEN"],
-                          self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"])
+            failed = write_reasons(mine, w, w["matures"], self.data["names"], rec, self.ctx.get_fold(), self.data["samples"],
+                                   self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"])
             if self.world > 1:
                 self._barrier()
                 if self.rank == 0:
@@ -297,6 +297,11 @@ class Pipeline:
                         for rr in range(self.world):
                             with open(rname + ".part%d" % rr) as fi:
                                 fo.write(fi.read())
+            failed = [m for part in self._all_gather(failed) for m in part]
+            if self.rank == 0 and os.path.getsize(rname):          # `if failed_reasons:` (MP:3534): the folder exists even when it stays empty
+                fcounts = mirna_read_counts(failed, self.data["names"], self.data["alns_all"], ns)
+                write_readmapping(failed, dict(self.data["contigs"]), self.data["names"], self.data["alns_all"], self.data["samples"], fcounts,
+                                  os.path.join(outdir, "failed_readmapping"))
         result = [m for part in self._all_gather(result_records(out, self.data["names"])) for m in part]   # rank order, as pieces in the reference
         if self.rank != 0:
             self._barrier()
@@ -551,7 +556,9 @@ def _expression_info_lines(r, samples, allow_3nt):
 
 def write_reasons(path, windows, matures, names, records_arr, fold_raw, samples, min_mature_len, max_mature_len, allow_3nt):
     """Text of write_dict_reasons for the regions that produced no miRNA.  Block order: contig by first appearance, '+' before '-', regions
-    by first appearance (the order of Python dicts under the reference's py3 shim; the py2 original iterates in hash order)."""
+    by first appearance (the order of Python dicts under the reference's py3 shim; the py2 original iterates in hash order).
+    -> the `ss_info` entries of the (mature, structure) pairs that reached the expression test and failed it, in file order: the
+    list the reference hands to gen_mirna_info / gen_map_result for the `failed_readmapping` folder (MP:2561-2567)."""
     win = windows["windows"]
     mat = matures
     per_window, pairs = {}, {}
@@ -581,7 +588,7 @@ def write_reasons(path, windows, matures, names, records_arr, fold_raw, samples,
         peak = "%d-%d" % (W["loc_s"], W["loc_e"])
         head = ["%s:%d-%d\t%s\tpeak-region:%s\t%s" % (chrom, region[0], region[1], strand, peak, which), "PEAK_PASS_DEPTH:PASSED"]
         pw = per_window[w]
-        tail = []
+        tail, failed_here = [], []
         if pw[2] == 0:
             head.append("HAS_STEMLOOP_STRUCTURE:FAILED")
         else:
@@ -605,11 +612,13 @@ def write_reasons(path, windows, matures, names, records_arr, fold_raw, samples,
                         if int(ln["energy"]) > 0:                                         # `if energy > lowest_energy: continue`, lowest stays 0 in a failing region
                             continue
                         ss = fold_raw["ss"][w, r[3], r[4]:r[4] + r[5]].tobytes().decode()
-                        lines = []
+                        lines, info = [], None
                         if r[6] != 0:
                             lines.append(MS_FAIL.get(int(r[6]), "FAIL_STRUCTURE_EXCEPTION") + "\tFAILED")
                         else:
                             f = int(r[7])
+                            if f & 127:                                                   # MP:2281-2340: every expression failure keeps its ss_info
+                                info = [chrom, int(r[8]), int(r[9]), m0, m1, int(r[10]), int(r[11]), ss, strand, not (f & (4 | 8))]
                             if f & 1: lines.append("FAIL_EXPRESS_PATTERN_MATURE_STAR_TOO_CLOSE\tFAILED")
                             if f & 2: lines.append("FAIL_EXPRESS_PATTERN_HAS_STAR_BUT_TOO_FEW_READS_MAPPED_TO_DUPLEX\tFAILED")
                             if f & 4: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_EXPRESSION_DISALLOW_NO_STAR\tFAILED")
@@ -619,14 +628,19 @@ def write_reasons(path, windows, matures, names, records_arr, fold_raw, samples,
                             if f & 64: lines.append("FAIL_EXPRESS_PATTERN_NO_STAR_MATURE_NOT_IN_ALL_SAMPLE\tFAILED")
                             if f & (4 | 8 | 16 | 32 | 64):
                                 lines += _expression_info_lines(r, samples, allow_3nt)
-                        entries[(m0, m1, strand, ss)] = ["MATURE region: %d-%d, SS: %s" % (m0, m1, ss)] + lines
-                for v in entries.values():
+                        entries[(m0, m1, strand, ss)] = (["MATURE region: %d-%d, SS: %s" % (m0, m1, ss)] + lines, info)
+                for v, info in entries.values():
                     tail += v
+                    if info is not None:
+                        failed_here.append(info)
         body = head + ["which:" + which, "peak:" + peak] + tail
-        blocks.setdefault(chrom, {"+": {}, "-": {}})[strand][region] = body
+        blocks.setdefault(chrom, {"+": {}, "-": {}})[strand][region] = (body, failed_here)
+    failed = []
     with open(path, "w") as f:
         for chrom in blocks:
             for strand in ("+", "-"):
-                for region, body in blocks[chrom][strand].items():
+                for region, (body, failed_here) in blocks[chrom][strand].items():
                     f.write("===========================================================\n")
                     f.write("\n".join(body) + "\n\n")
+                    failed += failed_here
+    return failed

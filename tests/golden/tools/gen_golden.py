@@ -190,6 +190,8 @@ def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_or
     rm = os.path.join(out, "readmapping")
     exp["readmapping"] = {fn: open(os.path.join(rm, fn)).read() for fn in sorted(os.listdir(rm))}   # gen_map_result, MP:2907-2959
     exp["reasons_txt"] = open(os.path.join(out, name + "_reason_why_not_miRNA.txt")).read()
+    frm = os.path.join(out, "failed_readmapping")             # write_dict_reasons' gen_map_result over the expression failures (MP:2561-2567)
+    exp["failed_readmapping"] = {fn: open(os.path.join(frm, fn)).read() for fn in sorted(os.listdir(frm))} if os.path.isdir(frm) else None
     d = os.path.join(GOLD, name)
     os.makedirs(d, exist_ok=True)
     for p in [fa] + sams:

@@ -58,6 +58,13 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     for k in want_b:
         assert got_b[k] == want_b[k], k
     assert len(want_b) > 50
+    # failed_readmapping: the read layouts of the (mature, structure) pairs that failed the expression test.  Files are numbered in block
+    # order, so the comparison is over the contents with the running number taken out.
+    def unnumbered(texts):
+        return sorted(t.split(" ", 1)[1] for t in texts)
+    got_f = [open(out / "failed_readmapping" / fn).read() for fn in sorted(os.listdir(out / "failed_readmapping"))]
+    assert unnumbered(got_f) == unnumbered(exp["failed_readmapping"].values())
+    assert all(t.startswith(">miRNA-precursor_") for t in got_f) and len(got_f) >= 3
     assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
     fasta = open(tmp / (prefix + ".rnalfold.in_0.fa")).read().splitlines()
     want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]
@@ -101,6 +108,8 @@ def test_pipeline_verb_sharded_over_two_ranks(tmp_path):
     assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
     for fn, text in exp["readmapping"].items():
         assert open(out / "readmapping" / fn).read() == text, fn
+    got_f = [open(out / "failed_readmapping" / fn).read() for fn in sorted(os.listdir(out / "failed_readmapping"))]
+    assert sorted(t.split(" ", 1)[1] for t in got_f) == sorted(t.split(" ", 1)[1] for t in exp["failed_readmapping"].values())
     # both pieces exist and together hold every FASTA entry of the reference run
     got = []
     for r in range(2):
