@@ -56,6 +56,8 @@ struct LdsTables {          // int16 copies of the hot parameter tables
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
 };
 #define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
+#define MIRP_CK(d) ((d) % 3)
+#define CRING_ROWS 33       // diagonal dd lives in row dd & 31; row 32 mirrors row 0, so "the row after row r" is always r + 1 (phase A1 mixes lanes of two diagonals)
 
 struct LTab {               // table accessors for the shared epilogue/backtrack
     const short* fml;       // triangular fML (per-window global slab in the epilogue kernel)
@@ -117,7 +119,7 @@ __device__ inline void fill_tri_off(int* off, int n) {
 }
 
 struct LdsLayout {
-    unsigned fml, aux, S, seq, pax, qb2, spec, list, off, tabs, misc, total;
+    unsigned fml, aux, S, seq, pax, qb2, list, off, tabs, misc, total;
 };
 __host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
 template <int MODEL>
@@ -125,12 +127,11 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     LdsLayout L{};
     unsigned o = 0;
     L.fml = o; o += lds_al((tri_off(LDMAX + 1, LCAP) + 2) * 2);                           // fML triangle, d = 4..LDMAX at n = LCAP
-    L.aux = o; o += lds_al(32 * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + 4 * LCAP * 4);   // c ring (32 diagonals), DML ring (3; 5 in the vienna-1.8.5 model), 2 x {ckey, mdec}
+    L.aux = o; o += lds_al(CRING_ROWS * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + 5 * LCAP * 4);   // c ring (32 diagonals + mirror row), DML ring (3; 5 in the vienna-1.8.5 model), 3 x ckey, 2 x mdec
     L.S = o; o += lds_al(LCAP + 8);
     L.seq = o; o += lds_al(LCAP + 8);
     L.pax = o; o += lds_al((LCAP + 8) * 2);
     L.qb2 = o; o += lds_al(LCAP + 8);
-    L.spec = o; o += lds_al(3 * (LCAP + 8) * 2);
     L.list = o; o += lds_al(3 * LSEG * 2);
     L.off = o; o += lds_al((LDMAX + 2) * 4);
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
@@ -306,21 +307,35 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     long long wB = 0, wA1 = 0, wA2 = 0, wW = 0, wt = 0; // per-wave: phase B, interior loops, multiloop splits, barrier wait (lane 0 of each wave)
     unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
     unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
-    short* dmlring = (short*)(cring + 32 * CSTR);                   // [DMLR][LCAP] int16
-    int* acc = (int*)(dmlring + DMLR * LCAP);                          // [2 (diagonal parity)][2 (cpart, mdec)][LCAP]
+    short* dmlring = (short*)(cring + CRING_ROWS * CSTR);           // [DMLR][LCAP] int16
+    int* acc = (int*)(dmlring + DMLR * LCAP);                          // ckey[3 (diagonal % 3)][LCAP], then mdec[2 (diagonal parity)][LCAP]
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
     unsigned short* pax = (unsigned short*)(smem + LY.pax);
     unsigned char* qbr = smem + LY.qb2;
-    short* spec = (short*)(smem + LY.spec);
-    unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LSEG]: i | type << 9, list of diagonal d in buffer d % 3, segment w = producer wave w
+    // special-hairpin energies by start position (tri-, tetra-, hexaloops): only read on diagonals 4, 5 and 7, so they borrow the ring rows
+    // of diagonals 29-31, which are first written on diagonal 29
+    short* spec = (short*)(cring + 29 * CSTR);
+    unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LSEG]: i | type << 9, paired cells of diagonal d in buffer d % 3 (compact, unordered)
     int* off = (int*)(smem + LY.off);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
-    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16 + 8 b + w: entries in segment w of list buffer b
-    int* lcnt = misc + 16;
+    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16..21: list lengths
+    int* lcnt = misc + 16;                                          // [6]: entries in the list of diagonal d at d % 6
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nc = LCAP + 8;
+    const int nc = CSTR;
+    // Appends this thread's cell (i, pair type t; t = 0: none) to the paired-cell list of diagonal dd: ballot compaction inside the wave, one
+    // LDS atomic per wave for its range.  The order of the ranges depends on which wave arrives first; nothing depends on the order of a
+    // list, only on it staying fixed once built.
+    auto list_append = [&](int dd, int i, int t) {
+        const unsigned long long bal = __ballot(t != 0);
+        if (bal) {      // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&lcnt[dd % 6], (int)__popcll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (t) list[(dd % 3) * LSEG + base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(i | (t << 9));
+        }
+    };
 
     // ---- one-time: hot parameter tables into LDS
     for (int x = tid; x < 64; x += LNT) T.stack[x] = (short)min(P->stack[x >> 3][x & 7], (int)I16_INF);
@@ -379,10 +394,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
         for (int x = tid; x < DMLR * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
-        for (int x = tid; x < 4 * LCAP; x += LNT) acc[x] = ((x / LCAP) & 1) ? INF : (int)KEY_NONE;   // [parity][ckey | mdec]
+        for (int x = tid; x < 5 * LCAP; x += LNT) acc[x] = x >= 3 * LCAP ? INF : (int)KEY_NONE;   // ckey x 3 | mdec x 2
         if (tid == 0) {
             fill_tri_off(off, n);
             misc[1] = 0;
+            for (int x = 0; x < 6; x++) lcnt[x] = 0;
         }
         __syncthreads();
         if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
@@ -404,39 +420,51 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 qbr[n + 1 - x] = (unsigned char)((S[x] * 5 + (x < n ? S[x + 1] : 0)) * 2);
             }
         }
-        // ordered paired-cell lists of the first two diagonals (ballot compaction; list of diagonal d lives in buffer d % 3)
-        for (int dd = 4; dd <= 5 && dd <= D; dd++) {
-            const int i = tid + 1;
+        // paired-cell lists of the first three diagonals (list of diagonal d lives in buffer d % 3, its length in lcnt[d % 6])
+        for (int dd = 4; dd <= 6 && dd <= D; dd++) {
             int t = 0;
-            if (tid < n - dd) t = pair_type(S[i], S[i + dd]);
-            const unsigned long long bal = __ballot(t != 0);
-            if (t) list[(dd % 3) * LSEG + wave * 64 + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(i | (t << 9));
-            if (lane == 0 && wave < 6) lcnt[(dd % 3) * 8 + wave] = __popcll(bal);
+            if (tid < n - dd) t = pair_type(S[tid + 1], S[tid + 1 + dd]);
+            list_append(dd, tid + 1, t);
         }
         __syncthreads();
 
         if (dbg_cycles && tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; }
         // ---- anti-diagonal wavefront, software-pipelined: phase B of diagonal d (one thread per cell) runs in the same barrier
         // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
+        int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
-            unsigned* ckey = reinterpret_cast<unsigned*>(acc + (d & 1) * 2 * LCAP);   // best interior-loop candidate key per cell
-            int* mdec = acc + (d & 1) * 2 * LCAP + LCAP;
+            unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);   // best interior-loop candidate key per cell
+            int* mdec = acc + (3 + (d & 1)) * LCAP;
             if (dbg_cycles && lane == 0) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
             if (!(dbg_flags & (1 | 64)) && d >= 6 && d <= D) {
                 const unsigned short* clist = list + (d % 3) * LSEG;
-                const int* lc = lcnt + (d % 3) * 8;
-                const int p1 = __builtin_amdgcn_readfirstlane(lc[0]), p2 = p1 + __builtin_amdgcn_readfirstlane(lc[1]),
-                          p3 = p2 + __builtin_amdgcn_readfirstlane(lc[2]), p4 = p3 + __builtin_amdgcn_readfirstlane(lc[3]),
-                          p5 = p4 + __builtin_amdgcn_readfirstlane(lc[4]), ncp = p5 + __builtin_amdgcn_readfirstlane(lc[5]);
+                // Lane fill: the blocks of 64 paired cells of diagonal d are topped up with the first cells of diagonal d+1.  All candidates of
+                // a cell of d+1 except the stacked pair have their inner pair on diagonals <= d-2, which are final in this interval; the stacked
+                // pair follows one interval later (`done` cells below).  Such a lane differs only in j = i + d + 1 and in its ring rows, which
+                // are the rows after those of diagonal d (CRING_ROWS).  Only once every loop size is admissible (um = MAXLOOP for both).
+                const bool mix = d - 2 - (TURN + 1) >= MAXLOOP && d + 1 <= D && !(dbg_flags & 256);
+                const int ncp = __builtin_amdgcn_readfirstlane(lcnt[d % 6]), ncp2 = __builtin_amdgcn_readfirstlane(lcnt[(d + 1) % 6]);
+                const int done = a1_done;                  // leading cells of this diagonal's list that were relaxed in the previous interval
+                const int rem = ncp - done;
+                const int nblk = (rem + 63) >> 6;
+                const int room = nblk * 64 - rem;          // < 64: idle lanes of the last block
+                const int take2 = mix ? (room < ncp2 ? room : ncp2) : 0;
+                a1_done = take2;
+                unsigned* ckey2 = reinterpret_cast<unsigned*>(acc + MIRP_CK(d + 1) * LCAP);
+                unsigned aent = 0;                         // list entry of a lane that goes ahead in the last block (0: none)
+                {
+                    const int ka = lane - (64 - room);
+                    if (ka >= 0 && ka < take2) aent = list[((d + 1) % 3) * LSEG + ka];
+                }
                 // roles (0-7: generic rows, 8-13: bulges / 1xn, 14-15: small shapes), measured job costs (MIRP_FOLD_CLOCKS): generic 2-row < small
                 // shapes < generic 4-row < bulges / 1xn.  Phase B of the previous diagonal runs on waves 0-5 (one thread per cell, wave 0 always,
                 // wave 5 rarely), so those waves take the cheapest jobs.
                 const int role = wave < 4 ? wave : wave < 6 ? wave + 10 : wave < 12 ? wave + 2 : wave - 8;
                 A1 a;
                 a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
-                for (int blk = 0; blk * 64 < ncp; blk++) {
+                for (int blk = 0; blk < nblk; blk++) {
                     {   // re-materialise the wave-uniform loop parameters per block: keeps the admissibility tests and row offsets as plain
                         // scalar compares inside the block instead of dozens of hoisted masks (SGPR spills)
                         int r0 = d - 2, um = d - 2 - (TURN + 1) < MAXLOOP ? d - 2 - (TURN + 1) : MAXLOOP;
@@ -444,15 +472,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         a.r0 = r0; a.um = um;
                     }
                     const int k = blk * 64 + lane;
-                    const bool act = k < ncp;
-                    int pre = 0, seg = 0;
-                    if (k >= p1) { pre = p1; seg = 64; }
-                    if (k >= p2) { pre = p2; seg = 128; }
-                    if (k >= p3) { pre = p3; seg = 192; }
-                    if (k >= p4) { pre = p4; seg = 256; }
-                    if (k >= p5) { pre = p5; seg = 320; }
-                    const unsigned ent = act ? (unsigned)clist[seg + k - pre] : (1u | (1u << 9));   // idle lanes: harmless dummy cell
-                    const int i = ent & 511, type = ent >> 9, j = i + d;
+                    const bool own = k < rem, ahead = !own && aent != 0;       // k >= rem only happens in the last block
+                    const bool act = own || ahead;
+                    const unsigned ent = own ? (unsigned)clist[done + k] : ahead ? aent : (1u | (1u << 9));   // idle lanes: harmless dummy cell
+                    const int i = ent & 511, type = ent >> 9, j = i + d + (ahead ? 1 : 0);
+                    a.cring = cring + (ahead ? CSTR : 0);
+                    unsigned* ck = ahead ? ckey2 : ckey;
                     unsigned res = KEY_NONE;
                     const int au1 = type > 2 ? (int)T.TerminalAU : 0;
                     if (role < 8) {
@@ -503,7 +528,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         unsigned ka, kb2;
                         if (role == 14) {
                             a1_small_g<1, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<1, 2>(a, i, j, type, si1, sj1, rb2, cb2);
-                            a1_small<0, 0>(a, i, j, type, si1, sj1, res); a1_small<0, 1>(a, i, j, type, si1, sj1, res); a1_small<1, 0>(a, i, j, type, si1, sj1, res);
+                            unsigned r00 = KEY_NONE;
+                            a1_small<0, 0>(a, i, j, type, si1, sj1, r00); a1_small<0, 1>(a, i, j, type, si1, sj1, res); a1_small<1, 0>(a, i, j, type, si1, sj1, res);
+                            if (!ahead) res = r00 < res ? r00 : res;          // the stacked pair of a lane of diagonal d+1 is not final yet
                             ka = 1 << 5 | 1; kb2 = 1 << 5 | 2;
                         } else {
                             a1_small_g<2, 1>(a, i, j, type, si1, sj1, ra, ca); a1_small_g<2, 2>(a, i, j, type, si1, sj1, rb2, cb2);
@@ -513,7 +540,23 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (ca < INF) { const unsigned k = ((unsigned)(ra + ca + KEY_BIAS) << 10) | ka; res = k < res ? k : res; }
                         if (cb2 < INF) { const unsigned k = ((unsigned)(rb2 + cb2 + KEY_BIAS) << 10) | kb2; res = k < res ? k : res; }
                     }
+                    if (act && res != KEY_NONE) atomicMin(&ck[i], res);
+                }
+                if (role == 14 && done > 0 && !(dbg_flags & 32)) {   // stacked pairs of the cells that went ahead in the previous interval (done <= 63)
+                    const bool act = lane < done;
+                    const unsigned ent = act ? (unsigned)clist[lane] : (1u | (1u << 9));
+                    const int i = ent & 511, type = ent >> 9, j = i + d;
+                    int r0 = d - 2, um = MAXLOOP;
+                    asm volatile("" : "+s"(r0), "+s"(um));
+                    a.r0 = r0; a.um = um; a.cring = cring;
+                    unsigned res = KEY_NONE;
+                    a1_small<0, 0>(a, i, j, type, S[i + 1], S[j - 1], res);
                     if (act && res != KEY_NONE) atomicMin(&ckey[i], res);
+                }
+                if (dbg_cycles && lane == 0 && wave == 9) {   // diagnostics: interior-loop time of one wave by number of blocks
+                    const int b = nblk < 3 ? nblk : 3;
+                    atomicAdd((unsigned long long*)&dbg_cycles[68 + b], (unsigned long long)(clock64() - wt));
+                    atomicAdd((unsigned long long*)&dbg_cycles[72 + b], 1ull);
                 }
             }
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA1 += t - wt; wt = t; }
@@ -593,11 +636,16 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         };
         auto phaseB = [&](const int d) {
             const int ncell = n - d;
-            unsigned* ckey = reinterpret_cast<unsigned*>(acc + (d & 1) * 2 * LCAP);
-            int* mdec = acc + (d & 1) * 2 * LCAP + LCAP;
+            unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
+            int* mdec = acc + (3 + (d & 1)) * LCAP;
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
-            int lt = 0;          // pair type of this thread's cell on diagonal d+2 (0: not in the list)
             const int x = tid;
+            if (d + 3 <= D && wave < 6) {   // paired-cell list of diagonal d+3 (phase A1 of this interval reads those of d+1 and d+2); first, so that the
+                int lt = 0;                 // atomic's latency is covered by the cell work below
+                if (x + 1 + d + 3 <= n) lt = pair_type(S[x + 1], S[x + 1 + d + 3]);
+                list_append(d + 3, x + 1, lt);
+            }
+            if (tid == 0) lcnt[(d + 4) % 6] = 0;   // the list of diagonal d-2 is dead: its counter serves diagonal d+4 in the next interval
             if (x < ncell) {
                 const int i = x + 1, j = i + d;
                 const int type = (MODEL && d > D) ? 0 : pair_type(S[i], S[j]);
@@ -682,18 +730,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     unsigned short g16 = 65535;
                     if (cv < INF) g16 = (unsigned short)(cv + T.mismatchI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] + 32768);
                     cring[(d & 31) * CSTR + i] = g16;
+                    if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
                 }
                 carch[off[d] + i] = c16;
                 tb_out[off[d] + i] = (unsigned short)tb;
                 fml[off[d] + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 ckey[i] = KEY_NONE; mdec[i] = INF;
-                if (d + 2 <= D && i + d + 2 <= n) lt = pair_type(S[i], S[i + d + 2]);
-            }
-            if (d + 2 <= D) {   // ordered paired-cell list of diagonal d+2: ballot compaction per producer wave
-                const unsigned long long bal = __ballot(lt != 0);
-                if (lt) list[((d + 2) % 3) * LSEG + wave * 64 + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
-                if (lane == 0 && wave < 6) lcnt[((d + 2) % 3) * 8 + wave] = __popcll(bal);
             }
         };
         if (Dm >= 4) phaseA(4);

@@ -279,13 +279,15 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 2, h.size(), f); std::fclose(f); }
         }
         if (dbg_cycles) {
-            long long cyc[4 + 64];
+            long long cyc[4 + 64 + 8];
             HIPCHK(c, hipMemcpy(cyc, dbg_cycles, sizeof(cyc), hipMemcpyDeviceToHost));
             std::fprintf(stderr, "[mirp fold clocks] windows=%d setup=%lld fillA=%lld fillB=%lld writeout=%lld (sum over workgroups, s_memtime ticks)\n", n_work,
                          cyc[0], cyc[1], cyc[2], cyc[3]);
             for (int w = 0; w < 16; w++)
                 std::fprintf(stderr, "[mirp fold clocks] wave %2d: phaseB=%lld interior=%lld splits=%lld barrier=%lld\n", w, cyc[4 + 4 * w], cyc[5 + 4 * w], cyc[6 + 4 * w],
                              cyc[7 + 4 * w]);
+            for (int b = 0; b < 4; b++)
+                std::fprintf(stderr, "[mirp fold clocks] wave 9, diagonals with %d%s blocks: %lld, interior ticks %lld\n", b, b == 3 ? "+" : "", cyc[72 + b], cyc[68 + b]);
         }
         if (nfb == 0) return 0;
         work_list = (const int*)c->flist.p;
