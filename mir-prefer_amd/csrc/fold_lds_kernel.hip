@@ -119,7 +119,7 @@ __device__ inline void fill_tri_off(int* off, int n) {
 }
 
 struct LdsLayout {
-    unsigned fml, aux, S, seq, pax, qb2, list, off, tabs, misc, total;
+    unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total;
 };
 __host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
 template <int MODEL>
@@ -133,7 +133,6 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.pax = o; o += lds_al((LCAP + 8) * 2);
     L.qb2 = o; o += lds_al(LCAP + 8);
     L.list = o; o += lds_al(3 * LSEG * 2);
-    L.off = o; o += lds_al((LDMAX + 2) * 4);
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
     L.misc = o; o += lds_al(48 * 4);
     L.total = o;
@@ -317,7 +316,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     // of diagonals 29-31, which are first written on diagonal 29
     short* spec = (short*)(cring + 29 * CSTR);
     unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LSEG]: i | type << 9, paired cells of diagonal d in buffer d % 3 (compact, unordered)
-    int* off = (int*)(smem + LY.off);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
     int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16..21: list lengths
     int* lcnt = misc + 16;                                          // [6]: entries in the list of diagonal d at d % 6
@@ -396,7 +394,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         for (int x = tid; x < DMLR * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
         for (int x = tid; x < 5 * LCAP; x += LNT) acc[x] = x >= 3 * LCAP ? INF : (int)KEY_NONE;   // ckey x 3 | mdec x 2
         if (tid == 0) {
-            fill_tri_off(off, n);
             misc[1] = 0;
             for (int x = 0; x < 6; x++) lcnt[x] = 0;
         }
@@ -432,6 +429,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // ---- anti-diagonal wavefront, software-pipelined: phase B of diagonal d (one thread per cell) runs in the same barrier
         // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
         int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
+        int a1_ncp = __builtin_amdgcn_readfirstlane(lcnt[0]);   // phase A1: length of the next diagonal's list (first: diagonal 6)
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);   // best interior-loop candidate key per cell
@@ -445,10 +443,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 // pair follows one interval later (`done` cells below).  Such a lane differs only in j = i + d + 1 and in its ring rows, which
                 // are the rows after those of diagonal d (CRING_ROWS).  Only once every loop size is admissible (um = MAXLOOP for both).
                 const bool mix = d - 2 - (TURN + 1) >= MAXLOOP && d + 1 <= D && !(dbg_flags & 256);
-                const int ncp = __builtin_amdgcn_readfirstlane(lcnt[d % 6]), ncp2 = __builtin_amdgcn_readfirstlane(lcnt[(d + 1) % 6]);
+                // the length of this list is known since the previous interval (a1_ncp); the first block's entries are fetched before anything
+                // else: every dependent LDS access in front of the shape code costs hundreds of cycles when the pipe is loaded
+                const int ncp = __builtin_amdgcn_readfirstlane(lcnt[d % 6]);
                 const int done = a1_done;                  // leading cells of this diagonal's list that were relaxed in the previous interval
                 const int rem = ncp - done;
                 const int nblk = (rem + 63) >> 6;
+                const int ncp2 = __builtin_amdgcn_readfirstlane(lcnt[(d + 1) % 6]);
+                a1_ncp = ncp2;
                 const int room = nblk * 64 - rem;          // < 64: idle lanes of the last block
                 const int take2 = mix ? (room < ncp2 ? room : ncp2) : 0;
                 a1_done = take2;
@@ -639,11 +641,16 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
             int* mdec = acc + (3 + (d & 1)) * LCAP;
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
+            const int od = tri_off(d, n), od1 = tri_off(d - 1, n);     // scalar arithmetic instead of a table read on the cell's dependency chain
             const int x = tid;
-            if (d + 3 <= D && wave < 6) {   // paired-cell list of diagonal d+3 (phase A1 of this interval reads those of d+1 and d+2); first, so that the
-                int lt = 0;                 // atomic's latency is covered by the cell work below
+            // paired-cell list of diagonal d+3 (phase A1 of this interval reads those of d+1 and d+2): the range is claimed first, the entry is
+            // written at the end, so that the atomic's latency is covered by the cell work in between
+            int lt = 0, lbase = 0;
+            unsigned long long lbal = 0;
+            if (d + 3 <= D && wave < 6) {
                 if (x + 1 + d + 3 <= n) lt = pair_type(S[x + 1], S[x + 1 + d + 3]);
-                list_append(d + 3, x + 1, lt);
+                lbal = __ballot(lt != 0);
+                if (lbal && lane == 0) lbase = atomicAdd(&lcnt[(d + 3) % 6], (int)__popcll(lbal));
             }
             if (tid == 0) lcnt[(d + 4) % 6] = 0;   // the list of diagonal d-2 is dead: its counter serves diagonal d+4 in the next interval
             if (x < ncell) {
@@ -694,7 +701,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 }
                 int m = INF;
                 if (d > 4) {
-                    int a = fml[off[d - 1] + i], b = fml[off[d - 1] + i + 1];
+                    int a = fml[od1 + i], b = fml[od1 + i + 1];
                     a = a == 65535 ? INF : a - FML_BIAS; b = b == 65535 ? INF : b - FML_BIAS;
                     m = a < b ? a : b;
                 }
@@ -732,12 +739,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     cring[(d & 31) * CSTR + i] = g16;
                     if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
                 }
-                carch[off[d] + i] = c16;
-                tb_out[off[d] + i] = (unsigned short)tb;
-                fml[off[d] + i] = m16;
+                carch[od + i] = c16;
+                tb_out[od + i] = (unsigned short)tb;
+                fml[od + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 ckey[i] = KEY_NONE; mdec[i] = INF;
             }
+            const int lb = __builtin_amdgcn_readfirstlane(lbase);      // lane 0 holds the claimed range
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
         };
         if (Dm >= 4) phaseA(4);
         __syncthreads();
@@ -760,7 +769,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         } else {
             // hand the tables to the epilogue kernel: c was archived on the fly, fML is copied out now (coalesced dwords)
             int tri = 0;
-            if (Dm >= 4) tri = off[Dm + 1] + 1;
+            if (Dm >= 4) tri = tri_off(Dm + 1, n) + 1;
             const unsigned int* src = reinterpret_cast<const unsigned int*>(fml);
             unsigned int* dst = reinterpret_cast<unsigned int*>(fml_out);
             for (int x = tid; x < (tri + 1) / 2; x += LNT) dst[x] = src[x];
