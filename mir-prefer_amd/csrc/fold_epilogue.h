@@ -233,6 +233,26 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
         }
         // (i,j) is a traced pair: follow stacks / interior loops until a hairpin or a multiloop
         for (;;) {
+            // With trace-back codes the chain is followed a whole helix per memory round trip: lane l fetches the code of (i+l, j-l); stacked
+            // pairs and symmetric loops stay on that line, so the walk below only goes back to memory after an asymmetric loop.  A code > 0
+            // also says that the hairpin does not realise c, so no energy is read along the way.
+            {
+                const int il = i + lane, jl = j - lane;
+                int cl = (jl - il >= TURN + 1) ? T.TB(jl - il, il) : 0;
+                if (__builtin_amdgcn_readfirstlane(cl) > 0) {
+                    int pos = 0;
+                    for (;;) {
+                        const int c = __builtin_amdgcn_readlane(cl, pos);
+                        if (c <= 0) break;                                  // (i,j) = line position pos: hairpin or multiloop
+                        const int n1 = (c - 1) >> 5, n2 = (c - 1) & 31;
+                        i += 1 + n1; j -= 1 + n2;
+                        if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+                        if (n1 != n2 || pos + 1 + n1 > 63) { pos = -1; break; }   // off the line (or past it): fetch again
+                        pos += 1 + n1;
+                    }
+                    if (pos < 0) continue;
+                }
+            }
             int type = ptype_at(X, i, j);
             int cij = T.C(j - i, i);
             if (cij == e_hairpin(X, i, j, type)) break;
@@ -320,36 +340,46 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     // are idle here and serve as scratch: part[NW], inner[NW][NW].
     constexpr int NW = NT / 64;
     constexpr int RB = 32;   // rows per block: 32 consecutive i share their cache lines of every archived diagonal
+    static_assert(RB == 32, "step 1 maps a half-wave onto the rows of a block");
     static_assert((RB + RB * RB) * 4 <= NW * 3 * BT_STACK * 4, "f3 scratch must fit the backtrack stacks");
     int* part = btstk;
     int* inner = btstk + RB;
     for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
     __syncthreads();
     for (int i_hi = n - TURN - 1; i_hi >= 1; i_hi -= RB) {
-        for (int r = wave; r < RB; r += NW) {
+        // Step 1 walks the block diagonal by diagonal: a half-wave holds the RB rows (lane = row), so its 32 cells of one archived diagonal
+        // are one contiguous 64-byte read that is consumed at once (row-major order re-fetched every line once per row from HBM when
+        // hundreds of windows share an L2).  Waves and half-waves stride over the diagonals; the per-row minima meet in LDS.
+        for (int x = tid; x < RB + RB * RB; x += NT) part[x] = INF;      // part[RB] and inner[RB][RB] are contiguous
+        __syncthreads();
+        {
+            const int r = lane & (RB - 1);
             const int i = i_hi - r;
-            if (i < 1) break;
             int best = INF;
-            const int jmax = (i + D < n) ? i + D : n;
-            const int j0 = (i + TURN + 1 > i_hi) ? i + TURN + 1 : i_hi;    // f3[j+1] final for j >= i_hi
-            for (int j = j0 + lane; j <= jmax; j += 64) {
-                int type = pair_type(X.S[i], X.S[j]);
-                if (type) {
-                    int e = f3[j + 1] + T.C(j - i, i) + ext_term(X, i, j, type);
-                    best = e < best ? e : best;
+            if (i >= 1) {
+                const int si = X.S[i];
+                constexpr int UNR = 8;      // archive reads in flight per lane: the sweep is a chain of memory round trips otherwise
+                for (int d0 = TURN + 1 + 2 * wave + (lane >> 5); d0 <= D && i + d0 <= n; d0 += 2 * NW * UNR) {
+                    int cv[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const int d = d0 + u * 2 * NW;
+                        cv[u] = (d <= D && i + d <= n) ? T.C(d, i) : INF;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const int d = d0 + u * 2 * NW, j = i + d;
+                        if (cv[u] >= INF) continue;
+                        const int type = pair_type(si, X.S[j]);
+                        if (type) {
+                            const int e = cv[u] + ext_term(X, i, j, type);
+                            if (j >= i_hi) { const int c = e + f3[j + 1]; best = c < best ? c : best; }   // f3[j+1] final: j+1 above the block
+                            else inner[r * RB + d - TURN - 1] = e;                                         // partner inside the block
+                        }
+                    }
                 }
             }
-            best = wave_min(best);
-            if (lane == 0) part[r] = best;
-            if (lane < RB) {                                             // partners inside the block: j = i+TURN+1+lane <= i_hi-1
-                const int j = i + TURN + 1 + lane;
-                int e = INF;
-                if (j <= i_hi - 1 && j <= jmax) {
-                    int type = pair_type(X.S[i], X.S[j]);
-                    if (type) e = T.C(j - i, i) + ext_term(X, i, j, type);
-                }
-                inner[r * RB + lane] = e;
-            }
+            if (best < INF) atomicMin(&part[r], best);
         }
         __syncthreads();
         if (wave == 0) {
