@@ -182,6 +182,24 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
         }
         // (i,j) is a traced pair: follow stacks / interior loops until a hairpin or a multiloop
         for (;;) {
+            // with trace-back codes the chain is followed a whole helix per memory round trip (see backtrack_wave in fold_epilogue.h)
+            {
+                const int il = i + lane, jl = j - lane;
+                int cl = (jl - il >= V_TURN + 1) ? T.TB(il, jl) : 0;
+                if (__builtin_amdgcn_readfirstlane(cl) > 0) {
+                    int pos = 0;
+                    for (;;) {
+                        const int c = __builtin_amdgcn_readlane(cl, pos);
+                        if (c <= 0) break;
+                        const int n1 = (c - 1) >> 5, n2 = (c - 1) & 31;
+                        i += 1 + n1; j -= 1 + n2;
+                        if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+                        if (n1 != n2 || pos + 1 + n1 > 63) { pos = -1; break; }
+                        pos += 1 + n1;
+                    }
+                    if (pos < 0) continue;
+                }
+            }
             const int type = ptype(X, i, j);
             const int cij = T.C(i, j);
             if (cij == hairpin(X, i, j, type)) break;
@@ -260,38 +278,78 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
     const int n = X.n, M = X.M;
     const PT* __restrict__ P = X.P;
     const unsigned char* S = X.S;
-        // ---- exterior sweep, sequential in i, partners j reduced in parallel
-        for (int i = n - V_TURN - 1; i >= 1; i--) {
-            int best = V_INF;
-            const int jmax = (i + M < n) ? i + M : n;
-            for (int j = i + V_TURN + 1 + tid; j <= jmax; j += NT) {
-                int t = ptype(X, i, j);
-                if (t) {
-                    const int e = T.C(i, j) + AU(X, t);
-                    if (j < n) {
-                        int v = f3[j + 1] + e; best = v < best ? v : best;
-                        v = f3[j + 2] + e + P->dangle3[t][S[j + 1]]; best = v < best ? v : best;
-                    } else best = e < best ? e : best;
+        // ---- exterior sweep: f3[i] = min(f3[i+1], min_j { c(i,j), c(i+1,j) + dangle5 } + AU, continued by f3[j+1] or dangle3 + f3[j+2]) is sequential in i only
+        // through f3, so rows go in blocks of RB.  Step 1 (all waves): a half-wave holds the rows of the block (lane = row) and walks the partners
+        // diagonal by diagonal -- its 32 cells of one archived diagonal are one contiguous read.  Partners at or above the block top have
+        // final f3 values and are reduced to one minimum per row; the few partners inside the block leave their two terms in LDS.  Step 2
+        // (wave 0): the short sequential chain through the block touches LDS only.  The backtrack stacks are idle here and serve as scratch.
+        {
+            constexpr int NW = NT / 64, RB = 32;
+            static_assert(RB + 2 * RB * RB <= NW * 3 * V_BT_STACK, "exterior-sweep scratch must fit the backtrack stacks");
+            int* part = btstk;                  // [RB] per-row minimum over the partners with final f3
+            int* innerA = btstk + RB;           // [RB][RB] term continued by f3[j+1]
+            int* innerB = innerA + RB * RB;     // [RB][RB] term continued by f3[j+2] (3' dangle)
+            for (int i_hi = n - V_TURN - 1; i_hi >= 1; i_hi -= RB) {
+                for (int x = tid; x < RB + 2 * RB * RB; x += NT) part[x] = V_INF;
+                __syncthreads();
+                {
+                    const int r = lane & (RB - 1), i = i_hi - r;
+                    int best = V_INF;
+                    if (i >= 1) {
+                        const int jmax = (i + M < n) ? i + M : n;
+                        for (int d = V_TURN + 1 + 2 * wave + (lane >> 5); i + d <= jmax; d += 2 * NW) {
+                            const int j = i + d;
+                            int a = V_INF, b = V_INF;
+                            int t = ptype(X, i, j);
+                            if (t) {
+                                const int e = T.C(i, j) + AU(X, t);
+                                a = e;
+                                if (j < n) b = e + P->dangle3[t][S[j + 1]];
+                            }
+                            t = ptype(X, i + 1, j);
+                            if (t) {
+                                const int e = T.C(i + 1, j) + P->dangle5[t][S[i]] + AU(X, t);
+                                a = e < a ? e : a;
+                                if (j < n) { const int v = e + P->dangle3[t][S[j + 1]]; b = v < b ? v : b; }
+                            }
+                            if (a < V_INF) {
+                                if (j >= i_hi) {        // f3[j+1], f3[j+2] final (f3[n+1] = f3[n+2] = 0)
+                                    int v = f3[j + 1] + a; best = v < best ? v : best;
+                                    if (j < n) { v = f3[j + 2] + b; best = v < best ? v : best; }
+                                } else {
+                                    innerA[r * RB + d - V_TURN - 1] = a;
+                                    innerB[r * RB + d - V_TURN - 1] = b;
+                                }
+                            }
+                        }
+                    }
+                    if (best < V_INF) atomicMin(&part[r], best);
                 }
-                t = ptype(X, i + 1, j);
-                if (t) {
-                    const int e = T.C(i + 1, j) + P->dangle5[t][S[i]] + AU(X, t);
-                    if (j < n) {
-                        int v = f3[j + 1] + e; best = v < best ? v : best;
-                        v = f3[j + 2] + e + P->dangle3[t][S[j + 1]]; best = v < best ? v : best;
-                    } else best = e < best ? e : best;
-                }
-            }
+                __syncthreads();
+                if (wave == 0) {
+                    const int i_lo = (i_hi - RB + 1 > 1) ? i_hi - RB + 1 : 1;
+                    for (int r = i_hi; r >= i_lo; r--) {
+                        const int w = i_hi - r;
+                        int best = f3[r + 1];
+                        const int p = part[w];
+                        best = p < best ? p : best;
+                        if (lane < RB) {
+                            const int a = innerA[w * RB + lane];
+                            if (a < V_INF) {
+                                const int j = r + V_TURN + 1 + lane;
+                                int v = a + f3[j + 1]; best = v < best ? v : best;
+                                v = innerB[w * RB + lane] + f3[j + 2]; best = v < best ? v : best;
+                            }
+                        }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(best, o); best = t < best ? t : best; }
-            if (lane == 0) red[wave] = best;
-            __syncthreads();
-            if (tid == 0) {
-                int b = f3[i + 1];
-                for (int w = 0; w < NT / 64; w++) b = red[w] < b ? red[w] : b;
-                f3[i] = b;
+                        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(best, o); best = t < best ? t : best; }
+                        if (lane == 0) f3[r] = best;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
 
         // ---- structure starts, descending: l >= 2 with f3[l] != f3[l+1] && f3[l-1] == f3[l]; l == 1 with f3[1] != f3[2], or when there is
