@@ -143,7 +143,16 @@ __device__ __forceinline__ int wave_min(int v) {
 // first set lane of a 64-bit ballot, or -1
 __device__ __forceinline__ int first_lane(unsigned long long mask) { return mask ? (__ffsll((long long)mask) - 1) : -1; }
 
+#ifdef MIRP_EPI_CLOCKS     // diagnostics build: phase clocks of wave 0 (lane 0) of every epilogue workgroup
+static __device__ unsigned long long g_epi_clk[16];
+#define EPI_T0() long long _t = clock64()
+#define EPI_T(k) do { if (threadIdx.x == 0) { const long long _n = clock64(); atomicAdd(&g_epi_clk[k], (unsigned long long)(_n - _t)); _t = _n; } else { _t = clock64(); } } while (0)
+#else
+#define EPI_T0() do {} while (0)
+#define EPI_T(k) do {} while (0)
+#endif
 #define BT_STACK 96
+#define BT_LINE 16      // cells of a helix line fetched per round trip (each is its own cache line of the trace-back triangle)
 
 // Wave-cooperative backtrack of one locally optimal structure (all 64 lanes call it with
 // wave-uniform arguments).  buf: per-wave LDS char buffer; stk: per-wave LDS sector stack.
@@ -174,10 +183,12 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
                 continue;
             }
             int found = -1;
-            for (int kb = j; kb >= i + TURN + 1 && found < 0; kb -= 64) {
+            // descending scan; the caller's j is its own hit + 2 for the first segment, so the top four candidates are probed alone first
+            // (every lane of a round pulls its own cache line of the archive: a full round costs 64 lines)
+            for (int kb = j, width = 4; kb >= i + TURN + 1 && found < 0; kb -= width, width = 64) {
                 int k = kb - lane;
                 bool ok = false;
-                if (k >= i + TURN + 1) {
+                if (lane < width && k >= i + TURN + 1) {
                     int type = ptype_at(X, i, k);
                     if (type) ok = (fij == T.C(k - i, i) + ext_term(X, i, k, type) + X.f3[k + 1]);
                 }
@@ -238,7 +249,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             // also says that the hairpin does not realise c, so no energy is read along the way.
             {
                 const int il = i + lane, jl = j - lane;
-                int cl = (jl - il >= TURN + 1) ? T.TB(jl - il, il) : 0;
+                int cl = (lane < BT_LINE && jl - il >= TURN + 1) ? T.TB(jl - il, il) : 0;
                 if (__builtin_amdgcn_readfirstlane(cl) > 0) {
                     int pos = 0;
                     for (;;) {
@@ -247,7 +258,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
                         const int n1 = (c - 1) >> 5, n2 = (c - 1) & 31;
                         i += 1 + n1; j -= 1 + n2;
                         if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
-                        if (n1 != n2 || pos + 1 + n1 > 63) { pos = -1; break; }   // off the line (or past it): fetch again
+                        if (n1 != n2 || pos + 1 + n1 >= BT_LINE) { pos = -1; break; }   // off the line (or past it): fetch again
                         pos += 1 + n1;
                     }
                     if (pos < 0) continue;
@@ -346,6 +357,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     int* inner = btstk + RB;
     for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
     __syncthreads();
+    EPI_T0();
     for (int i_hi = n - TURN - 1; i_hi >= 1; i_hi -= RB) {
         // Step 1 walks the block diagonal by diagonal: a half-wave holds the RB rows (lane = row), so its 32 cells of one archived diagonal
         // are one contiguous 64-byte read that is consumed at once (row-major order re-fetched every line once per row from HBM when
@@ -401,6 +413,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
         }
         __syncthreads();
     }
+    EPI_T(0);
     if (wave == 0) {
         // ---- structure starts, descending: l>=2 with f3[l]!=f3[l+1] && f3[l-1]==f3[l]; l==1 with f3[1]!=f3[2]
         int cnt = 0;
@@ -417,6 +430,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     }
     __syncthreads();
     const int nst = sh_misc[0];
+    EPI_T(1);
     // ---- backtracks: one wave per start
     char* mybuf = btbuf + wave * bufstride;
     int* mystk = btstk + wave * 3 * BT_STACK;
@@ -436,7 +450,9 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
             if (fl >= 0) pp = pb + fl;
         }
         int L = -10;
+        EPI_T(2);
         if (pp >= 0) L = backtrack_wave(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
+        EPI_T(3);
         if (L < 0) {
             if (lane == 0) { sh_misc[2] = L; lens[k] = 0; }
             continue;
@@ -457,8 +473,11 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
             ln.printed = 1;
             out_lines[(size_t)win * max_lines + k] = ln;
         }
+        EPI_T(4);
     }
+    EPI_T(5);
     __syncthreads();
+    EPI_T(6);
     // ---- RNALfold prints `prev` unless it is contained in `new` (the next start); the start-1
     // structure never takes part as `new`, and the last start>=2 structure is always printed.
     for (int k = wave; k + 1 < nst; k += NT / 64) {
@@ -479,6 +498,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
         bool print = (i + Ln < prev_i + lp) || anyd;
         if (lane == 0 && !print) out_lines[(size_t)win * max_lines + k].printed = 0;
     }
+    EPI_T(7);
     if (tid == 0) {
         out_nlines[win] = nst;
         out_mfe[win] = f3[1];

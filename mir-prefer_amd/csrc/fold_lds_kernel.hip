@@ -23,6 +23,7 @@
 // No MFMA: integer min-plus DP with irregular table lookups.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstdio>
 #include "fold_epilogue.h"
 #include "fold185_device.h"
 
@@ -991,6 +992,17 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
     }
     return hipGetLastError();
 }
+
+#ifdef MIRP_EPI_CLOCKS
+void fold_lds_epi_clocks_print() {
+    unsigned long long h[16];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_epi_clk), sizeof(h));
+    const char* nm[8] = {"f3 sweep", "enumeration", "partner scan", "backtrack", "output", "loop tail", "barrier", "containment"};
+    for (int k = 0; k < 8; k++) std::fprintf(stderr, "[mirp epi clocks] %-14s %llu\n", nm[k], h[k]);
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_epi_clk), z, sizeof(z));
+}
+#endif
 
 size_t fold_lds_slab_shorts(int n_cap) {   // triangle of d = 4..LDMAX for windows up to n_cap (+ slack for the dword copy)
     size_t tri = 0;

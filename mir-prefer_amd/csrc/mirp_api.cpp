@@ -289,6 +289,9 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             for (int b = 0; b < 4; b++)
                 std::fprintf(stderr, "[mirp fold clocks] wave 9, diagonals with %d%s blocks: %lld, interior ticks %lld\n", b, b == 3 ? "+" : "", cyc[72 + b], cyc[68 + b]);
         }
+#ifdef MIRP_EPI_CLOCKS
+        mirp::fold_lds_epi_clocks_print();
+#endif
         if (nfb == 0) return 0;
         work_list = (const int*)c->flist.p;
         n_generic = (int)nfb;

@@ -32,6 +32,9 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
 size_t fold_lds_bytes(int max_lines);
 size_t fold_lds_epilogue_bytes(int max_lines);
 size_t fold_lds_slab_shorts(int n_cap);
+#ifdef MIRP_EPI_CLOCKS
+void fold_lds_epi_clocks_print();
+#endif
 int fold_lds_max_n();
 int fold_lds_max_span();
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
