@@ -160,10 +160,10 @@ def main():
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
         valu_util = None
         try:
-            profk = json.load(open(os.path.join(ROOT, "profiles", "r1_h_hbm_traffic_and_sq_pmc.json")))["kernels"]
+            profk = json.load(open(os.path.join(ROOT, "profiles", "r1_i_hbm_traffic_and_sq_pmc.json")))["kernels"]
             if a.genome == CHR1_LEN and a.loci == N_LOCI:   # fill + epilogue kernels of the fold
                 traffic = sum(profk[k]["fetch_bytes_corrected"] + profk[k]["write_bytes"] for k in ("mirp::fold_lds_kernel", "mirp::fold_lds_epilogue_kernel"))
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_h_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_i_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
             # wave64 integer VALU ops occupy a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles); 1024 SIMDs
             valu_util = sq["SQ_INSTS_VALU"] * 4.0 / (sq["SQ_WAVE_CYCLES"] * 4.0 / 4.0) if a.genome == CHR1_LEN and a.loci == N_LOCI else None
         except Exception:

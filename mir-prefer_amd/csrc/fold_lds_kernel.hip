@@ -593,40 +593,38 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     us2 bu = {65535, 65535};
 #define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
 #define MIRP_LDW(o) (*reinterpret_cast<const unsigned*>(fb + (o)))
-                    auto relax = [&](auto ODD) {
+                    // K splits with all their reads in flight before the first use.  The tail of a wave's split range (up to 7 splits) goes through
+                    // the 4-, 2- and 1-deep groups: at most three LDS round trips instead of one per split.
+                    auto group = [&](auto ODD, auto KK) {
                         constexpr bool kOdd = decltype(ODD)::value;
-                        for (; t + 7 * s1 <= d - 5; t += 8 * s1) {     // 16 (24) reads in flight
-                            unsigned a[8], b[8], c[8];
+                        constexpr int K = decltype(KK)::value;
+                        unsigned a[K], b[K], c[K];
 #pragma unroll
-                            for (int k = 0; k < 8; k++) {
-                                a[k] = MIRP_LDW(so1); b[k] = MIRP_LDW(so2);
-                                if (!kOdd) c[k] = MIRP_LDW(so2 + 4);
-                                MIRP_SSTEP();
-                            }
-                            us2 e[8];
-#pragma unroll
-                            for (int k = 0; k < 8; k++) {
-                                const unsigned bw = kOdd ? b[k] : __builtin_amdgcn_alignbit(c[k], b[k], 16);
-                                us2 av, bv;
-                                __builtin_memcpy(&av, &a[k], 4); __builtin_memcpy(&bv, &bw, 4);
-                                e[k] = __builtin_elementwise_add_sat(av, bv);
-                            }
-                            e[0] = __builtin_elementwise_min(e[0], e[1]); e[2] = __builtin_elementwise_min(e[2], e[3]);
-                            e[4] = __builtin_elementwise_min(e[4], e[5]); e[6] = __builtin_elementwise_min(e[6], e[7]);
-                            e[0] = __builtin_elementwise_min(e[0], e[2]); e[4] = __builtin_elementwise_min(e[4], e[6]);
-                            bu = __builtin_elementwise_min(bu, __builtin_elementwise_min(e[0], e[4]));
-                        }
-                        so1 = __builtin_amdgcn_readfirstlane(so1); so2 = __builtin_amdgcn_readfirstlane(so2);
-                        si1 = __builtin_amdgcn_readfirstlane(si1); si2 = __builtin_amdgcn_readfirstlane(si2);
-                        for (; t <= d - 5; t += s1) {
-                            const unsigned aw = MIRP_LDW(so1), b0 = MIRP_LDW(so2);
-                            unsigned bw = b0;
-                            if (!kOdd) bw = __builtin_amdgcn_alignbit(MIRP_LDW(so2 + 4), b0, 16);
+                        for (int k = 0; k < K; k++) {
+                            a[k] = MIRP_LDW(so1); b[k] = MIRP_LDW(so2);
+                            if (!kOdd) c[k] = MIRP_LDW(so2 + 4);
                             MIRP_SSTEP();
-                            us2 av, bv;
-                            __builtin_memcpy(&av, &aw, 4); __builtin_memcpy(&bv, &bw, 4);
-                            bu = __builtin_elementwise_min(bu, __builtin_elementwise_add_sat(av, bv));
                         }
+                        us2 e[K];
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            const unsigned bw = kOdd ? b[k] : __builtin_amdgcn_alignbit(c[k], b[k], 16);
+                            us2 av, bv;
+                            __builtin_memcpy(&av, &a[k], 4); __builtin_memcpy(&bv, &bw, 4);
+                            e[k] = __builtin_elementwise_add_sat(av, bv);
+                        }
+#pragma unroll
+                        for (int w = 1; w < K; w *= 2)
+#pragma unroll
+                            for (int k = 0; k + w < K; k += 2 * w) e[k] = __builtin_elementwise_min(e[k], e[k + w]);
+                        bu = __builtin_elementwise_min(bu, e[0]);
+                        t += K * s1;
+                    };
+                    auto relax = [&](auto ODD) {
+                        while (t + 7 * s1 <= d - 5) group(ODD, std::integral_constant<int, 8>{});     // 16 (24) reads in flight
+                        if (t + 3 * s1 <= d - 5) group(ODD, std::integral_constant<int, 4>{});
+                        if (t + s1 <= d - 5) group(ODD, std::integral_constant<int, 2>{});
+                        if (t <= d - 5) group(ODD, std::integral_constant<int, 1>{});
                     };
                     if (odd) relax(std::true_type{}); else relax(std::false_type{});
 #undef MIRP_SSTEP
