@@ -270,7 +270,7 @@ class Pipeline:
         self._say("Done (fold stage)\n")
         self._barrier()
 
-    # ---- predict (MP:3498-3627): the loci list, gff3, fasta / ss / csv / stat / readmapping files (the html table is out of scope)
+    # ---- predict (MP:3498-3627): the loci list, gff3, fasta / ss / csv / html / stat / readmapping files
     def run_predict(self):
         if not previous_stage_saved(self.recovername, "fold"):
             self._fail_stage()
@@ -321,6 +321,7 @@ class Pipeline:
         counts = mirna_read_counts(result, self.data["names"], self.data["alns_all"], ns)
         write_csv_and_stat(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
                            os.path.join(outdir, "miRNA.stat.txt"))
+        write_html(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"))
         write_readmapping(result, contigs, self.data["names"], self.data["alns_all"], self.data["samples"], counts, os.path.join(outdir, "readmapping"))
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
@@ -519,6 +520,62 @@ def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
         f.write("Distribution of the nucleotide of the first base of the mature miRNAs:\n")
         for k in sorted(dict_first):
             f.write("%s: %d\n" % (k, dict_first[k]))
+
+
+def _mirbase_form(seq, taxon):
+    """The miRBase BLAST search form the reference attaches to every mature sequence (gen_search_miRBase_str, MP:2773-2791)."""
+    hidden = [("sequence", " " + seq), ("seqfile", ""), ("type", "mature"), ("search_method", "blastn"), ("evalue", "10"), ("maxalign", "100"),
+              ("taxon", " " + taxon)]
+    gap = " " * 5
+    parts = ['<form name="myform" action="http://www.mirbase.org/cgi-bin/blast.pl" method="POST">', '<div align="center">']
+    parts += ['<input type="hidden" size="25" name="%s" value="%s">' % kv for kv in hidden]
+    parts += ['<input type="submit" value="Search mature on miRBase ( %s )" onclick="this.form.target=\'_blank\';return true;">' % taxon, "</div>", "</form>"]
+    return gap.join(parts)
+
+
+def write_html(resultlist, contigs, samples, counts, htmlname):
+    """gen_html_table_file (MP:2793-2904): the two distribution tables of miRNA.stat.txt and the detail table of the csv as markup, with a miRBase
+    search form per mature sequence and a link to the locus' read-mapping file."""
+    dict_len, dict_first = {}, {}
+    rows = []
+    for idx, m in enumerate(resultlist):
+        pre = _faidx(contigs, m[0], m[1], m[2] - 1)
+        mat = _faidx(contigs, m[0], m[3], m[4] - 1)
+        star = _faidx(contigs, m[0], m[5], m[6] - 1)
+        dict_len[len(mat)] = dict_len.get(len(mat), 0) + 1                         # forward-strand text, as in the stat file
+        dict_first[mat[0]] = dict_first.get(mat[0], 0) + 1
+        if m[8] == "-":
+            pre, mat, star = _revcomp(pre), _revcomp(mat), _revcomp(star)
+        name = "miRNA-precursor_%d" % idx
+        cells = [name, m[0], str(m[1]), str(m[2]), m[8]]
+        tail = [mat + _mirbase_form(mat, "Viridiplantae") + _mirbase_form(mat, "ALL"), star]
+        for s in range(len(samples)):
+            tail += [str(int(v)) for v in counts[idx, s]]
+        td = "\t\t\t<td nowrap>%s</td>\n"
+        rows.append("\t\t<tr>\n" + "".join(td % c for c in cells) + "\t\t\t<td nowrap> <code>" + pre + "<BR>" + m[7] + " </code></td>" +
+                    "".join(td % c for c in tail) + '\t\t\t<td><a href="readmapping/' + name + '.map.txt" target="_blank">Click to see detailed mapping.</a></td>' +
+                    "\t\t</tr>\n")
+
+    def dist_table(title, head, dist):
+        out = "<h3>" + title + "</h3>\n<table border=\"1\">\n\t<thead>\n\t\t<tr>\n\t\t<th>" + head + "</th>\n\t\t<th>Count</th>\n\t\t</tr>\n\t</thead>\n\t<tbody>\n"
+        for k in sorted(dist):
+            out += "\t\t<tr>\n\t\t\t<td>%s </td>\n\t\t\t<td>%d </td>\n\t\t</tr>\n" % (k, dist[k])
+        return out + "\t</tbody>\n</table>\n</div>"
+
+    colors = ["#A9E2F3", "#ACFA58", "#F5A9BC"]
+    head1 = ["miRNA precursor ID", "Chromosome", "start position", "end position", "strand", "precursor sequence and secondary structure",
+             "mature sequence", "star sequence"]
+    per_sample = ["precursor", "mature", "star", "antisense region"]
+    with open(htmlname, "w") as f:
+        f.write("<h1 > microRNAs predicted by miR-PREFeR </h1>\n<div>\n<h2 > Total number of prediction:%d  </h2>\n" % len(resultlist))
+        f.write(dist_table("Distribution of the lengths of the mature sequences", "Length", dict_len) + "\n")
+        f.write(dist_table("Distribution of the nucleotide of the first base of the mature sequences", "Nucleotide", dict_first))
+        f.write("<div><h3>Detailed infomation </h3>\n<table border=\"1\">\n<colgroup>\n\t<col span=8 style=\"background-color:#CECEF6\">\n")
+        f.write("".join('\t<col span="4" style="background-color:%s">' % colors[i % len(colors)] for i in range(len(samples))) + "</colgroup>\n")
+        f.write("\t<thead>\n\t\t<tr>\n" + "".join('\t\t\t<th rowspan="2">%s</th>\n' % c for c in head1))
+        f.write("".join('\t\t\t<th colspan="4">%s</th>\n' % s for s in samples) + '\t\t\t<th colspan="2">read mappings</th>\n\t\t</tr>\n\t\t<tr>\n')
+        f.write("".join("\t\t\t<th> reads mapped to %s </th>\n" % w for _ in samples for w in per_sample) + "\t\t</tr>\n\t</thead>\n\t<tbody>\n")
+        f.write("".join(rows) + "\t</tbody>\n</table>\n</div>\n")
 
 
 # ---- -d artefact: <prefix>_reason_why_not_miRNA.txt (convert_failure_reasons_list MP:2505-2529, write_dict_reasons MP:2532-2567)

@@ -185,7 +185,8 @@ def gen_pipeline_golden(name, contig_lens, names, n_loci, n_samples, seed, sq_or
                       "precursor_fa": open(os.path.join(out, name + "_miRNA.precursor.fa")).read(),
                       "precursor_ss": open(os.path.join(out, name + "_miRNA.precursor.ss")).read(),
                       "detail_csv": open(os.path.join(out, name + "_miRNA.detail.csv")).read(),
-                      "stat_txt": open(os.path.join(out, "miRNA.stat.txt")).read()}
+                      "stat_txt": open(os.path.join(out, "miRNA.stat.txt")).read(),
+                      "detail_html": open(os.path.join(out, name + "_miRNA.detail.html")).read()}
     # -d artefact (convert_failure_reasons_list MP:2505-2529, write_dict_reasons MP:2532-2567); dict order = the shim's insertion order
     rm = os.path.join(out, "readmapping")
     exp["readmapping"] = {fn: open(os.path.join(rm, fn)).read() for fn in sorted(os.listdir(rm))}   # gen_map_result, MP:2907-2959

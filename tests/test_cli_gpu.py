@@ -44,6 +44,7 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     assert open(out / (prefix + "_miRNA.precursor.ss")).read() == rep["precursor_ss"]
     assert open(out / (prefix + "_miRNA.detail.csv")).read() == rep["detail_csv"]
     assert open(out / "miRNA.stat.txt").read() == rep["stat_txt"]
+    assert open(out / (prefix + "_miRNA.detail.html")).read() == rep["detail_html"]
     for fn, text in exp["readmapping"].items():
         assert open(out / "readmapping" / fn).read() == text, fn
     # -d artefact: why the other regions are not miRNAs -- every block with every failure line and the expression numbers.  Block order is

@@ -162,7 +162,7 @@ import pytest
 
 @pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
 def test_report_writers_match_reference_files(name, tmp_path):
-    """mature.fa / precursor.fa / precursor.ss / detail.csv / miRNA.stat.txt of the predict stage, byte for byte, from the reference's own
+    """mature.fa / precursor.fa / precursor.ss / detail.csv / detail.html / miRNA.stat.txt of the predict stage, byte for byte, from the reference's own
     result list (gen_mirna_fasta_ss_from_result MP:2963-3019, gen_mirna_info MP:2644-2728, gen_csv_table MP:2744-2779, MP:3585-3593)."""
     from mir_prefer_amd import pipeline
     from tests import golden_util as gu
@@ -182,6 +182,8 @@ def test_report_writers_match_reference_files(name, tmp_path):
     assert open(tmp_path / "p.ss").read() == rep["precursor_ss"]
     assert open(tmp_path / "d.csv").read() == rep["detail_csv"]
     assert open(tmp_path / "s.txt").read() == rep["stat_txt"]
+    pipeline.write_html(result, contigs, c["sample_names"], counts, str(tmp_path / "d.html"))      # gen_html_table_file MP:2793-2904
+    assert open(tmp_path / "d.html").read() == rep["detail_html"]
     # per-locus read layouts (gen_map_result MP:2907-2959); the synthetic reads are perfect matches, as bowtie -v 0 produces
     pipeline.write_readmapping(result, contigs, c["contig_names"], c["alns"], c["sample_names"], counts, str(tmp_path / "rm"))
     assert sorted(os.listdir(tmp_path / "rm")) == sorted(exp["readmapping"])
