@@ -309,8 +309,9 @@ class Context:
         self._check(self.lib.mirp_predict(self.h, pp, C.byref(res), C.byref(nres), C.byref(text), C.byref(stride), C.byref(npass), C.byref(nw)), "mirp_predict")
         r = _copy_out(self.lib, res, records.MIRNA_DTYPE, nres.value)
         t = _copy_out(self.lib, text, np.uint8, nres.value * stride.value).reshape(nres.value, stride.value)
-        return {"result": r, "ss": [t[i, :r[i]["ss_len"]].tobytes().decode() for i in range(len(r))],
-                "n_passed": _copy_out(self.lib, npass, np.int32, nw.value)}
+        tb, st = t.tobytes(), int(stride.value)
+        ss = [tb[o:o + l].decode("ascii") for o, l in zip(range(0, len(tb), st), r["ss_len"].tolist())] if len(r) else []
+        return {"result": r, "ss": ss, "n_passed": _copy_out(self.lib, npass, np.int32, nw.value)}
 
     def predict_reasons(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
         """-d mode: int32 records [n, stride] of mirp_predict_reasons (layout in include/mirprefer.h), sorted by (window, mature, structure);
