@@ -38,6 +38,23 @@ def test_fold_maximal_asymmetric_interior_loop_tie(gpu_ctx, oracle):
     _compare(gpu_ctx, oracle, [s], 300)
 
 
+def test_fold_lane_fill_is_transparent(gpu_ctx, oracle, monkeypatch):
+    """The interior-loop phase tops its blocks of paired cells up with cells of the next diagonal (whose stacked pair follows one interval
+    later).  With that switched off (diagnostic flag 256 of MIRP_FOLD_DEBUG, re-read on every call) the fill kernel must archive the same
+    tables: same lines from both modes, and both equal to the oracle.  GU-rich windows put hundreds of paired cells on a diagonal."""
+    import random
+    r = random.Random(5)
+    seqs = seqgen.windows(14, 24, 280, 350) + ["".join(r.choice("GU") for _ in range(330)), "".join(r.choice("GGGUUC") for _ in range(300))]
+    with_fill = gpu_ctx.fold_batch(seqs, 300)
+    monkeypatch.setenv("MIRP_FOLD_DEBUG", "256")
+    without = gpu_ctx.fold_batch(seqs, 300)
+    monkeypatch.delenv("MIRP_FOLD_DEBUG")
+    for s, g, h in zip(seqs, with_fill, without):
+        want = oracle.lfold(s, 300)
+        assert g["status"] == 0 and h["status"] == 0
+        assert g["lines"] == want["lines"] and h["lines"] == want["lines"] and g["mfe"] == h["mfe"] == want["mfe"], s
+
+
 def test_fold_edge_cases(gpu_ctx, oracle):
     seqs = ["A", "ACGU", "GGGGAAAACCCC", "A" * 24, "N" * 30, "GGGAAAUCCCGGGAAAUCCCAAAAGGGGGGAUUUCCCCCCUUUUGGGAUUUCCCGGAUUUCCC",
             "GC" * 150, "G" * 150 + "C" * 150, ""]
