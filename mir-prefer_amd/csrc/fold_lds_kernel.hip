@@ -435,6 +435,81 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);   // best interior-loop candidate key per cell
             int* mdec = acc + (3 + (d & 1)) * LCAP;
+            // phase A2: multiloop splits DML(i,j) = min_t fML(i, i+t) + fML(i+t+1, j).
+            // The split point t is wave-uniform (scalar address arithmetic); every lane owns TWO consecutive cells (i, i+1), i odd.  Operand a
+            // (diagonal t, cells i, i+1) is one aligned 32-bit word; operand b (diagonal d-t-1, cells i+t+1, i+t+2) is one aligned word for odd t
+            // and straddles two words for even t (one v_alignbit).  The step between the splits of a wave is even, so that parity is
+            // wave-uniform.  One packed saturating add and one packed min then relax both cells.
+            auto splits = [&]() {
+                const int npair = (ncell + 1) >> 1;
+                const int ncpad = (npair + 63) & ~63;
+                const int nsub = (LNT / ncpad) & ~1;     // even, >= 4 for ncell <= 384
+                const int pair = tid % ncpad;
+                const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
+                if (sub < nsub && !(dbg_flags & 2)) {
+                    const int i = 2 * pair + 1;
+                    // every split t in [4, d-5] is relaxed unconditionally: with the biased uint16 encoding a sum that involves an INF entry
+                    // saturates at 65535 and any sum of two finite entries is <= 65534, so no per-lane range bookkeeping is needed.
+                    // The byte offsets of the two operand diagonals live in SGPRs and advance by second-order recurrences (tri_off above):
+                    //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1   (minus one short for even t: the aligned word below the pair)
+                    const int s1 = nsub;
+                    int t = 4 + sub;
+                    const int uu = d - t - 1;
+                    const int odd = t & 1;
+                    int so1 = __builtin_amdgcn_readfirstlane(2 * tri_off(t, n));
+                    int so2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu, n) + t + 1 - (odd ? 0 : 1)));
+                    int si1 = __builtin_amdgcn_readfirstlane(2 * (tri_off(t + s1, n) - tri_off(t, n)));
+                    int si2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu - s1, n) - tri_off(uu, n) + s1));
+                    const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
+                    const char* fb = reinterpret_cast<const char*>(fml + i);
+                    us2 bu = {65535, 65535};
+#define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
+#define MIRP_LDW(o) (*reinterpret_cast<const unsigned*>(fb + (o)))
+                    // K splits with all their reads in flight before the first use.  The tail of a wave's split range (up to 7 splits) goes through
+                    // the 4-, 2- and 1-deep groups: at most three LDS round trips instead of one per split.
+                    auto group = [&](auto ODD, auto KK) {
+                        constexpr bool kOdd = decltype(ODD)::value;
+                        constexpr int K = decltype(KK)::value;
+                        unsigned a[K], b[K], c[K];
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            a[k] = MIRP_LDW(so1); b[k] = MIRP_LDW(so2);
+                            if (!kOdd) c[k] = MIRP_LDW(so2 + 4);
+                            MIRP_SSTEP();
+                        }
+                        us2 e[K];
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            const unsigned bw = kOdd ? b[k] : __builtin_amdgcn_alignbit(c[k], b[k], 16);
+                            us2 av, bv;
+                            __builtin_memcpy(&av, &a[k], 4); __builtin_memcpy(&bv, &bw, 4);
+                            e[k] = __builtin_elementwise_add_sat(av, bv);
+                        }
+#pragma unroll
+                        for (int w = 1; w < K; w *= 2)
+#pragma unroll
+                            for (int k = 0; k + w < K; k += 2 * w) e[k] = __builtin_elementwise_min(e[k], e[k + w]);
+                        bu = __builtin_elementwise_min(bu, e[0]);
+                        t += K * s1;
+                    };
+                    auto relax = [&](auto ODD) {
+                        while (t + 7 * s1 <= d - 5) group(ODD, std::integral_constant<int, 8>{});     // 16 (24) reads in flight
+                        if (t + 3 * s1 <= d - 5) group(ODD, std::integral_constant<int, 4>{});
+                        if (t + s1 <= d - 5) group(ODD, std::integral_constant<int, 2>{});
+                        if (t <= d - 5) group(ODD, std::integral_constant<int, 1>{});
+                    };
+                    if (odd) relax(std::true_type{}); else relax(std::false_type{});
+#undef MIRP_SSTEP
+#undef MIRP_LDW
+                    const unsigned r0 = bu[0], r1 = bu[1];
+                    if (i <= ncell && r0 < 65535u) atomicMin(&mdec[i], (int)r0 - 2 * FML_BIAS);
+                    if (i + 1 <= ncell && r1 < 65535u) atomicMin(&mdec[i + 1], (int)r1 - 2 * FML_BIAS);
+                }
+            };
+            // Half of the waves run the splits before the interior loops: the split loop loads the LDS pipe much more than the interior loops do,
+            // so the two halves even out the LDS load of the interval (the phases are independent: both only feed phase B of this diagonal).
+            const bool swap_order = (wave & 1) && !(dbg_flags & 2048);
+            if (swap_order) splits();
             if (dbg_cycles && lane == 0) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
             if (!(dbg_flags & (1 | 64)) && d >= 6 && d <= D) {
@@ -563,77 +638,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 }
             }
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA1 += t - wt; wt = t; }
-            // phase A2: multiloop splits DML(i,j) = min_t fML(i, i+t) + fML(i+t+1, j).
-            // The split point t is wave-uniform (scalar address arithmetic); every lane owns TWO consecutive cells (i, i+1), i odd.  Operand a
-            // (diagonal t, cells i, i+1) is one aligned 32-bit word; operand b (diagonal d-t-1, cells i+t+1, i+t+2) is one aligned word for odd t
-            // and straddles two words for even t (one v_alignbit).  The step between the splits of a wave is even, so that parity is
-            // wave-uniform.  One packed saturating add and one packed min then relax both cells.
-            {
-                const int npair = (ncell + 1) >> 1;
-                const int ncpad = (npair + 63) & ~63;
-                const int nsub = (LNT / ncpad) & ~1;     // even, >= 4 for ncell <= 384
-                const int pair = tid % ncpad;
-                const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
-                if (sub < nsub && !(dbg_flags & 2)) {
-                    const int i = 2 * pair + 1;
-                    // every split t in [4, d-5] is relaxed unconditionally: with the biased uint16 encoding a sum that involves an INF entry
-                    // saturates at 65535 and any sum of two finite entries is <= 65534, so no per-lane range bookkeeping is needed.
-                    // The byte offsets of the two operand diagonals live in SGPRs and advance by second-order recurrences (tri_off above):
-                    //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1   (minus one short for even t: the aligned word below the pair)
-                    const int s1 = nsub;
-                    int t = 4 + sub;
-                    const int uu = d - t - 1;
-                    const int odd = t & 1;
-                    int so1 = __builtin_amdgcn_readfirstlane(2 * tri_off(t, n));
-                    int so2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu, n) + t + 1 - (odd ? 0 : 1)));
-                    int si1 = __builtin_amdgcn_readfirstlane(2 * (tri_off(t + s1, n) - tri_off(t, n)));
-                    int si2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu - s1, n) - tri_off(uu, n) + s1));
-                    const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
-                    const char* fb = reinterpret_cast<const char*>(fml + i);
-                    us2 bu = {65535, 65535};
-#define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
-#define MIRP_LDW(o) (*reinterpret_cast<const unsigned*>(fb + (o)))
-                    // K splits with all their reads in flight before the first use.  The tail of a wave's split range (up to 7 splits) goes through
-                    // the 4-, 2- and 1-deep groups: at most three LDS round trips instead of one per split.
-                    auto group = [&](auto ODD, auto KK) {
-                        constexpr bool kOdd = decltype(ODD)::value;
-                        constexpr int K = decltype(KK)::value;
-                        unsigned a[K], b[K], c[K];
-#pragma unroll
-                        for (int k = 0; k < K; k++) {
-                            a[k] = MIRP_LDW(so1); b[k] = MIRP_LDW(so2);
-                            if (!kOdd) c[k] = MIRP_LDW(so2 + 4);
-                            MIRP_SSTEP();
-                        }
-                        us2 e[K];
-#pragma unroll
-                        for (int k = 0; k < K; k++) {
-                            const unsigned bw = kOdd ? b[k] : __builtin_amdgcn_alignbit(c[k], b[k], 16);
-                            us2 av, bv;
-                            __builtin_memcpy(&av, &a[k], 4); __builtin_memcpy(&bv, &bw, 4);
-                            e[k] = __builtin_elementwise_add_sat(av, bv);
-                        }
-#pragma unroll
-                        for (int w = 1; w < K; w *= 2)
-#pragma unroll
-                            for (int k = 0; k + w < K; k += 2 * w) e[k] = __builtin_elementwise_min(e[k], e[k + w]);
-                        bu = __builtin_elementwise_min(bu, e[0]);
-                        t += K * s1;
-                    };
-                    auto relax = [&](auto ODD) {
-                        while (t + 7 * s1 <= d - 5) group(ODD, std::integral_constant<int, 8>{});     // 16 (24) reads in flight
-                        if (t + 3 * s1 <= d - 5) group(ODD, std::integral_constant<int, 4>{});
-                        if (t + s1 <= d - 5) group(ODD, std::integral_constant<int, 2>{});
-                        if (t <= d - 5) group(ODD, std::integral_constant<int, 1>{});
-                    };
-                    if (odd) relax(std::true_type{}); else relax(std::false_type{});
-#undef MIRP_SSTEP
-#undef MIRP_LDW
-                    const unsigned r0 = bu[0], r1 = bu[1];
-                    if (i <= ncell && r0 < 65535u) atomicMin(&mdec[i], (int)r0 - 2 * FML_BIAS);
-                    if (i + 1 <= ncell && r1 < 65535u) atomicMin(&mdec[i + 1], (int)r1 - 2 * FML_BIAS);
-                }
-            }
+            if (!swap_order) splits();
         };
         auto phaseB = [&](const int d) {
             const int ncell = n - d;
