@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the candidate -> fold -> predict hot path on MI355X.
 
-Metric (BASELINE.json): precursor windows folded+filtered per second at L = 300, inputs resident in HBM.
-A step = one pass of the whole hot path (coverage scan -> peaks -> windows -> payload -> local fold ->
-filter -> loci list) over one synthetic batch.  Workload at N = 1: BASELINE config[1], an A. thaliana
-chr1-sized contig (30,427,671 bp), 1 sample, L = 300, 12,000 synthetic loci (~20 k windows), SURVEY.md 8d.
-For N > 1 every rank owns one such contig (contig sharding, weak scaling) and the final loci lists are
-gathered to rank 0 over RCCL.
+Metric (BASELINE.json): precursor windows folded+filtered per second at L = 300, inputs resident in HBM; end-to-end wall-clock beside it.
+A step = one pass of the whole hot path (coverage scan -> peaks -> windows -> payload -> local fold -> filter -> loci list) over one
+synthetic batch.  Workload at N = 1: BASELINE config[1], an A. thaliana chr1-sized contig (30,427,671 bp), 1 sample, L = 300,
+12,000 synthetic loci (~20 k windows), SURVEY.md 8d.  For N > 1 every rank owns one such contig (contig sharding, weak scaling) and the
+final loci lists are gathered to rank 0 over RCCL.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: re-launches itself under torch.distributed.run before any GPU call)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+The JSON line carries, beside the contract's keys:
+  roofline       the dominant kernel (fold_lds_kernel, the dynamic program) against the roof that bounds it -- integer min-plus relaxations
+                 out of LDS, LDS-read / VALU-issue bound, both roofs micro-benchmarked on this GPU in this run (mirp_microbench);
+  roofline_hbm   the HBM view north_star asks for (algorithmic bytes / measured time / 8 TB/s), expected << 1 for an LDS-resident DP;
+  roofline_coverage  the one HBM-bound stage (memset + scatter + scan);
+  cpu_baseline   the CPU oracle (the build's own restatement of the reference, "port") timed on this box AFTER the GPU timing: 1-thread and
+                 one-process-per-physical-core legs over candidate + fold + filter;
+  e2e            the CLI `pipeline` verb on files of the same workload (SAM + FASTA in -> gff3 and reports out), wall-clock by stage.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,41 +35,7 @@ CUT, GAP, L = 10, 100, 300
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def _cpu_worker(args):
-    """cpu_baseline leg: fold + filter a slice of windows with the CPU oracle (the checker, timed as the 'port' baseline)."""
-    seqs, = args
-    from tests import oracle_binding
-    o = oracle_binding.load()
-    t = time.time()
-    n = 0
-    for s in seqs:
-        r = o.lfold(s, L)
-        o.structures_from_lines(r["lines"], 55)
-        n += 1
-    return n, time.time() - t
-
-
-def cpu_baseline(window_seqs, budget_s=20.0):
-    import concurrent.futures as cf
-    from tests import oracle_binding
-    oracle_binding.load()
-    cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    per_core = max(2, int(budget_s * 15))           # ~15 windows/s/core on a 2-3 GHz core
-    sample = window_seqs[:cores * per_core]
-    chunks = [sample[i::cores] for i in range(cores)]
-    chunks = [c for c in chunks if c]
-    t = time.time()
-    with cf.ProcessPoolExecutor(max_workers=len(chunks)) as ex:
-        res = list(ex.map(_cpu_worker, [(c,) for c in chunks]))
-    wall = time.time() - t
-    n = sum(r[0] for r in res)
-    return {"value": n / wall, "unit": "windows/s", "cores": len(chunks), "kind": "port",
-            "sample": "first %d windows of the same workload, fold (oracle/lfold.c, Turner-2004 d2) + structure filter, %d processes, %.1f s wall" % (n, len(chunks), wall),
-            "per_core": n / sum(r[1] for r in res)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -70,10 +43,192 @@ def main():
     ap.add_argument("--loci", type=int, default=N_LOCI)
     ap.add_argument("--genome", type=int, default=CHR1_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of wall-clock per CPU-baseline leg")
     ap.add_argument("--fold-model", default="vienna-2.1.2", choices=["vienna-2.1.2", "vienna-1.8.5"],
                     help="RNALfold flavour to reproduce (the headline metric is quoted on the default, Turner-2004)")
-    a = ap.parse_args()
+    return ap.parse_args()
 
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = checker, timed as the "port" baseline; never on the product path)
+# ---------------------------------------------------------------------------------------------------------------------------------
+_CPU = {}
+
+
+def _cpu_init(win, alns, sample_names):
+    from tests import oracle_binding
+    _CPU["o"] = oracle_binding.load()
+    _CPU["win"], _CPU["alns"], _CPU["samples"] = win, alns, sample_names
+
+
+def _cpu_fold_filter(idx):
+    """fold (oracle/lfold.c) + structure list + check_loci (duplex + expression + decision, oracle/predict.c) of the windows idx."""
+    o, win, alns = _CPU["o"], _CPU["win"], _CPU["alns"]
+    params = (len(_CPU["samples"]), 18, 23, 0, 1, 55)
+    t0 = time.time()
+    t_fold = t_filt = 0.0
+    for k in idx:
+        b = win["windows"][k]
+        a = time.time()
+        r = o.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+        c = time.time()
+        st = o.structures_from_lines(r["lines"], 55)
+        mats = win["matures"][b["mature_off"]:b["mature_off"] + b["n_matures"]]
+        o.check_loci(st, mats, b, alns, params)
+        d = time.time()
+        t_fold += c - a; t_filt += d - c
+    return len(idx), time.time() - t0, t_fold, t_filt
+
+
+def _cpu_info():
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_phys = len(phys) if phys else max(1, usable // 2)
+    return model, min(n_phys, usable), usable
+
+
+def cpu_baseline(ds, alns, order, budget_s):
+    import multiprocessing as mp
+    from tests import oracle_binding
+    o = oracle_binding.load()
+    model, phys, logical = _cpu_info()
+    # leg 0 (1 thread): candidate stage over the whole input (coverage -> peaks -> windows -> payload)
+    t = time.time()
+    _, peaks = o.coverage_peaks(alns, ds.contig_lens, CUT)
+    win = o.make_windows(peaks, alns, ds.contigs, order, GAP, L, CUT * 0.5)
+    t_cand = time.time() - t
+    nwin = len(win["windows"])
+    # leg 1 (1 thread): fold + filter on a bounded sample
+    _cpu_init(win, alns, ds.sample_names)
+    n1, t1, f1, p1 = _cpu_fold_filter(range(min(8, nwin)))
+    per = t1 / max(n1, 1)
+    m1 = max(8, min(nwin, int(budget_s / per)))
+    n1, t1, f1, p1 = _cpu_fold_filter(range(m1))
+    # leg 2: one worker process per physical core, each its own slice (spawned: the parent holds a GPU context)
+    per_core = max(4, int(budget_s / (t1 / n1)))
+    total = min(nwin, phys * per_core)
+    chunks = [list(range(i, total, phys)) for i in range(phys)]
+    chunks = [c for c in chunks if c]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(len(chunks), initializer=_cpu_init, initargs=(win, alns, ds.sample_names)) as pool:
+        pool.map(_cpu_fold_filter, [c[:1] for c in chunks])          # start-up (imports, library load) outside the timing
+        t = time.time()
+        res = pool.map(_cpu_fold_filter, chunks)
+        wall = time.time() - t
+    n2 = sum(r[0] for r in res)
+    cand_share = t_cand * n2 / max(nwin, 1)       # the candidate stage is serial in the port; charge the sample its share
+    return {"value": n2 / (wall + cand_share), "unit": "windows/s", "cores": len(chunks), "kind": "port",
+            "sample": "CPU oracle (oracle/*.c: candidate.c + lfold.c Turner-2004 d2 + predict.c) on the same workload: candidate stage over the whole input "
+                      "(1 thread, %.2f s for %d windows); fold + filter on the first %d windows, one process per physical core (%d), %.1f s wall; "
+                      "1-thread leg on the first %d windows, %.1f s" % (t_cand, nwin, n2, len(chunks), wall, n1, t1),
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+            "one_thread": {"value": n1 / (t1 + t_cand * n1 / max(nwin, 1)), "unit": "windows/s", "windows": n1, "fold_s_per_window": f1 / n1, "filter_s_per_window": p1 / n1},
+            "all_cores": {"windows": n2, "wall_s": wall, "per_process_windows_per_s": n2 / sum(r[1] for r in res),
+                          "fold_s_per_window": sum(r[2] for r in res) / n2, "filter_s_per_window": sum(r[3] for r in res) / n2},
+            "candidate_stage_s_1thread": t_cand}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# exact relaxation count of a batch (SURVEY.md 8d): R = R_ml + R_int + R_f3 from the actual pair-type counts
+# ---------------------------------------------------------------------------------------------------------------------------------
+def relaxation_count(seq_bytes, offs, lens, span):
+    import numpy as np
+    nw = len(lens)
+    width = int(lens.max()) if nw else 0
+    own = np.zeros(256, np.uint8); partner = np.zeros(256, np.uint8)
+    for ch, b, m in ((b"A", 1, 8), (b"C", 2, 4), (b"G", 4, 2 | 8), (b"U", 8, 1 | 4), (b"T", 8, 1 | 4)):
+        for c in (ch, ch.lower()):
+            own[c[0]] = b; partner[c[0]] = m
+    S = np.zeros((nw, width), np.uint8)
+    for k in range(nw):
+        S[k, :lens[k]] = seq_bytes[offs[k]:offs[k] + lens[k]]
+    O, P = own[S], partner[S]
+    r_int = 0
+    r_ml = 0
+    r_f3 = float((lens.astype(np.float64) * span / 2.0).sum())
+    for d in range(4, min(span - 1, width - 1) + 1):
+        cells = np.maximum(lens - d, 0).astype(np.float64).sum()
+        r_ml += cells * max(d - 8, 0)
+        if d >= 6:
+            m = min(30, d - 6)
+            paired = np.count_nonzero(O[:, :width - d] & P[:, d:])
+            r_int += float(paired) * ((m + 1) * (m + 2) // 2)
+    return {"total": float(r_ml + r_int + r_f3), "multiloop_splits": float(r_ml), "interior_candidates": float(r_int), "exterior": float(r_f3)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def e2e_cli(ds, fold_model):
+    """The product CLI's `pipeline` verb on files of the bench workload: SAM + FASTA in -> gff3 / fasta / ss / csv / html / readmapping out."""
+    import shutil
+    import tempfile
+    from mir_prefer_amd import config, pipeline
+    tmp = tempfile.mkdtemp(prefix="mirp_e2e_")
+    try:
+        sams = ds.write_sams(tmp)
+        fa = os.path.join(tmp, "genome.fa")
+        ds.write_fasta(fa)
+        cfg = os.path.join(tmp, "config")
+        with open(cfg, "w") as f:
+            f.write("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = bench\nPRECURSOR_LEN = %d\nREADS_DEPTH_CUTOFF = %d\nMAX_GAP = %d\n"
+                    % (fa, ", ".join(sams), os.path.join(tmp, "out"), L, CUT, GAP))
+        in_bytes = sum(os.path.getsize(p) for p in sams) + os.path.getsize(fa)
+        so = sys.stdout
+        sys.stdout = open(os.devnull, "w")
+        try:
+            t0 = time.time()
+            opt = config.parse_configfile(cfg)
+            opt["OUTPUT_DETAILS_FOR_DEBUG"] = False
+            p = pipeline.Pipeline(opt, 0, fold_model=fold_model)
+            stages = {}
+            for st in ("prepare", "candidate", "fold", "predict"):
+                t = time.time()
+                res = getattr(p, "run_" + st)()
+                stages[st] = time.time() - t
+            wall = time.time() - t0
+            p.ctx.close()
+        finally:
+            sys.stdout.close()
+            sys.stdout = so
+        out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs)
+        return {"wall_s": wall, "stage_s": stages, "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": len(res or []),
+                "note": "in-process CLI stage drivers (config parse -> prepare -> candidate -> fold -> predict incl. every stage artefact and report file); "
+                        "interpreter start-up not included"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start one worker process per GPU under torch.distributed.run BEFORE anything touches the GPU
+        # (no HIP call has happened in this process; it only waits for the child and passes its exit code on)
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from mir_prefer_amd import capi, synth
@@ -82,7 +237,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 or world > 1 or "RANK" in os.environ:
+    if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -104,22 +259,22 @@ def main():
         rec = np.zeros((len(out["result"]), 16), dtype=np.int32)
         if len(out["result"]):
             rec[:] = np.frombuffer(out["result"].tobytes(), dtype=np.int32).reshape(-1, 16)
-        if not dist.is_initialized():
+        if world == 1:
             return rec.shape[0]
         allrec = mdist.gather_records(rec, device=dev, dst=0)
         n_all = torch.tensor([0 if allrec is None else allrec.shape[0]], device=dev, dtype=torch.int64)
         dist.broadcast(n_all, src=0)
         return int(n_all.item())
 
-    fb = [0]
+    fb = [0, 0]
 
     def step():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)
         ctx.fold(L)
-        fb[0] = ctx.last_fold_fallbacks()
+        fb[0], fb[1] = ctx.last_fold_fallbacks(), ctx.last_fold_overflow()
         out = ctx.predict(1, 18, 23, False, True)
         total = gather_loci(out)
-        return nwin, total, ctx.last_timings()
+        return nwin, total, ctx.last_timings(), ctx.last_fold_kernel_ms()
 
     def sync():
         torch.cuda.synchronize()
@@ -131,11 +286,12 @@ def main():
         step()
     sync()
     t0 = time.time()
-    fold_ms, cov_ms, rest_ms, pred_ms = [], [], [], []
+    fold_ms, cov_ms, rest_ms, pred_ms, fill_ms, epi_ms = [], [], [], [], [], []
     nwin = nres = 0
     for _ in range(a.steps):
-        nwin, nres, tm = step()
+        nwin, nres, tm, km = step()
         fold_ms.append(tm["fold_ms"]); cov_ms.append(tm["coverage_ms"]); rest_ms.append(tm["candidate_rest_ms"]); pred_ms.append(tm["predict_ms"])
+        fill_ms.append(km[0]); epi_ms.append(km[1])
     sync()
     elapsed = time.time() - t0
     if world > 1:
@@ -149,53 +305,69 @@ def main():
 
     if rank == 0:
         fold_s = float(np.mean(fold_ms)) / 1e3
+        fill_s = float(np.mean(fill_ms)) / 1e3
+        epi_s = float(np.mean(epi_ms)) / 1e3
         cov_s = float(np.mean(cov_ms)) / 1e3
-        # algorithmic HBM bytes of the fold (fill + epilogue kernels): the c, fML and trace-back triangles are written once as 16-bit values,
-        # c and fML are read once: n + 64 + 10*cells + ~6 KB of structure lines per window, cells(300,300) = 43,956
-        w = ctx.get_windows()["windows"]
-        lens = w["seq_len"].astype(np.int64)
+        wins = ctx.get_windows()
+        W = wins["windows"]
+        lens = W["seq_len"].astype(np.int64)
+        # ---- dominant kernel: the fill kernel (dynamic program).  Unit of algorithmic work = one relaxation; R is counted
+        # exactly for this batch from its pair-type counts.  Roofs measured on this GPU now: LDS = 2 reads per relaxation at the measured
+        # conflict-free ds_read rate, VALU = 3 integer lane-operations per relaxation at the measured 32-bit issue rate.
+        R = relaxation_count(wins["seq"], W["seq_off"].astype(np.int64), lens, L)
+        mb = ctx.microbench()
+        lds_roof = mb["ds_read_b32_per_s"] * 64.0 / 2.0
+        valu_roof = mb["valu_u32_per_s"] * 64.0 / 3.0
+        roof = min(lds_roof, valu_roof)
+        achieved = R["total"] / fill_s if fill_s > 0 else 0.0
         D = np.minimum(L - 1, lens - 1)
         cells = np.where(D > 3, (D - 3) * lens - (D * (D + 1) // 2 - 6), 0)
-        b_fold = float((lens + 64 + 10 * cells + 6000).sum())
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), same workload
-        valu_util = None
+        b_fold = float((lens + 64 + 10 * cells + 6000).sum())     # c, fML, trace-back triangles written once (16-bit), c + fML read once, ~6 KB of lines
+        prof = {}
         try:
-            profk = json.load(open(os.path.join(ROOT, "profiles", "r1_i_hbm_traffic_and_sq_pmc.json")))["kernels"]
-            if a.genome == CHR1_LEN and a.loci == N_LOCI:   # fill + epilogue kernels of the fold
-                traffic = sum(profk[k]["fetch_bytes_corrected"] + profk[k]["write_bytes"] for k in ("mirp::fold_lds_kernel", "mirp::fold_lds_epilogue_kernel"))
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r1_i_hbm_traffic_and_sq_pmc.json")))["fold_lds_kernel_sq_per_launch"]
-            # wave64 integer VALU ops occupy a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles); 1024 SIMDs
-            valu_util = sq["SQ_INSTS_VALU"] * 4.0 / (sq["SQ_WAVE_CYCLES"] * 4.0 / 4.0) if a.genome == CHR1_LEN and a.loci == N_LOCI else None
+            prof = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
         except Exception:
-            traffic = None
-        # relaxations per window (ML splits + interior candidates on paired cells are data dependent; use the fixed accounting figure)
-        relax = 1.12e7 * float((lens / 300.0).mean()) * nwin
+            pass
+        same_workload = a.genome == CHR1_LEN and a.loci == N_LOCI and a.fold_model == "vienna-2.1.2"
+        traffic = prof.get("fold_fill_hbm_bytes_per_launch") if same_workload else None
         g_tot = float(a.genome + 1)
         b_cov = 16.0 * len(alns) + 16.0 * g_tot
         line = {
             "metric": "precursor windows folded+filtered/sec (L=300)", "value": total_windows * a.steps / elapsed, "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "int16/int32 (energies in 0.01 kcal/mol)", "data": "synthetic",
             "config": {"workload": "BASELINE config[1]: A. thaliana chr1-sized contig per GPU (%d bp), 1 sample, L=300, %d synthetic loci -> %d windows/GPU; "
                                    "candidate+fold+predict, inputs resident in HBM" % (a.genome, a.loci, nwin),
-                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)), "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)" if a.fold_model == "vienna-2.1.2" else "vienna-1.8.5 (Turner-1999, d1)",
-                       "fold_generic_fallback_windows": int(fb[0])},
-            "roofline": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": fold_s * 1e3,
-                         "note": "integer min-plus DP: LDS/VALU-bound by design, HBM fraction << 1 is expected (DESIGN.md)"},
-            "roofline_fold_valu": {"relaxations_per_s": relax / fold_s, "peak_lane_ops_per_s": 256 * 64 * 2.4e9,
-                                   "frac_at_3_ops_per_relaxation": 3.0 * relax / fold_s / (256 * 64 * 2.4e9), "valu_issue_util_profiled": valu_util},
+                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)),
+                       "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)" if a.fold_model == "vienna-2.1.2" else "vienna-1.8.5 (Turner-1999, d1)",
+                       "fold_generic_fallback_windows": int(fb[0]), "fold_line_overflow_windows": int(fb[1])},
+            "roofline": {"kernel": "fold_lds_kernel<%d>" % (0 if a.fold_model == "vienna-2.1.2" else 1),
+                         "bound": "lds" if lds_roof <= valu_roof else "valu", "achieved": achieved / 1e12, "peak": roof / 1e12, "unit": "T relaxations/s",
+                         "frac": achieved / roof if roof > 0 else None, "avg_launch_ms": fill_s * 1e3,
+                         "relaxations_per_launch": R, "lds_roof_T": lds_roof / 1e12, "valu_roof_T": valu_roof / 1e12, "microbench_wave_insts_per_s": mb,
+                         "traffic": traffic, "traffic_source": prof.get("source") if traffic is not None else None,
+                         "note": "integer min-plus dynamic program out of LDS: bounded by LDS reads (2 per relaxation) or VALU issue (3 lane-ops per relaxation), "
+                                 "SURVEY.md 8d; both roofs micro-benchmarked on this GPU in this run; traffic = HBM bytes per launch from the committed rocprofv3 PMC passes"},
+            "roofline_hbm": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": fold_s * 1e3,
+                             "note": "HBM view of the fold (algorithmic bytes / time / 8 TB/s); << 1 is expected: the tables are LDS-resident"},
             "roofline_coverage": {"kernel": "memset + cov_scatter_kernel + cov_scan_kernel", "bound": "hbm", "achieved": b_cov / cov_s / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cov / cov_s / 1e9 / HBM_PEAK_GBS, "avg_ms": cov_s * 1e3},
-            "stage_ms": {"coverage": cov_s * 1e3, "candidate_rest": float(np.mean(rest_ms)), "fold": fold_s * 1e3, "predict": float(np.mean(pred_ms))},
+            "stage_ms": {"coverage": cov_s * 1e3, "candidate_rest": float(np.mean(rest_ms)), "fold": fold_s * 1e3, "fold_fill_kernel": fill_s * 1e3,
+                         "fold_epilogue_kernel": epi_s * 1e3, "predict": float(np.mean(pred_ms))},
         }
-        if not a.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
-            wins = ctx.get_windows()
-            seqs = [wins["seq"][x["seq_off"]:x["seq_off"] + x["seq_len"]].tobytes() for x in wins["windows"][:4096]]
-            line["cpu_baseline"] = cpu_baseline(seqs)
+        if world == 1:      # reported baselines: rank 0 at N = 1 only, AFTER the GPU timing
+            if not a.no_e2e:
+                try:
+                    line["e2e"] = e2e_cli(ds, a.fold_model)
+                    line["e2e_wall_s"] = line["e2e"]["wall_s"]
+                except SystemExit as e:
+                    line["e2e"] = {"error": "CLI exited with %r" % (e.code,)}
+            if not a.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(ds, alns, order, a.cpu_budget)
         print(json.dumps(line))
     ctx.close()
-    if dist.is_initialized():
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -139,11 +139,22 @@ int mirp_get_loci(mirp_ctx* ctx, MirpLocus** loci, int64_t* n_loci, MirpPeak** p
  * (seqs[window.seq_off .. +seq_len)). wpeaks/matures are slot arrays indexed by peak_off / mature_off. */
 int mirp_get_windows(mirp_ctx* ctx, MirpWindow** windows, int64_t* n_windows, MirpPeak** wpeaks, int64_t* n_wpeaks, MirpMature** matures,
                      int64_t* n_matures, char** seqs, int64_t* n_seq_bytes);
-/* Replaces run_fold's RNALfold subprocesses (MP:3047-3119) for the resident windows. */
+/* Inspection copy of the per-position read table of gen_loci_alignment_info (MP:1395-1468) that the candidate stage keeps in LDS only: for every
+ * window and start position ws + x, x in [0, width), of the window's own strand {length of the most abundant read, its depth, total depth}
+ * (first-seen maximum, MP:1457), table[(w*width + x)*3 + k]; zeros where no read starts. */
+int mirp_get_window_readtable(mirp_ctx* ctx, int32_t** table, int32_t* width, int64_t* n_windows);
+/* Replaces run_fold's RNALfold subprocesses (MP:3047-3119) for the resident windows.  max_lines is the structure-line capacity of the main
+ * output buffers; RNALfold itself has no limit (MP:3053), so the windows that produce more lines (tandem repeats) are folded again, alone, at the
+ * capacity no window can exceed, into side buffers (mirp_get_fold_overflow) that mirp_predict and mirp_write_fold_text read for those windows. */
 int mirp_fold(mirp_ctx* ctx, int32_t span, int32_t max_lines);
 /* Fold output of the resident windows, same layout as mirp_fold_batch. */
 int mirp_get_fold(mirp_ctx* ctx, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t* max_lines, int32_t** n_lines, int32_t** mfe,
                   int32_t** status);
+/* The windows of the last mirp_fold that needed more than max_lines structure lines: windows[n] (indices into the window list), their complete
+ * output lines[n*max_lines2], ss[n*max_lines2*ss_stride], n_lines[n].  The slots of these windows in mirp_get_fold hold their first max_lines lines only;
+ * n_lines / mfe / status of mirp_get_fold(_summary) are the ones of the complete run. */
+int mirp_get_fold_overflow(mirp_ctx* ctx, int32_t** windows, int64_t* n, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t* max_lines2,
+                           int32_t** n_lines);
 /* Per-window summary of the resident fold output (no structure text): n_lines, mfe, status as in mirp_fold_batch. */
 int mirp_get_fold_summary(mirp_ctx* ctx, int32_t** n_lines, int32_t** mfe, int32_t** status, int64_t* n_windows);
 /* Writes the fold stage artefact `<prefix>_rnalfoldoutput_<i>` in RNALfold's own text format (MP:3085-3098; consumed by MP:1541-1599):
@@ -152,9 +163,11 @@ int mirp_get_fold_summary(mirp_ctx* ctx, int32_t** n_lines, int32_t** mfe, int32
 int mirp_write_fold_text(mirp_ctx* ctx, const char* fasta_path, const char* out_path);
 /* Replaces gen_miRNA_loci_nopredict (MP:2435-2502) for the resident windows: per-window check_loci, the 0/(L,R) pairing
  * of filter_next_loci (MP:2373-2432) and the "first mature only" rule (MP:2494).  Out: result[n_result] in window order,
- * ss_text[n_result*ss_stride] NUL-terminated structure strings, n_passed[n_windows] = len(miRNAs) per FASTA entry. */
+ * ss_text[n_result*ss_stride] NUL-terminated structure strings, n_passed[n_windows] = len(miRNAs) per FASTA entry, status[n_windows] = 0 or the
+ * capacity flag of the filter kernel (2: more structure pieces than its table holds, 3: more candidate matures than its table holds): a caller
+ * must treat a non-zero status as an error, the window's candidates were truncated. */
 int mirp_predict(mirp_ctx* ctx, const MirpPredictParams* params, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride,
-                 int32_t** n_passed, int64_t* n_windows);
+                 int32_t** n_passed, int32_t** status, int64_t* n_windows);
 /*
  * -d mode (OUTPUT_DETAILS_FOR_DEBUG): why a region is not reported, replaces the dict_why_not_miRNA_reasons bookkeeping of check_loci
  * (MP:2206-2347) that convert_failure_reasons_list / write_dict_reasons (MP:2505-2567) print.  Returns int32 records of `stride` ints:
@@ -172,6 +185,16 @@ int mirp_last_timings(mirp_ctx* ctx, double ms[4]);
 /* Number of windows of the last fold call that the LDS-resident kernel handed to the generic kernel (window longer than 350 nt,
  * or energies outside the fast path's 16-bit ranges); purely informational -- results are identical either way. */
 int64_t mirp_last_fold_fallbacks(mirp_ctx* ctx);
+/* Number of windows of the last mirp_fold that needed more than max_lines structure lines and were folded again at full capacity. */
+int64_t mirp_last_fold_overflow(mirp_ctx* ctx);
+
+/* Device time of the kernels of the last mirp_fold, HIP events on the context's stream: ms[0] = fill kernel(s) (fold_lds_kernel: the
+ * dynamic program), ms[1] = epilogue kernel(s) (exterior sweep, enumeration, backtracks), summed over the sub-batches of the main pass. */
+int mirp_last_fold_kernel_ms(mirp_ctx* ctx, double ms[2]);
+/* Measures the two roofs of the fold's fill kernel on this GPU with its own geometry (one 1024-thread workgroup per CU): out[0] ds_read_b32 and
+ * out[1] ds_read_u16 wave-instructions per second (conflict-free, reads in flight), out[2] packed 16-bit add+min and out[3] 32-bit shift-add+min
+ * VALU wave-instructions per second.  Measurement only; bench.py prices the fill kernel against them. */
+int mirp_microbench(mirp_ctx* ctx, double out[4]);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side native ingest (no device involved).

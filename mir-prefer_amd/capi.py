@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmirprefer.so")
+LIB_PATH = os.environ.get("MIRP_LIB") or os.path.join(_HERE, "libmirprefer.so")   # MIRP_LIB: dev tools load the diagnostics build (make DIAG=1)
 
 
 class MirpError(RuntimeError):
@@ -50,6 +50,15 @@ def ingest_sams(paths, n_threads=0):
 
 
 FOLD_LINE_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("energy", "<i4"), ("printed", "<i4")])
+
+
+def fold_window_lines(raw, w):
+    """(lines, ss) record arrays of window w of a Context.get_fold() result: the side buffer for a window that needed more
+    lines than the main buffers hold, its slot in the main buffers otherwise."""
+    ov = raw.get("overflow")
+    if ov and int(w) in ov:
+        return ov[int(w)]
+    return raw["lines"][w], raw["ss"][w]
 
 _lib = None
 
@@ -95,12 +104,22 @@ def load_library():
     lib.mirp_set_contig_shard.restype = C.c_int
     lib.mirp_set_fold_model.restype = C.c_int
     lib.mirp_get_fold.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
-    lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), i64p]
+    lib.mirp_predict.argtypes = [vp, vp, C.POINTER(vp), i64p, C.POINTER(vp), i32p, C.POINTER(vp), C.POINTER(vp), i64p]
+    lib.mirp_get_fold_overflow.argtypes = [vp, C.POINTER(vp), i64p, C.POINTER(vp), C.POINTER(vp), i32p, i32p, C.POINTER(vp)]
+    lib.mirp_get_fold_overflow.restype = C.c_int
     lib.mirp_predict_reasons.argtypes = [vp, vp, C.POINTER(vp), i64p, i32p]
     lib.mirp_predict_reasons.restype = C.c_int
     lib.mirp_last_timings.argtypes = [vp, C.POINTER(C.c_double)]
     lib.mirp_last_fold_fallbacks.argtypes = [vp]
     lib.mirp_last_fold_fallbacks.restype = C.c_int64
+    lib.mirp_get_window_readtable.argtypes = [vp, C.POINTER(vp), i32p, i64p]
+    lib.mirp_get_window_readtable.restype = C.c_int
+    lib.mirp_last_fold_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.mirp_last_fold_kernel_ms.restype = C.c_int
+    lib.mirp_microbench.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.mirp_microbench.restype = C.c_int
+    lib.mirp_last_fold_overflow.argtypes = [vp]
+    lib.mirp_last_fold_overflow.restype = C.c_int64
     lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mirp_write_fold_text.restype = C.c_int
     lib.mirp_get_fold_summary.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
@@ -256,6 +275,12 @@ class Context:
         return {"windows": _copy_out(self.lib, w, records.WINDOW_DTYPE, nw.value), "wpeaks": _copy_out(self.lib, pk, records.PEAK_DTYPE, npk.value),
                 "matures": _copy_out(self.lib, mt, records.MATURE_DTYPE, nmt.value), "seq": _copy_out(self.lib, sq, np.uint8, nsq.value)}
 
+    def get_window_readtable(self):
+        """int32 [n_windows, width, 3]: {length of the most abundant read, its depth, total depth} per start position ws + x of the window's strand."""
+        t, w, n = C.c_void_p(), C.c_int32(), C.c_int64()
+        self._check(self.lib.mirp_get_window_readtable(self.h, C.byref(t), C.byref(w), C.byref(n)), "mirp_get_window_readtable")
+        return _copy_out(self.lib, t, np.int32, n.value * w.value * 3).reshape(n.value, w.value, 3)
+
     FOLD_MODELS = {"vienna-2.1.2": 0, "vienna-1.8.5": 1}
 
     def set_fold_model(self, model):
@@ -274,6 +299,9 @@ class Context:
 
     def last_fold_fallbacks(self):
         return int(self.lib.mirp_last_fold_fallbacks(self.h))
+
+    def last_fold_overflow(self):
+        return int(self.lib.mirp_last_fold_overflow(self.h))
 
     def fold_summary(self):
         vp = C.c_void_p
@@ -295,23 +323,41 @@ class Context:
         self._check(self.lib.mirp_get_fold(self.h, C.byref(lines), C.byref(ss), C.byref(stride), C.byref(ml), C.byref(nl), C.byref(mfe), C.byref(st)),
                     "mirp_get_fold")
         n, stride, ml = self._n_windows, stride.value, ml.value
-        return {"lines": _copy_out(self.lib, lines, FOLD_LINE_DTYPE, n * ml).reshape(n, ml),
-                "ss": _copy_out(self.lib, ss, np.uint8, n * ml * stride).reshape(n, ml, stride), "stride": stride, "max_lines": ml,
-                "n_lines": _copy_out(self.lib, nl, np.int32, n), "mfe": _copy_out(self.lib, mfe, np.int32, n),
-                "status": _copy_out(self.lib, st, np.int32, n)}
+        raw = {"lines": _copy_out(self.lib, lines, FOLD_LINE_DTYPE, n * ml).reshape(n, ml),
+               "ss": _copy_out(self.lib, ss, np.uint8, n * ml * stride).reshape(n, ml, stride), "stride": stride, "max_lines": ml,
+               "n_lines": _copy_out(self.lib, nl, np.int32, n), "mfe": _copy_out(self.lib, mfe, np.int32, n),
+               "status": _copy_out(self.lib, st, np.int32, n)}
+        raw["overflow"] = self.fold_overflow()
+        return raw
+
+    def fold_overflow(self):
+        """Windows of the last fold() that needed more structure lines than the main buffers hold (mirp_get_fold_overflow):
+        {window index: (lines[max_lines2], ss[max_lines2, stride])}; use fold_window_lines() to read any window's lines."""
+        vp = C.c_void_p
+        wl, lines, ss, nl = vp(), vp(), vp(), vp()
+        n, stride, ml = C.c_int64(), C.c_int32(), C.c_int32()
+        self._check(self.lib.mirp_get_fold_overflow(self.h, C.byref(wl), C.byref(n), C.byref(lines), C.byref(ss), C.byref(stride), C.byref(ml), C.byref(nl)),
+                    "mirp_get_fold_overflow")
+        n, stride, ml = n.value, stride.value, ml.value
+        wins = _copy_out(self.lib, wl, np.int32, n)
+        a_l = _copy_out(self.lib, lines, FOLD_LINE_DTYPE, n * ml).reshape(n, ml)
+        a_s = _copy_out(self.lib, ss, np.uint8, n * ml * stride).reshape(n, ml, stride)
+        _copy_out(self.lib, nl, np.int32, n)
+        return {int(w): (a_l[k], a_s[k]) for k, w in enumerate(wins)}
 
     def predict(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
         from . import records
         pp = (C.c_int32 * 6)(int(n_samples), int(min_mature_len), int(max_mature_len), 1 if allow_3nt else 0, 1 if allow_no_star else 0, int(minlen))
         vp = C.c_void_p
-        res, text, npass = vp(), vp(), vp()
+        res, text, npass, stat = vp(), vp(), vp(), vp()
         nres, nw, stride = C.c_int64(), C.c_int64(), C.c_int32()
-        self._check(self.lib.mirp_predict(self.h, pp, C.byref(res), C.byref(nres), C.byref(text), C.byref(stride), C.byref(npass), C.byref(nw)), "mirp_predict")
+        self._check(self.lib.mirp_predict(self.h, pp, C.byref(res), C.byref(nres), C.byref(text), C.byref(stride), C.byref(npass), C.byref(stat), C.byref(nw)),
+                    "mirp_predict")
         r = _copy_out(self.lib, res, records.MIRNA_DTYPE, nres.value)
         t = _copy_out(self.lib, text, np.uint8, nres.value * stride.value).reshape(nres.value, stride.value)
         tb, st = t.tobytes(), int(stride.value)
         ss = [tb[o:o + l].decode("ascii") for o, l in zip(range(0, len(tb), st), r["ss_len"].tolist())] if len(r) else []
-        return {"result": r, "ss": ss, "n_passed": _copy_out(self.lib, npass, np.int32, nw.value)}
+        return {"result": r, "ss": ss, "n_passed": _copy_out(self.lib, npass, np.int32, nw.value), "status": _copy_out(self.lib, stat, np.int32, nw.value)}
 
     def predict_reasons(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
         """-d mode: int32 records [n, stride] of mirp_predict_reasons (layout in include/mirprefer.h), sorted by (window, mature, structure);
@@ -323,6 +369,18 @@ class Context:
         if len(a):
             a = a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
         return a
+
+    def last_fold_kernel_ms(self):
+        """(fill kernel ms, epilogue kernel ms) of the last fold(), HIP events on the context's stream."""
+        ms = (C.c_double * 2)()
+        self.lib.mirp_last_fold_kernel_ms(self.h, ms)
+        return ms[0], ms[1]
+
+    def microbench(self):
+        """Measured roofs of the fill kernel on this GPU (mirp_microbench): wave-instructions per second."""
+        out = (C.c_double * 4)()
+        self._check(self.lib.mirp_microbench(self.h, out), "mirp_microbench")
+        return {"ds_read_b32_per_s": out[0], "ds_read_u16_per_s": out[1], "valu_pk16_per_s": out[2], "valu_u32_per_s": out[3]}
 
     def last_timings(self):
         ms = (C.c_double * 4)()

@@ -73,12 +73,21 @@ def main(argv=None):
             tdist.init_process_group(backend)
     try:
         p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"], rank=rank, world=world)
+        def removetmp():                        # run_removetmp (MP:3630-3639): unless -k; DELETE_IF_SUCCESS is parsed but unused, as in the reference
+            if not o["keeptmp"]:
+                if world > 1:
+                    import torch.distributed as tdist
+                    tdist.barrier()
+                if rank == 0:
+                    pipeline._msg("Removing the temporary folder.")
+                    shutil.rmtree(p.tmp, ignore_errors=True)
+                    sys.stdout.write("Temporary folder removed.\n\n")
         if o["action"] == "pipeline":
             p.run_pipeline()
-            if not o["keeptmp"] and opt["DELETE_IF_SUCCESS"].upper().startswith("Y"):
-                shutil.rmtree(p.tmp, ignore_errors=True)   # run_removetmp
+            removetmp()
         elif o["action"] == "recover":
-            p.run_recover()
+            if p.run_recover():
+                removetmp()
         else:
             getattr(p, "run_" + o["action"])()
     except capi.MirpError as e:

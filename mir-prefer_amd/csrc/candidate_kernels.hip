@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
                                                             const MirpAln* __restrict__ alns, long long n_alns, const unsigned char* __restrict__ genome,
                                                             const long long* __restrict__ gboff, const long long* __restrict__ clen,
                                                             double min_mature_depth, int wmax,
-                                                            char* __restrict__ seqs, MirpMature* __restrict__ matures) {
+                                                            char* __restrict__ seqs, MirpMature* __restrict__ matures, int* __restrict__ rt_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     int* dmax = (int*)smem;                       // [wmax]  depth of the most abundant read of the window strand at pos, 0 = none
     unsigned short* lmax = (unsigned short*)(dmax + wmax);   // [wmax]
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
         // ---- a5: per start position, most abundant read of the window's strand; first seen wins ties (MP:1457)
         const int width = we - ws + 1;
         for (int x = lane; x < width; x += 64) {
-            int pos = ws + x, best_d = 0, best_l = 0;
+            int pos = ws + x, best_d = 0, best_l = 0, total = 0;
             long long lo = 0, hi = n_alns;
             while (lo < hi) { long long mid = (lo + hi) >> 1; MirpAln r = alns[mid]; if (r.tid < tid || (r.tid == tid && r.pos < pos)) lo = mid + 1; else hi = mid; }
             for (long long k = lo; k < n_alns; k++) {
@@ -446,8 +446,13 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
                 if (r.tid != tid || r.pos != pos) break;
                 if ((int)r.strand != strand) continue;
                 if ((int)r.depth > best_d) { best_d = (int)r.depth; best_l = r.len; }
+                total += (int)r.depth;
             }
             dmax[x] = best_d; lmax[x] = (unsigned short)best_l;
+            if (rt_out) {   // inspection copy of the a5 table (mirp_get_window_readtable): [len of max, depth of max, total depth] per start position
+                int* o = rt_out + ((size_t)w * wmax + x) * 3;
+                o[0] = best_l; o[1] = best_d; o[2] = total;
+            }
         }
         __syncthreads();
         // ---- a6: gen_matures_one_peak per same-strand peak of the region (MP:1472-1510)
@@ -477,8 +482,8 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
                 if (n == 0) cand[n++] = hi;
                 for (int x = 0; x < n; x++) out[nm++] = cand[x];
             }
-            win.n_matures = nm; win.pad0 = 0; win.pad1 = 0; win.seq_len = len;
-            W[w] = win;
+            win.n_matures = nm; win.seq_len = len;
+            if (!rt_out) { win.pad0 = 0; win.pad1 = 0; W[w] = win; }   // inspection mode re-runs on finished windows: leave them untouched
         }
         __syncthreads();
     }
@@ -548,11 +553,11 @@ void launch_region_emit(hipStream_t st, const MirpPeak* P, const long long* rfir
 }
 void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, const MirpPeak* P, const MirpAln* alns, long long n_alns,
                            const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
-                           MirpMature* matures) {
+                           MirpMature* matures, int* rt_out) {
     if (n_windows <= 0) return;
     size_t lds = (size_t)wmax * 6 + 16;
     hipLaunchKernelGGL(window_payload_kernel, dim3(grid_for(n_windows, 1, 16384)), dim3(64), lds, st, W, n_windows, P, alns, n_alns, genome, gboff, clen,
-                       min_mature_depth, wmax, seqs, matures);
+                       min_mature_depth, wmax, seqs, matures, rt_out);
 }
 
 }  // namespace mirp

@@ -966,7 +966,7 @@ int fold_lds_max_span() { return LSPAN; }
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
-                           int* out_status, int dbg_flags, long long* dbg_cycles) {
+                           int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between) {
     const size_t lds = model ? lds_layout<1>().total : lds_layout<0>().total;
     const void* fn = model ? (const void*)fold_lds_kernel<1> : (const void*)fold_lds_kernel<0>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -979,6 +979,7 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
                            fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (ev_between) { e = hipEventRecord(ev_between, stream); if (e != hipSuccess) return e; }   // fill | epilogue boundary (mirp_last_fold_kernel_ms)
     if (!(dbg_flags & 16)) {
         if (model) {
             const size_t el = fold185_lds_epilogue_bytes(max_lines);

@@ -10,7 +10,7 @@
 #include <vector>
 #include "mirp_internal.h"
 
-#define MIRP_ABI_VERSION 2   // 2: mirp_set_fold_model, mirp_ingest_sams
+#define MIRP_ABI_VERSION 3   // 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
 #define MIRP_NMAX 3096
 
 #include "mirp_ctx.h"
@@ -83,9 +83,11 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,
                       &c->keep, &c->kscan, &c->csq, &c->cdest, &c->peaks_sq, &c->peaks_sorted, &c->head, &c->hscan, &c->rfirst, &c->nent,
                       &c->isloc, &c->nslots, &c->escan, &c->lscan, &c->sscan, &c->windows, &c->roles, &c->loci, &c->wpeaks, &c->matures,
-                      &c->wseqs, &c->woffs, &c->wlens, &c->p_out, &c->p_nout, &c->p_status, &c->p_keep, &c->p_kscan, &c->p_res, &c->p_text})
+                      &c->wseqs, &c->woffs, &c->wlens, &c->side_cnt, &c->side_idx, &c->side_list, &c->side_offs, &c->side_lens, &c->lines2, &c->ss2,
+                      &c->nlines2, &c->mfe2, &c->status2, &c->p_out, &c->p_nout, &c->p_status, &c->p_keep, &c->p_kscan, &c->p_res, &c->p_text})
         b->release();
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t ev : c->fold_ev) (void)hipEventDestroy(ev);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_params185) (void)hipFree(c->d_params185);
     if (c->d_params185l) (void)hipFree(c->d_params185l);
@@ -254,25 +256,45 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             return fail(c, -6, "device allocation failed (fold LDS kernel)");
         HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 1024, c->stream));
         unsigned int* ctl = (unsigned int*)c->fctl.p;
-        // diagnostics (never set in production): MIRP_FOLD_DEBUG=<flags> ablates phases (results then wrong), MIRP_FOLD_CLOCKS=1 prints phase clocks
+        // diagnostics exist only in a -DMIRP_DIAG build (`make DIAG=1`, profiles/tools/): MIRP_FOLD_DEBUG=<flags> ablates phases (results then
+        // wrong), MIRP_FOLD_CLOCKS=1 prints phase clocks, MIRP_FOLD_DUMP=<path> dumps slabs.  The shipped library reads no environment.
+#ifdef MIRP_DIAG
         const char* dbg_env = std::getenv("MIRP_FOLD_DEBUG");
         const int dbg_flags = dbg_env ? std::atoi(dbg_env) : 0;
         long long* dbg_cycles = std::getenv("MIRP_FOLD_CLOCKS") ? (long long*)(ctl + 8) : nullptr;
+#else
+        const int dbg_flags = 0;
+        long long* dbg_cycles = nullptr;
+#endif
+        int n_sub = 0;
         for (int b0 = 0; b0 < n_work; b0 += sub) {
             const int nb = std::min(sub, n_work - b0);
             if (b0 > 0) HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 8, c->stream));   // the two work counters; the fallback count keeps accumulating
             const int grid = std::min(nb, c->n_cu);
             const int grid_epi = std::min(nb, c->n_cu * 8);
+            while ((int)c->fold_ev.size() < 3 * (n_sub + 1)) { hipEvent_t ev; HIPCHK(c, hipEventCreate(&ev)); c->fold_ev.push_back(ev); }
+            hipEvent_t* ev3 = &c->fold_ev[3 * n_sub];
+            HIPCHK(c, hipEventRecord(ev3[0], c->stream));
             hipError_t e = mirp::launch_fold_lds(c->stream, m185 ? 1 : 0, grid, grid_epi, m185 ? c->d_params185l : c->d_params, d_seqs, d_offs + b0, d_lens ? d_lens + b0 : nullptr, nb, b0, span,
                                                  (short*)c->carch.p, slab, (int*)c->wstate.p, ctl, (int*)c->flist.p, ctl + 4, max_lines, stride,
                                                  d_lines + (size_t)b0 * max_lines, d_ss + (size_t)b0 * max_lines * stride, d_nlines + b0, d_mfe + b0,
-                                                 d_status + b0, dbg_flags, dbg_cycles);
+                                                 d_status + b0, dbg_flags, dbg_cycles, ev3[1]);
             if (e != hipSuccess) return fail(c, -2, std::string("fold LDS kernel launch failed: ") + hipGetErrorString(e));
+            HIPCHK(c, hipEventRecord(ev3[2], c->stream));
+            n_sub++;
         }
         unsigned int nfb = 0;
         HIPCHK(c, hipMemcpyAsync(&nfb, ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->last_fallback = nfb;
+        c->fold_kernel_ms[0] = c->fold_kernel_ms[1] = 0;
+        for (int k = 0; k < n_sub; k++) {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, c->fold_ev[3 * k], c->fold_ev[3 * k + 1]);
+            (void)hipEventElapsedTime(&b, c->fold_ev[3 * k + 1], c->fold_ev[3 * k + 2]);
+            c->fold_kernel_ms[0] += a; c->fold_kernel_ms[1] += b;
+        }
+#ifdef MIRP_DIAG
         if (const char* dump = std::getenv("MIRP_FOLD_DUMP")) {   // diagnostics: c / fML slabs of the first window of the last sub-batch
             std::vector<short> h(3 * slab);
             HIPCHK(c, hipMemcpy(h.data(), c->carch.p, 6 * slab, hipMemcpyDeviceToHost));
@@ -289,6 +311,7 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             for (int b = 0; b < 4; b++)
                 std::fprintf(stderr, "[mirp fold clocks] wave 9, diagonals with %d%s blocks: %lld, interior ticks %lld\n", b, b == 3 ? "+" : "", cyc[72 + b], cyc[68 + b]);
         }
+#endif
 #ifdef MIRP_EPI_CLOCKS
         mirp::fold_lds_epi_clocks_print();
 #endif

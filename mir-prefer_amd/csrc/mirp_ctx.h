@@ -52,12 +52,18 @@ struct mirp_ctx {
     DevBuf diff, stat, starts, totals, runs, keep, kscan, csq, cdest, peaks_sq, peaks_sorted;
     DevBuf head, hscan, rfirst, nent, isloc, nslots, escan, lscan, sscan, windows, roles, loci, wpeaks, matures, wseqs, woffs, wlens;
     DevBuf p_out, p_nout, p_status, p_keep, p_kscan, p_res, p_text;
+    // windows whose structure lines exceed the default capacity: re-folded alone at full capacity into these side buffers (mirp_fold)
+    DevBuf side_cnt, side_idx, side_list, side_offs, side_lens, lines2, ss2, nlines2, mfe2, status2;
+    long long n_side = 0;
+    int side_max_lines = 0;
     MirpCandidateParams cand = {0, 0, 0, 0};
     long long n_runs = 0, n_above = 0, n_peaks = 0, n_regions = 0, n_loci = 0, n_windows = 0, n_slots = 0;
     int seq_stride = 0, fold_stride = 0, fold_max_lines = 0, fold_span = 0;
     bool have_candidate = false, have_fold = false;
     int shard_first_run_double = 0;   // contig shard whose first covered contig is not the first covered contig of the whole genome
     double ms[4] = {0, 0, 0, 0};
+    double fold_kernel_ms[2] = {0, 0};   // fill / epilogue kernels of the last mirp_run_fold (LDS-resident path)
+    std::vector<hipEvent_t> fold_ev;     // 3 events per sub-batch, created on demand
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -26,7 +26,8 @@ size_t predict_lds_bytes(int max_lines, int ss_stride);
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount = nullptr,
-                          int* rpool = nullptr, unsigned int rcap = 0, int rstride = 0);
+                          int* rpool = nullptr, unsigned int rcap = 0, int rstride = 0, const int* wsel = nullptr, int n_sel = 0,
+                          const int* skip = nullptr);
 
 // fold_lds_kernel.hip
 size_t fold_lds_bytes(int max_lines);
@@ -40,7 +41,7 @@ int fold_lds_max_span();
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
-                           int* out_status, int dbg_flags, long long* dbg_cycles);
+                           int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between = nullptr);
 
 // candidate_kernels.hip
 void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m);
@@ -64,6 +65,6 @@ void launch_region_emit(hipStream_t st, const MirpPeak* P, const long long* rfir
                         int* roles, int seq_stride);
 void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, const MirpPeak* P, const MirpAln* alns, long long n_alns,
                            const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
-                           MirpMature* matures);
+                           MirpMature* matures, int* rt_out = nullptr);
 
 }  // namespace mirp

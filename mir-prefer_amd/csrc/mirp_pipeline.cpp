@@ -20,7 +20,8 @@ __global__ void result_keep_kernel(const int* __restrict__ roles, const int* __r
     }
 }
 __global__ void result_gather_kernel(const int* __restrict__ keep, const long long* __restrict__ kscan, long long n, const MirpMirna* __restrict__ out,
-                                     const char* __restrict__ ss, int ss_stride, int max_lines, MirpMirna* __restrict__ res, char* __restrict__ text) {
+                                     const char* __restrict__ ss, int ss_stride, int max_lines, const int* __restrict__ side_idx,
+                                     const char* __restrict__ ss2, int max_lines2, MirpMirna* __restrict__ res, char* __restrict__ text) {
     // one wavefront per window
     const int lane = threadIdx.x & 63;
     for (long long w = blockIdx.x * (long long)(blockDim.x / 64) + (threadIdx.x >> 6); w < n; w += (long long)gridDim.x * (blockDim.x / 64)) {
@@ -28,9 +29,35 @@ __global__ void result_gather_kernel(const int* __restrict__ keep, const long lo
         MirpMirna m = out[w * MIRP_MAX_MIRNA_PER_WINDOW];
         long long i = kscan[w];
         if (lane == 0) res[i] = m;
-        const char* src = ss + ((size_t)w * max_lines + m.line) * ss_stride + m.ss_off;
+        const int sk = side_idx ? side_idx[w] : -1;   // re-folded at full capacity: its lines live in the side buffer
+        const char* src = sk >= 0 ? ss2 + ((size_t)sk * max_lines2 + m.line) * ss_stride + m.ss_off
+                                  : ss + ((size_t)w * max_lines + m.line) * ss_stride + m.ss_off;
         char* dst = text + (size_t)i * ss_stride;
         for (int x = lane; x < ss_stride; x += 64) dst[x] = (x < m.ss_len) ? src[x] : (char)0;
+    }
+}
+// Windows whose structure lines did not fit the default capacity (status 1): compact list + per-window slot (unordered; the slot map is what counts)
+__global__ void side_compact_kernel(const int* __restrict__ status, long long n, int* __restrict__ side_idx, int* __restrict__ side_list,
+                                    unsigned int* __restrict__ count) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        int slot = -1;
+        if (status[k] == 1) { slot = (int)atomicAdd(count, 1u); side_list[slot] = (int)k; }
+        side_idx[k] = slot;
+    }
+}
+__global__ void side_gather_kernel(const int* __restrict__ side_list, int n_side, const long long* __restrict__ offs, const int* __restrict__ lens,
+                                   long long* __restrict__ soffs, int* __restrict__ slens) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_side; k += gridDim.x * blockDim.x) {
+        soffs[k] = offs[side_list[k]];
+        slens[k] = lens[side_list[k]];
+    }
+}
+// the per-window summary of a re-folded window is the one of its full-capacity run
+__global__ void side_scatter_kernel(const int* __restrict__ side_list, int n_side, const int* __restrict__ nl2, const int* __restrict__ mfe2,
+                                    const int* __restrict__ st2, int* __restrict__ nl, int* __restrict__ mfe, int* __restrict__ st) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_side; k += gridDim.x * blockDim.x) {
+        const int w = side_list[k];
+        nl[w] = nl2[k]; mfe[w] = mfe2[k]; st[w] = st2[k];
     }
 }
 }  // namespace mirp
@@ -273,6 +300,28 @@ extern "C" int mirp_get_windows(mirp_ctx* c, MirpWindow** windows, int64_t* n_wi
     return 0;
 }
 
+extern "C" int mirp_get_window_readtable(mirp_ctx* c, int32_t** table, int32_t* width, int64_t* n_windows) {
+    if (!c) return -1;
+    if (!table || !width || !n_windows) return fail(c, -1, "mirp_get_window_readtable: null argument");
+    if (!c->have_candidate) return fail(c, -1, "mirp_get_window_readtable: run mirp_candidate first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int wmax = c->cand.precursor_len + 52;
+    const long long nw = c->n_windows;
+    TmpDevice T;
+    int* d = (int*)T.get(sizeof(int) * 3 * (size_t)wmax * (size_t)std::max<long long>(nw, 1));
+    if (!d) return fail(c, -6, "device allocation failed (read table)");
+    HIPCHK(c, hipMemsetAsync(d, 0, sizeof(int) * 3 * (size_t)wmax * (size_t)std::max<long long>(nw, 1), c->stream));
+    mirp::launch_window_payload(c->stream, (MirpWindow*)c->windows.p, nw, (const MirpPeak*)c->peaks_sorted.p, (const MirpAln*)c->alns.p, c->n_alns,
+                                (const unsigned char*)c->genome.p, (const long long*)c->gboff.p, (const long long*)c->clen.p, c->cand.cutoff * 0.5, wmax,
+                                (char*)c->wseqs.p, (MirpMature*)c->matures.p, d);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    int32_t* h = host_copy<int32_t>(c, d, 3 * (size_t)wmax * (size_t)nw);
+    if (!h) return fail(c, -2, "D2H failed");
+    *table = h; *width = wmax; *n_windows = nw;
+    return 0;
+}
+
 extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
     if (!c) return -1;
     if (!c->have_candidate) return fail(c, -1, "mirp_fold: run mirp_candidate first");
@@ -287,11 +336,47 @@ extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
         c->status.ensure(4 * w1))
         return fail(c, -6, "device allocation failed (fold)");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    c->n_side = 0; c->side_max_lines = 0;
+    long long fallbacks = 0;
     {
         int rc = mirp_run_fold(c, (const unsigned char*)c->wseqs.p, (const long long*)c->woffs.p, (const int*)c->wlens.p, (int)nw, n_cap, span, max_lines,
                                stride, (MirpFoldLine*)c->lines.p, (char*)c->ss.p, (int*)c->nlines.p, (int*)c->mfe.p, (int*)c->status.p);
         if (rc) return rc;
+        fallbacks = c->last_fallback;
     }
+    const double main_kernel_ms[2] = {c->fold_kernel_ms[0], c->fold_kernel_ms[1]};
+    // RNALfold has no limit on the number of structure lines (MP:3053); a window that produced more than max_lines (tandem repeats: up to
+    // one line per start position) was flagged, not truncated.  Only those windows are folded again, at the capacity no window can
+    // exceed, into side buffers that the predict stage and the text writers read instead of the window's slot in the main buffers.
+    const int big = n_cap + 2;
+    if (nw > 0 && max_lines < big) {
+        if (c->side_idx.ensure(4 * w1) || c->side_list.ensure(4 * w1) || c->side_cnt.ensure(64)) return fail(c, -6, "device allocation failed (fold overflow list)");
+        unsigned int* cnt = (unsigned int*)c->side_cnt.p;
+        HIPCHK(c, hipMemsetAsync(cnt, 0, 4, c->stream));
+        hipLaunchKernelGGL(mirp::side_compact_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                           (const int*)c->status.p, nw, (int*)c->side_idx.p, (int*)c->side_list.p, cnt);
+        unsigned int ns = 0;
+        HIPCHK(c, hipMemcpyAsync(&ns, cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ns > 0) {
+            const size_t per2 = (size_t)big * stride;
+            if (c->side_offs.ensure(8 * (size_t)ns + 8) || c->side_lens.ensure(4 * (size_t)ns) || c->lines2.ensure(sizeof(MirpFoldLine) * (size_t)ns * big) ||
+                c->ss2.ensure((size_t)ns * per2) || c->nlines2.ensure(4 * (size_t)ns) || c->mfe2.ensure(4 * (size_t)ns) || c->status2.ensure(4 * (size_t)ns))
+                return fail(c, -6, "device allocation failed (fold overflow buffers)");
+            const dim3 g((ns + 255) / 256), b(256);
+            hipLaunchKernelGGL(mirp::side_gather_kernel, g, b, 0, c->stream, (const int*)c->side_list.p, (int)ns, (const long long*)c->woffs.p,
+                               (const int*)c->wlens.p, (long long*)c->side_offs.p, (int*)c->side_lens.p);
+            int rc = mirp_run_fold(c, (const unsigned char*)c->wseqs.p, (const long long*)c->side_offs.p, (const int*)c->side_lens.p, (int)ns, n_cap, span, big,
+                                   stride, (MirpFoldLine*)c->lines2.p, (char*)c->ss2.p, (int*)c->nlines2.p, (int*)c->mfe2.p, (int*)c->status2.p);
+            if (rc) return rc;
+            fallbacks += c->last_fallback;
+            hipLaunchKernelGGL(mirp::side_scatter_kernel, g, b, 0, c->stream, (const int*)c->side_list.p, (int)ns, (const int*)c->nlines2.p,
+                               (const int*)c->mfe2.p, (const int*)c->status2.p, (int*)c->nlines.p, (int*)c->mfe.p, (int*)c->status.p);
+            c->n_side = ns; c->side_max_lines = big;
+        }
+    }
+    c->last_fallback = fallbacks;
+    c->fold_kernel_ms[0] = main_kernel_ms[0]; c->fold_kernel_ms[1] = main_kernel_ms[1];
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -334,6 +419,22 @@ extern "C" int mirp_get_fold_summary(mirp_ctx* c, int32_t** n_lines, int32_t** m
     return 0;
 }
 
+extern "C" int mirp_get_fold_overflow(mirp_ctx* c, int32_t** windows, int64_t* n, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t* max_lines,
+                                      int32_t** n_lines) {
+    if (!c) return -1;
+    if (!windows || !n || !lines || !ss || !ss_stride || !max_lines || !n_lines) return fail(c, -1, "mirp_get_fold_overflow: null argument");
+    if (!c->have_fold) return fail(c, -1, "mirp_get_fold_overflow: run mirp_fold first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ns = (size_t)c->n_side, ml = (size_t)c->side_max_lines;
+    int32_t* hw = host_copy<int32_t>(c, c->side_list.p, ns);
+    MirpFoldLine* hl = host_copy<MirpFoldLine>(c, c->lines2.p, ns * ml);
+    char* hs = host_copy<char>(c, c->ss2.p, ns * ml * c->fold_stride);
+    int32_t* hn = host_copy<int32_t>(c, c->nlines2.p, ns);
+    if (!hw || !hl || !hs || !hn) { std::free(hw); std::free(hl); std::free(hs); std::free(hn); return fail(c, -2, "D2H failed"); }
+    *windows = hw; *n = (int64_t)ns; *lines = hl; *ss = hs; *ss_stride = c->fold_stride; *max_lines = c->side_max_lines; *n_lines = hn;
+    return 0;
+}
+
 extern "C" int mirp_write_fold_text(mirp_ctx* c, const char* fasta_path, const char* out_path) {
     if (!c) return -1;
     if (!fasta_path || !out_path) return fail(c, -1, "mirp_write_fold_text: null argument");
@@ -344,8 +445,13 @@ extern "C" int mirp_write_fold_text(mirp_ctx* c, const char* fasta_path, const c
     char* hs = host_copy<char>(c, c->ss.p, nw * ml * stride);
     int32_t* hn = host_copy<int32_t>(c, c->nlines.p, nw);
     int32_t* hm = host_copy<int32_t>(c, c->mfe.p, nw);
-    auto done = [&](int rc, const char* msg) { std::free(hl); std::free(hs); std::free(hn); std::free(hm); return rc ? fail(c, rc, msg) : 0; };
-    if (!hl || !hs || !hn || !hm) return done(-2, "D2H failed");
+    // windows folded again at full line capacity: their lines come from the side buffers
+    const size_t ns = (size_t)c->n_side, ml2 = (size_t)c->side_max_lines;
+    int32_t* hsi = ns ? host_copy<int32_t>(c, c->side_idx.p, nw) : nullptr;
+    MirpFoldLine* hl2 = ns ? host_copy<MirpFoldLine>(c, c->lines2.p, ns * ml2) : nullptr;
+    char* hs2 = ns ? host_copy<char>(c, c->ss2.p, ns * ml2 * stride) : nullptr;
+    auto done = [&](int rc, const char* msg) { std::free(hl); std::free(hs); std::free(hn); std::free(hm); std::free(hsi); std::free(hl2); std::free(hs2); return rc ? fail(c, rc, msg) : 0; };
+    if (!hl || !hs || !hn || !hm || (ns && (!hsi || !hl2 || !hs2))) return done(-2, "D2H failed");
     FILE* fin = std::fopen(fasta_path, "r");
     if (!fin) return done(-8, "mirp_write_fold_text: cannot open the FASTA file");
     FILE* fo = std::fopen(out_path, "w");
@@ -355,10 +461,13 @@ extern "C" int mirp_write_fold_text(mirp_ctx* c, const char* fasta_path, const c
     for (size_t w = 0; w < nw; w++) {
         if (!std::fgets(head.data(), (int)head.size(), fin) || !std::fgets(seq.data(), (int)seq.size(), fin)) { rc = -8; break; }
         std::fputs(head.data(), fo);
+        const bool side = ns && hsi[w] >= 0;
+        const MirpFoldLine* wl = side ? hl2 + (size_t)hsi[w] * ml2 : hl + w * ml;
+        const char* wt = side ? hs2 + (size_t)hsi[w] * ml2 * stride : hs + w * ml * stride;
         for (int k = 0; k < hn[w]; k++) {
-            const MirpFoldLine& ln = hl[w * ml + k];
+            const MirpFoldLine& ln = wl[k];
             if (!ln.printed) continue;
-            std::fwrite(hs + (w * ml + k) * stride, 1, (size_t)ln.len, fo);
+            std::fwrite(wt + (size_t)k * stride, 1, (size_t)ln.len, fo);
             std::fprintf(fo, " (%6.2f) %4d\n", ln.energy / 100., ln.start);
         }
         for (char* p = seq.data(); *p && *p != '\n' && *p != '\r'; p++) {
@@ -374,10 +483,32 @@ extern "C" int mirp_write_fold_text(mirp_ctx* c, const char* fasta_path, const c
     return done(rc, "mirp_write_fold_text: I/O error or FASTA shorter than the window list");
 }
 
+// the filter kernel over the resident windows: the main launch (fold output at the default line capacity) and, when windows were folded
+// again at full capacity, a second launch over those with the side buffers
+static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride) {
+    const long long nw = c->n_windows;
+    const int grid = (int)std::min<long long>(nw, (long long)c->n_cu * 16);
+    const int* skip = c->n_side > 0 ? (const int*)c->side_idx.p : nullptr;
+    if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+                             (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, pp,
+                             (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip) != hipSuccess)
+        return fail(c, -2, "predict kernel launch failed");
+    if (c->n_side > 0) {
+        if (mirp::predict_lds_bytes(c->side_max_lines, c->fold_stride) > 160 * 1024)
+            return fail(c, -5, "mirp_predict: a window with more structure lines than the default capacity exceeds the LDS budget of the predict kernel at this PRECURSOR_LEN");
+        if (mirp::launch_predict(c->stream, (int)std::min<long long>(c->n_side, (long long)c->n_cu * 4), (const MirpWindow*)c->windows.p, (int)nw,
+                                 (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns, (const MirpFoldLine*)c->lines2.p, (const char*)c->ss2.p,
+                                 c->fold_stride, c->side_max_lines, (const int*)c->nlines2.p, pp, (MirpMirna*)c->p_out.p, (int*)c->p_nout.p,
+                                 (int*)c->p_status.p, rcount, rpool, rcap, rstride, (const int*)c->side_list.p, (int)c->n_side, nullptr) != hipSuccess)
+            return fail(c, -2, "predict kernel launch failed (windows over the default line capacity)");
+    }
+    return 0;
+}
+
 extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride,
-                            int32_t** n_passed, int64_t* n_windows) {
+                            int32_t** n_passed, int32_t** status, int64_t* n_windows) {
     if (!c) return -1;
-    if (!pp || !result || !n_result || !ss_text || !ss_stride || !n_passed || !n_windows) return fail(c, -1, "mirp_predict: null argument");
+    if (!pp || !result || !n_result || !ss_text || !ss_stride || !n_passed || !status || !n_windows) return fail(c, -1, "mirp_predict: null argument");
     if (!c->have_fold) return fail(c, -1, "mirp_predict: run mirp_fold first");
     if (pp->n_samples < 1 || pp->n_samples > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_predict: n_samples out of range");
     HIPCHK(c, hipSetDevice(c->device));
@@ -392,11 +523,7 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     long long nres = 0;
     if (nw > 0) {
-        int grid = (int)std::min<long long>(nw, (long long)c->n_cu * 16);
-        if (mirp::launch_predict(st, grid, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
-                                 (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, *pp,
-                                 (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p) != hipSuccess)
-            return fail(c, -2, "predict kernel launch failed");
+        if (int rc = launch_predict_resident(c, *pp, nullptr, nullptr, 0u, 0)) return rc;
         HIPCHK(c, hipEventRecord(c->ev[1], st));
         hipLaunchKernelGGL(mirp::result_keep_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, st, (const int*)c->roles.p,
                            (const int*)c->p_nout.p, nw, (int*)c->p_keep.p);
@@ -406,6 +533,7 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
             return fail(c, -6, "device allocation failed (result)");
         hipLaunchKernelGGL(mirp::result_gather_kernel, dim3((unsigned)std::min<long long>((nw + 3) / 4, 8192)), dim3(256), 0, st, (const int*)c->p_keep.p,
                            (const long long*)c->p_kscan.p, nw, (const MirpMirna*)c->p_out.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines,
+                           c->n_side > 0 ? (const int*)c->side_idx.p : (const int*)nullptr, (const char*)c->ss2.p, c->side_max_lines,
                            (MirpMirna*)c->p_res.p, (char*)c->p_text.p);
     } else {
         HIPCHK(c, hipEventRecord(c->ev[1], st));
@@ -418,8 +546,9 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
     MirpMirna* hr = host_copy<MirpMirna>(c, c->p_res.p, (size_t)nres);
     char* ht = host_copy<char>(c, c->p_text.p, (size_t)nres * c->fold_stride);
     int32_t* hn = host_copy<int32_t>(c, c->p_nout.p, (size_t)nw);
-    if (!hr || !ht || !hn) { std::free(hr); std::free(ht); std::free(hn); return fail(c, -2, "D2H failed"); }
-    *result = hr; *n_result = nres; *ss_text = ht; *ss_stride = c->fold_stride; *n_passed = hn; *n_windows = nw;
+    int32_t* hst = host_copy<int32_t>(c, c->p_status.p, (size_t)nw);
+    if (!hr || !ht || !hn || !hst) { std::free(hr); std::free(ht); std::free(hn); std::free(hst); return fail(c, -2, "D2H failed"); }
+    *result = hr; *n_result = nres; *ss_text = ht; *ss_stride = c->fold_stride; *n_passed = hn; *status = hst; *n_windows = nw;
     return 0;
 }
 
@@ -450,11 +579,7 @@ extern "C" int mirp_predict_reasons(mirp_ctx* c, const MirpPredictParams* pp, in
         int* d_pool = (int*)T.get((size_t)cap * rstride * 4);
         if (!d_pool) return fail(c, -6, "device allocation failed (reasons pool)");
         HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
-        int grid = (int)std::min<long long>(nw, (long long)c->n_cu * 16);
-        if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
-                                 (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, *pp,
-                                 (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, d_cnt, d_pool, cap, rstride) != hipSuccess)
-            return fail(c, -2, "predict (reasons) kernel launch failed");
+        if (int rc = launch_predict_resident(c, *pp, d_cnt, d_pool, cap, rstride)) return rc;
         unsigned int n = 0;
         HIPCHK(c, hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -476,4 +601,11 @@ extern "C" int mirp_last_timings(mirp_ctx* c, double ms[4]) {
     return 0;
 }
 
+extern "C" int mirp_last_fold_kernel_ms(mirp_ctx* c, double ms[2]) {
+    if (!c || !ms) return -1;
+    ms[0] = c->fold_kernel_ms[0]; ms[1] = c->fold_kernel_ms[1];
+    return 0;
+}
+
 extern "C" int64_t mirp_last_fold_fallbacks(mirp_ctx* c) { return c ? (int64_t)c->last_fallback : -1; }
+extern "C" int64_t mirp_last_fold_overflow(mirp_ctx* c) { return c ? (int64_t)c->n_side : -1; }

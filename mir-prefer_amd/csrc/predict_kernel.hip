@@ -262,7 +262,10 @@ __global__ void __launch_bounds__(64) predict_kernel(
     const MirpAln* __restrict__ alns, long long n_alns, const MirpFoldLine* __restrict__ lines, const char* __restrict__ ss,
     int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
     MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status,
-    unsigned int* __restrict__ rcount, int* __restrict__ rpool, unsigned int rcap, int rstride) {
+    unsigned int* __restrict__ rcount, int* __restrict__ rpool, unsigned int rcap, int rstride,
+    const int* __restrict__ wsel, int n_sel, const int* __restrict__ skip) {
+    // wsel == nullptr: every window w in [0, n_windows) with its fold output at slot w, except those with skip[w] >= 0 (folded again at full
+    // line capacity: a second launch handles them); wsel != nullptr: the windows wsel[k], k in [0, n_sel), with their fold output at slot k.
     extern __shared__ __align__(16) unsigned char smem[];
     const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
     unsigned* textw = (unsigned*)smem;                                   // max_lines * wpl
@@ -271,14 +274,17 @@ __global__ void __launch_bounds__(64) predict_kernel(
     PStruct* slot = sts + max_structs;                                // 64 * PW_MAX_PIECES
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
     const int lane = threadIdx.x;
-    for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
+    const int n_iter = wsel ? n_sel : n_windows;
+    for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const int w = wsel ? wsel[it] : it;
+        if (!wsel && skip && skip[it] >= 0) continue;      // block-uniform
         const MirpWindow W = windows[w];
-        const int nl = n_lines[w] < max_lines ? n_lines[w] : max_lines;
-        const MirpFoldLine* wl = lines + (size_t)w * max_lines;
+        const int nl = n_lines[it] < max_lines ? n_lines[it] : max_lines;
+        const MirpFoldLine* wl = lines + (size_t)it * max_lines;
         int st_flag = 0;
         // stage the window's structure text, 2 bits per character (lane = one packed word = 16 characters)
         {
-            const char* src = ss + (size_t)w * max_lines * ss_stride;
+            const char* src = ss + (size_t)it * max_lines * ss_stride;
             for (int x = lane; x < nl * wpl; x += 64) {
                 const int ln = x / wpl, wi = x - ln * wpl;
                 const char* p = src + (size_t)ln * ss_stride + wi * 16;
@@ -491,7 +497,7 @@ size_t predict_lds_bytes(int max_lines, int ss_stride) {
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount, int* rpool,
-                          unsigned int rcap, int rstride) {
+                          unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip) {
     size_t lds = predict_lds_bytes(max_lines, ss_stride);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(rpool ? (const void*)predict_kernel<true> : (const void*)predict_kernel<false>,
@@ -500,10 +506,10 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
     }
     if (rpool)
         hipLaunchKernelGGL(predict_kernel<true>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                           max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride);
+                           max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride, wsel, n_sel, skip);
     else
         hipLaunchKernelGGL(predict_kernel<false>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                           max_lines, n_lines, pp, out, n_out, status, nullptr, nullptr, 0u, 0);
+                           max_lines, n_lines, pp, out, n_out, status, nullptr, nullptr, 0u, 0, wsel, n_sel, skip);
     return hipGetLastError();
 }
 

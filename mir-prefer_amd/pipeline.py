@@ -96,16 +96,45 @@ class Pipeline:
         tdist.all_gather_object(out, obj)
         return out
 
+    def _agree_ok(self, ok, what=""):
+        """Every rank learns whether any rank failed BEFORE the next collective, so that all of them leave with exit status -1 together
+        instead of the healthy ones hanging in a barrier until the watchdog fires (the reference's workers just die, MP:3103-3106)."""
+        flags = self._all_gather(bool(ok))
+        if not all(flags):
+            if ok and self.rank == 0:
+                sys.stderr.write("Error: rank %d failed%s; stopping all ranks.\n" % (flags.index(False), (" (" + what + ")") if what else ""))
+            sys.exit(-1)
+
     def _fail_stage(self):
-        _msg("Error: can not start the pipeline from this stage, the files needed are not generated or have been removed/moved. "
+        self._say("Error: can not start the pipeline from this stage, the files needed are not generated or have been removed/moved. "
              "Please run previous stages first, or run the pipeline in the recover mode to automatically continue from where the job was ceased.")
         sys.exit(-1)
 
     # ---- prepare (MP:3320-3358): SAM/FASTA ingest replaces sam2bam / cat / sort / expand / strand split
     def run_prepare(self):
-        if self.rank != 0:          # the ingest is one host job; the other ranks pick its output up in _load_inputs
-            self._barrier()
+        """Rank 0 ingests; the other ranks wait on a token FILE, not inside a collective (a cfg5-sized ingest outlasts the NCCL watchdog)."""
+        token = self._all_gather("%d.%d" % (os.getpid(), int(time.time() * 1e3)))[0]      # rank 0's token names this run
+        done, failed = self._p("prepare.done." + token), self._p("prepare.failed." + token)
+        if self.rank != 0:
+            while not (os.path.exists(done) or os.path.exists(failed)):
+                time.sleep(0.2)
+            if os.path.exists(failed):
+                sys.exit(-1)
             return
+        try:
+            self._prepare_rank0()
+        except SystemExit:
+            open(failed, "w").close()
+            raise
+        except BaseException:
+            open(failed, "w").close()
+            raise
+        for old in os.listdir(self.tmp):
+            if old.startswith("prepare.done.") or old.startswith("prepare.failed."):
+                os.remove(os.path.join(self.tmp, old))
+        open(done, "w").close()
+
+    def _prepare_rank0(self):
         _msg("Starting preparing data for the 'candidate' stage.")
         names, lens, samples, alns = ingest.read_sams(self.opt["ALIGNMENT_FILE"])
         # GFF masking (MP:817-859): keep regions as the reference's BED file, applied like `samtools view -L` on the combined records
@@ -128,21 +157,26 @@ class Pipeline:
         prepared = self._p("prepared.npz")
         np.savez(prepared, contig_names=np.array(names, dtype=object), contig_lens=lens, sample_names=np.array(samples, dtype=object), alns=alns,
                  allow_pickle=True)
-        d = {"last_stage": "prepare", "finished_stages": {"prepare": {"preparedname": prepared}}, "files": {"prepare": [prepared]}}
+        d = {"last_stage": "prepare", "finished_stages": {"prepare": {"preparedname": prepared}}, "files": {"prepare": [prepared]}, "world": self.world}
         _save_recover(self.recovername, d)
         _msg("Done (prepare stage)\n")
-        self._barrier()
 
     def _load_inputs(self):
         if self.data is not None:
             return
         d = load_recover_file(self.recovername)
+        if d.get("world", 1) != self.world:      # piece files and contig shards are laid out per rank: the stages of one run share one world size
+            if self.rank == 0:
+                sys.stderr.write("Error: the stage files in %s were written by a run with %d rank(s); this run has %d. Run the stages with the same "
+                                 "number of ranks, or start again from 'prepare'.\n" % (self.tmp, d.get("world", 1), self.world))
+            sys.exit(-1)
         z = np.load(d["finished_stages"]["prepare"]["preparedname"], allow_pickle=True)
         names = [str(x) for x in z["contig_names"]]
         fa = dict(ingest.read_fasta(self.opt["FASTA_FILE"]))
         missing = [n for n in names if n not in fa]
-        if missing:
-            sys.stderr.write("Error: sequence %s of the SAM header is not in the FASTA file\n" % missing[0])
+        if missing:          # every rank reads the same files and leaves together
+            if self.rank == 0:
+                sys.stderr.write("Error: sequence %s of the SAM header is not in the FASTA file\n" % missing[0])
             sys.exit(-1)
         alns = z["alns"]
         self.data = {"names": names, "lens": z["contig_lens"], "samples": [str(x) for x in z["sample_names"]], "alns": alns, "alns_all": alns,
@@ -188,9 +222,12 @@ class Pipeline:
             part = depthname + ".part%d" % r
             spans = {}
             with open(part, "w") as f:
-                for t in np.unique(depth["tid"]) if len(depth) else []:
+                tids = np.unique(depth["tid"]) if len(depth) else []
+                lo = np.searchsorted(depth["tid"], tids, side="left") if len(depth) else []          # depth lines are in (tid, pos) order
+                hi = np.searchsorted(depth["tid"], tids, side="right") if len(depth) else []
+                for t, i0, i1 in zip(tids, lo, hi):
                     a = f.tell()
-                    f.write(records.depth_text(depth[depth["tid"] == t], names))
+                    f.write(records.depth_text(depth[i0:i1], names))
                     spans[int(t)] = (a, f.tell())
             all_spans = self._all_gather(spans)
             if r == 0:
@@ -209,6 +246,11 @@ class Pipeline:
         if r == 0:
             with open(lociname, "wb") as f:
                 pickle.dump(dict_loci, f, protocol=2)
+        # <prefix>_ExRegionA.gff3 (MP:1357-1369): every extended region with the peaks of its locus, numbered per contig
+        exname = self._p(prefix + "_ExRegionA.gff3")
+        if r == 0:
+            with open(exname, "w") as f:
+                f.write(records.exregion_gff_text(dict_loci))
         w = self.ctx.get_windows()
         fastaname = self._p(prefix + ".rnalfold.in_%d.fa" % r)       # one piece per rank, like the reference's pieces per process
         with open(fastaname, "w") as f:
@@ -232,14 +274,10 @@ class Pipeline:
 
     def _fold_device(self):
         """Fold every window on the device; returns the per-window status array.  A window can produce more structure lines than the
-        default capacity of 96 (tandem repeats do: one line per start position is possible); RNALfold has no such limit, so the stage is
-        repeated once with the capacity no window can exceed."""
+        default capacity of 96 (tandem repeats do: one line per start position is possible); RNALfold has no such limit (MP:3053), so
+        mirp_fold folds just those windows again at the capacity no window can exceed, into side buffers the later stages read."""
         self.ctx.fold(self.opt["PRECURSOR_LEN"])
-        status = self.ctx.fold_status()
-        if np.any(status == 1):
-            self.ctx.fold(self.opt["PRECURSOR_LEN"], max_lines=self.opt["PRECURSOR_LEN"] + 52)
-            status = self.ctx.fold_status()
-        return status
+        return self.ctx.fold_status()
 
     # ---- fold (MP:3441-3495)
     def run_fold(self, write_text=True):
@@ -254,7 +292,7 @@ class Pipeline:
         bad = np.nonzero(status != 0)[0]
         if len(bad):
             sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (bad[0], status[bad[0]]))
-            sys.exit(-1)
+        self._agree_ok(len(bad) == 0, "fold")
         if write_text:
             d = load_recover_file(self.recovername)
             self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][self.rank], foldname)
@@ -281,6 +319,10 @@ class Pipeline:
             self.state = "fold"
         ns = len(self.data["samples"])
         out = self.ctx.predict(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
+        bad = np.nonzero(out["status"] != 0)[0]
+        if len(bad):      # a capacity of the filter kernel was exceeded (structure pieces / candidate matures of one window): never truncate silently
+            sys.stderr.write("Error occurred when predicting miRNAs: window %d exceeds the capacity of the filter kernel (status %d).\n" % (bad[0], out["status"][bad[0]]))
+        self._agree_ok(len(bad) == 0, "predict")
         prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
         if self.opt.get("OUTPUT_DETAILS_FOR_DEBUG"):          # -d: why the other regions are not miRNAs (MP:3532-3543)
             rec = self.ctx.predict_reasons(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"],
@@ -343,12 +385,25 @@ class Pipeline:
         return self.run_predict()
 
     def run_recover(self):
-        last = detect_stage_last_finished(self.recovername)
-        nxt = STAGES[STAGES.index(last) + 1:] if last else STAGES
+        """The `recover` verb (MP:3740-3774): continue after the last recorded stage; nothing recorded -> a message, no action.  Returns True
+        when stages ran to the end (the caller then removes the temporary folder unless -k, as the reference does)."""
+        d = load_recover_file(self.recovername)
+        last = d["last_stage"] if d else None
         if last:
-            _msg("Last finished stage: %s. Continue from the next stage." % last)
+            self._say("The pipeline was stopped after stage '" + last + "'.")
+        if last == "predict":
+            if self.rank == 0:
+                sys.stdout.write("*** The pipeline has been finished on the input. No action is performed.\n\n")
+            return False
+        if last not in STAGES:
+            self._say("No recovery information found. Please run the pipeline in the 'pipeline' mode.\n")
+            return False
+        nxt = STAGES[STAGES.index(last) + 1:]
+        if self.rank == 0:
+            sys.stdout.write("*** Starting the pipeline from stage '%s'.\n" % nxt[0])
         for s in nxt:
             getattr(self, "run_" + s)()
+        return True
 
 
 def result_records(out, names):
@@ -665,10 +720,11 @@ def write_reasons(path, windows, matures, names, records_arr, fold_raw, samples,
                         r = by_pair.get((k, s))
                         if r is None:
                             continue
-                        ln = fold_raw["lines"][w, r[3]]
+                        wl, wss = capi.fold_window_lines(fold_raw, w)
+                        ln = wl[r[3]]
                         if int(ln["energy"]) > 0:                                         # `if energy > lowest_energy: continue`, lowest stays 0 in a failing region
                             continue
-                        ss = fold_raw["ss"][w, r[3], r[4]:r[4] + r[5]].tobytes().decode()
+                        ss = wss[r[3], r[4]:r[4] + r[5]].tobytes().decode()
                         lines, info = [], None
                         if r[6] != 0:
                             lines.append(MS_FAIL.get(int(r[6]), "FAIL_STRUCTURE_EXCEPTION") + "\tFAILED")

@@ -53,6 +53,22 @@ def loci_to_dict(loci, peaks, contig_names, precursor_len=300):
     return d
 
 
+def exregion_gff_text(dict_loci):
+    """`<prefix>_ExRegionA.gff3` (miR_PREFeR.py:1357-1369) from dict_loci: one line per extended region, `Other=` = the peaks of the locus
+    as `start:end:strand|`, names numbered per contig in sorted contig order."""
+    out = []
+    for seqid in sorted(dict_loci):
+        cnt = 0
+        for info in dict_loci[seqid]:
+            for win, peaks in info[1:]:
+                ws, we = win[0], win[1]       # a single-peak region longer than PRECURSOR_LEN is the peak tuple itself (start, end, strand)
+                other = "".join("%d:%d:%s|" % (p[0], p[1], p[2]) for p in peaks)
+                name = "ExRegionA_%d" % cnt
+                cnt += 1
+                out.append("\t".join([seqid, "miR-PREFeR", "ExRegionA", str(ws), str(we), ".", "+", ".", "ID=%s;NAME=%s;Other=%s" % (name, name, other)]))
+    return "\n".join(out) + "\n" if out else ""
+
+
 def mature_tuple(m):
     if m["strand"] < 0:
         return (0, 0, 0, 0)

@@ -1,6 +1,7 @@
 """Dev tool: fold-phase ablation timings in one process (MIRP_FOLD_DEBUG is re-read on every fold call).
 usage: python profiles/tools/ablate.py 0 4 8 ...   (results of ablated runs are wrong by construction)"""
 import os, sys
+# needs the diagnostics build: make -C mir-prefer_amd/csrc DIAG=1, then MIRP_LIB=mir-prefer_amd/libmirprefer_diag.so python <this file>
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mir_prefer_amd import synth, capi

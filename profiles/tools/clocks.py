@@ -1,5 +1,6 @@
 """Dev tool: per-wave phase clocks of the fold fill kernel (MIRP_FOLD_CLOCKS=1) on the benchmark workload."""
 import os, sys
+# needs the diagnostics build: make -C mir-prefer_amd/csrc DIAG=1, then MIRP_LIB=mir-prefer_amd/libmirprefer_diag.so python <this file>
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mir_prefer_amd import synth, capi

@@ -67,6 +67,7 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     assert unnumbered(got_f) == unnumbered(exp["failed_readmapping"].values())
     assert all(t.startswith(">miRNA-precursor_") for t in got_f) and len(got_f) >= 3
     assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
+    assert open(tmp / (prefix + "_ExRegionA.gff3")).read() == exp["exregion_gff"]          # the candidate stage's debug artefact (MP:1357-1369)
     fasta = open(tmp / (prefix + ".rnalfold.in_0.fa")).read().splitlines()
     want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]
     assert fasta == want
@@ -88,18 +89,24 @@ def test_stage_verbs_and_recover(tmp_path):
     assert open(out / "mini_miRNA.gff3").read() == exp["gff3"]
 
 
-def test_pipeline_verb_sharded_over_two_ranks(tmp_path):
-    """Contig sharding: two processes (one per rank; here both on GPU 0, exchanging the small host objects over gloo) must produce the
-    files of the single-process run -- including the strand-vote quirk at the first run of a shard (mirp_set_contig_shard)."""
+def _run_ranks(world, args, port):
     import subprocess
     import sys
-    exp, cfg, out = _setup("mini", tmp_path)
-    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", MIRP_DIST_BACKEND="gloo")
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MIRP_DIST_BACKEND="gloo")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    procs = [subprocess.Popen([sys.executable, "-m", "mir_prefer_amd.cli", "-k", "-d", "--device", "0", "pipeline", cfg], cwd=root,
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-m", "mir_prefer_amd.cli"] + args, cwd=root,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), logs
+    return [p.returncode for p in procs], logs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_verb_sharded_over_ranks(world, tmp_path):
+    """Contig sharding: one process per rank (here all on GPU 0, exchanging the small host objects over gloo) must produce the files of the
+    single-process run, -d output included -- and with it the strand-vote quirk at the first run of a shard (mirp_set_contig_shard)."""
+    exp, cfg, out = _setup("mini", tmp_path)
+    codes, logs = _run_ranks(world, ["-k", "-d", "--device", "0", "pipeline", cfg], 29517 + world)
+    assert all(c == 0 for c in codes), logs
     prefix = exp["config"]["NAME_PREFIX"]
     tmp = out / (prefix + "_tmp")
     assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"]
@@ -107,13 +114,37 @@ def test_pipeline_verb_sharded_over_two_ranks(tmp_path):
     assert open(out / (prefix + "_miRNA.detail.csv")).read() == rep["detail_csv"]
     assert open(out / (prefix + "_miRNA.precursor.ss")).read() == rep["precursor_ss"]
     assert open(tmp / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() == exp["depth_cut"]
+    assert open(tmp / (prefix + "_ExRegionA.gff3")).read() == exp["exregion_gff"]          # the candidate stage's debug artefact (MP:1357-1369)
     for fn, text in exp["readmapping"].items():
         assert open(out / "readmapping" / fn).read() == text, fn
     got_f = [open(out / "failed_readmapping" / fn).read() for fn in sorted(os.listdir(out / "failed_readmapping"))]
     assert sorted(t.split(" ", 1)[1] for t in got_f) == sorted(t.split(" ", 1)[1] for t in exp["failed_readmapping"].values())
-    # both pieces exist and together hold every FASTA entry of the reference run
+    # every block of the -d reasons file of the single-process reference run, line for line
+    def blocks(text):
+        return sorted(b for b in text.split("===========================================================\n") if b.strip())
+    assert blocks(open(out / (prefix + "_reason_why_not_miRNA.txt")).read()) == blocks(exp["reasons_txt"])
+    # all pieces exist and together hold every FASTA entry of the reference run
     got = []
-    for r in range(2):
+    for r in range(world):
         got += open(tmp / (prefix + ".rnalfold.in_%d.fa" % r)).read().splitlines()
     want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]
     assert sorted(got) == sorted(want) and len(got) == len(want)
+    assert pipeline.load_recover_file(str(tmp / (prefix + "_recover")))["world"] == world
+
+
+def test_sharded_run_fails_on_every_rank_together(tmp_path):
+    """A failure that only rank 0 can see (the GFF file leaves no region) must end every rank with a non-zero status instead of leaving the
+    others in a collective; and stage files of one world size are refused by a run of another."""
+    exp, cfg, out = _setup("mini", tmp_path)
+    gff = tmp_path / "all.gff"
+    names = [l.split("\t")[1][3:] for l in gzip.open(os.path.join(gu.GOLD, "mini", exp["sample_names"][0] + ".sam.gz"), "rt") if l.startswith("@SQ")]
+    gff.write_text("".join("%s\tx\tgene\t1\t100000000\t.\t+\t.\tID=g\n" % n for n in names))
+    cfg2 = tmp_path / "config_gff"
+    cfg2.write_text(open(cfg).read() + "GFF_FILE_EXCLUDE = %s\n" % gff)
+    codes, logs = _run_ranks(2, ["-k", "pipeline", str(cfg2)], 29531)
+    assert all(c != 0 for c in codes), logs
+    # world-size mismatch between stages
+    codes, logs = _run_ranks(2, ["-k", "prepare", cfg], 29533)
+    assert all(c == 0 for c in codes), logs
+    with pytest.raises(SystemExit):
+        cli.main(["candidate", cfg])

@@ -136,6 +136,13 @@ def test_full_size_config1_properties(gpu_ctx, oracle):
     assert hit > 0.6 * len(ds.planted)
 
 
+def _window_lines(raw, k):
+    """Printed structure lines (text, energy, start) of window k of a get_fold() result, overflow windows included."""
+    from mir_prefer_amd import capi
+    wl, wss = capi.fold_window_lines(raw, k)
+    return [(wss[j, :wl[j]["len"]].tobytes().decode(), int(wl[j]["energy"]), int(wl[j]["start"])) for j in range(raw["n_lines"][k]) if wl[j]["printed"]]
+
+
 def _repeat_dataset():
     """A 60 kb contig with a 700-nt (GTGG)n tandem repeat under a read peak: its window folds into > 96 structure lines."""
     ds = synth.make_dataset([60000], 30, n_samples=1, seed=5, contig_names=["c1"])
@@ -174,9 +181,15 @@ def test_pipeline_with_a_window_over_the_default_line_capacity(gpu_ctx, oracle):
     npk, nloci, nwin = gpu_ctx.candidate(cut, gap, L, order)
     assert nwin == len(win["windows"])
     gpu_ctx.fold(L)
-    assert (gpu_ctx.fold_status() == 1).any()                       # the repeat window overflows 96 lines ...
-    gpu_ctx.fold(L, max_lines=L + 52)                               # ... and the host's retry (pipeline.Pipeline._fold_device) clears it
-    assert (gpu_ctx.fold_status() == 0).all()
+    # the repeat window overflows the default capacity of 96 lines: mirp_fold folds it (alone) again at full capacity into the side buffers
+    assert gpu_ctx.last_fold_overflow() >= 1 and (gpu_ctx.fold_status() == 0).all()
+    raw = gpu_ctx.get_fold()
+    assert len(raw["overflow"]) == gpu_ctx.last_fold_overflow()
+    for k in raw["overflow"]:
+        b = win["windows"][k]
+        ref = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+        assert raw["n_lines"][k] > 96 and raw["mfe"][k] == ref["mfe"]
+        assert _window_lines(raw, k) == ref["lines"]
     out = gpu_ctx.predict(1, 18, 23, False, True)
     structs = []
     for b in win["windows"]:
@@ -189,3 +202,57 @@ def test_pipeline_with_a_window_over_the_default_line_capacity(gpu_ctx, oracle):
     got = [[names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
             records.STRAND[m["strand"]], bool(m["has_star"])] for m, ss in zip(out["result"], out["ss"])]
     assert got == want
+
+
+def test_planted_repeat_windows_are_refolded_alone(gpu_ctx, oracle):
+    """BASELINE config[1] size with 60 planted tandem repeats under read peaks: only those windows are folded again (RNALfold has no line
+    limit, miR_PREFeR.py:3053), the stage costs about what the repeat-free run costs, and their lines equal the oracle's."""
+    G = 30427671
+    ds = synth.make_dataset([G], 12000, n_samples=1, seed=2, contig_names=["Chr1"])
+    alns0 = ds.sorted_alns()
+    order = np.zeros(1, np.int32)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns0)
+    _, _, nwin0 = gpu_ctx.candidate(10, 100, 300, order)
+    base = []
+    for _ in range(3):
+        gpu_ctx.fold(300)
+        base.append(gpu_ctx.last_timings()["fold_ms"])
+    assert gpu_ctx.last_fold_overflow() == 0
+    # plant (GTGG)n repeats of 700 nt in read-free stretches and put a small read stack on each
+    name, seq = ds.contigs[0]
+    seq = seq.copy()
+    # read-free gaps of >= 1,700 nt between consecutive alignments: a repeat goes into the middle of every such gap until 60 are planted
+    ends = np.maximum.accumulate(alns0["pos"].astype(np.int64) + alns0["len"])
+    gap_lo, gap_hi = ends[:-1], alns0["pos"][1:].astype(np.int64)
+    extra, planted = [], 0
+    for k in np.nonzero(gap_hi - gap_lo >= 1700)[0][::7]:
+        p = int((gap_lo[k] + gap_hi[k]) // 2) - 350
+        seq[p:p + 700] = np.frombuffer(("GTGG" * 175).encode(), dtype=np.uint8)
+        extra += [(0, p + 301, 60, 21, 0, 0), (0, p + 301, 20, 22, 0, 0), (0, p + 302, 15, 21, 0, 0), (0, p + 360, 8, 21, 0, 0)]
+        planted += 1
+        if planted == 60:
+            break
+    assert planted == 60
+    ds.contigs[0] = (name, seq)
+    ds.alns = np.concatenate([ds.alns, np.array(extra, dtype=synth.ALN_DTYPE)])
+    alns = ds.sorted_alns()
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(10, 100, 300, order)
+    assert nwin >= nwin0 + 60
+    rep = []
+    for _ in range(3):
+        gpu_ctx.fold(300)
+        rep.append(gpu_ctx.last_timings()["fold_ms"])
+    nov = gpu_ctx.last_fold_overflow()
+    assert nov >= 50 and (gpu_ctx.fold_status() == 0).all() and gpu_ctx.last_fold_fallbacks() == 0
+    assert min(rep) <= 1.10 * min(base) * nwin / nwin0, (base, rep)
+    raw = gpu_ctx.get_fold()
+    win = gpu_ctx.get_windows()
+    W = win["windows"]
+    for k in sorted(raw["overflow"])[:12]:
+        ref = oracle.lfold(win["seq"][W[k]["seq_off"]:W[k]["seq_off"] + W[k]["seq_len"]].tobytes(), 300)
+        assert raw["n_lines"][k] > 96 and raw["mfe"][k] == ref["mfe"] and _window_lines(raw, k) == ref["lines"]
+    out = gpu_ctx.predict(1, 18, 23, False, True)
+    assert (out["status"] == 0).all() and len(out["result"]) > 1000

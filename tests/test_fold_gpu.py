@@ -98,3 +98,20 @@ def test_fold_vienna185_mode_matches_the_bundled_binary(gpu_ctx):
         assert n >= 330
     finally:
         gpu_ctx.set_fold_model("vienna-2.1.2")
+
+
+def test_fold_vienna212_matches_the_bundled_binary(gpu_ctx):
+    """Default model against the golden of the REAL RNALfold 2.1.2 (dependency/Mac/osx-10.9/RNALfold-2.1.2 run through the dev Mach-O loader,
+    tests/golden/tools/gen_golden.py): every structure line (text, energy, start column) and the MFE, all span groups, through the C-ABI."""
+    from tests import golden_util as gu
+    gold = gu.load_json("fold_rnalfold212.json.gz")
+    gpu_ctx.set_fold_model("vienna-2.1.2")
+    n, spans = 0, set()
+    for case in gold["cases"]:
+        got = gpu_ctx.fold_batch(case["seqs"], case["span"], max_lines=352)
+        spans.add(case["span"])
+        for g, exp, seq in zip(got, case["expected"], case["seqs"]):
+            assert g["status"] == 0 and g["mfe"] == exp["mfe"], seq
+            assert [list(l) for l in g["lines"]] == exp["lines"], seq
+            n += 1
+    assert n >= 300 and {300, 100, 40, 20} <= spans

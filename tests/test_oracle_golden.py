@@ -59,6 +59,8 @@ def test_loci_and_windows(case):
     exp = gu.unjson(case["exp"]["dict_loci"])
     exp = {k: v for k, v in exp.items() if v}
     assert got == exp
+    # the candidate stage's debug artefact <prefix>_ExRegionA.gff3 (MP:1357-1369) is a rendering of the same dict
+    assert records.exregion_gff_text(got) == case["exp"]["exregion_gff"]
 
 
 def _fasta_entries(case):

@@ -41,6 +41,7 @@ def _check_pipeline_fixture(c, gpu_ctx):
     loci, psorted = gpu_ctx.get_loci()
     want = {k: v for k, v in gu.unjson(exp["dict_loci"]).items() if v}
     assert records.loci_to_dict(loci, psorted, names, cfg["PRECURSOR_LEN"]) == want
+    assert records.exregion_gff_text(records.loci_to_dict(loci, psorted, names, cfg["PRECURSOR_LEN"])) == exp["exregion_gff"]   # MP:1357-1369
     # a4-a6: FASTA entries (headers incl. matures, sequences)
     w = gpu_ctx.get_windows()
     entries = [e for p in exp["pieces"] for e in p["fasta"]]
@@ -48,6 +49,16 @@ def _check_pipeline_fixture(c, gpu_ctx):
     for win, (hdr, seq) in zip(w["windows"], entries):
         assert records.fasta_header(win, w["wpeaks"], w["matures"], names) == hdr
         assert w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes().decode() == seq
+    # a5: the per-position read table (gen_loci_alignment_info, MP:1395-1468) against the alndump's dict_loci_info, window strand:
+    # [length of the most abundant read, its depth, total depth] per start position; no other start position carries a read
+    rt = gpu_ctx.get_window_readtable()
+    dumps = [gu.unjson(d) for p in exp["pieces"] for d in p["alndump"]]
+    assert len(dumps) == nwin
+    for k, (win, d) in enumerate(zip(w["windows"], dumps)):
+        info, strand = d[2][0], records.STRAND[win["strand"]]
+        want_rows = {int(pos): [int(x) for x in v[strand][0]] for pos, v in info.items() if strand in v}
+        got_rows = {int(win["ws"]) + x: [int(v) for v in rt[k, x]] for x in np.nonzero(rt[k, :, 1])[0]}
+        assert got_rows == want_rows, k
     # a7: fold output of every window == the RNALfold text of the reference run
     gpu_ctx.fold(cfg["PRECURSOR_LEN"])
     raw = gpu_ctx.get_fold()
