@@ -105,6 +105,21 @@ def _cpu_info():
     return model, min(n_phys, usable), usable
 
 
+def _cpu_quota():
+    """CPUs the cgroup grants this process (cpu.max), or None when unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else float(q) / p
+    except Exception:
+        return None
+
+
 def cpu_baseline(ds, alns, order, budget_s):
     import multiprocessing as mp
     from tests import oracle_binding
@@ -122,24 +137,30 @@ def cpu_baseline(ds, alns, order, budget_s):
     per = t1 / max(n1, 1)
     m1 = max(8, min(nwin, int(budget_s / per)))
     n1, t1, f1, p1 = _cpu_fold_filter(range(m1))
-    # leg 2: one worker process per physical core, each its own slice (spawned: the parent holds a GPU context)
-    per_core = max(4, int(budget_s / (t1 / n1)))
-    total = min(nwin, phys * per_core)
-    chunks = [list(range(i, total, phys)) for i in range(phys)]
-    chunks = [c for c in chunks if c]
+    # leg 2: one worker process per usable physical core (spawned: the parent holds a GPU context), small tasks handed out dynamically and the
+    # leg cut off at the time budget, so a box whose cgroup grants fewer CPUs than it shows cannot stretch the run
+    quota = _cpu_quota()
+    nproc = max(1, min(phys, int(quota + 0.5)) if quota else phys)
+    tasks = [list(range(k, min(k + 4, nwin))) for k in range(0, nwin, 4)]
     ctx = mp.get_context("spawn")
-    with ctx.Pool(len(chunks), initializer=_cpu_init, initargs=(win, alns, ds.sample_names)) as pool:
-        pool.map(_cpu_fold_filter, [c[:1] for c in chunks])          # start-up (imports, library load) outside the timing
+    res = []
+    with ctx.Pool(nproc, initializer=_cpu_init, initargs=(win, alns, ds.sample_names)) as pool:
+        pool.map(_cpu_fold_filter, [t[:1] for t in tasks[:nproc]])          # start-up (imports, library load) outside the timing
         t = time.time()
-        res = pool.map(_cpu_fold_filter, chunks)
-        wall = time.time() - t
+        for r in pool.imap_unordered(_cpu_fold_filter, tasks):
+            res.append(r)
+            wall = time.time() - t
+            if wall >= budget_s:
+                break
+        pool.terminate()
+    chunks = list(range(nproc))
     n2 = sum(r[0] for r in res)
     cand_share = t_cand * n2 / max(nwin, 1)       # the candidate stage is serial in the port; charge the sample its share
     return {"value": n2 / (wall + cand_share), "unit": "windows/s", "cores": len(chunks), "kind": "port",
             "sample": "CPU oracle (oracle/*.c: candidate.c + lfold.c Turner-2004 d2 + predict.c) on the same workload: candidate stage over the whole input "
-                      "(1 thread, %.2f s for %d windows); fold + filter on the first %d windows, one process per physical core (%d), %.1f s wall; "
+                      "(1 thread, %.2f s for %d windows); fold + filter on %d windows handed out 4 at a time to one process per usable physical core (%d), %.1f s wall; "
                       "1-thread leg on the first %d windows, %.1f s" % (t_cand, nwin, n2, len(chunks), wall, n1, t1),
-            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "cgroup_cpu_quota": quota,
             "one_thread": {"value": n1 / (t1 + t_cand * n1 / max(nwin, 1)), "unit": "windows/s", "windows": n1, "fold_s_per_window": f1 / n1, "filter_s_per_window": p1 / n1},
             "all_cores": {"windows": n2, "wall_s": wall, "per_process_windows_per_s": n2 / sum(r[1] for r in res),
                           "fold_s_per_window": sum(r[2] for r in res) / n2, "filter_s_per_window": sum(r[3] for r in res) / n2},

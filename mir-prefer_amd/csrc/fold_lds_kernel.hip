@@ -178,11 +178,11 @@ __device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
     return b >= KEY_INF ? KEY_NONE : ((unsigned)((int)(b >> 10) + adj + KEY_BIAS) << 10) | (b & 1023u);
 }
 template <bool CHECK, int... Us>
-__device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int type) {
+__device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int mm_outer) {
     unsigned bg = KEY_INF;
     const unsigned short* rb = a.cring + i + 1;
     (a1_gen_row<CHECK, Us>(a, rb, bg), ...);
-    return a1_key(bg, -32768 + (int)a.T->mismatchI[type * 25 + a.S[i + 1] * 5 + a.S[j - 1]]);
+    return a1_key(bg, -32768 + mm_outer);      // mm_outer = mismatchI of the outer pair (i, j), fetched by the caller ahead of the rows
 }
 
 // bulges, n1 = 0, n2 = U in [LO, HI]: p = i+1, q = j-1-U
@@ -291,6 +291,147 @@ __device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, 
     }
 }
 
+// ---- "fast" variants of the jobs above for the steady state (every loop size admissible: um = MAXLOOP).  Same candidates, same keys; the
+// difference is the order of the loads: everything whose address is known up front (pair codes, ring entries, bases) is issued as one batch,
+// the table reads that depend on it as a second one, then the arithmetic.  The straightforward versions interleave a volatile read (kept
+// narrow on purpose, see a1_gen_row) with the reads that depend on it, and a volatile access is an ordering point for the scheduler: they
+// compile to one LDS round trip per candidate.
+#define A1_CHUNK 10
+template <int LO, int HI>
+__device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best) {
+    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_b0f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_b0f<LO + A1_CHUNK, HI>(a, i, j, best); }
+    else {
+        constexpr int N = HI - LO + 1;
+        const unsigned idxp = a.pax[i + 1];
+        lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
+        const unsigned short* rb = a.cring + i + 1;
+        const char* xb = reinterpret_cast<const char*>(a.T->XB);
+        unsigned code[N], g[N];
+        int x[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR];
+#pragma unroll
+        for (int k = 0; k < N; k++) code[k] = ql[LO + k];
+#pragma unroll
+        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb0_key[LO + k]; best = e < best ? e : best; }
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best) {
+    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_b1f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_b1f<LO + A1_CHUNK, HI>(a, i, j, best); }
+    else {
+        constexpr int N = HI - LO + 1;
+        const unsigned idxq = a.qbr[a.n + 2 - j];
+        lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+        const unsigned short* rb = a.cring + i + 1;
+        const char* xb = reinterpret_cast<const char*>(a.T->XB);
+        unsigned code[N], g[N];
+        int x[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR + (LO + k)];
+#pragma unroll
+        for (int k = 0; k < N; k++) code[k] = pl[LO + k];
+#pragma unroll
+        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb1_key[LO + k]; best = e < best ? e : best; }
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best) {
+    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_i0f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_i0f<LO + A1_CHUNK, HI>(a, i, j, best); }
+    else {
+        constexpr int N = HI - LO + 1;
+        const unsigned idxp = a.pax[i + 2];
+        lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
+        const unsigned short* rb = a.cring + i + 2;
+        const char* xb = reinterpret_cast<const char*>(a.T->X1);
+        unsigned code[N], g[N];
+        int x[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR];
+#pragma unroll
+        for (int k = 0; k < N; k++) code[k] = ql[LO + k];
+#pragma unroll
+        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n0_key[LO + k]; best = e < best ? e : best; }
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best) {
+    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_i1f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_i1f<LO + A1_CHUNK, HI>(a, i, j, best); }
+    else {
+        constexpr int N = HI - LO + 1;
+        const unsigned idxq = a.qbr[a.n + 3 - j];
+        lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+        const unsigned short* rb = a.cring + i + 1;
+        const char* xb = reinterpret_cast<const char*>(a.T->X1);
+        unsigned code[N], g[N];
+        int x[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR + (LO + k)];
+#pragma unroll
+        for (int k = 0; k < N; k++) code[k] = pl[LO + k];
+#pragma unroll
+        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
+#pragma unroll
+        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n1_key[LO + k]; best = e < best ? e : best; }
+    }
+}
+
+// key of one small shape from its ring entry g (G0 + 32768, 65535 = none), the inner pair's mismatchI term (G0 = c + that term) and the loop energy
+__device__ __forceinline__ unsigned a1_small_key(unsigned g, int mm_inner, int e_loop, unsigned code) {
+    const int e = e_loop + (int)g - 32768 - mm_inner;
+    return g == 65535u ? KEY_NONE : ((unsigned)(e + KEY_BIAS) << 10) | code;
+}
+// stack, the two 1-bulges, 1x1, 1x2 of the lane's cell (i, j): the seven bases and five ring entries first, pair types by arithmetic, then the table reads
+__device__ __forceinline__ unsigned a1_small14f(const A1& a, int i, int j, int type, bool ahead, bool noglobal = false) {
+    lds_vu8 Sv = (lds_vu8)a.S;
+    const int s_i = Sv[i], s_i1 = Sv[i + 1], s_i2 = Sv[i + 2], s_j3 = Sv[j - 3], s_j2 = Sv[j - 2], s_j1 = Sv[j - 1], s_j = Sv[j];
+    const unsigned short* rb = a.cring;
+    const unsigned g00 = rb[((a.r0) & 31) * CSTR + i + 1], g01 = rb[((a.r0 - 1) & 31) * CSTR + i + 1], g10 = rb[((a.r0 - 1) & 31) * CSTR + i + 2];
+    const unsigned g11 = rb[((a.r0 - 2) & 31) * CSTR + i + 2], g12 = rb[((a.r0 - 3) & 31) * CSTR + i + 2];
+    const int t00 = rtype_of(pair_type(s_i1, s_j1)), t01 = rtype_of(pair_type(s_i1, s_j2)), t10 = rtype_of(pair_type(s_i2, s_j1));
+    const int t11 = rtype_of(pair_type(s_i2, s_j2)), t12 = rtype_of(pair_type(s_i2, s_j3));
+    const LdsTables& T = *a.T;
+    const int m00 = T.mismatchI[t00 * 25 + s_j * 5 + s_i], m01 = T.mismatchI[t01 * 25 + s_j1 * 5 + s_i], m10 = T.mismatchI[t10 * 25 + s_j * 5 + s_i1];
+    const int m11 = T.mismatchI[t11 * 25 + s_j1 * 5 + s_i1], m12 = T.mismatchI[t12 * 25 + s_j2 * 5 + s_i1];
+    const int st00 = T.stack[type * 8 + t00], st01 = T.stack[type * 8 + t01], st10 = T.stack[type * 8 + t10], b1 = T.bulge[1];
+    const int r11 = noglobal ? 0 : a.P->int11[type][t11][s_i1][s_j1];
+    const int r12 = noglobal ? 0 : a.P->int21[type][t12][s_i1][s_j2][s_j1];
+    unsigned res = a1_small_key(g01, m01, b1 + st01, 0u << 5 | 1u);
+    unsigned k = a1_small_key(g10, m10, b1 + st10, 1u << 5 | 0u); res = k < res ? k : res;
+    k = a1_small_key(g00, m00, st00, 0u); if (!ahead) res = k < res ? k : res;     // the stacked pair of a lane of diagonal d+1 is not final yet
+    k = a1_small_key(g11, m11, r11, 1u << 5 | 1u); res = k < res ? k : res;
+    k = a1_small_key(g12, m12, r12, 1u << 5 | 2u); res = k < res ? k : res;
+    return res;
+}
+// 2x1, 2x2, 2x3, 3x2
+__device__ __forceinline__ unsigned a1_small15f(const A1& a, int i, int j, int type, bool noglobal = false) {
+    lds_vu8 Sv = (lds_vu8)a.S;
+    const int s_i1 = Sv[i + 1], s_i2 = Sv[i + 2], s_i3 = Sv[i + 3], s_i4 = Sv[i + 4], s_j4 = Sv[j - 4], s_j3 = Sv[j - 3], s_j2 = Sv[j - 2], s_j1 = Sv[j - 1];
+    const unsigned short* rb = a.cring;
+    const unsigned g21 = rb[((a.r0 - 3) & 31) * CSTR + i + 3], g22 = rb[((a.r0 - 4) & 31) * CSTR + i + 3], g23 = rb[((a.r0 - 5) & 31) * CSTR + i + 3];
+    const unsigned g32 = rb[((a.r0 - 5) & 31) * CSTR + i + 4];
+    // (n1, n2): p = i + 1 + n1, q = j - 1 - n2; sp1 = S[p - 1], sq1 = S[q + 1]
+    const int t21 = rtype_of(pair_type(s_i3, s_j2)), t22 = rtype_of(pair_type(s_i3, s_j3)), t23 = rtype_of(pair_type(s_i3, s_j4)), t32 = rtype_of(pair_type(s_i4, s_j3));
+    const LdsTables& T = *a.T;
+    const int m21 = T.mismatchI[t21 * 25 + s_j1 * 5 + s_i2], m22 = T.mismatchI[t22 * 25 + s_j2 * 5 + s_i2], m23 = T.mismatchI[t23 * 25 + s_j3 * 5 + s_i2];
+    const int m32 = T.mismatchI[t32 * 25 + s_j2 * 5 + s_i3];
+    const int o23 = T.mismatch23I[type * 25 + s_i1 * 5 + s_j1], i23 = T.mismatch23I[t23 * 25 + s_j3 * 5 + s_i2], i32 = T.mismatch23I[t32 * 25 + s_j2 * 5 + s_i3];
+    const int base23 = T.internal_loop[5] + T.ninio;
+    const int r21 = noglobal ? 0 : a.P->int21[t21][type][s_j1][s_i1][s_i2];
+    const int r22 = noglobal ? 0 : a.P->int22[type][t22][s_i1][s_i2][s_j2][s_j1];
+    unsigned res = a1_small_key(g23, m23, base23 + o23 + i23, 2u << 5 | 3u);
+    unsigned k = a1_small_key(g32, m32, base23 + o23 + i32, 3u << 5 | 2u); res = k < res ? k : res;
+    k = a1_small_key(g21, m21, r21, 2u << 5 | 1u); res = k < res ? k : res;
+    k = a1_small_key(g22, m22, r22, 2u << 5 | 2u); res = k < res ? k : res;
+    return res;
+}
+
 // MODEL 0: vienna-2.1.2 (Turner-2004, dangles 2).  MODEL 1: vienna-1.8.5 (Turner-1999 values in the same parameter layout, dangles 1: four-way
 // dangle minima in the multiloop closing and the fML pair terms, fML also on the diagonal d = span; SURVEY.md Appendix B, d1 column).
 template <int MODEL>
@@ -299,9 +440,21 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     int n_work, int win_base, int span, short* __restrict__ slabs, size_t slab_shorts, int* __restrict__ win_state,
     unsigned int* __restrict__ work_counter, int* __restrict__ fallback_list,
     unsigned int* __restrict__ fallback_count, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
-    int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags, long long* __restrict__ dbg_cycles) {
+    int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags_arg, long long* __restrict__ dbg_cycles_arg) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr LdsLayout LY = lds_layout<MODEL>();
+    // phase ablation flags and phase clocks exist in the diagnostics build only (make DIAG=1); the product kernel carries none of that code
+#ifdef MIRP_DIAG
+    const int dbg_flags = dbg_flags_arg;
+    long long* const dbg_cycles = dbg_cycles_arg;
+#else
+#ifndef MIRP_ABLATE
+#define MIRP_ABLATE 0      // dev builds only (make ABLATE=<flags>): phases removed at compile time, to time product-like code without them
+#endif
+    constexpr int dbg_flags = MIRP_ABLATE;
+    constexpr long long* dbg_cycles = nullptr;
+    (void)dbg_flags_arg; (void)dbg_cycles_arg;
+#endif
     constexpr int DMLR = MODEL ? 5 : 3;      // depth of the DML ring
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     long long wB = 0, wA1 = 0, wA2 = 0, wW = 0, wt = 0; // per-wave: phase B, interior loops, multiloop splits, barrier wait (lane 0 of each wave)
@@ -461,10 +614,15 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     int si1 = __builtin_amdgcn_readfirstlane(2 * (tri_off(t + s1, n) - tri_off(t, n)));
                     int si2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu - s1, n) - tri_off(uu, n) + s1));
                     const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
-                    const char* fb = reinterpret_cast<const char*>(fml + i);
                     us2 bu = {65535, 65535};
-#define MIRP_SSTEP() asm volatile("s_add_i32 %0, %0, %2\n\ts_sub_i32 %2, %2, %4\n\ts_add_i32 %1, %1, %3\n\ts_sub_i32 %3, %3, %4" : "+s"(so1), "+s"(so2), "+s"(si1), "+s"(si2) : "s"(sss) : "scc")
-#define MIRP_LDW(o) (*reinterpret_cast<const unsigned*>(fb + (o)))
+                    // the two operand addresses run in VGPRs (LDS byte addresses of this lane's pair): per split one vector add each, and only the
+                    // second-order terms of the recurrences stay on the scalar unit, which is the busiest pipe of this kernel
+                    typedef const __attribute__((address_space(3))) unsigned* lds_cu32;
+                    const unsigned fb0 = (unsigned)(size_t)(lds_cu32)reinterpret_cast<const unsigned*>(fml + i);
+                    unsigned va = fb0 + (unsigned)so1, vb = fb0 + (unsigned)so2;
+#define MIRP_SSTEP() do { va += (unsigned)si1; vb += (unsigned)si2; asm volatile("s_sub_i32 %0, %0, %2\n\ts_sub_i32 %1, %1, %2" : "+s"(si1), "+s"(si2) : "s"(sss) : "scc"); } while (0)
+#define MIRP_LDA() (*(lds_cu32)(va))
+#define MIRP_LDB(o) (*(lds_cu32)(vb + (o)))
                     // K splits with all their reads in flight before the first use.  The tail of a wave's split range (up to 7 splits) goes through
                     // the 4-, 2- and 1-deep groups: at most three LDS round trips instead of one per split.
                     auto group = [&](auto ODD, auto KK) {
@@ -473,8 +631,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         unsigned a[K], b[K], c[K];
 #pragma unroll
                         for (int k = 0; k < K; k++) {
-                            a[k] = MIRP_LDW(so1); b[k] = MIRP_LDW(so2);
-                            if (!kOdd) c[k] = MIRP_LDW(so2 + 4);
+                            a[k] = MIRP_LDA(); b[k] = MIRP_LDB(0);
+                            if (!kOdd) c[k] = MIRP_LDB(4);
                             MIRP_SSTEP();
                         }
                         us2 e[K];
@@ -500,7 +658,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     };
                     if (odd) relax(std::true_type{}); else relax(std::false_type{});
 #undef MIRP_SSTEP
-#undef MIRP_LDW
+#undef MIRP_LDA
+#undef MIRP_LDB
                     const unsigned r0 = bu[0], r1 = bu[1];
                     if (i <= ncell && r0 < 65535u) atomicMin(&mdec[i], (int)r0 - 2 * FML_BIAS);
                     if (i + 1 <= ncell && r1 < 65535u) atomicMin(&mdec[i + 1], (int)r1 - 2 * FML_BIAS);
@@ -521,7 +680,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const bool mix = d - 2 - (TURN + 1) >= MAXLOOP && d + 1 <= D && !(dbg_flags & 256);
                 // the length of this list is known since the previous interval (a1_ncp); the first block's entries are fetched before anything
                 // else: every dependent LDS access in front of the shape code costs hundreds of cycles when the pipe is loaded
-                const int ncp = __builtin_amdgcn_readfirstlane(lcnt[d % 6]);
+                const int ncp = a1_ncp;                    // = lcnt[d % 6], read one interval ago as ncp2: no LDS round trip in front of the first block
                 const int done = a1_done;                  // leading cells of this diagonal's list that were relaxed in the previous interval
                 const int rem = ncp - done;
                 const int nblk = (rem + 63) >> 6;
@@ -542,6 +701,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int role = wave < 4 ? wave : wave < 6 ? wave + 10 : wave < 12 ? wave + 2 : wave - 8;
                 A1 a;
                 a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
+                const bool slow = (dbg_flags & 8192) != 0;     // diagnostics build: the one-round-trip-per-candidate versions of the jobs
                 for (int blk = 0; blk < nblk; blk++) {
                     {   // re-materialise the wave-uniform loop parameters per block: keeps the admissibility tests and row offsets as plain
                         // scalar compares inside the block instead of dozens of hoisted masks (SGPR spills)
@@ -557,26 +717,34 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     a.cring = cring + (ahead ? CSTR : 0);
                     unsigned* ck = ahead ? ckey2 : ckey;
                     unsigned res = KEY_NONE;
-                    const int au1 = type > 2 ? (int)T.TerminalAU : 0;
+                    // the terms of the outer pair that turn a job's running minimum into the cell's key: fetched before the shape code, so that
+                    // their two round trips (bases, then tables) overlap the job's own reads instead of following them
+                    int au1 = 0, mmo = 0, mm1 = 0;
+                    if (role < 14) {
+                        lds_vu8 Sv = (lds_vu8)S;
+                        const int oi = type * 25 + (int)Sv[i + 1] * 5 + (int)Sv[j - 1];
+                        au1 = type > 2 ? (int)T.TerminalAU : 0;
+                        mmo = T.mismatchI[oi]; mm1 = T.mismatch1nI[oi];
+                    }
                     if (role < 8) {
                         if (!(dbg_flags & 4)) {
 #define MIRP_GEN(CK)                                                                      \
     switch (role) {                                                                       \
-    case 0: res = a1_generic<CK, 30, 23>(a, i, j, type); a1_i1<CK, 28, 29>(a, i, j, xi); break;      \
-    case 1: res = a1_generic<CK, 29, 24>(a, i, j, type); a1_i1<CK, 25, 27>(a, i, j, xi); break;      \
-    case 2: res = a1_generic<CK, 28, 25>(a, i, j, type); a1_i0<CK, 26, 29>(a, i, j, xi); break;      \
-    case 3: res = a1_generic<CK, 27, 26>(a, i, j, type); a1_b1<CK, 26, 30>(a, i, j, xb); break;      \
-    case 4: res = a1_generic<CK, 22, 17, 12, 7>(a, i, j, type); break;                    \
-    case 5: res = a1_generic<CK, 21, 18, 11, 8>(a, i, j, type); break;                    \
-    case 6: res = a1_generic<CK, 20, 16, 13, 9>(a, i, j, type); break;                    \
-    default: res = a1_generic<CK, 19, 15, 14, 10, 6>(a, i, j, type); break;               \
+    case 0: res = a1_generic<CK, 30, 23>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 28, 29>(a, i, j, xi); else a1_i1f<28, 29>(a, i, j, xi); break;      \
+    case 1: res = a1_generic<CK, 29, 24>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 25, 27>(a, i, j, xi); else a1_i1f<25, 27>(a, i, j, xi); break;      \
+    case 2: res = a1_generic<CK, 28, 25>(a, i, j, mmo); if (CK || slow) a1_i0<CK, 26, 29>(a, i, j, xi); else a1_i0f<26, 29>(a, i, j, xi); break;      \
+    case 3: res = a1_generic<CK, 27, 26>(a, i, j, mmo); if (CK || slow) a1_b1<CK, 26, 30>(a, i, j, xb); else a1_b1f<26, 30>(a, i, j, xb); break;      \
+    case 4: res = a1_generic<CK, 22, 17, 12, 7>(a, i, j, mmo); break;                    \
+    case 5: res = a1_generic<CK, 21, 18, 11, 8>(a, i, j, mmo); break;                    \
+    case 6: res = a1_generic<CK, 20, 16, 13, 9>(a, i, j, mmo); break;                    \
+    default: res = a1_generic<CK, 19, 15, 14, 10, 6>(a, i, j, mmo); break;               \
     }
                             // the 2-row generic groups run on the phase-B waves, which have slack left: they also take a few bulge / 1xn shapes
                             unsigned xb = KEY_INF, xi = KEY_INF;
                             if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
                             if (role < 4) {
                                 const unsigned rb = a1_key(xb, -32768 - OTH_BIAS + au1);
-                                const unsigned ri = a1_key(xi, -32768 - OTH_BIAS + (int)T.mismatch1nI[type * 25 + S[i + 1] * 5 + S[j - 1]]);
+                                const unsigned ri = a1_key(xi, -32768 - OTH_BIAS + mm1);
                                 res = rb < res ? rb : res;
                                 res = ri < res ? ri : res;
                             }
@@ -594,12 +762,23 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     case 12: a1_i0<CK, 16, 25>(a, i, j, bi); a1_i1<CK, 3, 8>(a, i, j, bi); break;         \
     default: a1_i1<CK, 9, 24>(a, i, j, bi); break;                                        \
     }
-                            if (a.um >= MAXLOOP) { MIRP_OTH(false) } else { MIRP_OTH(true) }
+                            if (a.um >= MAXLOOP && !slow) {
+                                switch (role) {
+                                case 8: a1_b0f<2, 18>(a, i, j, bb); break;
+                                case 9: a1_b0f<19, 30>(a, i, j, bb); a1_b1f<2, 6>(a, i, j, bb); break;
+                                case 10: a1_b1f<7, 22>(a, i, j, bb); break;
+                                case 11: a1_b1f<23, 25>(a, i, j, bb); a1_i0f<3, 15>(a, i, j, bi); break;
+                                case 12: a1_i0f<16, 25>(a, i, j, bi); a1_i1f<3, 8>(a, i, j, bi); break;
+                                default: a1_i1f<9, 24>(a, i, j, bi); break;
+                                }
+                            } else if (a.um >= MAXLOOP) { MIRP_OTH(false) } else { MIRP_OTH(true) }
 #undef MIRP_OTH
                             const unsigned rb = a1_key(bb, -32768 - OTH_BIAS + au1);
-                            const unsigned ri = a1_key(bi, -32768 - OTH_BIAS + (int)T.mismatch1nI[type * 25 + S[i + 1] * 5 + S[j - 1]]);
+                            const unsigned ri = a1_key(bi, -32768 - OTH_BIAS + mm1);
                             res = rb < ri ? rb : ri;
                         }
+                    } else if (!(dbg_flags & 32) && a.um >= MAXLOOP && !slow) {
+                        res = role == 14 ? a1_small14f(a, i, j, type, ahead, (dbg_flags & 16384) != 0) : a1_small15f(a, i, j, type, (dbg_flags & 16384) != 0);
                     } else if (!(dbg_flags & 32)) {
                         const int si1 = S[i + 1], sj1 = S[j - 1];
                         int ra, ca, rb2, cb2;
@@ -752,12 +931,96 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int lb = __builtin_amdgcn_readfirstlane(lbase);      // lane 0 holds the claimed range
             if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
         };
+        // Phase B of the default model, written as two rounds of loads and then arithmetic: every LDS read whose address depends on (i, j, d)
+        // only is issued first (round 1), the parameter-table reads that need the pair type and the neighbouring bases follow together
+        // (round 2), and nothing is read inside a branch.  The straightforward version (phaseB above, still the vienna-1.8.5 path) compiles
+        // to a chain of a dozen read-wait pairs, which is what the waves that own cells spend their interval on.
+        auto phaseB0 = [&](const int d) {
+            const int ncell = n - d;
+            unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
+            int* mdec = acc + (3 + (d & 1)) * LCAP;
+            const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
+            const int od = tri_off(d, n), od1 = tri_off(d - 1, n);
+            const int x = tid;
+            int lt = 0, lbase = 0;
+            unsigned long long lbal = 0;
+            if (d + 3 <= D && wave < 6) {
+                if (x + 1 + d + 3 <= n) lt = pair_type(S[x + 1], S[x + 1 + d + 3]);
+                lbal = __ballot(lt != 0);
+                if (lbal && lane == 0) lbase = atomicAdd(&lcnt[(d + 3) % 6], (int)__popcll(lbal));
+            }
+            if (tid == 0) lcnt[(d + 4) % 6] = 0;
+            if (x < ncell) {
+                const int i = x + 1, j = i + d, u = d - 1;
+                // ---- round 1
+                lds_vu8 Sv = (lds_vu8)S;
+                const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
+                const int md = mdec[i];
+                const unsigned kk = ckey[i];
+                const int dmlv = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1];
+                int fa = 65535, fb = 65535;
+                if (d > 4) { fa = fml[od1 + i]; fb = fml[od1 + i + 1]; }
+                int sv = -32768;
+                if (u == 4) sv = spec[nc + i]; else if (u == 6) sv = spec[2 * nc + i]; else if (u == 3) sv = spec[i];
+                // ---- pair type (arithmetic) and round 2: parameter tables; a type-0 row of a table is valid memory, its value is never used
+                const int type = pair_type(s_i, s_j);
+                const int rt = rtype_of(type);
+                const int tau = T.TerminalAU, mli = T.ML_intern, mlc = T.ML_closing;
+                const int mmH = T.mismatchH[type * 25 + s_ip1 * 5 + s_jm1];
+                const int mmMc = T.mismatchM[rt * 25 + s_jm1 * 5 + s_ip1];
+                const int mmMs = T.mismatchM[type * 25 + s_im1 * 5 + s_jp1];
+                const int dg5 = T.dangle5[type * 5 + s_im1], dg3 = T.dangle3[type * 5 + s_jp1];
+                const int mmI = T.mismatchI[rt * 25 + s_jp1 * 5 + s_im1];
+                // ---- arithmetic
+                const int au = type > 2 ? tau : 0;
+                int cv = INF, tb = 0;
+                if (type) {
+                    const int cint = kk == KEY_NONE ? INF : (int)(kk >> 10) - KEY_BIAS;
+                    int h;
+                    if (sv != -32768) h = sv;
+                    else if (u == 3) h = hp_u + au;
+                    else h = hp_u + mmH;
+                    cv = h < cint ? h : cint;
+                    if (dmlv != I16_INF) {
+                        const int e = dmlv + mlc + mli + (rt > 2 ? tau : 0) + mmMc;
+                        cv = e < cv ? e : cv;
+                    }
+                    if (cint < INF && cint == cv && h != cv) tb = (int)(kk & 1023u) + 1;
+                }
+                int m = INF;
+                {
+                    const int a = fa == 65535 ? INF : fa - FML_BIAS, b = fb == 65535 ? INF : fb - FML_BIAS;
+                    m = a < b ? a : b;
+                }
+                if (type) {
+                    // lds_mlstem(type, i > 1 ? S[i-1] : -1, j < n ? S[j+1] : -1)
+                    const int stem = mli + au + ((i > 1 && j < n) ? mmMs : (i > 1) ? dg5 : (j < n) ? dg3 : 0);
+                    const int e = cv + stem;
+                    m = e < m ? e : m;
+                }
+                m = md < m ? md : m;
+                if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
+                    (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
+                const short c16 = cv >= INF ? (short)I16_INF : (short)cv;
+                const unsigned short m16 = m >= INF ? (unsigned short)65535 : (unsigned short)(m + FML_BIAS);
+                const unsigned short g16 = cv < INF ? (unsigned short)(cv + mmI + 32768) : (unsigned short)65535;
+                cring[(d & 31) * CSTR + i] = g16;
+                if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
+                carch[od + i] = c16;
+                tb_out[od + i] = (unsigned short)tb;
+                fml[od + i] = m16;
+                dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
+                ckey[i] = KEY_NONE; mdec[i] = INF;
+            }
+            const int lb = __builtin_amdgcn_readfirstlane(lbase);
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
+        };
         if (Dm >= 4) phaseA(4);
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
         for (int d = 4; d <= Dm; d++) {
             if (dbg_cycles && lane == 0) wt = clock64();
-            phaseB(d);
+            if constexpr (MODEL == 0) { if (dbg_flags & 4096) phaseB(d); else phaseB0(d); } else phaseB(d);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wB += t - wt; wt = t; }
             if (d + 1 <= Dm) phaseA(d + 1);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA2 += t - wt; wt = t; }

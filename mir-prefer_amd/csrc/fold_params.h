@@ -10,6 +10,15 @@
 #define MIRP_HP_MAX 3104          // hairpin size table (log-extrapolated above 30 on the host)
 
 struct FoldParams {
+    // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes).  An interior-loop candidate is ranked by the key
+    // (energy term << 10) | (n1 << 5 | n2): the minimum key is the minimum energy and, among equal energies, the first shape in the
+    // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
+    unsigned gen_key[25][32];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
+    unsigned kb0_key[31];         // bulge n1 = 0, n2 = u:   (bulge[u] + 2048) << 10 | u
+    unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
+    unsigned k1n0_key[31];        // 1 x k loop (n1 = 1, n2 = k): (internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048) << 10 | 1 << 5 | k
+    unsigned k1n1_key[31];        // k x 1 loop (n1 = k, n2 = 1): ... | k << 5 | 1
+    // (the key tables come first so that the fill kernel's scalar loads reach them with immediate offsets from the one base pointer)
     int stack[8][8];
     int bulge[31];
     int internal_loop[31];
@@ -21,9 +30,6 @@ struct FoldParams {
     int mismatchExt[8][5][5];     // clamped <= 0
     int dangle5[8][5];            // clamped <= 0
     int dangle3[8][5];            // clamped <= 0
-    int int11[8][8][5][5];
-    int int21[8][8][5][5][5];
-    int int22[8][8][5][5][5][5];
     int hairpinE[MIRP_HP_MAX];
     int tetraE[32], triE[2], hexaE[4];
     char tetra[32][8];
@@ -31,14 +37,10 @@ struct FoldParams {
     char hexa[4][12];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
     int n_tri, n_tetra, n_hexa;   // motifs in use
-    // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes).  An interior-loop candidate is ranked by the key
-    // (energy term << 10) | (n1 << 5 | n2): the minimum key is the minimum energy and, among equal energies, the first shape in the
-    // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
-    unsigned gen_key[25][32];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
-    unsigned kb0_key[31];         // bulge n1 = 0, n2 = u:   (bulge[u] + 2048) << 10 | u
-    unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
-    unsigned k1n0_key[31];        // 1 x k loop (n1 = 1, n2 = k): (internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048) << 10 | 1 << 5 | k
-    unsigned k1n1_key[31];        // k x 1 loop (n1 = k, n2 = 1): ... | k << 5 | 1
+    // the three big tables last: everything above stays within the immediate-offset range of scalar loads
+    int int11[8][8][5][5];
+    int int21[8][8][5][5][5];
+    int int22[8][8][5][5][5][5];
 };
 
 // Energy model of the "vienna-1.8.5" compatibility mode (Turner-1999 parameters as shipped in ViennaRNA 1.8.5, dangles = 1).

@@ -10,5 +10,9 @@ ctx.load_genome(ds.contigs); ctx.load_alignments(ds.sorted_alns())
 ctx.candidate(10, 100, 300, np.zeros(1, dtype=np.int32))
 ctx.fold(300)
 os.environ["MIRP_FOLD_CLOCKS"] = "1"
-ctx.fold(300)
-print(ctx.last_timings())
+for f in (sys.argv[1:] or ["0"]):
+    os.environ["MIRP_FOLD_DEBUG"] = f
+    print("==== MIRP_FOLD_DEBUG=%s" % f, flush=True)
+    sys.stderr.write("==== MIRP_FOLD_DEBUG=%s\n" % f); sys.stderr.flush()
+    ctx.fold(300)
+    print(ctx.last_timings(), flush=True)
