@@ -114,6 +114,8 @@ __device__ __forceinline__ int lds_intloop(const LdsTables& T, const FoldParams*
 // misaligned 32-bit DS read is replayed on gfx950).  off(d) = 1 + (d-4) n - (d(d-1)/2 - 6) + #{odd lengths among diagonals 4..d-1}.
 __host__ __device__ constexpr int tri_off(int d, int n) { return 1 + (d - 4) * n - (d * (d - 1) / 2 - 6) + (((d - 4) + (n & 1)) >> 1); }
 __host__ __device__ constexpr int tri_len(int d, int n) { return n - d > 0 ? (n - d) + ((n - d) & 1) : 0; }
+// tri_off(d + 1, n) - tri_off(d, n) of the closed form, for any d (also below the first diagonal, where tri_len is cut off)
+__host__ __device__ constexpr int tri_len_any(int d, int n) { return (n - d) + ((n - d) & 1); }
 __device__ inline void fill_tri_off(int* off, int n) {
     int o = 1;
     for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += tri_len(d, n); }
@@ -582,6 +584,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (dbg_cycles && tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; }
         // ---- anti-diagonal wavefront, software-pipelined: phase B of diagonal d (one thread per cell) runs in the same barrier
         // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
+        // split loop state carried across diagonals (see splits below)
+        int sp_ncpad = 0, sp_nsub = 0, sp_pair = 0, sp_sub = 0, sp_so1 = 0, sp_si1 = 0, sp_so2 = 0, sp_si2 = 0;
         int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
         int a1_ncp = __builtin_amdgcn_readfirstlane(lcnt[0]);   // phase A1: length of the next diagonal's list (first: diagonal 6)
         auto phaseA = [&](const int d) {
@@ -596,24 +600,40 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             auto splits = [&]() {
                 const int npair = (ncell + 1) >> 1;
                 const int ncpad = (npair + 63) & ~63;
-                const int nsub = (LNT / ncpad) & ~1;     // even, >= 4 for ncell <= 384
-                const int pair = tid % ncpad;
-                const int sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
+                // The lane mapping (pair, sub) and the start offsets / first differences of the two operand walks depend on d only through the
+                // diagonal of operand b, which moves up by one per diagonal: they are carried across diagonals in registers and advanced with
+                // two scalar adds; everything is set up again only when the number of cell pairs crosses a multiple of 64 (the mapping changes).
+                // Recomputing the closed forms (integer division by ncpad, four triangle offsets) on every diagonal cost more scalar and vector
+                // instructions than the split loop itself.
+                if (ncpad != sp_ncpad) {
+                    sp_ncpad = ncpad;
+                    sp_nsub = (LNT / ncpad) & ~1;     // even, >= 4 for ncell <= 384
+                    sp_pair = tid % ncpad;
+                    sp_sub = __builtin_amdgcn_readfirstlane(tid / ncpad);
+                    const int t0 = 4 + sp_sub, u0 = d - t0 - 1, s1 = sp_nsub;
+                    sp_so1 = __builtin_amdgcn_readfirstlane(2 * tri_off(t0, n));
+                    sp_si1 = __builtin_amdgcn_readfirstlane(2 * (tri_off(t0 + s1, n) - tri_off(t0, n)));
+                    sp_so2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(u0, n) + t0 + 1 - ((t0 & 1) ? 0 : 1)));
+                    sp_si2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(u0 - s1, n) - tri_off(u0, n) + s1));
+                } else {
+                    // d advanced by one since the last call: operand b starts one diagonal higher (tri_off(u + 1) = tri_off(u) + tri_len(u)), and its
+                    // first difference grows by s1 cells (s1 is even, so the paddings of the two diagonals involved cancel)
+                    const int uprev = d - 1 - (4 + sp_sub) - 1;
+                    sp_so2 += 2 * tri_len_any(uprev, n);
+                    sp_si2 += 2 * sp_nsub;
+                }
+                const int nsub = sp_nsub, pair = sp_pair, sub = sp_sub;
                 if (sub < nsub && !(dbg_flags & 2)) {
                     const int i = 2 * pair + 1;
                     // every split t in [4, d-5] is relaxed unconditionally: with the biased uint16 encoding a sum that involves an INF entry
                     // saturates at 65535 and any sum of two finite entries is <= 65534, so no per-lane range bookkeeping is needed.
-                    // The byte offsets of the two operand diagonals live in SGPRs and advance by second-order recurrences (tri_off above):
+                    // The byte offsets of the two operand diagonals advance by second-order recurrences (tri_off above):
                     //   o1(t) = off(t),  o2(t) = off(d-t-1) + t + 1   (minus one short for even t: the aligned word below the pair)
                     const int s1 = nsub;
                     int t = 4 + sub;
-                    const int uu = d - t - 1;
                     const int odd = t & 1;
-                    int so1 = __builtin_amdgcn_readfirstlane(2 * tri_off(t, n));
-                    int so2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu, n) + t + 1 - (odd ? 0 : 1)));
-                    int si1 = __builtin_amdgcn_readfirstlane(2 * (tri_off(t + s1, n) - tri_off(t, n)));
-                    int si2 = __builtin_amdgcn_readfirstlane(2 * (tri_off(uu - s1, n) - tri_off(uu, n) + s1));
-                    const int sss = __builtin_amdgcn_readfirstlane(2 * s1 * s1);
+                    int so1 = sp_so1, so2 = sp_so2, si1 = sp_si1, si2 = sp_si2;
+                    const int sss = 2 * s1 * s1;
                     us2 bu = {65535, 65535};
                     // the two operand addresses run in VGPRs (LDS byte addresses of this lane's pair): per split one vector add each, and only the
                     // second-order terms of the recurrences stay on the scalar unit, which is the busiest pipe of this kernel
