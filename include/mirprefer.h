@@ -120,6 +120,11 @@ typedef struct {
 int mirp_load_genome(mirp_ctx* ctx, int32_t n_contigs, const int64_t* contig_len, const uint8_t* seq_concat);
 /* Alignments sorted as described at MirpAln. Replaces the prepare-stage BAMs (MP:772-874) as device-resident records. */
 int mirp_load_alignments(mirp_ctx* ctx, const MirpAln* alns, int64_t n_alns);
+/* Coverage segments of gapped alignments (records of the MirpAln layout, any order): `samtools depth` counts only the M / = / X bases of an
+ * alignment (MP:937-941) while the read bookkeeping of the reference works on POS and len(SEQ).  Such an alignment is
+ * one MirpAln record (POS, len(SEQ)) plus segments: strand bit 1 set = subtract the interval [pos, pos+len) (takes the record's own interval
+ * back out), clear = add it (one per M / = / X block).  Replaces any segments loaded before; mirp_load_alignments clears them. */
+int mirp_load_coverage_segments(mirp_ctx* ctx, const MirpAln* segs, int64_t n_segs);
 /* Contig sharding across GPUs (one context per shard, whole contigs per shard): the strand vote of the reference double-counts the first
  * position of the first covered run of every contig except the very first run of the depth file (MP:905-906 + 926-929).  A shard whose first
  * covered contig is preceded, in @SQ order, by a covered contig held by ANOTHER shard sets this to 1 so that its first run is double-counted
@@ -204,12 +209,23 @@ typedef struct {
     int64_t* contig_len;
     int32_t n_samples; char* sample_names;   /* one per SAM file (MP:3300-3308) */
     MirpAln* alns; int64_t n_alns;           /* stably sorted by (tid, pos) over the sample-ordered concatenation */
+    MirpAln* segs; int64_t n_segs;           /* coverage segments of the gapped alignments (see mirp_load_coverage_segments), unordered */
 } MirpSamData;
 /* Replaces sam2bam / samtools cat / sort / expand_bamfile / strand split of prepare_data (MP:656-746, 772-874): parses the
- * sample SAM files (ungapped `<len>M` alignments, read ids `sample_rA_xN`) with n_threads threads (0 = all cores).
+ * sample SAM files (read ids `sample_rA_xN`) with n_threads threads (0 = all cores) and sorts on the host.  A record keeps POS and len(SEQ),
+ * which is what the reference's read bookkeeping uses (MP:1439-1457, 2021); an alignment whose CIGAR is not `<len(SEQ)>M` also yields
+ * coverage segments (`samtools depth` counts M / = / X bases only).
  * Returns 0 or -1 with a message in errbuf; release with mirp_free_sam_data. */
 int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32_t n_threads, MirpSamData* out, char* errbuf, size_t errbuf_len);
 void mirp_free_sam_data(MirpSamData* data);
+/* One keep region of the GFF options as the reference's BED file has it (MP:543-652): contig index, 0-based half-open [start, end). */
+typedef struct { int32_t tid, start, end; } MirpRegion;
+/* The same ingest with the device doing the record work: host threads tokenize, the GPU applies the keep regions like `samtools view -L`
+ * (MP:817-859; n_regions = 0: no filter) and sorts stably by (tid, pos) (LSD radix sort, ties keep sample-then-file order).  The sorted
+ * records and segments stay resident as the context's alignments (as after mirp_load_alignments + mirp_load_coverage_segments) and are
+ * returned in *out.  seconds (optional): {tokenize, upload + filter, sort, download}.  Errors: mirp_last_error. */
+int mirp_ingest_sams_gpu(mirp_ctx* ctx, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
+                         int64_t n_regions, MirpSamData* out, double seconds[4]);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(256) cov_scatter_kernel(const MirpAln* __restr
         if (s < 1) s = 1;
         if (e > L + 1) e = L + 1;
         if (s >= e || w == 0) continue;
-        int* d = r.strand ? diff_m : diff_p;
+        if (r.strand & 2) w = -w;          // coverage segment that takes a gapped alignment's own interval back out (mirp_load_coverage_segments)
+        int* d = (r.strand & 1) ? diff_m : diff_p;
         long long base = goff[r.tid];
         atomicAdd(&d[base + s - 1], w);
         atomicAdd(&d[base + e - 1], -w);

@@ -10,7 +10,7 @@
 #include <vector>
 #include "mirp_internal.h"
 
-#define MIRP_ABI_VERSION 3   // 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
+#define MIRP_ABI_VERSION 4   // 4: MirpSamData.segs, mirp_ingest_sams_gpu, mirp_load_coverage_segments; 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
 #define MIRP_NMAX 3096
 
 #include "mirp_ctx.h"
@@ -83,7 +83,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,
                       &c->keep, &c->kscan, &c->csq, &c->cdest, &c->peaks_sq, &c->peaks_sorted, &c->head, &c->hscan, &c->rfirst, &c->nent,
                       &c->isloc, &c->nslots, &c->escan, &c->lscan, &c->sscan, &c->windows, &c->roles, &c->loci, &c->wpeaks, &c->matures,
-                      &c->wseqs, &c->woffs, &c->wlens, &c->side_cnt, &c->side_idx, &c->side_list, &c->side_offs, &c->side_lens, &c->lines2, &c->ss2,
+                      &c->wseqs, &c->woffs, &c->wlens, &c->segs, &c->sort_tmp, &c->sort_counts, &c->side_cnt, &c->side_idx, &c->side_list, &c->side_offs, &c->side_lens, &c->lines2, &c->ss2,
                       &c->nlines2, &c->mfe2, &c->status2, &c->p_out, &c->p_nout, &c->p_status, &c->p_keep, &c->p_kscan, &c->p_res, &c->p_text})
         b->release();
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

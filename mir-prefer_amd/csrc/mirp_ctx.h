@@ -48,7 +48,10 @@ struct mirp_ctx {
     int n_contigs = 0;
     long long gtot = 0, gbytes = 0, n_alns = 0;
     std::vector<long long> h_clen, h_goff, h_gboff;
-    DevBuf genome, clen, goff, gboff, alns, order;
+    DevBuf genome, clen, goff, gboff, alns, order, segs, sort_tmp, sort_counts;
+    long long n_segs = 0;
+    bool ingest_resident = false;     // the alignments came from mirp_ingest_sams_gpu (already validated and sorted on the device)
+    int ingest_n_contigs = 0;
     DevBuf diff, stat, starts, totals, runs, keep, kscan, csq, cdest, peaks_sq, peaks_sorted;
     DevBuf head, hscan, rfirst, nent, isloc, nslots, escan, lscan, sscan, windows, roles, loci, wpeaks, matures, wseqs, woffs, wlens;
     DevBuf p_out, p_nout, p_status, p_keep, p_kscan, p_res, p_text;
@@ -80,5 +83,10 @@ static inline int fail(mirp_ctx* c, int code, const std::string& msg) {
 
 // Folds n_work device-resident windows (seqs/offs/lens as the kernels expect) into the context's fold output buffers.
 // Uses the LDS-resident kernel when span allows and re-runs flagged windows (length / int16 range) with the generic kernel.
+// sort_kernels.hip: stable device sort by (tid, pos) / keep-region filter of the resident record array
+int mirp_device_sort_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long n, int posbits, int tidbits);
+int mirp_device_mask_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long* n_io, MirpAln* d_segs, MirpAln* d_segtmp, const int* d_owner, long long* nseg_io,
+                          const long long* d_rfirst, const int* d_rstart, const int* d_remax);
+
 int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,
                   int max_lines, int stride, MirpFoldLine* d_lines, char* d_ss, int* d_nlines, int* d_mfe, int* d_status);

@@ -1,22 +1,27 @@
-// Native SAM ingest: multi-threaded tokenizer + stable (tid, pos) sort producing the packed 16-byte
-// alignment records the kernels consume.  Replaces the reference's prepare-stage plumbing -- sam2bam, `samtools cat`,
-// `samtools sort`, expand_bamfile, strand split (/root/reference/miR_PREFeR.py:656-746, 772-874) -- with an in-memory
-// equivalent; record order = sample order, then file order, stably sorted by (tid, pos), which is what the reference's
-// combined sorted BAM presents to gen_loci_alignment_info (first-seen maximum at MP:1457).
-// Host-only code: no device is touched.
+// Native SAM ingest: multi-threaded tokenizer producing the packed 16-byte alignment records the kernels consume, then the
+// stable (tid, pos) sort -- on the device (mirp_ingest_sams_gpu: radix sort + optional GFF region filter, sort_kernels.hip) or on the host
+// (mirp_ingest_sams, no device needed).  Replaces the reference's prepare-stage plumbing -- sam2bam, `samtools cat`, `samtools sort`,
+// `samtools view -L`, expand_bamfile, strand split (/root/reference/miR_PREFeR.py:656-746, 772-874) -- with an in-memory equivalent; record
+// order = sample order, then file order, stably sorted by (tid, pos), which is what the reference's combined sorted BAM presents to
+// gen_loci_alignment_info (first-seen maximum at MP:1457).
+//
+// Gapped alignments (CIGAR with I / D / N / S / H / P / = / X): the record keeps POS and the SEQ length, which is all the reference's read
+// bookkeeping looks at (`samtools view` fields 3 and 9, MP:1439-1457, 2021); the per-base coverage of `samtools depth` counts the M / = / X
+// blocks only, so such a read also emits coverage segments: one that takes its [POS, POS + len(SEQ)) interval back out
+// and one per M / = / X block (mirp_load_coverage_segments).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
-#include <unordered_map>
 #include <vector>
-#include "../../include/mirprefer.h"
+#include "mirp_ctx.h"
 
 namespace {
 
@@ -33,6 +38,7 @@ struct Mapped {
         if (n == 0) { p = ""; return true; }
         void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m == MAP_FAILED) return false;
+        (void)madvise(m, n, MADV_SEQUENTIAL);
         p = (const char*)m;
         return true;
     }
@@ -42,65 +48,139 @@ struct Mapped {
     }
 };
 
-inline const char* field_end(const char* s, const char* e) { while (s < e && *s != '\t' && *s != '\n') s++; return s; }
+// contig name -> index: open addressing over FNV-1a of the name bytes (no allocation per line)
+struct NameTable {
+    std::vector<std::string> names;
+    std::vector<int> slot;      // -1 = empty
+    unsigned mask = 0;
+    static unsigned hash(const char* s, size_t n) { unsigned h = 2166136261u; for (size_t k = 0; k < n; k++) { h ^= (unsigned char)s[k]; h *= 16777619u; } return h; }
+    void build() {
+        unsigned cap = 16;
+        while (cap < 4 * names.size() + 8) cap <<= 1;
+        slot.assign(cap, -1); mask = cap - 1;
+        for (size_t t = 0; t < names.size(); t++) {
+            unsigned h = hash(names[t].data(), names[t].size()) & mask;
+            while (slot[h] >= 0) { if (names[slot[h]] == names[t]) break; h = (h + 1) & mask; }
+            if (slot[h] < 0) slot[h] = (int)t;      // a repeated @SQ name keeps its first index
+        }
+    }
+    int find(const char* s, size_t n) const {
+        unsigned h = hash(s, n) & mask;
+        while (slot[h] >= 0) {
+            const std::string& c = names[slot[h]];
+            if (c.size() == n && std::memcmp(c.data(), s, n) == 0) return slot[h];
+            h = (h + 1) & mask;
+        }
+        return -1;
+    }
+};
 
 struct ChunkOut {
-    std::vector<MirpAln> recs;
+    std::vector<MirpAln> recs, segs;
+    std::vector<int32_t> seg_owner;      // index of the owning record inside this chunk
     std::string err;
 };
 
+inline bool parse_uint(const char* s, const char* e, long* out) {
+    if (s >= e) return false;
+    long v = 0;
+    for (; s < e; s++) { const unsigned d = (unsigned)(*s - '0'); if (d > 9) return false; v = v * 10 + d; if (v > 0x7fffffffffffL / 16) return false; }
+    *out = v;
+    return true;
+}
+
 // parse the alignment lines in [b, e) (b at a line start)
-void parse_chunk(const char* b, const char* e, const std::unordered_map<std::string, int>& tid_of, int sample, ChunkOut* out) {
+void parse_chunk(const char* b, const char* e, const NameTable* tab, int sample, ChunkOut* out) {
     const char* s = b;
-    std::string key;
+    out->recs.reserve((size_t)(e - b) / 64 + 16);
+    int last_tid = -1;
+    const char* last_name = nullptr;
+    size_t last_len = 0;
     while (s < e) {
         const char* le = (const char*)memchr(s, '\n', (size_t)(e - s));
         if (!le) le = e;
-        if (le > s && *s != '@') {
+        const char* lend = (le > s && le[-1] == '\r') ? le - 1 : le;
+        if (lend > s && *s != '@') {
             const char* f[11];
             const char* fe[11];
             int nf = 0;
             const char* q = s;
-            while (nf < 11 && q <= le) {
+            while (nf < 11) {
                 f[nf] = q;
-                const char* t = field_end(q, le);
-                fe[nf] = t;
-                nf++;
-                if (t >= le) break;
+                const char* t = (const char*)memchr(q, '\t', (size_t)(lend - q));
+                if (!t) t = lend;
+                fe[nf++] = t;
+                if (t >= lend) break;
                 q = t + 1;
             }
             if (nf >= 10) {
-                long flag = strtol(f[1], nullptr, 10);
+                long flag = 0;
+                if (!parse_uint(f[1], fe[1], &flag)) { out->err = "SAM flag is not a number"; return; }
                 if (!(flag & 0x704)) {
-                    // depth: ^\S+_x([0-9]+)  (get_read_depth_fromID_as_string, MP:242-253): greedy \S+ -> last "_x<digits>" with digits following
+                    // depth: ^\S+_x([0-9]+)  (get_read_depth_fromID_as_string, MP:242-253): greedy \S+ -> the LAST "_x" that digits follow
                     const char* id = f[0];
                     const char* ide = fe[0];
                     long depth = -1;
                     for (const char* t = ide - 1; t > id + 2; t--) {
-                        if (*t >= '0' && *t <= '9' && t[-1] == 'x' && t[-2] == '_') {   // candidate start of the digit run
-                            const char* d0 = t;
-                            // the regex takes the LAST position where "_x" is followed by >= 1 digit; scanning from the right finds it first
-                            depth = strtol(d0, nullptr, 10);
+                        if (*t >= '0' && *t <= '9' && t[-1] == 'x' && t[-2] == '_') {
+                            long v = 0;
+                            for (const char* d = t; d < ide && *d >= '0' && *d <= '9'; d++) { v = v * 10 + (*d - '0'); if (v > 0xffffffffL) { v = 0xffffffffL; break; } }
+                            depth = v;
                             break;
                         }
                     }
                     if (depth < 0) { out->err = "Read Id format is not right. Read id must be in \"samplename_rA_xN\" format."; return; }
-                    key.assign(f[2], fe[2]);
-                    auto it = tid_of.find(key);
-                    if (it == tid_of.end()) { out->err = "alignment refers to a sequence that is not in the @SQ header: " + key; return; }
-                    long pos = strtol(f[3], nullptr, 10);
-                    long rl = (long)(fe[9] - f[9]);
-                    // ungapped alignments only: CIGAR must be "<len>M"
-                    char* cend = nullptr;
-                    long cl = strtol(f[5], &cend, 10);
-                    if (!(cend && cend + 1 == fe[5] && *cend == 'M' && cl == rl)) {
-                        out->err = "only ungapped alignments (<len>M) are supported, got CIGAR " + std::string(f[5], fe[5]);
-                        return;
+                    const size_t nl = (size_t)(fe[2] - f[2]);
+                    int tid;
+                    if (last_name && nl == last_len && std::memcmp(last_name, f[2], nl) == 0) tid = last_tid;
+                    else {
+                        tid = tab->find(f[2], nl);
+                        if (tid < 0) { out->err = "alignment refers to a sequence that is not in the @SQ header: " + std::string(f[2], fe[2]); return; }
+                        last_tid = tid; last_name = f[2]; last_len = nl;
                     }
+                    long pos = 0;
+                    if (!parse_uint(f[3], fe[3], &pos) || pos > 0x7ffffff0L) { out->err = "SAM position is not a number"; return; }
+                    const long rl = (long)(fe[9] - f[9]);
                     if (rl > 65535) { out->err = "read longer than 65535"; return; }
                     MirpAln r;
-                    r.tid = it->second; r.pos = (int32_t)pos; r.depth = (uint32_t)depth; r.len = (uint16_t)rl;
+                    r.tid = tid; r.pos = (int32_t)pos; r.depth = (uint32_t)depth; r.len = (uint16_t)rl;
                     r.strand = (flag & 16) ? 1 : 0; r.sample = (uint8_t)sample;
+                    // CIGAR: "<len>M" with len == len(SEQ) is the plain case; anything else gets coverage segments
+                    const char* c = f[5];
+                    const char* ce = fe[5];
+                    long cl = 0;
+                    const char* p = c;
+                    while (p < ce && *p >= '0' && *p <= '9') { cl = cl * 10 + (*p - '0'); p++; }
+                    const bool plain = p > c && p + 1 == ce && *p == 'M' && cl == rl;
+                    if (!plain) {
+                        if (ce - c == 1 && *c == '*') { out->err = "alignment without a CIGAR string"; return; }
+                        const int32_t owner = (int32_t)out->recs.size();
+                        MirpAln sg = r;
+                        sg.strand = (uint8_t)(r.strand | 2);                 // bit 1: subtract (takes the record's own interval back out)
+                        out->segs.push_back(sg); out->seg_owner.push_back(owner);
+                        long ref = pos;
+                        p = c;
+                        while (p < ce) {
+                            long len = 0;
+                            const char* d0 = p;
+                            while (p < ce && *p >= '0' && *p <= '9') { len = len * 10 + (*p - '0'); p++; if (len > 0x7ffffff0L) break; }
+                            if (p == d0 || p >= ce) { out->err = "malformed CIGAR " + std::string(c, ce); return; }
+                            const char op = *p++;
+                            if (op == 'M' || op == '=' || op == 'X') {
+                                long off = 0;
+                                while (off < len) {                          // blocks longer than 65535 are cut
+                                    const long part = std::min<long>(len - off, 65535);
+                                    MirpAln bsg = r;
+                                    bsg.pos = (int32_t)(ref + off); bsg.len = (uint16_t)part;
+                                    out->segs.push_back(bsg); out->seg_owner.push_back(owner);
+                                    off += part;
+                                }
+                                ref += len;
+                            } else if (op == 'D' || op == 'N') ref += len;
+                            else if (op == 'I' || op == 'S' || op == 'H' || op == 'P') { /* consume no reference */ }
+                            else { out->err = "malformed CIGAR " + std::string(c, ce); return; }
+                        }
+                    }
                     out->recs.push_back(r);
                 }
             }
@@ -111,31 +191,22 @@ void parse_chunk(const char* b, const char* e, const std::unordered_map<std::str
 
 inline uint64_t key_of(const MirpAln& r) { return ((uint64_t)(uint32_t)r.tid << 32) | (uint32_t)r.pos; }
 
-}  // namespace
-
-extern "C" void mirp_free_sam_data(MirpSamData* d) {
-    if (!d) return;
-    std::free(d->contig_names); std::free(d->contig_len); std::free(d->sample_names); std::free(d->alns);
-    std::memset(d, 0, sizeof(*d));
-}
-
-extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32_t n_threads, MirpSamData* out, char* errbuf, size_t errbuf_len) {
-    auto fail = [&](const std::string& m) {
-        if (errbuf && errbuf_len) { std::snprintf(errbuf, errbuf_len, "%s", m.c_str()); }
-        return -1;
-    };
-    if (!paths || n_paths < 1 || !out) return fail("mirp_ingest_sams: bad argument");
-    if (n_paths > MIRP_MAX_SAMPLES) return fail("mirp_ingest_sams: too many samples");
-    std::memset(out, 0, sizeof(*out));
-    if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    std::vector<std::string> names;
+struct Parsed {
+    std::vector<std::string> names, samples;
     std::vector<int64_t> lens;
-    std::unordered_map<std::string, int> tid_of;
-    std::vector<std::string> samples;
-    std::vector<std::vector<ChunkOut>> per_file(n_paths);
+    std::vector<std::vector<ChunkOut>> per_file;
+    size_t n_recs = 0, n_segs = 0, bytes = 0;
+};
+
+// header + threaded tokenizer over every file; records stay in per-chunk vectors (sample, then file order)
+int parse_all(const char* const* paths, int32_t n_paths, int32_t n_threads, Parsed* P, std::string* err) {
+    if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    NameTable tab;
+    P->per_file.resize(n_paths);
     for (int fi = 0; fi < n_paths; fi++) {
         Mapped m;
-        if (!m.open(paths[fi])) return fail(std::string("cannot open ") + paths[fi]);
+        if (!m.open(paths[fi])) { *err = std::string("cannot open ") + paths[fi]; return -1; }
+        P->bytes += m.n;
         const char* b = m.p;
         const char* e = m.p + m.n;
         // header (get_length_from_sam, MP:500-509: @SQ order of the FIRST file defines the contig indices)
@@ -154,19 +225,24 @@ extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32
                     if (line.compare(p, 3, "LN:") == 0) ln = strtol(line.c_str() + p + 3, nullptr, 10);
                     p = t + 1;
                 }
-                if (!sn.empty() && ln >= 0) { tid_of[sn] = (int)names.size(); names.push_back(sn); lens.push_back(ln); }
+                while (!sn.empty() && (sn.back() == '\r' || sn.back() == '\n')) sn.pop_back();
+                if (!sn.empty() && ln >= 0) { tab.names.push_back(sn); P->lens.push_back(ln); }
             }
             s = le < e ? le + 1 : e;
         }
-        if (fi == 0 && names.empty()) return fail("Can not get the sequence length from the input SAM files. Make sure SAM files have headers.");
+        if (fi == 0) {
+            if (tab.names.empty()) { *err = "Can not get the sequence length from the input SAM files. Make sure SAM files have headers."; return -1; }
+            tab.build();
+        }
         // sample name from the first alignment line (get_samplename_from_sam, MP:3300-3308)
         {
-            const char* t = field_end(s, e);
+            const char* t = s;
+            while (t < e && *t != '\t' && *t != '\n') t++;
             std::string id(s, t), sname;
             std::vector<size_t> us;
             for (size_t k = 0; k < id.size(); k++) if (id[k] == '_') us.push_back(k);
             if (us.size() >= 2) sname = id.substr(0, us[us.size() - 2]);
-            samples.push_back(sname);
+            P->samples.push_back(sname);
         }
         // split the body at line starts
         const size_t body = (size_t)(e - s);
@@ -178,19 +254,78 @@ extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32
             const char* le = (const char*)memchr(c, '\n', (size_t)(e - c));
             cuts[k] = le ? le + 1 : e;
         }
-        per_file[fi].resize(nt);
+        P->per_file[fi].resize(nt);
         std::vector<std::thread> th;
-        for (int k = 0; k < nt; k++) th.emplace_back(parse_chunk, cuts[k], cuts[k + 1], std::cref(tid_of), fi, &per_file[fi][k]);
+        for (int k = 0; k < nt; k++) th.emplace_back(parse_chunk, cuts[k], cuts[k + 1], &tab, fi, &P->per_file[fi][k]);
         for (auto& t : th) t.join();
-        for (auto& c : per_file[fi]) if (!c.err.empty()) return fail(c.err);
+        for (auto& c : P->per_file[fi]) if (!c.err.empty()) { *err = c.err; return -1; }
     }
-    // concatenate in (sample, file) order
-    size_t total = 0;
-    for (auto& f : per_file) for (auto& c : f) total += c.recs.size();
+    for (auto& f : P->per_file) for (auto& c : f) { P->n_recs += c.recs.size(); P->n_segs += c.segs.size(); }
+    P->names = tab.names;
+    return 0;
+}
+
+// concatenation in (sample, file) order; segment owners become indices into the concatenated record array
+void concat(Parsed& P, MirpAln* all, MirpAln* segs, int32_t* owner) {
+    size_t o = 0, so = 0;
+    for (auto& f : P.per_file)
+        for (auto& c : f) {
+            if (!c.recs.empty()) std::memcpy(all + o, c.recs.data(), c.recs.size() * sizeof(MirpAln));
+            if (!c.segs.empty()) {
+                std::memcpy(segs + so, c.segs.data(), c.segs.size() * sizeof(MirpAln));
+                for (size_t k = 0; k < c.segs.size(); k++) owner[so + k] = (int32_t)(o + (size_t)c.seg_owner[k]);
+                so += c.segs.size();
+            }
+            o += c.recs.size();
+            std::vector<MirpAln>().swap(c.recs); std::vector<MirpAln>().swap(c.segs); std::vector<int32_t>().swap(c.seg_owner);
+        }
+}
+
+int fill_meta(const Parsed& P, MirpSamData* out) {
+    size_t nb = 0;
+    for (auto& s : P.names) nb += s.size() + 1;
+    out->contig_names = (char*)std::malloc(std::max<size_t>(nb, 1));
+    out->contig_len = (int64_t*)std::malloc(std::max<size_t>(P.names.size(), 1) * sizeof(int64_t));
+    size_t sb = 0;
+    for (auto& s : P.samples) sb += s.size() + 1;
+    out->sample_names = (char*)std::malloc(std::max<size_t>(sb, 1));
+    if (!out->contig_names || !out->contig_len || !out->sample_names) return -1;
+    char* w = out->contig_names;
+    for (size_t k = 0; k < P.names.size(); k++) { std::memcpy(w, P.names[k].c_str(), P.names[k].size() + 1); w += P.names[k].size() + 1; out->contig_len[k] = P.lens[k]; }
+    w = out->sample_names;
+    for (auto& s : P.samples) { std::memcpy(w, s.c_str(), s.size() + 1); w += s.size() + 1; }
+    out->n_contigs = (int32_t)P.names.size(); out->n_samples = (int32_t)P.samples.size();
+    return 0;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+extern "C" void mirp_free_sam_data(MirpSamData* d) {
+    if (!d) return;
+    std::free(d->contig_names); std::free(d->contig_len); std::free(d->sample_names); std::free(d->alns); std::free(d->segs);
+    std::memset(d, 0, sizeof(*d));
+}
+
+extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32_t n_threads, MirpSamData* out, char* errbuf, size_t errbuf_len) {
+    auto fail = [&](const std::string& m) {
+        if (errbuf && errbuf_len) { std::snprintf(errbuf, errbuf_len, "%s", m.c_str()); }
+        return -1;
+    };
+    if (!paths || n_paths < 1 || !out) return fail("mirp_ingest_sams: bad argument");
+    if (n_paths > MIRP_MAX_SAMPLES) return fail("mirp_ingest_sams: too many samples");
+    std::memset(out, 0, sizeof(*out));
+    if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    Parsed P;
+    std::string err;
+    if (parse_all(paths, n_paths, n_threads, &P, &err)) return fail(err);
+    const size_t total = P.n_recs;
     MirpAln* all = (MirpAln*)std::malloc(std::max<size_t>(total, 1) * sizeof(MirpAln));
-    if (!all) return fail("out of memory");
-    size_t o = 0;
-    for (auto& f : per_file) for (auto& c : f) { std::memcpy(all + o, c.recs.data(), c.recs.size() * sizeof(MirpAln)); o += c.recs.size(); std::vector<MirpAln>().swap(c.recs); }
+    MirpAln* segs = (MirpAln*)std::malloc(std::max<size_t>(P.n_segs, 1) * sizeof(MirpAln));
+    std::vector<int32_t> owner(std::max<size_t>(P.n_segs, 1));
+    if (!all || !segs) { std::free(all); std::free(segs); return fail("out of memory"); }
+    concat(P, all, segs, owner.data());
     // stable sort by (tid, pos): sort equal slices in parallel (stable), then merge neighbours (std::inplace_merge is stable)
     {
         int nt = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, total / (1 << 16)));
@@ -209,19 +344,89 @@ extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32
             for (auto& t : mt) t.join();
         }
     }
-    // outputs
-    size_t nb = 0;
-    for (auto& s : names) nb += s.size() + 1;
-    out->contig_names = (char*)std::malloc(std::max<size_t>(nb, 1));
-    out->contig_len = (int64_t*)std::malloc(std::max<size_t>(names.size(), 1) * sizeof(int64_t));
-    size_t sb = 0;
-    for (auto& s : samples) sb += s.size() + 1;
-    out->sample_names = (char*)std::malloc(std::max<size_t>(sb, 1));
-    if (!out->contig_names || !out->contig_len || !out->sample_names) { std::free(all); mirp_free_sam_data(out); return fail("out of memory"); }
-    char* w = out->contig_names;
-    for (size_t k = 0; k < names.size(); k++) { std::memcpy(w, names[k].c_str(), names[k].size() + 1); w += names[k].size() + 1; out->contig_len[k] = lens[k]; }
-    w = out->sample_names;
-    for (auto& s : samples) { std::memcpy(w, s.c_str(), s.size() + 1); w += s.size() + 1; }
-    out->n_contigs = (int32_t)names.size(); out->n_samples = (int32_t)samples.size(); out->alns = all; out->n_alns = (int64_t)total;
+    if (fill_meta(P, out)) { std::free(all); std::free(segs); mirp_free_sam_data(out); return fail("out of memory"); }
+    out->alns = all; out->n_alns = (int64_t)total; out->segs = segs; out->n_segs = (int64_t)P.n_segs;
+    return 0;
+}
+
+// Device path: host threads tokenize, the records go to the GPU in (sample, file) order, the optional keep-region filter
+// (`samtools view -L`, MP:817-859) and the stable radix sort run there, and the sorted records stay resident as the context's alignments
+// (as after mirp_load_alignments + mirp_load_coverage_segments) besides being returned to the host.
+extern "C" int mirp_ingest_sams_gpu(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
+                                    int64_t n_regions, MirpSamData* out, double seconds[4]) {
+    if (!c) return -1;
+    if (!paths || n_paths < 1 || !out) return fail(c, -1, "mirp_ingest_sams_gpu: bad argument");
+    if (n_paths > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_ingest_sams_gpu: too many samples");
+    std::memset(out, 0, sizeof(*out));
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_s();
+    Parsed P;
+    std::string err;
+    if (parse_all(paths, n_paths, n_threads, &P, &err)) return fail(c, -1, err);
+    const double t1 = now_s();
+    long long n = (long long)P.n_recs, ns = (long long)P.n_segs;
+    if (n > 0x7fffffffLL) return fail(c, -5, "mirp_ingest_sams_gpu: more than 2^31 records");
+    MirpAln* all = (MirpAln*)std::malloc(std::max<size_t>((size_t)n, 1) * sizeof(MirpAln));
+    MirpAln* segs = (MirpAln*)std::malloc(std::max<size_t>((size_t)ns, 1) * sizeof(MirpAln));
+    std::vector<int32_t> owner(std::max<size_t>((size_t)ns, 1));
+    auto bail = [&](int code, const std::string& m) { std::free(all); std::free(segs); mirp_free_sam_data(out); return fail(c, code, m); };
+    if (!all || !segs) return bail(-6, "out of memory");
+    concat(P, all, segs, owner.data());
+    // contig count / lengths decide the key width
+    int64_t maxlen = 1;
+    for (int64_t l : P.lens) maxlen = std::max(maxlen, l);
+    int posbits = 1, tidbits = 1;
+    while ((1LL << posbits) <= maxlen + 65536 && posbits < 31) posbits++;
+    while ((1LL << tidbits) < (long long)P.names.size() && tidbits < 31) tidbits++;
+    if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
+        c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1)))
+        return bail(-6, "device allocation failed (ingest)");
+    if (n && hipMemcpyAsync(c->alns.p, all, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(-2, "H2D failed");
+    if (ns && hipMemcpyAsync(c->segs.p, segs, sizeof(MirpAln) * (size_t)ns, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(-2, "H2D failed");
+    if (n_regions > 0 && keep_regions && n > 0) {
+        // per-contig slices of the regions, sorted by start, with the running maximum of the ends
+        const int nc = (int)P.names.size();
+        std::vector<std::vector<std::pair<int, int>>> by(nc);
+        for (int64_t k = 0; k < n_regions; k++)
+            if (keep_regions[k].tid >= 0 && keep_regions[k].tid < nc && keep_regions[k].end > keep_regions[k].start)
+                by[keep_regions[k].tid].push_back({keep_regions[k].start, keep_regions[k].end});
+        std::vector<long long> rfirst(nc + 1, 0);
+        std::vector<int> rs, rm;
+        for (int t = 0; t < nc; t++) {
+            std::stable_sort(by[t].begin(), by[t].end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+            rfirst[t] = (long long)rs.size();
+            int mx = 0;
+            for (auto& iv : by[t]) { mx = std::max(mx, iv.second); rs.push_back(iv.first); rm.push_back(mx); }
+        }
+        rfirst[nc] = (long long)rs.size();
+        TmpDevice T;
+        long long* d_rf = (long long*)T.get(8 * rfirst.size());
+        int* d_rs = (int*)T.get(4 * std::max<size_t>(rs.size(), 1));
+        int* d_rm = (int*)T.get(4 * std::max<size_t>(rm.size(), 1));
+        int* d_own = (int*)T.get(4 * (size_t)std::max<long long>(ns, 1));
+        MirpAln* d_segtmp = (MirpAln*)T.get(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1));
+        if (!d_rf || !d_rs || !d_rm || !d_own || !d_segtmp) return bail(-6, "device allocation failed (regions)");
+        if (hipMemcpy(d_rf, rfirst.data(), 8 * rfirst.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            (!rs.empty() && (hipMemcpy(d_rs, rs.data(), 4 * rs.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                             hipMemcpy(d_rm, rm.data(), 4 * rm.size(), hipMemcpyHostToDevice) != hipSuccess)) ||
+            (ns && hipMemcpy(d_own, owner.data(), 4 * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess))
+            return bail(-2, "H2D failed");
+        if (int rc = mirp_device_mask_alns(c, (MirpAln*)c->alns.p, (MirpAln*)c->sort_tmp.p, &n, (MirpAln*)c->segs.p, d_segtmp, d_own, &ns, d_rf, d_rs, d_rm)) {
+            std::free(all); std::free(segs); mirp_free_sam_data(out); return rc;
+        }
+    }
+    const double t2 = now_s();
+    if (int rc = mirp_device_sort_alns(c, (MirpAln*)c->alns.p, (MirpAln*)c->sort_tmp.p, n, posbits, tidbits)) { std::free(all); std::free(segs); mirp_free_sam_data(out); return rc; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(-2, "device sort failed");
+    const double t3 = now_s();
+    if (n && hipMemcpy(all, c->alns.p, sizeof(MirpAln) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return bail(-2, "D2H failed");
+    if (ns && hipMemcpy(segs, c->segs.p, sizeof(MirpAln) * (size_t)ns, hipMemcpyDeviceToHost) != hipSuccess) return bail(-2, "D2H failed");
+    const double t4 = now_s();
+    if (fill_meta(P, out)) return bail(-6, "out of memory");
+    out->alns = all; out->n_alns = n; out->segs = segs; out->n_segs = ns;
+    c->n_alns = n; c->n_segs = ns;
+    c->have_candidate = c->have_fold = false;
+    c->ingest_resident = true; c->ingest_n_contigs = (int)P.names.size();
+    if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = t3 - t2; seconds[3] = t4 - t3; }
     return 0;
 }

@@ -114,7 +114,21 @@ extern "C" int mirp_load_alignments(mirp_ctx* c, const MirpAln* alns, int64_t n)
     }
     if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<int64_t>(n, 1))) return fail(c, -6, "device allocation failed (alignments)");
     if (n) HIPCHK(c, hipMemcpy(c->alns.p, alns, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice));
-    c->n_alns = n;
+    c->n_alns = n; c->n_segs = 0; c->ingest_resident = false;
+    c->have_candidate = c->have_fold = false;
+    return 0;
+}
+
+extern "C" int mirp_load_coverage_segments(mirp_ctx* c, const MirpAln* segs, int64_t n) {
+    if (!c) return -1;
+    if (n < 0 || (n > 0 && !segs)) return fail(c, -1, "mirp_load_coverage_segments: bad argument");
+    if (c->n_contigs == 0) return fail(c, -1, "mirp_load_coverage_segments: load the genome first");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int64_t k = 0; k < n; k++)
+        if (segs[k].tid < 0 || segs[k].tid >= c->n_contigs) return fail(c, -1, "mirp_load_coverage_segments: tid out of range");
+    if (c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<int64_t>(n, 1))) return fail(c, -6, "device allocation failed (segments)");
+    if (n) HIPCHK(c, hipMemcpy(c->segs.p, segs, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice));
+    c->n_segs = n;
     c->have_candidate = c->have_fold = false;
     return 0;
 }
@@ -136,6 +150,9 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, 64, c->stream));
     mirp::launch_cov_scatter(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p, c->cand.cutoff,
                              diff_p, diff_m);
+    if (c->n_segs > 0)       // gapped alignments: their own [pos, pos + len(SEQ)) taken back out, their M / = / X blocks added
+        mirp::launch_cov_scatter(c->stream, (const MirpAln*)c->segs.p, c->n_segs, (const long long*)c->goff.p, (const long long*)c->clen.p, c->cand.cutoff,
+                                 diff_p, diff_m);
     mirp::launch_cov_scan(c->stream, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p, std::max<long long>(c->n_alns, 1),
                           depth_out, depth_cap, depth_gx, (unsigned long long*)c->totals.p);
     HIPCHK(c, hipGetLastError());
@@ -154,6 +171,7 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
     if (!c) return -1;
     if (!params || !contig_order) return fail(c, -1, "mirp_candidate: null argument");
     if (c->n_contigs == 0) return fail(c, -1, "mirp_candidate: no genome loaded");
+    if (c->ingest_resident && c->ingest_n_contigs != c->n_contigs) return fail(c, -1, "mirp_candidate: the SAM header and the genome do not have the same contigs");
     if (params->precursor_len < 60 || params->precursor_len > 3000) return fail(c, -1, "Error: allowed precursor range: 60-3000");
     if (params->cutoff < 2) return fail(c, -1, "Error: READS_DEPTH_CUTOFF should >=2.");
     HIPCHK(c, hipSetDevice(c->device));
