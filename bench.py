@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of wall-clock per CPU-baseline leg")
+    ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--ingest-records", type=int, default=8000000,
+                    help="records of the synthetic SAM of the ingest leg (a cfg[4] rank shard is 25,000,000; the default keeps the run short)")
     ap.add_argument("--fold-model", default="vienna-2.1.2", choices=["vienna-2.1.2", "vienna-1.8.5"],
                     help="RNALfold flavour to reproduce (the headline metric is quoted on the default, Turner-2004)")
     return ap.parse_args()
@@ -236,6 +239,44 @@ def e2e_cli(ds, fold_model):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def ingest_leg(ctx, n_records):
+    """SAM text -> sorted packed records resident in HBM: a synthetic unsorted SAM of a cfg[4]-shard-like shape (8 contigs x
+    31.25 Mb, clusters of isomiR-like reads, 3 sample files), host threads tokenize, the GPU sorts stably by (tid, pos)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from mir_prefer_amd import synth
+    tmp = tempfile.mkdtemp(prefix="mirp_ingest_")
+    try:
+        nc, clen = 8, 31250000
+        names, lens = ["ctg%02d" % t for t in range(nc)], [clen] * nc
+        rng = np.random.RandomState(77)
+        per = n_records // 3
+        paths, nbytes = [], 0
+        for s in range(3):
+            a = np.zeros(per, dtype=synth.ALN_DTYPE)
+            centre = rng.randint(0, 150000, size=per).astype(np.int64) * 1600 + 200           # loci on a grid, reads scattered around them
+            a["tid"] = (centre // clen).astype(np.int32) % nc
+            a["pos"] = (centre % (clen - 2000) + rng.randint(0, 60, size=per) + 1).astype(np.int32)
+            a["depth"] = rng.randint(1, 40, size=per)
+            a["len"] = rng.randint(18, 26, size=per)
+            a["strand"] = rng.randint(0, 2, size=per)
+            p = os.path.join(tmp, "S%d.sam" % (s + 1))
+            nbytes += synth.write_sam_fast(p, "S%d" % (s + 1), a, names, lens)
+            paths.append(p)
+        ctx.ingest_sams(paths[:1])                        # warm-up (page cache of the first file, kernels loaded)
+        t = time.time()
+        cn, cl, sn, alns, segs, sec = ctx.ingest_sams(paths)
+        wall = time.time() - t
+        key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
+        assert len(alns) == 3 * per and (np.diff(key) >= 0).all()
+        return {"records": int(len(alns)), "sam_bytes": int(nbytes), "wall_s": wall, "records_per_s": len(alns) / wall, "sam_MB_per_s": nbytes / wall / 1e6,
+                "seconds": sec, "note": "3 unsorted SAM files -> mirp_ingest_sams_gpu (host tokenizer threads, H2D, device LSD radix sort by (tid, pos), D2H copy for the host stages); "
+                                        "files in the page cache"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse_args()
@@ -384,6 +425,8 @@ def main():
                     line["e2e_wall_s"] = line["e2e"]["wall_s"]
                 except SystemExit as e:
                     line["e2e"] = {"error": "CLI exited with %r" % (e.code,)}
+            if not a.no_ingest:
+                line["ingest"] = ingest_leg(ctx, a.ingest_records)
             if not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(ds, alns, order, a.cpu_budget)
         print(json.dumps(line))

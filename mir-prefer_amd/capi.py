@@ -20,18 +20,15 @@ class FoldLine(C.Structure):
 
 class SamData(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("contig_names", C.c_void_p), ("contig_len", C.POINTER(C.c_int64)), ("n_samples", C.c_int32),
-                ("sample_names", C.c_void_p), ("alns", C.c_void_p), ("n_alns", C.c_int64)]
+                ("sample_names", C.c_void_p), ("alns", C.c_void_p), ("n_alns", C.c_int64), ("segs", C.c_void_p), ("n_segs", C.c_int64)]
 
 
-def ingest_sams(paths, n_threads=0):
-    """Native multi-threaded SAM ingest (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns)."""
+class Region(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("start", C.c_int32), ("end", C.c_int32)]
+
+
+def _unpack_sam_data(lib, d):
     from .synth import ALN_DTYPE
-    lib = load_library()
-    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
-    d = SamData()
-    err = C.create_string_buffer(512)
-    if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
-        raise ValueError(err.value.decode())
     try:
         def names(ptr, n):
             out, off = [], 0
@@ -42,11 +39,25 @@ def ingest_sams(paths, n_threads=0):
         cn = names(d.contig_names, d.n_contigs)
         sn = names(d.sample_names, d.n_samples)
         lens = np.array([d.contig_len[k] for k in range(d.n_contigs)], dtype=np.int64)
-        n = d.n_alns
-        alns = np.frombuffer((C.c_char * (n * 16)).from_address(d.alns), dtype=ALN_DTYPE, count=n).copy() if n else np.zeros(0, dtype=ALN_DTYPE)
+
+        def recs(ptr, n):
+            return np.frombuffer((C.c_char * (n * 16)).from_address(ptr), dtype=ALN_DTYPE, count=n).copy() if n else np.zeros(0, dtype=ALN_DTYPE)
+        alns, segs = recs(d.alns, d.n_alns), recs(d.segs, d.n_segs)
     finally:
         lib.mirp_free_sam_data(C.byref(d))
-    return cn, lens, sn, alns
+    return cn, lens, sn, alns, segs
+
+
+def ingest_sams(paths, n_threads=0, with_segments=False):
+    """Native multi-threaded SAM ingest, host sort (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns[, segs])."""
+    lib = load_library()
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    d = SamData()
+    err = C.create_string_buffer(512)
+    if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
+        raise ValueError(err.value.decode())
+    out = _unpack_sam_data(lib, d)
+    return out if with_segments else out[:4]
 
 
 FOLD_LINE_DTYPE = np.dtype([("start", "<i4"), ("len", "<i4"), ("energy", "<i4"), ("printed", "<i4")])
@@ -131,6 +142,10 @@ def load_library():
     lib.mirp_ingest_sams.restype = C.c_int
     lib.mirp_free_sam_data.argtypes = [C.POINTER(SamData)]
     lib.mirp_free_sam_data.restype = None
+    lib.mirp_ingest_sams_gpu.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, vp, C.c_int64, C.POINTER(SamData), C.POINTER(C.c_double)]
+    lib.mirp_ingest_sams_gpu.restype = C.c_int
+    lib.mirp_load_coverage_segments.argtypes = [vp, vp, C.c_int64]
+    lib.mirp_load_coverage_segments.restype = C.c_int
     _lib = lib
     return lib
 
@@ -239,6 +254,29 @@ class Context:
         alns = np.ascontiguousarray(alns)
         assert alns.dtype.itemsize == 16
         self._check(self.lib.mirp_load_alignments(self.h, alns.ctypes.data, len(alns)), "mirp_load_alignments")
+
+    def load_coverage_segments(self, segs):
+        """Coverage segments of gapped alignments (see mirp_load_coverage_segments); call after load_alignments."""
+        segs = np.ascontiguousarray(segs)
+        assert segs.dtype.itemsize == 16
+        self._check(self.lib.mirp_load_coverage_segments(self.h, segs.ctypes.data, len(segs)), "mirp_load_coverage_segments")
+
+    def ingest_sams(self, paths, regions=None, n_threads=0):
+        """SAM files -> sorted records with the device doing the record work (mirp_ingest_sams_gpu): host threads tokenize, the GPU filters by
+        the keep regions [(tid, start0, end0), ...] like `samtools view -L` and sorts stably by (tid, pos).  The records stay resident as this
+        context's alignments.  -> (contig_names, contig_lens, sample_names, alns, segs, seconds{tokenize, upload_filter, sort, download})."""
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        nreg = len(regions) if regions else 0
+        reg = (Region * max(nreg, 1))()
+        for k in range(nreg):
+            reg[k].tid, reg[k].start, reg[k].end = int(regions[k][0]), int(regions[k][1]), int(regions[k][2])
+        d = SamData()
+        sec = (C.c_double * 4)()
+        rc = self.lib.mirp_ingest_sams_gpu(self.h, arr, len(paths), int(n_threads), C.cast(reg, C.c_void_p), nreg, C.byref(d), sec)
+        if rc != 0:
+            raise ValueError(self.lib.mirp_last_error(self.h).decode())
+        cn, lens, sn, alns, segs = _unpack_sam_data(self.lib, d)
+        return cn, lens, sn, alns, segs, {"tokenize_s": sec[0], "upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3]}
 
     def candidate(self, cutoff, max_gap, precursor_len, contig_order, min_peak_len=19):
         pp = (C.c_int32 * 4)(int(cutoff), int(min_peak_len), int(max_gap), int(precursor_len))

@@ -158,7 +158,10 @@ void parse_chunk(const char* b, const char* e, const NameTable* tab, int sample,
                         MirpAln sg = r;
                         sg.strand = (uint8_t)(r.strand | 2);                 // bit 1: subtract (takes the record's own interval back out)
                         out->segs.push_back(sg); out->seg_owner.push_back(owner);
-                        long ref = pos;
+                        // Two passes over the CIGAR.  The bundled samtools 0.1.18 piles a read up only below its bam_calend(), which adds up the
+                        // M, D and N lengths but not = and X: blocks are cut at pos + sum(M, D, N) (probed against the binary with
+                        // tests/golden/tools/gen_gapped_golden.py; an alignment written with = / X loses its tail there, as in the reference run).
+                        long calend = pos;
                         p = c;
                         while (p < ce) {
                             long len = 0;
@@ -166,19 +169,27 @@ void parse_chunk(const char* b, const char* e, const NameTable* tab, int sample,
                             while (p < ce && *p >= '0' && *p <= '9') { len = len * 10 + (*p - '0'); p++; if (len > 0x7ffffff0L) break; }
                             if (p == d0 || p >= ce) { out->err = "malformed CIGAR " + std::string(c, ce); return; }
                             const char op = *p++;
+                            if (op == 'M' || op == 'D' || op == 'N') calend += len;
+                            else if (!(op == 'I' || op == 'S' || op == 'H' || op == 'P' || op == '=' || op == 'X')) { out->err = "malformed CIGAR " + std::string(c, ce); return; }
+                        }
+                        long ref = pos;
+                        p = c;
+                        while (p < ce) {
+                            long len = 0;
+                            while (p < ce && *p >= '0' && *p <= '9') { len = len * 10 + (*p - '0'); p++; }
+                            const char op = *p++;
                             if (op == 'M' || op == '=' || op == 'X') {
-                                long off = 0;
-                                while (off < len) {                          // blocks longer than 65535 are cut
-                                    const long part = std::min<long>(len - off, 65535);
+                                const long stop = std::min(ref + len, calend);
+                                long off = ref;
+                                while (off < stop) {                         // blocks longer than 65535 are cut
+                                    const long part = std::min<long>(stop - off, 65535);
                                     MirpAln bsg = r;
-                                    bsg.pos = (int32_t)(ref + off); bsg.len = (uint16_t)part;
+                                    bsg.pos = (int32_t)off; bsg.len = (uint16_t)part;
                                     out->segs.push_back(bsg); out->seg_owner.push_back(owner);
                                     off += part;
                                 }
                                 ref += len;
                             } else if (op == 'D' || op == 'N') ref += len;
-                            else if (op == 'I' || op == 'S' || op == 'H' || op == 'P') { /* consume no reference */ }
-                            else { out->err = "malformed CIGAR " + std::string(c, ce); return; }
                         }
                     }
                     out->recs.push_back(r);

@@ -72,16 +72,16 @@ def keep_regions_include(path, minlen=55):
     return out
 
 
-def apply_keep(alns, names, regions):
-    """`samtools view -L bed`: keep the records that overlap any BED interval (0-based, half-open).  alns: ALN_DTYPE, pos 1-based."""
+def keep_mask(alns, regions):
+    """`samtools view -L bed` as a boolean mask: True for the records that overlap any keep region.  regions: [(tid, start0, end0)] 0-based
+    half-open; alns: ALN_DTYPE in any order, pos 1-based."""
     keep = np.zeros(len(alns), dtype=bool)
-    tid_of = {n: t for t, n in enumerate(names)}
     a0 = alns["pos"].astype(np.int64) - 1
     a1 = a0 + alns["len"].astype(np.int64)
     by_tid = {}
-    for seqid, s, e in regions:
-        if seqid in tid_of and e > s:
-            by_tid.setdefault(tid_of[seqid], []).append((s, e))
+    for t, s, e in regions:
+        if e > s:
+            by_tid.setdefault(int(t), []).append((s, e))
     for t, ivs in by_tid.items():
         idx = np.nonzero(alns["tid"] == t)[0]
         if not len(idx):
@@ -96,4 +96,15 @@ def apply_keep(alns, names, regions):
         hit = k > 0
         hit[hit] = emax[k[hit] - 1] > a0[idx][hit]
         keep[idx] = hit
-    return alns[keep]
+    return keep
+
+
+def regions_by_tid(regions, names):
+    """(seqid, start0, end0) BED regions -> (tid, start0, end0) for the contigs of the SAM header (unknown sequence ids drop out)."""
+    tid_of = {n: t for t, n in enumerate(names)}
+    return [(tid_of[seqid], int(s), int(e)) for seqid, s, e in regions if seqid in tid_of]
+
+
+def apply_keep(alns, names, regions):
+    """`samtools view -L bed`: keep the records that overlap any BED interval (0-based, half-open).  alns: ALN_DTYPE, pos 1-based."""
+    return alns[keep_mask(alns, regions_by_tid(regions, names))]

@@ -49,27 +49,58 @@ def read_sam_header(path):
     return names, lens
 
 
-def read_sams(paths, native=True):
+_CIGAR_RE = re.compile(r"([0-9]+)([MIDNSHP=X])")
+
+
+def cigar_segments(rec, cigar):
+    """Coverage segments of a gapped alignment (see mirp_load_coverage_segments in include/mirprefer.h): `samtools depth` counts the
+    M / = / X bases only.  rec = (tid, pos, depth, len(SEQ), strand, sample) -> list of such tuples, the first one
+    with strand bit 1 set (takes the record's own [pos, pos + len(SEQ)) back out), then one per M / = / X block."""
+    tid, pos, depth, rl, strand, sample = rec
+    if cigar == "*" or "".join(a + b for a, b in _CIGAR_RE.findall(cigar)) != cigar:
+        raise ValueError("malformed CIGAR %s" % cigar)
+    out = [(tid, pos, depth, rl, strand | 2, sample)]
+    # the bundled samtools 0.1.18 piles a read up only below its bam_calend() = pos + sum of the M, D and N lengths (= and X are not added):
+    # blocks are cut there (probed against the binary, tests/golden/tools/gen_gapped_golden.py)
+    calend = pos + sum(int(ln) for ln, op in _CIGAR_RE.findall(cigar) if op in "MDN")
+    ref = pos
+    for ln, op in _CIGAR_RE.findall(cigar):
+        ln = int(ln)
+        if op in "M=X":
+            off, stop = ref, min(ref + ln, calend)
+            while off < stop:
+                part = min(stop - off, 65535)
+                out.append((tid, off, depth, part, strand, sample))
+                off += part
+            ref += ln
+        elif op in "DN":
+            ref += ln
+    return out
+
+
+def read_sams(paths, native=True, regions=None, with_segments=False):
     """Uses the native multi-threaded parser of libmirprefer.so for plain-text SAM files; gzip-compressed files (test fixtures)
     go through the Python parser below, which implements the same rules.
 
-    -> (contig_names, contig_lens, sample_names, alns) with alns stably sorted by (tid, pos) over
-    the sample-ordered concatenation (what `samtools cat` + `samtools sort` produce for the reference).
-    Only ungapped alignments (`<len>M`, as bowtie -v 0 emits) are accepted; unmapped reads are skipped."""
-    if native and not any(str(p).endswith(".gz") for p in paths):
+    -> (contig_names, contig_lens, sample_names, alns[, segs]) with alns stably sorted by (tid, pos) over
+    the sample-ordered concatenation (what `samtools cat` + `samtools sort` produce for the reference).  A record keeps POS and len(SEQ);
+    alignments whose CIGAR is not `<len(SEQ)>M` also yield coverage segments (cigar_segments).  regions: keep regions
+    [(tid, start0, end0)] applied like `samtools view -L` before the sort.  Unmapped reads are skipped."""
+    if native and not any(str(p).endswith(".gz") for p in paths) and regions is None:
         from . import capi
-        return capi.ingest_sams(paths)
+        out = capi.ingest_sams(paths, with_segments=True)
+        return out if with_segments else out[:4]
     names, lens = read_sam_header(paths[0])
     tid_of = {n: i for i, n in enumerate(names)}
     sample_names = []
-    recs = []
+    recs, segs, owner = [], [], []
     for si, p in enumerate(paths):
         sname = None
         with _open(p) as f:
             for line in f:
                 if line.startswith("@"):
                     continue
-                sp = line.split("\t")
+                sp = line.rstrip("\r\n").split("\t")
                 if sname is None:
                     sname = "_".join(sp[0].split("_")[0:-2])  # get_samplename_from_sam, miR_PREFeR.py:3300-3308
                 flag = int(sp[1])
@@ -80,11 +111,22 @@ def read_sams(paths, native=True):
                     raise ValueError('Read Id format is not right. Read id must be in "samplename_rA_xN" format.')
                 cigar = sp[5]
                 rl = len(sp[9])
+                rec = (tid_of[sp[2]], int(sp[3]), int(m.group(1)), rl, 1 if flag & 16 else 0, si)
                 if cigar != "%dM" % rl:
-                    raise ValueError("only ungapped alignments (<len>M) are supported, got CIGAR %s" % cigar)
-                recs.append((tid_of[sp[2]], int(sp[3]), int(m.group(1)), rl, 1 if flag & 16 else 0, si))
+                    for sg in cigar_segments(rec, cigar):
+                        segs.append(sg); owner.append(len(recs))
+                recs.append(rec)
         sample_names.append(sname)
-    a = np.array(recs, dtype=[("tid", "<i4"), ("pos", "<i4"), ("depth", "<u4"), ("len", "<u2"), ("strand", "u1"), ("sample", "u1")]).astype(ALN_DTYPE)
+    dt = [("tid", "<i4"), ("pos", "<i4"), ("depth", "<u4"), ("len", "<u2"), ("strand", "u1"), ("sample", "u1")]
+    a = np.array(recs, dtype=dt).astype(ALN_DTYPE)
+    sg = np.array(segs, dtype=dt).astype(ALN_DTYPE) if segs else np.zeros(0, dtype=ALN_DTYPE)
+    if regions is not None:
+        from . import gffmask
+        keep = gffmask.keep_mask(a, regions)
+        if len(sg):
+            sg = sg[keep[np.array(owner, dtype=np.int64)]]
+        a = a[keep]
     key = a["tid"].astype(np.int64) << 32 | a["pos"].astype(np.int64)
     a = a[np.argsort(key, kind="stable")]
-    return names, np.array(lens, dtype=np.int64), sample_names, a
+    out = (names, np.array(lens, dtype=np.int64), sample_names, a)
+    return out + (sg,) if with_segments else out

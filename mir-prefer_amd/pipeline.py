@@ -136,7 +136,8 @@ class Pipeline:
 
     def _prepare_rank0(self):
         _msg("Starting preparing data for the 'candidate' stage.")
-        names, lens, samples, alns = ingest.read_sams(self.opt["ALIGNMENT_FILE"])
+        paths = self.opt["ALIGNMENT_FILE"]
+        names, lens = ingest.read_sam_header(paths[0])
         # GFF masking (MP:817-859): keep regions as the reference's BED file, applied like `samtools view -L` on the combined records
         gff_ex, gff_in = self.opt.get("GFF_FILE_EXCLUDE", ""), self.opt.get("GFF_FILE_INCLUDE", "")
         regions = None
@@ -153,10 +154,18 @@ class Pipeline:
                 _msg("!!! No regions in the GFF_FILE_INCLUDE file or all regions are shorter than 55, stop analyze!")
                 sys.exit(-1)
         if regions is not None:
-            alns = gffmask.apply_keep(alns, names, regions)
+            regions = gffmask.regions_by_tid(regions, names)
+        if any(str(p).endswith(".gz") for p in paths):        # compressed inputs: host parser (same rules), host filter and sort
+            names, lens, samples, alns, segs = ingest.read_sams(paths, regions=regions, with_segments=True)
+        else:       # tokenizer on the host threads; keep-region filter and the stable (tid, pos) sort on the GPU (mirp_ingest_sams_gpu)
+            try:
+                names, lens, samples, alns, segs, self.ingest_seconds = self.ctx.ingest_sams(paths, regions=regions)
+            except ValueError as e:
+                sys.stderr.write(str(e) + "\n")
+                sys.exit(-1)
         prepared = self._p("prepared.npz")
         np.savez(prepared, contig_names=np.array(names, dtype=object), contig_lens=lens, sample_names=np.array(samples, dtype=object), alns=alns,
-                 allow_pickle=True)
+                 segs=segs, allow_pickle=True)
         d = {"last_stage": "prepare", "finished_stages": {"prepare": {"preparedname": prepared}}, "files": {"prepare": [prepared]}, "world": self.world}
         _save_recover(self.recovername, d)
         _msg("Done (prepare stage)\n")
@@ -179,14 +188,18 @@ class Pipeline:
                 sys.stderr.write("Error: sequence %s of the SAM header is not in the FASTA file\n" % missing[0])
             sys.exit(-1)
         alns = z["alns"]
+        segs = z["segs"] if "segs" in z.files else alns[:0]
         self.data = {"names": names, "lens": z["contig_lens"], "samples": [str(x) for x in z["sample_names"]], "alns": alns, "alns_all": alns,
                      "contigs": [(n, fa[n]) for n in names]}
         if self.world > 1:          # contig sharding: whole contigs per rank, balanced by length
             mine = np.zeros(len(names), dtype=bool)
             mine[dist.partition_contigs(self.data["lens"], self.world)[self.rank]] = True
             self.data["alns"] = alns[mine[alns["tid"]]]
+            segs = segs[mine[segs["tid"]]]
         self.ctx.load_genome(self.data["contigs"])
         self.ctx.load_alignments(self.data["alns"])
+        if len(segs):
+            self.ctx.load_coverage_segments(segs)
 
     def _ensure_candidate(self):
         if self.state in ("candidate", "fold"):

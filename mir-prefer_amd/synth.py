@@ -197,3 +197,46 @@ def _plant_edge_cases(rng, contigs, add_read):
     contigs[t2][base + 9150:base + 9156] = ord("N")
     add_read(t2, base + 9020, 22, 1, 90); add_read(t2, base + 9060, 21, 1, 40)
     add_read(t2, base + 9140, 24, 0, 70)
+
+
+def write_sam_fast(path, sample_name, recs, contig_names, contig_lens, cigars=None):
+    """Vectorised SAM writer for large record arrays (bench / scale tests): one line per record of `recs` (ALN_DTYPE, any order), read ids
+    `<sample>_r<k>_x<depth>` with zero-padded numbers (fixed-width lines per read length, so a whole group is one numpy byte matrix),
+    sequence = poly-A (the ingest keeps coordinates, not bases).  Returns the number of bytes written."""
+    names = [n.encode() for n in contig_names]
+    total = 0
+    with open(path, "wb") as f:
+        f.write(b"@HD\tVN:1.0\tSO:unsorted\n")
+        for n, l in zip(names, contig_lens):
+            f.write(b"@SQ\tSN:" + n + b"\tLN:%d\n" % int(l))
+        order = np.argsort(recs["len"], kind="stable")
+        r = recs[order]
+        idx = order.astype(np.int64)
+        bounds = np.flatnonzero(np.diff(r["len"].astype(np.int64))) + 1
+        for a, b in zip(np.concatenate([[0], bounds]), np.concatenate([bounds, [len(r)]])):
+            g = r[a:b]
+            if len(g) == 0:
+                continue
+            rl = int(g["len"][0])
+            for t in np.unique(g["tid"]):
+                gt = g[g["tid"] == t]
+                it = idx[a:b][g["tid"] == t]
+                tpl = b"%s_r%010d_x%010d\t%02d\t%s\t%010d\t255\t%dM\t*\t0\t0\t%s\t%s\n" % (sample_name.encode(), 0, 0, 0, names[int(t)], 0, rl, b"A" * rl, b"I" * rl)
+                m = np.tile(np.frombuffer(tpl, dtype=np.uint8), (len(gt), 1))
+                o_id = len(sample_name) + 2
+                o_dp = o_id + 10 + 2
+                o_fl = o_dp + 10 + 1
+                o_pos = o_fl + 2 + 1 + len(names[int(t)]) + 1
+
+                def digits(col, vals, width):
+                    v = vals.astype(np.int64)
+                    for k in range(width):
+                        m[:, col + width - 1 - k] = 48 + (v % 10)
+                        v //= 10
+                digits(o_id, it, 10)
+                digits(o_dp, gt["depth"], 10)
+                digits(o_fl, np.where(gt["strand"] != 0, 16, 0), 2)
+                digits(o_pos, gt["pos"], 10)
+                f.write(m.tobytes())
+                total += m.size
+    return total

@@ -231,3 +231,37 @@ def test_decisions_and_result(case, oracle):
     exp_res = gu.unjson(case["exp"]["result_raw"])
     assert [mirna_record(m, case["contig_names"]) for _, m in result] == [e[:10] for e in exp_res]
     assert len(exp_res) > 5
+
+
+def _coverage_records(alns, segs):
+    """Records whose [pos, pos + len) is the covered interval: the ungapped alignments plus the M / = / X blocks of the gapped ones
+    (a negative segment names the gapped alignment it takes out)."""
+    neg = segs[(segs["strand"] & 2) != 0]
+    pos = segs[(segs["strand"] & 2) == 0]
+    drop = {}
+    for s in neg:
+        k = (int(s["tid"]), int(s["pos"]), int(s["depth"]), int(s["len"]), int(s["strand"]) & 1, int(s["sample"]))
+        drop[k] = drop.get(k, 0) + 1
+    keep = np.ones(len(alns), dtype=bool)
+    for i, a in enumerate(alns):
+        k = (int(a["tid"]), int(a["pos"]), int(a["depth"]), int(a["len"]), int(a["strand"]), int(a["sample"]))
+        if drop.get(k, 0) > 0:
+            drop[k] -= 1
+            keep[i] = False
+    both = np.concatenate([alns[keep], pos])
+    key = both["tid"].astype(np.int64) << 32 | both["pos"].astype(np.int64)
+    return both[np.argsort(key, kind="stable")]
+
+
+def test_gapped_alignments_depth_matches_samtools(oracle, tmp_path):
+    """Gapped CIGARs (I / D / N / S / H / = / X): thresholded depth lines against the bundled samtools 0.1.18 run on the expanded, strand-split
+    BAMs exactly as the reference does (tests/golden/tools/gen_gapped_golden.py); the host ingest turns the M / = / X blocks into segments."""
+    from mir_prefer_amd import ingest
+    g = gu.load_json("gapped.json.gz")
+    sam = tmp_path / "S1.sam"
+    sam.write_text(g["sam"])
+    for native in (True, False):
+        names, lens, samples, alns, segs = ingest.read_sams([str(sam)], native=native, with_segments=True)
+        assert names == [c[0] for c in g["contigs"]] and len(segs) > 50
+        depth, _ = oracle.coverage_peaks(_coverage_records(alns, segs), lens, g["cutoff"])
+        assert records.depth_text(depth, names) == g["depth_cut"]
