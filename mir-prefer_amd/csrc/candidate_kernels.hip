@@ -36,12 +36,30 @@ __global__ void __launch_bounds__(256) cov_scatter_kernel(const MirpAln* __restr
     }
 }
 
+// The difference arrays are zero outside the few positions the records touch: instead of clearing 8 bytes per genome base before every pass
+// (hipMemset), the positions a pass wrote are cleared again after it (two stores per record).  Invariant: the arrays are all zero between passes.
+__global__ void __launch_bounds__(256) cov_unscatter_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
+                                                            const long long* __restrict__ clen, int* __restrict__ diff_p, int* __restrict__ diff_m) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        MirpAln r = alns[k];
+        long long L = clen[r.tid];
+        long long s = r.pos, e = (long long)r.pos + r.len;
+        if (s < 1) s = 1;
+        if (e > L + 1) e = L + 1;
+        if (s >= e) continue;
+        int* d = (r.strand & 1) ? diff_m : diff_p;
+        long long base = goff[r.tid];
+        d[base + s - 1] = 0;
+        d[base + e - 1] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // a2 (first half): single-pass scan of both difference arrays -> depth, threshold, run starts.
 // Decoupled look-back over 64-bit {flag, d+, d-} and {flag, n_starts, n_above} tile descriptors.
 // ------------------------------------------------------------------------------------------
 #define SCAN_NT 256
-#define SCAN_IPT 16
+#define SCAN_IPT 32
 #define SCAN_TILE (SCAN_NT * SCAN_IPT)
 
 __device__ __forceinline__ unsigned long long ld_status(const unsigned long long* p) {
@@ -55,30 +73,52 @@ __device__ __forceinline__ unsigned long long pack2(unsigned flag, unsigned a, u
     return ((unsigned long long)flag << 62) | ((unsigned long long)(a & 0x7fffffffu) << 31) | (unsigned long long)(b & 0x7fffffffu);
 }
 
-// block-wide exclusive scan of (a,b) pairs across SCAN_NT threads; returns exclusive prefix, totals in tot_a/tot_b
-__device__ __forceinline__ void block_excl_scan2(int a, int b, int& ea, int& eb, int& tot_a, int& tot_b, int* sh /* 2*(NT/64)+2 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int ia = a, ib = b;
+// inclusive prefix sum over the 64 lanes of a wave in registers (DPP row shifts inside the rows of 16, then the row broadcasts)
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+// Exclusive prefixes of a per-thread (a, b) pair sequence g[0..NV) in POSITION order for the wave-striped tile layout below: the order is
+// (wave, v, lane).  On return ea[v], eb[v] = sum over everything before (wave, v, lane) inside the tile; tot_a / tot_b = tile totals.
+template <int NV>
+__device__ __forceinline__ void tile_excl_scan2(const int (&a)[NV], const int (&b)[NV], int (&ea)[NV], int (&eb)[NV], int& tot_a, int& tot_b,
+                                                int* sh /* 2 * (SCAN_NT / 64) */) {
+    const int wave = threadIdx.x >> 6;
+    int ra = 0, rb = 0;                 // running row bases inside the wave
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o);
-        if (lane >= o) { ia += ta; ib += tb; }
+    for (int v = 0; v < NV; v++) {
+        const int ia = wave_incl_scan(a[v]), ib = wave_incl_scan(b[v]);
+        ea[v] = ra + ia - a[v]; eb[v] = rb + ib - b[v];
+        ra += __builtin_amdgcn_readlane(ia, 63); rb += __builtin_amdgcn_readlane(ib, 63);
     }
-    if (lane == 63) { sh[wave * 2] = ia; sh[wave * 2 + 1] = ib; }
+    if ((threadIdx.x & 63) == 0) { sh[wave * 2] = ra; sh[wave * 2 + 1] = rb; }
     __syncthreads();
     int wa = 0, wb = 0, ta = 0, tb = 0;
 #pragma unroll
     for (int w = 0; w < SCAN_NT / 64; w++) {
-        int xa = sh[w * 2], xb = sh[w * 2 + 1];
+        const int xa = sh[w * 2], xb = sh[w * 2 + 1];
         if (w < wave) { wa += xa; wb += xb; }
         ta += xa; tb += xb;
     }
-    ea = wa + ia - a; eb = wb + ib - b; tot_a = ta; tot_b = tb;
+#pragma unroll
+    for (int v = 0; v < NV; v++) { ea[v] += wa; eb[v] += wb; }
+    tot_a = ta; tot_b = tb;
     __syncthreads();
 }
 
 struct RunStart { long long gx; int dp, dm; };
 
+// Tile layout ("wave-striped"): a tile is SCAN_NT * SCAN_IPT consecutive positions; every wave owns a contiguous chunk of 64 * SCAN_IPT of
+// them and reads it in SCAN_IPT / 4 rows of 256 positions, lane l taking the 16-byte vector l of the row: every load instruction of a wave is
+// one fully coalesced kilobyte (a thread-contiguous layout makes each instruction touch 64 cache lines for 16 bytes apiece and thrashes the
+// vector L1).  A thread therefore holds SCAN_NV groups of four consecutive positions, 256 positions apart.
+#define SCAN_NV (SCAN_IPT / 4)
 __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict__ diff_p, const int* __restrict__ diff_m, long long gtot,
                                                            int cutoff, unsigned long long* __restrict__ stat_d,
                                                            unsigned long long* __restrict__ stat_c, unsigned int* __restrict__ ticket,
@@ -89,20 +129,19 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict
     __shared__ int sh[2 * (SCAN_NT / 64) + 2];
     __shared__ unsigned int s_tile;
     __shared__ int s_carry[4];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const unsigned int tile = s_tile;
     const long long base = (long long)tile * SCAN_TILE;
-    // each thread owns SCAN_IPT consecutive positions: 4 x int4 loads per strand (16-B vectors, coalesced across the wave per vector)
+    const long long wbase = base + (long long)wave * (64 * SCAN_IPT);
     int vp[SCAN_IPT], vm[SCAN_IPT];
-    const long long my0 = base + (long long)tid * SCAN_IPT;
 #pragma unroll
-    for (int v = 0; v < SCAN_IPT / 4; v++) {
-        long long x = my0 + v * 4;
+    for (int v = 0; v < SCAN_NV; v++) {
+        const long long x = wbase + v * 256 + lane * 4;
         if (x + 3 < gtot) {
-            int4 a = *reinterpret_cast<const int4*>(diff_p + x);
-            int4 b = *reinterpret_cast<const int4*>(diff_m + x);
+            const int4 a = *reinterpret_cast<const int4*>(diff_p + x);
+            const int4 b = *reinterpret_cast<const int4*>(diff_m + x);
             vp[v * 4] = a.x; vp[v * 4 + 1] = a.y; vp[v * 4 + 2] = a.z; vp[v * 4 + 3] = a.w;
             vm[v * 4] = b.x; vm[v * 4 + 1] = b.y; vm[v * 4 + 2] = b.z; vm[v * 4 + 3] = b.w;
         } else {
@@ -113,11 +152,11 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict
             }
         }
     }
-    int sp = 0, sm = 0;
+    int gp[SCAN_NV], gm[SCAN_NV], ep[SCAN_NV], em[SCAN_NV];
 #pragma unroll
-    for (int j = 0; j < SCAN_IPT; j++) { sp += vp[j]; sm += vm[j]; }
-    int ep, em, tp, tm;
-    block_excl_scan2(sp, sm, ep, em, tp, tm, sh);
+    for (int v = 0; v < SCAN_NV; v++) { gp[v] = vp[v * 4] + vp[v * 4 + 1] + vp[v * 4 + 2] + vp[v * 4 + 3]; gm[v] = vm[v * 4] + vm[v * 4 + 1] + vm[v * 4 + 2] + vm[v * 4 + 3]; }
+    int tp, tm;
+    tile_excl_scan2<SCAN_NV>(gp, gm, ep, em, tp, tm, sh);
     // ---- look-back #1: depth carried into this tile
     if (tid == 0) st_status(&stat_d[tile], pack2(tile == 0 ? 2u : 1u, (unsigned)tp, (unsigned)tm));
     if (tid < 64) {
@@ -146,25 +185,28 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict
     __syncthreads();
     // depths are >= 0 everywhere, but tile aggregates of a *difference* array can be negative: they are
     // carried modulo 2^31, which is exact as long as true depths stay below 2^31.
-    int dp = (int)(((unsigned)s_carry[0] + (unsigned)ep) & 0x7fffffffu), dm = (int)(((unsigned)s_carry[1] + (unsigned)em) & 0x7fffffffu);
-    // ---- per-position depth, threshold, run-start flags
-    // previous position's "above": last element of the previous thread; for thread 0 the carried-in depth
-    unsigned abovemask = 0;
-    int d_p[SCAN_IPT], d_m[SCAN_IPT];
-    {
-        int cp = dp, cm = dm;
+    // ---- per-position depth, threshold, run-start flags.  Bit v*4+j of the masks = position j of group v; the depth just before a group is its
+    // exclusive prefix, so "was the previous position above the threshold" needs no neighbour.
+    unsigned abovemask = 0, startmask = 0;
+    int ns[SCAN_NV], na[SCAN_NV];
 #pragma unroll
-        for (int j = 0; j < SCAN_IPT; j++) {
-            cp = (int)(((unsigned)cp + (unsigned)vp[j]) & 0x7fffffffu); cm = (int)(((unsigned)cm + (unsigned)vm[j]) & 0x7fffffffu);
-            d_p[j] = cp; d_m[j] = cm;
-            if ((my0 + j < gtot) && (cp + cm > cutoff)) abovemask |= 1u << j;
+    for (int v = 0; v < SCAN_NV; v++) {
+        int cp = (int)(((unsigned)s_carry[0] + (unsigned)ep[v]) & 0x7fffffffu), cm = (int)(((unsigned)s_carry[1] + (unsigned)em[v]) & 0x7fffffffu);
+        const long long x0 = wbase + v * 256 + lane * 4;
+        unsigned prev = (cp + cm > cutoff) ? 1u : 0u;
+        unsigned am = 0, sm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cp = (int)(((unsigned)cp + (unsigned)vp[v * 4 + j]) & 0x7fffffffu); cm = (int)(((unsigned)cm + (unsigned)vm[v * 4 + j]) & 0x7fffffffu);
+            const unsigned ab = ((x0 + j < gtot) && (cp + cm > cutoff)) ? 1u : 0u;
+            am |= ab << j; sm |= (ab & ~prev) << j;
+            prev = ab;
         }
+        abovemask |= am << (v * 4); startmask |= sm << (v * 4);
+        ns[v] = __popc(sm); na[v] = __popc(am);
     }
-    int prev_above = (dp + dm > cutoff) ? 1 : 0;   // depth just before my first position (exclusive prefix)
-    unsigned startmask = abovemask & ~((abovemask << 1) | (unsigned)prev_above);
-    int ns = __popc(startmask), na = __popc(abovemask);
-    int es, ea, ts, ta;
-    block_excl_scan2(ns, na, es, ea, ts, ta, sh);
+    int es[SCAN_NV], ea[SCAN_NV], ts, ta;
+    tile_excl_scan2<SCAN_NV>(ns, na, es, ea, ts, ta, sh);
     // ---- look-back #2: ordered output offsets
     if (tid == 0) st_status(&stat_c[tile], pack2(tile == 0 ? 2u : 1u, (unsigned)ts, (unsigned)ta));
     if (tid < 64) {
@@ -191,22 +233,33 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict
         if (lane == 0) { s_carry[2] = (int)cs; s_carry[3] = (int)ca; }
     }
     __syncthreads();
-    long long os = (long long)s_carry[2] + es, oa = (long long)s_carry[3] + ea;
+    if (abovemask) {     // the depths are recomputed here instead of being held in registers across the two look-backs (most threads own no covered base)
 #pragma unroll
-    for (int j = 0; j < SCAN_IPT; j++) {
-        if (startmask & (1u << j)) {
-            if (os < starts_cap) { RunStart r; r.gx = my0 + j; r.dp = d_p[j]; r.dm = d_m[j]; starts[os] = r; }
-            os++;
-        }
-        if (abovemask & (1u << j)) {
-            if (depth_out && oa < depth_cap) {
-                MirpDepthPos d; d.tid = 0; d.pos = 0; d.dp = d_p[j]; d.dm = d_m[j];
-                depth_out[oa] = d; depth_gx[oa] = my0 + j;
+        for (int v = 0; v < SCAN_NV; v++) {
+            if (!((abovemask >> (v * 4)) & 15u)) continue;
+            int cp = (int)(((unsigned)s_carry[0] + (unsigned)ep[v]) & 0x7fffffffu), cm = (int)(((unsigned)s_carry[1] + (unsigned)em[v]) & 0x7fffffffu);
+            long long os = (long long)s_carry[2] + es[v], oa = (long long)s_carry[3] + ea[v];
+            const long long x0 = wbase + v * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cp = (int)(((unsigned)cp + (unsigned)vp[v * 4 + j]) & 0x7fffffffu); cm = (int)(((unsigned)cm + (unsigned)vm[v * 4 + j]) & 0x7fffffffu);
+                if (startmask & (1u << (v * 4 + j))) {
+                    if (os < starts_cap) { RunStart r; r.gx = x0 + j; r.dp = cp; r.dm = cm; starts[os] = r; }
+                    os++;
+                }
+                if (abovemask & (1u << (v * 4 + j))) {
+                    if (depth_out && oa < depth_cap) {
+                        MirpDepthPos d; d.tid = 0; d.pos = 0; d.dp = cp; d.dm = cm;
+                        depth_out[oa] = d; depth_gx[oa] = x0 + j;
+                    }
+                    oa++;
+                }
             }
-            oa++;
         }
     }
-    if ((long long)(tile + 1) * SCAN_TILE >= gtot && tid == SCAN_NT - 1) { totals[0] = (unsigned long long)os; totals[1] = (unsigned long long)oa; }
+    if ((long long)(tile + 1) * SCAN_TILE >= gtot && tid == 0) {      // last tile: the totals are its inclusive prefix
+        totals[0] = (unsigned long long)((long long)s_carry[2] + ts); totals[1] = (unsigned long long)((long long)s_carry[3] + ta);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -503,6 +556,10 @@ static inline int grid_for(long long n, int block, int cap) {
 void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m) {
     if (n <= 0) return;
     hipLaunchKernelGGL(cov_scatter_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, cutoff, diff_p, diff_m);
+}
+void launch_cov_unscatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int* diff_p, int* diff_m) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cov_unscatter_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, diff_p, diff_m);
 }
 long long cov_scan_tiles(long long gtot) { return (gtot + SCAN_TILE - 1) / SCAN_TILE; }
 void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d,

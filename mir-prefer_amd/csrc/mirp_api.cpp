@@ -38,7 +38,7 @@ extern "C" int mirp_create(int device, mirp_ctx** out) {
         delete hp; delete c; return -2;
     }
     delete hp;
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 6; i++)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { mirp_destroy(c); return -2; }
     *out = c;
     return 0;
@@ -86,7 +86,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
                       &c->wseqs, &c->woffs, &c->wlens, &c->segs, &c->sort_tmp, &c->sort_counts, &c->side_cnt, &c->side_idx, &c->side_list, &c->side_offs, &c->side_lens, &c->lines2, &c->ss2,
                       &c->nlines2, &c->mfe2, &c->status2, &c->p_out, &c->p_nout, &c->p_status, &c->p_keep, &c->p_kscan, &c->p_res, &c->p_text})
         b->release();
-    for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (hipEvent_t ev : c->fold_ev) (void)hipEventDestroy(ev);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_params185) (void)hipFree(c->d_params185);

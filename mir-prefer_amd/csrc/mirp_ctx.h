@@ -50,6 +50,8 @@ struct mirp_ctx {
     std::vector<long long> h_clen, h_goff, h_gboff;
     DevBuf genome, clen, goff, gboff, alns, order, segs, sort_tmp, sort_counts;
     long long n_segs = 0;
+    void* diff_clean_ptr = nullptr;   // the difference arrays at this address are all zero (run_coverage / clean_coverage)
+    size_t diff_clean_bytes = 0;
     bool ingest_resident = false;     // the alignments came from mirp_ingest_sams_gpu (already validated and sorted on the device)
     int ingest_n_contigs = 0;
     DevBuf diff, stat, starts, totals, runs, keep, kscan, csq, cdest, peaks_sq, peaks_sorted;
@@ -67,7 +69,7 @@ struct mirp_ctx {
     double ms[4] = {0, 0, 0, 0};
     double fold_kernel_ms[2] = {0, 0};   // fill / epilogue kernels of the last mirp_run_fold (LDS-resident path)
     std::vector<hipEvent_t> fold_ev;     // 3 events per sub-batch, created on demand
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static inline int fail(mirp_ctx* c, int code, const std::string& msg) {

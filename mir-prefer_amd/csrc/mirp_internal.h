@@ -45,6 +45,7 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
 
 // candidate_kernels.hip
 void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m);
+void launch_cov_unscatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int* diff_p, int* diff_m);
 long long cov_scan_tiles(long long gtot);
 size_t run_start_bytes();
 void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d,

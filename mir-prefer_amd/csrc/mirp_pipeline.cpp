@@ -138,14 +138,20 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     const long long gtot = c->gtot;
     const long long tiles = mirp::cov_scan_tiles(gtot);
     if (c->diff.ensure(8 * (size_t)(gtot + 8)) || c->stat.ensure(16 * (size_t)tiles + 64) ||
-        c->starts.ensure(mirp::run_start_bytes() * (size_t)std::max<long long>(c->n_alns, 1)) || c->totals.ensure(64))
+        c->starts.ensure(mirp::run_start_bytes() * (size_t)std::max<long long>(c->n_alns + c->n_segs, 1)) || c->totals.ensure(64))
         return fail(c, -6, "device allocation failed (coverage)");
     int* diff_p = (int*)c->diff.p;
     int* diff_m = diff_p + ((gtot + 3) / 4) * 4;   // keep 16-B alignment of both arrays
     unsigned long long* stat_d = (unsigned long long*)c->stat.p;
     unsigned long long* stat_c = stat_d + tiles;
     unsigned int* ticket = (unsigned int*)(stat_c + tiles);
-    HIPCHK(c, hipMemsetAsync(c->diff.p, 0, 8 * (size_t)(gtot + 8), c->stream));
+    // the difference arrays are all zero between passes (clean_coverage clears what a pass wrote); a full clear only for a new buffer or after
+    // a pass that did not get to clean up
+    if (c->diff_clean_ptr != c->diff.p || c->diff_clean_bytes < 8 * (size_t)(gtot + 8)) {
+        HIPCHK(c, hipMemsetAsync(c->diff.p, 0, c->diff.cap, c->stream));
+        c->diff_clean_bytes = c->diff.cap;
+    }
+    c->diff_clean_ptr = nullptr;          // dirty from here until clean_coverage
     HIPCHK(c, hipMemsetAsync(c->stat.p, 0, 16 * (size_t)tiles + 64, c->stream));
     HIPCHK(c, hipMemsetAsync(c->totals.p, 0, 64, c->stream));
     mirp::launch_cov_scatter(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p, c->cand.cutoff,
@@ -153,9 +159,21 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     if (c->n_segs > 0)       // gapped alignments: their own [pos, pos + len(SEQ)) taken back out, their M / = / X blocks added
         mirp::launch_cov_scatter(c->stream, (const MirpAln*)c->segs.p, c->n_segs, (const long long*)c->goff.p, (const long long*)c->clen.p, c->cand.cutoff,
                                  diff_p, diff_m);
-    mirp::launch_cov_scan(c->stream, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p, std::max<long long>(c->n_alns, 1),
+    mirp::launch_cov_scan(c->stream, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p, std::max<long long>(c->n_alns + c->n_segs, 1),
                           depth_out, depth_cap, depth_gx, (unsigned long long*)c->totals.p);
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// clears the positions the last run_coverage wrote (two per record / segment): the arrays are all zero again
+static int clean_coverage(mirp_ctx* c) {
+    int* diff_p = (int*)c->diff.p;
+    int* diff_m = diff_p + ((c->gtot + 3) / 4) * 4;
+    mirp::launch_cov_unscatter(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p, diff_p, diff_m);
+    if (c->n_segs > 0)
+        mirp::launch_cov_unscatter(c->stream, (const MirpAln*)c->segs.p, c->n_segs, (const long long*)c->goff.p, (const long long*)c->clen.p, diff_p, diff_m);
+    HIPCHK(c, hipGetLastError());
+    c->diff_clean_ptr = c->diff.p;
     return 0;
 }
 
@@ -189,7 +207,7 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
     HIPCHK(c, hipMemcpyAsync(tot, c->totals.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->n_runs = tot[0]; c->n_above = tot[1];
-    if (c->n_runs > std::max<long long>(c->n_alns, 1)) return fail(c, -7, "internal: run-start capacity exceeded");
+    if (c->n_runs > std::max<long long>(c->n_alns + c->n_segs, 1)) return fail(c, -7, "internal: run-start capacity exceeded");
     const long long nr = c->n_runs;
     const int* diff_p = (const int*)c->diff.p;
     const int* diff_m = diff_p + ((c->gtot + 3) / 4) * 4;
@@ -198,6 +216,9 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
         return fail(c, -6, "device allocation failed (runs)");
     mirp::launch_run_walk(st, c->starts.p, nr, diff_p, diff_m, c->gtot, c->cand.cutoff, (const long long*)c->goff.p, nc, c->cand.min_peak_len,
                           (MirpPeak*)c->runs.p, (int*)c->keep.p, c->shard_first_run_double);
+    HIPCHK(c, hipEventRecord(c->ev[4], st));
+    if (int rc2 = clean_coverage(c)) return rc2;          // the run walk was the last reader of the difference arrays
+    HIPCHK(c, hipEventRecord(c->ev[5], st));
     mirp::launch_excl_scan(st, (const int*)c->keep.p, (long long*)c->kscan.p, nr);
     long long np = 0;
     if (read_ll(c, (const long long*)c->kscan.p + nr, &np)) return fail(c, -2, "D2H failed");
@@ -249,9 +270,11 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     float a = 0, b = 0;
+    float cl = 0;
     (void)hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
-    c->ms[0] = a; c->ms[1] = b;
+    (void)hipEventElapsedTime(&cl, c->ev[4], c->ev[5]);
+    c->ms[0] = a + cl; c->ms[1] = b - cl;      // coverage = scatter + scan + clearing what the pass wrote
     c->have_candidate = true;
     if (n_peaks_out) *n_peaks_out = np;
     if (n_loci_out) *n_loci_out = nl;
@@ -271,6 +294,7 @@ extern "C" int mirp_get_depth(mirp_ctx* c, MirpDepthPos** depth, int64_t* n_dept
     if (!d || !gx) return fail(c, -6, "device allocation failed (depth)");
     int rc = run_coverage(c, d, na, gx);
     if (rc) return rc;
+    if (int rc2 = clean_coverage(c)) return rc2;
     mirp::launch_depth_fix(c->stream, d, gx, na, (const long long*)c->goff.p, c->n_contigs);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     MirpDepthPos* h = host_copy<MirpDepthPos>(c, d, (size_t)na);
