@@ -202,6 +202,17 @@ int mirp_last_fold_kernel_ms(mirp_ctx* ctx, double ms[2]);
 int mirp_microbench(mirp_ctx* ctx, double out[4]);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: there is deliberately NO mirp_gather_loci entry point (SURVEY.md 8b item 4 proposed one).  The path shards by contig, one context
+ * per GPU and process, with no data-path collective; the one exchange step is the gather of the final loci list (MirpMirna records + structure
+ * text, a few MB at most, latency-bound) to rank 0, the analogue of the reference's `multiprocessing.Queue.put(list)` per piece (MP:2461-2499).
+ * That gather runs over RCCL in the host binding (mir-prefer_amd/dist.py: all_gather of the counts + gather of max-padded 64-byte records, through
+ * the `nccl` backend of torch.distributed, which IS RCCL on ROCm): the host process already owns that communicator, and a C entry point would
+ * need either a second RCCL communicator inside this library (a ncclUniqueId exchange of its own, and two RCCL instances in one process) or a
+ * torch type in its signature.  What the boundary provides for sharding is mirp_set_contig_shard (the one quirk of the reference that crosses
+ * shard boundaries) and records that are plain 64-byte PODs, ready to be sent as they are.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------------------------------
  * Host-side native ingest (no device involved).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
