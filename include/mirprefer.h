@@ -87,7 +87,8 @@ int mirp_set_fold_model(mirp_ctx* ctx, int32_t model);
  * seqs: concatenated sequence bytes (any case, T or U); offsets[n_seqs+1]: byte offsets into seqs.
  * Out (library-owned): lines[n_seqs*max_lines], ss[n_seqs*max_lines*ss_stride] (NUL-terminated texts),
  * n_lines[n_seqs], mfe[n_seqs] (0.01 kcal/mol, RNALfold's final " (%6.2f)" line), status[n_seqs]
- * (0 ok, 1 = more than max_lines structures, <0 = error for that sequence).
+ * (0 ok, 1 = more than max_lines structures: the first max_lines are returned and n_lines holds the number the sequence needs,
+ * <0 = error for that sequence).
  */
 int mirp_fold_batch(mirp_ctx* ctx, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
                     int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t** n_lines,

@@ -190,7 +190,7 @@ class Context:
         out = []
         for w in range(len(seqs)):
             ls = []
-            for k in range(int(raw["n_lines"][w])):
+            for k in range(min(int(raw["n_lines"][w]), max_lines)):      # a window over the capacity (status 1) reports the count it needs
                 ln = raw["lines"][w, k]
                 if not ln["printed"]:
                     continue

@@ -369,7 +369,7 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
                 if (lane == 0 && cnt < max_lines) starts[cnt] = 1;
                 cnt++;
             }
-            if (lane == 0) { red[8] = cnt < max_lines ? cnt : max_lines; red[9] = cnt > max_lines ? 1 : 0; red[10] = 0; }
+            if (lane == 0) { red[8] = cnt < max_lines ? cnt : max_lines; red[9] = cnt > max_lines ? 1 : 0; red[10] = 0; red[11] = cnt; }
         }
         __syncthreads();
         const int nst = red[8];
@@ -411,12 +411,12 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
             if (lane == 0 && !print) out_lines[(size_t)win * max_lines + k].printed = 0;
         }
         if (tid == 0) {
-            out_nlines[win] = nst;
+            out_nlines[win] = red[9] ? red[11] : nst;      // over capacity (status 1): the number of lines the window needs
             out_mfe[win] = f3[1];
             out_status[win] = red[10] ? red[10] : (red[9] ? 1 : 0);
         }
         if (tid == 0) {
-            out_nlines[win] = nst;
+            out_nlines[win] = red[9] ? red[11] : nst;      // over capacity (status 1): the number of lines the window needs
             out_mfe[win] = f3[1];
             out_status[win] = red[10] ? red[10] : (red[9] ? 1 : 0);
         }

@@ -426,7 +426,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
             if (is && cnt + rank < max_lines) starts[cnt + rank] = l;
             cnt += __popcll(mask);
         }
-        if (lane == 0) { sh_misc[0] = cnt < max_lines ? cnt : max_lines; sh_misc[1] = cnt > max_lines ? 1 : 0; sh_misc[2] = 0; }
+        if (lane == 0) { sh_misc[0] = cnt < max_lines ? cnt : max_lines; sh_misc[1] = cnt > max_lines ? 1 : 0; sh_misc[2] = 0; sh_misc[3] = cnt; }
     }
     __syncthreads();
     const int nst = sh_misc[0];
@@ -500,7 +500,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     }
     EPI_T(7);
     if (tid == 0) {
-        out_nlines[win] = nst;
+        out_nlines[win] = sh_misc[1] ? sh_misc[3] : nst;      // over capacity (status 1): the number of lines the window needs
         out_mfe[win] = f3[1];
         out_status[win] = sh_misc[2] ? sh_misc[2] : (sh_misc[1] ? 1 : 0);
     }

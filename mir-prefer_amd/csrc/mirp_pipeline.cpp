@@ -390,7 +390,7 @@ extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
     // RNALfold has no limit on the number of structure lines (MP:3053); a window that produced more than max_lines (tandem repeats: up to
     // one line per start position) was flagged, not truncated.  Only those windows are folded again, at the capacity no window can
     // exceed, into side buffers that the predict stage and the text writers read instead of the window's slot in the main buffers.
-    const int big = n_cap + 2;
+    int big = n_cap + 2;
     if (nw > 0 && max_lines < big) {
         if (c->side_idx.ensure(4 * w1) || c->side_list.ensure(4 * w1) || c->side_cnt.ensure(64)) return fail(c, -6, "device allocation failed (fold overflow list)");
         unsigned int* cnt = (unsigned int*)c->side_cnt.p;
@@ -401,6 +401,13 @@ extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
         HIPCHK(c, hipMemcpyAsync(&ns, cnt, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (ns > 0) {
+            // a flagged window reports the number of lines it needs: the side buffers get the largest of them (<= n + 2), not the worst case
+            std::vector<int> hnl((size_t)nw), hst((size_t)nw);
+            HIPCHK(c, hipMemcpy(hnl.data(), c->nlines.p, 4 * (size_t)nw, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(hst.data(), c->status.p, 4 * (size_t)nw, hipMemcpyDeviceToHost));
+            int need = max_lines + 1;
+            for (long long w = 0; w < nw; w++) if (hst[(size_t)w] == 1) need = std::max(need, hnl[(size_t)w]);
+            big = std::min(big, ((need + 7) / 8) * 8);
             const size_t per2 = (size_t)big * stride;
             if (c->side_offs.ensure(8 * (size_t)ns + 8) || c->side_lens.ensure(4 * (size_t)ns) || c->lines2.ensure(sizeof(MirpFoldLine) * (size_t)ns * big) ||
                 c->ss2.ensure((size_t)ns * per2) || c->nlines2.ensure(4 * (size_t)ns) || c->mfe2.ensure(4 * (size_t)ns) || c->status2.ensure(4 * (size_t)ns))

@@ -256,3 +256,27 @@ def test_planted_repeat_windows_are_refolded_alone(gpu_ctx, oracle):
         assert raw["n_lines"][k] > 96 and raw["mfe"][k] == ref["mfe"] and _window_lines(raw, k) == ref["lines"]
     out = gpu_ctx.predict(1, 18, 23, False, True)
     assert (out["status"] == 0).all() and len(out["result"]) > 1000
+
+
+def test_filter_capacity_overflow_is_reported_not_truncated(gpu_ctx):
+    """PRECURSOR_LEN well above 350: a dense region with more candidate matures than the filter kernel's table holds (40) must come back
+    with a non-zero per-window status (mirp_predict returns it; the stage driver turns it into exit status -1), never as a silently
+    shortened candidate list."""
+    L = 1000
+    ds = synth.make_dataset([40000], 0, n_samples=1, seed=9, contig_names=["c1"])
+    recs = []
+    # 26 peaks 35 nt apart (each >= 19 nt above the threshold, separated by uncovered bases): one 900-nt region, two matures per peak
+    for k in range(26):
+        p = 5000 + 35 * k
+        recs += [(0, p, 60, 21, 0, 0), (0, p + 1, 40, 21, 0, 0), (0, p + 2, 30, 20, 0, 0)]
+    alns = np.array(recs, dtype=synth.ALN_DTYPE)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    npk, nloci, nwin = gpu_ctx.candidate(10, 100, L, np.zeros(1, np.int32))
+    assert npk == 26 and nloci == 1 and nwin == 1
+    W = gpu_ctx.get_windows()["windows"]
+    assert W[0]["n_matures"] > 40
+    gpu_ctx.fold(L)
+    assert (gpu_ctx.fold_status() == 0).all()
+    out = gpu_ctx.predict(1, 18, 23, False, True)
+    assert out["status"][0] == 3
