@@ -4,6 +4,7 @@
 // /root/reference/miR_PREFeR.py:3053-3064.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "fold_device.h"
 #include "mirp_internal.h"
 
@@ -20,6 +21,7 @@ struct EpiTables {
     short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200], mismatchExt[200];
     short dangle5[40], dangle3[40];
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
+    short hairpin[304];     // size term for loops of 3..303 unpaired bases (pair distances up to 304)
 };
 
 __device__ inline void fill_epi_tables(EpiTables* E, const FoldParams* __restrict__ P, int tid, int nt) {
@@ -31,8 +33,26 @@ __device__ inline void fill_epi_tables(EpiTables* E, const FoldParams* __restric
         E->mismatchM[x] = (short)P->mismatchM[t][a][b]; E->mismatch1nI[x] = (short)min(P->mismatch1nI[t][a][b], 32767);
         E->mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], 32767); E->mismatchExt[x] = (short)P->mismatchExt[t][a][b];
     }
+    for (int x = tid; x < 304; x += nt) E->hairpin[x] = (short)min(P->hairpinE[x], 32767);
     for (int x = tid; x < 40; x += nt) { E->dangle5[x] = (short)P->dangle5[x / 5][x % 5]; E->dangle3[x] = (short)P->dangle3[x / 5][x % 5]; }
-    if (tid == 0) { E->ML_closing = (short)P->ML_closing; E->ML_intern = (short)P->ML_intern; E->TerminalAU = (short)P->TerminalAU; E->ninio = (short)P->ninio; E->MAX_NINIO = (short)P->MAX_NINIO; }
+    if (tid == 0) { E->ML_closing = (short)P->ML_closing; E->ML_intern = (short)P->ML_intern; E->TerminalAU = (short)P->TerminalAU; E->ninio = (short)P->ninio; E->MAX_NINIO = (short)P->MAX_NINIO; E->pad[0] = 0; }
+}
+
+#define XTAB_N 900
+// exterior-loop term by bases: xtab[((si * 6 + a) * 5 + sj) * 6 + b] = e_extloop(pair_type(si, sj), a, b) with a / b = 5 for "no neighbour" (window end)
+__device__ inline void fill_ext_table(short* xtab, const FoldParams* __restrict__ P, int tid, int nt) {
+    for (int x = tid; x < XTAB_N; x += nt) {
+        const int b = x % 6, sj = x / 6 % 5, a = x / 30 % 6, si = x / 180;
+        const int type = pair_type(si, sj);
+        int e = 0;
+        if (type) {
+            e = type > 2 ? P->TerminalAU : 0;
+            if (a < 5 && b < 5) e += P->mismatchExt[type][a][b];
+            else if (a < 5) e += P->dangle5[type][a];
+            else if (b < 5) e += P->dangle3[type][b];
+        }
+        xtab[x] = (short)e;
+    }
 }
 
 struct WinCtx {
@@ -44,6 +64,10 @@ struct WinCtx {
     const short* spec;        // LDS, special hairpin energy per i for u==3,4,6 at [k*ldspec + i], SHRT_MIN = none
     int ldspec;
     int n, D;                 // D = max pair distance (min(span-1, n-1))
+    // tiled exterior sweep only (f3_sweep_tiled): the exterior-loop term of a pair as ONE table read
+    const short* xtab = nullptr;          // LDS [5 (S[i])][6 (5' neighbour, 5 = none)][5 (S[j])][6 (3' neighbour, 5 = none)], TerminalAU included
+    const unsigned char* pq2 = nullptr;   // LDS per position j: byte offset (S[j] * 6 + 3' neighbour code) * 2 into a row of xtab
+    short* pp = nullptr;                  // LDS per row i (written by the sweep): the first partner j that realises f3[i], where f3[i] != f3[i+1]
 };
 
 // special hairpin motifs (tri/tetra/hexa loops) per closing position i: spec[k*ld + i], -32768 = none
@@ -75,9 +99,10 @@ __device__ __forceinline__ int e_hairpin(const WinCtx& X, int i, int j, int type
     else if (u == 3) {
         int s = X.spec[i];
         if (s != -32768) return s;
+        if (X.E) return X.E->hairpin[3] + (type > 2 ? X.E->TerminalAU : 0);
         return X.P->hairpinE[3] + (type > 2 ? X.P->TerminalAU : 0);
     }
-    if (X.E) return X.P->hairpinE[u] + X.E->mismatchH[type * 25 + X.S[i + 1] * 5 + X.S[j - 1]];
+    if (X.E && u < 304) return X.E->hairpin[u] + X.E->mismatchH[type * 25 + X.S[i + 1] * 5 + X.S[j - 1]];
     return X.P->hairpinE[u] + X.P->mismatchH[type][X.S[i + 1]][X.S[j - 1]];
 }
 
@@ -143,15 +168,23 @@ __device__ __forceinline__ int wave_min(int v) {
 // first set lane of a 64-bit ballot, or -1
 __device__ __forceinline__ int first_lane(unsigned long long mask) { return mask ? (__ffsll((long long)mask) - 1) : -1; }
 
-#ifdef MIRP_EPI_CLOCKS     // diagnostics build: phase clocks of wave 0 (lane 0) of every epilogue workgroup
-static __device__ unsigned long long g_epi_clk[16];
+#ifdef MIRP_EPI_CLOCKS     // diagnostics build: phase clocks of wave 0 (lane 0) of every epilogue workgroup, summed in LDS, flushed once per workgroup
+static __device__ unsigned long long g_epi_clk[32];
+__device__ inline long long* epi_acc() { __shared__ long long acc[32]; return acc; }
+#define EPI_CNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)&epi_acc()[k], 1ull); } while (0)
 #define EPI_T0() long long _t = clock64()
-#define EPI_T(k) do { if (threadIdx.x == 0) { const long long _n = clock64(); atomicAdd(&g_epi_clk[k], (unsigned long long)(_n - _t)); _t = _n; } else { _t = clock64(); } } while (0)
+#define EPI_T(k) do { if (threadIdx.x == 0) { const long long _n = clock64(); epi_acc()[k] += _n - _t; _t = clock64(); } else { _t = clock64(); } } while (0)
+#define EPI_INIT() do { if (threadIdx.x < 32) epi_acc()[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define EPI_FLUSH() do { __syncthreads(); if (threadIdx.x < 32) atomicAdd(&g_epi_clk[threadIdx.x], (unsigned long long)epi_acc()[threadIdx.x]); } while (0)
 #else
 #define EPI_T0() do {} while (0)
 #define EPI_T(k) do {} while (0)
+#define EPI_INIT() do {} while (0)
+#define EPI_FLUSH() do {} while (0)
+#define EPI_CNT(k) do {} while (0)
 #endif
 #define BT_STACK 96
+#define MIRP_EPI_DMAX 300   // largest pair distance a tiled archive holds (fold_lds_kernel.hip: LDMAX)
 #define BT_LINE 16      // cells of a helix line fetched per round trip (each is its own cache line of the trace-back triangle)
 
 // Wave-cooperative backtrack of one locally optimal structure (all 64 lanes call it with
@@ -186,6 +219,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             // descending scan; the caller's j is its own hit + 2 for the first segment, so the top four candidates are probed alone first
             // (every lane of a round pulls its own cache line of the archive: a full round costs 64 lines)
             for (int kb = j, width = 4; kb >= i + TURN + 1 && found < 0; kb -= width, width = 64) {
+                EPI_CNT(16);
                 int k = kb - lane;
                 bool ok = false;
                 if (lane < width && k >= i + TURN + 1) {
@@ -209,6 +243,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             }
         } else {
             int d = j - i;
+            EPI_CNT(17);
             int fij = T.M(d, i);
             if (T.M(d - 1, i) == fij) {
                 if (lane == 0) { stk[3 * sp] = i; stk[3 * sp + 1] = j - 1; stk[3 * sp + 2] = 1; }
@@ -222,10 +257,12 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             }
             int type = ptype_at(X, i, j);
             bool ok = false;
+            EPI_CNT(18);
             if (type) ok = (T.C(d, i) + ml_term(X, i, j, type) == fij);
             if (!ok) {
                 int found = -1;
                 for (int kb = i + 1 + TURN; kb <= j - 2 - TURN && found < 0; kb += 64) {
+                    EPI_CNT(19);
                     int k = kb + lane;
                     bool hit = false;
                     if (k <= j - 2 - TURN) hit = (fij == T.M(k - i, i) + T.M(j - k - 1, k + 1));
@@ -249,6 +286,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             // also says that the hairpin does not realise c, so no energy is read along the way.
             {
                 const int il = i + lane, jl = j - lane;
+                EPI_CNT(20);
                 int cl = (lane < BT_LINE && jl - il >= TURN + 1) ? T.TB(jl - il, il) : 0;
                 if (__builtin_amdgcn_readfirstlane(cl) > 0) {
                     int pos = 0;
@@ -265,12 +303,14 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
                 }
             }
             int type = ptype_at(X, i, j);
+            EPI_CNT(21);
             int cij = T.C(j - i, i);
             if (cij == e_hairpin(X, i, j, type)) break;
             int pmax = (j - 2 - TURN < i + MAXLOOP + 1) ? j - 2 - TURN : i + MAXLOOP + 1;
             int fp = -1, fq = -1;
             // Trace-back code of the fill kernel (T.TB >= 0): 1 + (n1 << 5 | n2) names the interior loop this search would find first,
             // 0 says that none realises c(i,j) (multiloop).  Tables without codes (TB < 0) are searched: p ascending, q descending.
+            EPI_CNT(22);
             const int code = __builtin_amdgcn_readfirstlane(T.TB(j - i, i));
             if (code > 0) { fp = i + 1 + ((code - 1) >> 5); fq = j - 1 - ((code - 1) & 31); }
             if (code < 0)
@@ -298,6 +338,7 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
             int mm = X.P->ML_closing + mlstem_x(X, rtype_of(type), X.S[j - 1], X.S[i + 1]);
             int found = -1;
             for (int kb = i + 2 + TURN; kb <= j - 3 - TURN && found < 0; kb += 64) {
+                EPI_CNT(23);
                 int k = kb + lane;
                 bool hit = false;
                 if (k <= j - 3 - TURN) hit = (cij == T.M(k - i - 1, i + 1) + T.M(j - k - 2, k + 1) + mm);
@@ -332,6 +373,315 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
     return L;
 }
 
+// Backtrack over a TILED archive with trace-back codes (Tab::kTiled).  Same search orders and results as backtrack_wave; what changes is how often
+// it goes to memory: the walk is a chain of dependent round trips (~2 us each under load), so every fetch brings an 8 x 8 PATCH of the archive
+// anchored at the current pair or segment (i, j) -- lane (a, b) holds cell (i + a, j - b), a handful of 128-byte tiles -- and the walk continues
+// in registers (v_readlane) until it leaves the patch:
+//   * helix: trace-back codes and c of the patch; stacked pairs, bulges and interior loops are followed inside it (an asymmetric loop no longer
+//     costs a fetch), the closing pair's c is already there for the hairpin test;
+//   * multiloop segment: fML and c of the patch; the run of unpaired bases that the reference trims one pop at a time (j first, then i) is walked
+//     inside it, the pair test of the segment's final (i, j) needs no further fetch;
+//   * multiloop splits: all split points of the segment are fetched at once (two fML reads per lane and 64 points), first match ascending.
+template <class Tab>
+__device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, int jend, int span, char* buf, int* stk) {
+    const int lane = threadIdx.x & 63;
+    const int n = X.n;
+    const int pa = lane >> 3, pb = lane & 7;
+    constexpr int NSR = (MIRP_EPI_DMAX + 63) / 64;   // rounds of 64 split points that cover any segment
+    int len0 = (n - start < span + 1 ? n - start : span + 1) + 2;
+    for (int x = lane; x < len0; x += 64) buf[x] = '-';
+    int sp = 0;
+    if (lane == 0) { stk[0] = start; stk[1] = jend; stk[2] = 0; }
+    sp = 1;
+    __builtin_amdgcn_wave_barrier();
+    while (sp > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        sp--;
+        int i = stk[3 * sp], j = stk[3 * sp + 1], ml = stk[3 * sp + 2];
+        i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); ml = __builtin_amdgcn_readfirstlane(ml);
+        if (j < i + TURN + 1) continue;
+        if (sp + 3 >= BT_STACK) return -20;
+        if (ml == 0) {
+            // unpaired 5' bases: the reference pops (i + 1, j) while f3[i] == f3[i + 1]; here 64 positions per step
+            for (;;) {
+                const int x = i + lane;
+                const bool diff = x <= n ? (X.f3[x] != X.f3[x + 1]) : true;
+                const int fl = first_lane(__ballot(diff));
+                if (fl < 0) { i += 64; continue; }
+                i += fl;
+                break;
+            }
+            if (j < i + TURN + 1) continue;
+            const int fij = X.f3[i];
+            int found = -1;
+            // partners descending.  The caller's j is its own hit + 2 for a structure's first segment, so the top four candidates are probed alone first
+            // (one or two tiles); a full round of 64 is a row of the archive = 8 tiles
+            for (int kb = j, width = 4; kb >= i + TURN + 1 && found < 0; kb -= width, width = 64) {
+                EPI_CNT(16);
+                const int k = kb - lane;
+                bool ok = false;
+                if (lane < width && k >= i + TURN + 1) {
+                    const int type = ptype_at(X, i, k);
+                    if (type) ok = (fij == T.C(k - i, i) + ext_term(X, i, k, type) + X.f3[k + 1]);
+                }
+                const int fl = first_lane(__ballot(ok));
+                if (fl >= 0) found = kb - fl;
+            }
+            if (found < 0) return -21;
+            const int k = found;
+            if (j == n) {
+                if (lane == 0) { stk[3 * sp] = k + 1; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 0; }
+                sp++;
+            }
+            j = k;
+            if (lane == 0) {
+                buf[i - start] = '(';
+                buf[j - start] = ')';
+                if (j < n) buf[j + 1 - start] = '.';
+            }
+        } else {
+            int fij, cij;
+            for (;;) {      // trim unpaired bases inside patches of fML: j first, then i (the reference's order), until neither matches
+                EPI_CNT(17);
+                const int ia = i + pa, jb = j - pb, dd = jb - ia;
+                int mv = INF, cv = INF;
+                if (dd >= TURN + 1) { mv = T.M(dd, ia); cv = T.C(dd, ia); }
+                fij = __builtin_amdgcn_readlane(mv, 0);
+                int r = 0, c = 0;
+                bool edge = false;
+                for (;;) {
+                    if (r == 7 || c == 7) { edge = true; break; }
+                    if (__builtin_amdgcn_readlane(mv, r * 8 + c + 1) == fij) { c++; continue; }
+                    if (__builtin_amdgcn_readlane(mv, (r + 1) * 8 + c) == fij) { r++; continue; }
+                    break;
+                }
+                i += r; j -= c;
+                if (edge && (r | c)) continue;      // left the patch: fetch again at the new segment
+                if (edge) return -24;               // (0, 0) is never on the edge
+                cij = __builtin_amdgcn_readlane(cv, r * 8 + c);
+                break;
+            }
+            const int type = ptype_at(X, i, j);
+            bool ok = false;
+            if (type) ok = (cij + ml_term(X, i, j, type) == fij);
+            if (!ok) {
+                // all split points at once, first match ascending
+                EPI_CNT(19);
+                int m1[NSR], m2[NSR];
+                const int k0 = i + 1 + TURN, k1 = j - 2 - TURN;
+#pragma unroll
+                for (int q = 0; q < NSR; q++) {
+                    const int k = k0 + 64 * q + lane;
+                    m1[q] = INF; m2[q] = INF;
+                    if (k <= k1) { m1[q] = T.M(k - i, i); m2[q] = T.M(j - k - 1, k + 1); }
+                }
+                int found = -1;
+#pragma unroll
+                for (int q = 0; q < NSR; q++) {
+                    const int fl = first_lane(__ballot(fij == m1[q] + m2[q]));
+                    if (fl >= 0 && found < 0) found = k0 + 64 * q + fl;
+                }
+                if (found < 0) return -22;
+                if (lane == 0) {
+                    stk[3 * sp] = i; stk[3 * sp + 1] = found; stk[3 * sp + 2] = 1;
+                    stk[3 * sp + 3] = found + 1; stk[3 * sp + 4] = j; stk[3 * sp + 5] = 1;
+                }
+                sp += 2;
+                continue;
+            }
+            if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+        }
+        // (i,j) is a traced pair: follow the trace-back codes through patches until a hairpin or a multiloop
+        for (;;) {
+            EPI_CNT(20);
+            const int ia = i + pa, jb = j - pb, dd = jb - ia;
+            int tbv = 0, cv = INF;
+            if (dd >= TURN + 1) { tbv = T.TB(dd, ia); cv = T.C(dd, ia); }
+            int r = 0, c = 0;
+            bool off_patch = false;
+            for (;;) {
+                const int code = __builtin_amdgcn_readlane(tbv, r * 8 + c);
+                if (code <= 0) break;                               // hairpin or multiloop closes here
+                const int n1 = (code - 1) >> 5, n2 = (code - 1) & 31;
+                i += 1 + n1; j -= 1 + n2;
+                if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+                r += 1 + n1; c += 1 + n2;
+                if (r > 7 || c > 7) { off_patch = true; break; }
+            }
+            if (off_patch) continue;
+            const int cij = __builtin_amdgcn_readlane(cv, r * 8 + c);
+            const int type = ptype_at(X, i, j);
+            if (cij == e_hairpin(X, i, j, type)) break;
+            const int mm = X.P->ML_closing + mlstem_x(X, rtype_of(type), X.S[j - 1], X.S[i + 1]);
+            EPI_CNT(23);
+            int m1[NSR], m2[NSR];
+            const int k0 = i + 2 + TURN, k1 = j - 3 - TURN;
+#pragma unroll
+            for (int q = 0; q < NSR; q++) {
+                const int k = k0 + 64 * q + lane;
+                m1[q] = INF; m2[q] = INF;
+                if (k <= k1) { m1[q] = T.M(k - i - 1, i + 1); m2[q] = T.M(j - k - 2, k + 1); }
+            }
+            int found = -1;
+#pragma unroll
+            for (int q = 0; q < NSR; q++) {
+                const int fl = first_lane(__ballot(cij == m1[q] + m2[q] + mm));
+                if (fl >= 0 && found < 0) found = k0 + 64 * q + fl;
+            }
+            if (found < 0) return -23;
+            if (lane == 0) {
+                stk[3 * sp] = i + 1; stk[3 * sp + 1] = found; stk[3 * sp + 2] = 1;
+                stk[3 * sp + 3] = found + 1; stk[3 * sp + 4] = j - 1; stk[3 * sp + 5] = 1;
+            }
+            sp += 2;
+            break;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int last = 0;
+    for (int x = lane; x < len0; x += 64)
+        if (buf[x] != '-') last = x;
+    {
+        int v = last;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
+        last = v;
+    }
+    int L = last + 1;
+    for (int x = lane; x < L; x += 64)
+        if (buf[x] == '-') buf[x] = '.';
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return L;
+}
+
+// Exterior sweep over a TILED archive (Tab::kTiled: 8 x 8 tiles over (row, diagonal), see fold_lds_kernel.hip).
+// f3[i] = min(f3[i+1], min_j c(i,j) + ext(i,j) + f3[j+1]) is sequential in i, but only through f3.  Rows are taken in blocks of 8 x (waves) rows,
+// top block first.  Step 1: every wave takes ONE row block of the archive (8 rows) and has ALL of its tiles in flight at once: lane = diagonal
+// (d = 4 + lane, + 64 per group), a lane's 16-byte load is the 8 rows of its diagonal, a wave-wide load is 1 KB of consecutive tiles.  A cell then
+// costs three LDS reads (position code of j, the exterior term from xtab, f3[j+1]) and eight VALU instructions: c is finite only where (i, j)
+// pairs, so no pair type is computed, and the term table is indexed by bases and neighbour codes, so nothing is selected.  Partners j whose
+// f3[j+1] is final (j+1 above the block) go into the lane's eight running minima, which meet in LDS (ds_min); the few partners inside the block
+// (first group only) are parked in LDS, transposed: innerT[j+1][row].
+// Step 2 (wave 0, lane = row): the sequential chain through the block runs in registers -- one v_readlane + add + min per row, the innerT reads do
+// not depend on the chain.  The backtrack stacks are idle here and serve as scratch.
+template <class Tab, int NT>
+__device__ void f3_sweep_tiled(const WinCtx& X, const Tab& T, int* f3, int* scratch) {
+    constexpr int NW = NT / 64, RBK = 8 * NW;
+    constexpr int NG = (MIRP_EPI_DMAX - TURN - 1) / 64 + 1;   // groups of 64 diagonals
+    constexpr int SW_BIAS = 1 << 17, KEY_INF = 0x7fffffff;     // energies of an exterior decomposition stay far inside +-2^17
+    static_assert(RBK <= 64, "step 2 maps the rows of a block onto the lanes of one wave");
+    static_assert(RBK <= 64 + TURN, "only the first group of diagonals has partners inside the block");
+    static_assert((RBK + RBK * RBK / 2) * 4 <= NW * 3 * BT_STACK * 4, "f3 scratch must fit the backtrack stacks");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = X.n, D = X.D;
+    int* part = scratch;                                       // [RBK] per-row minimum over the partners above the block
+    short* innerT = reinterpret_cast<short*>(scratch + RBK);   // [RBK (j+1 - blk_lo)][RBK (row - blk_lo)] c + ext of the partners inside the block
+    const char* xtab = reinterpret_cast<const char*>(X.xtab);
+    const int top = n - TURN - 1;                              // highest row that can pair
+    EPI_T0();
+    for (int g = top >= 1 ? (top - 1) / RBK : -1; g >= 0; g--) {
+        const int blk_lo = g * RBK + 1, blk_hi = blk_lo + RBK - 1;
+        const int tb = g * NW + wave;                          // this wave's row block: rows i0 .. i0 + 7
+        const int i0 = 8 * tb + 1;
+        const int dmax_b = D < n - i0 ? D : n - i0;            // wave-uniform: the block's first row reaches furthest
+        // all tiles of the row block in flight: 16 bytes = the 8 rows of diagonal d (cells past a row's end are never looked at)
+        uint4 cg[NG];
+        const uint4* base = reinterpret_cast<const uint4*>(T.carch + T.off[tb]) + lane;
+#pragma unroll
+        for (int u = 0; u < NG; u++) {
+            cg[u] = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+            if (TURN + 1 + 64 * u + lane <= dmax_b) cg[u] = base[64 * u];
+        }
+        for (int x = tid; x < RBK; x += NT) part[x] = KEY_INF;
+        for (int x = tid; x < RBK * RBK / 2; x += NT) reinterpret_cast<int*>(innerT)[x] = 0x7fff7fff;
+        __syncthreads();
+        EPI_T(8);
+#ifdef MIRP_EPI_CLOCKS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EPI_T(9);
+#endif
+        {
+            int best[8];      // keys (c + f3[j+1] + SW_BIAS) << 9 | j: the minimum is the minimum energy and, among equal energies, the first partner
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) best[rr] = KEY_INF;
+            // byte offset of row i's part of xtab (lanes 0-7 hold the block's rows): wave-uniform per row, fetched with v_readlane
+            int vrow = 0;
+            {
+                const int i = i0 + (lane & 7);
+                if (i <= n) vrow = (X.S[i] * 6 + (i > 1 ? (int)X.S[i - 1] : 5)) * 60;
+            }
+#pragma unroll
+            for (int u = 0; u < NG; u++) {
+                if (TURN + 1 + 64 * u <= dmax_b) {              // wave-uniform
+                    const int d = TURN + 1 + 64 * u + lane;
+                    const int j0 = i0 + d;                      // partner of row i0; row i0 + rr pairs with j0 + rr
+                    const int nrow_ok = d <= D ? n - j0 : -1;   // rows rr <= nrow_ok have j <= n
+                    const int kb0 = (SW_BIAS << 9) + j0;
+                    const unsigned cw[4] = {cg[u].x, cg[u].y, cg[u].z, cg[u].w};
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4) {            // four rows at a time (registers)
+                        int pq[4], fj[4], tv[4];
+                        // lanes past the window's end read whatever LDS holds there (out of range: zero): their cells are not valid
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pq[q] = X.pq2[j0 + h + q];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) fj[q] = f3[j0 + h + q + 1];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) tv[q] = *reinterpret_cast<const short*>(xtab + __builtin_amdgcn_readlane(vrow, h + q) + pq[q]);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int rr = h + q;
+                            const int cv = (int)(short)((rr & 1) ? cw[rr >> 1] >> 16 : cw[rr >> 1] & 0xffffu);
+                            bool valid = cv != 0x7fff && rr <= nrow_ok;     // c is finite only where (i, j) pairs
+                            if (u == 0) {
+                                const bool above = j0 + rr >= blk_hi;       // f3[j+1] final: j+1 above the block
+                                if (valid && !above) innerT[(j0 + rr + 1 - blk_lo) * RBK + 8 * wave + rr] = (short)(cv + tv[q]);   // partner inside the block
+                                valid = valid && above;
+                            }
+                            const int c = cv + tv[q] + fj[q];
+                            const int cm = valid ? (c << 9) + kb0 + rr : KEY_INF;
+                            best[rr] = cm < best[rr] ? cm : best[rr];
+                        }
+                    }
+                }
+            }
+            // hand-issued ds_min: the compiler's atomic optimizer would turn each atomicMin into a loop over the active lanes
+            {
+                const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) int*)(part + 8 * wave);
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) asm volatile("ds_min_i32 %0, %1 offset:%2" : : "v"(pa), "v"(best[rr]), "n"(4 * rr) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        EPI_T(10);
+        __syncthreads();
+        EPI_T(11);
+        if (wave == 0) {
+            const int r = lane & (RBK - 1);
+            int best = part[r];
+            int fx = blk_hi + 1 <= n + 2 ? f3[blk_hi + 1] : 0, fo = 0, po = 0;
+#pragma unroll 4
+            for (int xr = RBK - 1; xr >= 0; xr--) {
+                const int bx = __builtin_amdgcn_readlane(best, xr);
+                const int bv = (bx >> 9) - SW_BIAS;                // KEY_INF decodes to a large positive value
+                fx = bv < fx ? bv : fx;                            // f3 of row blk_lo + xr
+                fo = lane == xr ? fx : fo;
+                po = lane == xr ? (bx & 511) : po;                 // its first partner (meaningful where f3 drops at this row)
+                const int e = innerT[xr * RBK + r];                // rows that have row xr + blk_lo - 1 as a partner
+                const int c = ((e + fx) << 9) + (SW_BIAS << 9) + (blk_lo + xr - 1);
+                best = (e != 0x7fff && c < best) ? c : best;
+            }
+            if (lane < RBK && blk_lo + lane <= n) { f3[blk_lo + lane] = fo; X.pp[blk_lo + lane] = (short)po; }
+        }
+        EPI_T(12);
+        __syncthreads();
+        EPI_T(13);
+    }
+}
+
 // Shared epilogue: f3 sweep, enumeration of structure starts, parallel backtracks, RNALfold's
 // "print prev unless contained in new" rule, output records.  Called by every thread of the
 // workgroup after the tables are complete (and visible).
@@ -349,15 +699,17 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     // final (j+1 above the block) are reduced to one partial minimum per row, and the few partners inside the block (span < NW)
     // are fetched to LDS.  Step 2 (wave 0): the short sequential chain through the block touches LDS only.  The backtrack stacks
     // are idle here and serve as scratch: part[NW], inner[NW][NW].
+    for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
+    __syncthreads();
+    EPI_T0();
+    if constexpr (Tab::kTiled) f3_sweep_tiled<Tab, NT>(X, T, f3, btstk);
+    else {
     constexpr int NW = NT / 64;
     constexpr int RB = 32;   // rows per block: 32 consecutive i share their cache lines of every archived diagonal
     static_assert(RB == 32, "step 1 maps a half-wave onto the rows of a block");
     static_assert((RB + RB * RB) * 4 <= NW * 3 * BT_STACK * 4, "f3 scratch must fit the backtrack stacks");
     int* part = btstk;
     int* inner = btstk + RB;
-    for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
-    __syncthreads();
-    EPI_T0();
     for (int i_hi = n - TURN - 1; i_hi >= 1; i_hi -= RB) {
         // Step 1 walks the block diagonal by diagonal: a half-wave holds the RB rows (lane = row), so its 32 cells of one archived diagonal
         // are one contiguous 64-byte read that is consumed at once (row-major order re-fetched every line once per row from HBM when
@@ -413,6 +765,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
         }
         __syncthreads();
     }
+    }
     EPI_T(0);
     if (wave == 0) {
         // ---- structure starts, descending: l>=2 with f3[l]!=f3[l+1] && f3[l-1]==f3[l]; l==1 with f3[1]!=f3[2]
@@ -426,7 +779,7 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
             if (is && cnt + rank < max_lines) starts[cnt + rank] = l;
             cnt += __popcll(mask);
         }
-        if (lane == 0) { sh_misc[0] = cnt < max_lines ? cnt : max_lines; sh_misc[1] = cnt > max_lines ? 1 : 0; sh_misc[2] = 0; sh_misc[3] = cnt; }
+        if (lane == 0) { sh_misc[0] = cnt < max_lines ? cnt : max_lines; sh_misc[1] = cnt > max_lines ? 1 : 0; sh_misc[2] = 0; sh_misc[3] = cnt; sh_misc[4] = 0; }
     }
     __syncthreads();
     const int nst = sh_misc[0];
@@ -434,12 +787,25 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     // ---- backtracks: one wave per start
     char* mybuf = btbuf + wave * bufstride;
     int* mystk = btstk + wave * 3 * BT_STACK;
-    for (int k = wave; k < nst; k += NT / 64) {
+    // (the trip count is bounded on purpose: with an endless for (;;) around the counter draw this loop was miscompiled -- the kernel hung on a
+    // one-window batch -- and any bound made it go away)
+    for (int it = 0; it <= nst; it++) {
+        int k = wave + it * (NT / 64);
+        if constexpr (Tab::kTiled) {      // structures differ a lot in length: the waves draw them from a counter instead of striding
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&sh_misc[4], 1);
+            k = __builtin_amdgcn_readfirstlane(t);
+        }
+        if (k >= nst) break;
         int lind = starts[k];
+        EPI_CNT(25);
         int fij = f3[lind];
-        // "short backtrack": first partner (ascending) that realises f3[lind]
+        // "short backtrack": first partner (ascending) that realises f3[lind]; the tiled sweep has recorded it
         int pp = -1;
+        if constexpr (Tab::kTiled) pp = X.pp[lind];
+        else
         for (int pb = lind + TURN; pb <= lind + span && pp < 0; pb += 64) {
+            EPI_CNT(24);
             int q = pb + lane;
             bool hit = false;
             if (q <= lind + span && q <= n) {
@@ -451,7 +817,10 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
         }
         int L = -10;
         EPI_T(2);
-        if (pp >= 0) L = backtrack_wave(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
+        if (pp >= 0) {
+            if constexpr (Tab::kTiled) L = backtrack_wave_tiled(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
+            else L = backtrack_wave(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
+        }
         EPI_T(3);
         if (L < 0) {
             if (lane == 0) { sh_misc[2] = L; lens[k] = 0; }

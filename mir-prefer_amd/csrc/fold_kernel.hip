@@ -17,6 +17,7 @@ namespace mirp {
 #define INF MIRP_INF
 
 struct GTab {
+    static constexpr bool kTiled = false;
     int* __restrict__ c;
     int* __restrict__ m;
     int ld;

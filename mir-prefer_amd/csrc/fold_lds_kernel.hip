@@ -61,15 +61,17 @@ struct LdsTables {          // int16 copies of the hot parameter tables
 #define CRING_ROWS 33       // diagonal dd lives in row dd & 31; row 32 mirrors row 0, so "the row after row r" is always r + 1 (phase A1 mixes lanes of two diagonals)
 
 struct LTab {               // table accessors for the shared epilogue/backtrack
-    const short* fml;       // triangular fML (per-window global slab in the epilogue kernel)
-    const int* off;         // LDS: triangular offset of diagonal d (valid for d >= 4)
-    const short* carch;     // global archive of c, triangular like fML: (d,i) -> off[d] + i (keeps a workgroup's slab ~88 KB, L2-friendly)
-    const unsigned short* tb;   // trace-back codes written by the fill kernel, same triangle
-    __device__ __forceinline__ int TB(int d, int i) const { return tb[off[d] + i]; }
-    __device__ __forceinline__ int C(int d, int i) const { int v = carch[off[d] + i]; return v == I16_INF ? INF : v; }
+    static constexpr bool kTiled = true;   // 8 x 8 tiles over (row, diagonal): see the archive layout below
+    const short* fml;       // fML slab (per-window, global), tiled like the other two
+    const int* off;         // LDS: rowblk_off of the tiled archive layout (arch_rowblk_off)
+    const short* carch;     // global archive of c
+    const unsigned short* tb;   // trace-back codes written by the fill kernel
+    __device__ __forceinline__ int at(int d, int i) const { return off[(i - 1) >> 3] + ((i - 1) & 7) + 8 * (d - 4); }
+    __device__ __forceinline__ int TB(int d, int i) const { return tb[at(d, i)]; }
+    __device__ __forceinline__ int C(int d, int i) const { int v = carch[at(d, i)]; return v == I16_INF ? INF : v; }
     __device__ __forceinline__ int M(int d, int i) const {
         if (d < 4) return INF;
-        const int v = (unsigned short)fml[off[d] + i];
+        const int v = (unsigned short)fml[at(d, i)];
         return v == 65535 ? INF : v - FML_BIAS;
     }
 };
@@ -121,6 +123,26 @@ __device__ inline void fill_tri_off(int* off, int n) {
     for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += tri_len(d, n); }
 }
 
+// Archive layout in HBM (the c, fML and trace-back slabs a window hands to its epilogue): 8 x 8 tiles over (row i, diagonal d), one tile =
+// one 128-byte line.  Rows are cut into row blocks of 8 (block b = rows 8b+1 .. 8b+8); a block holds the diagonals 4 .. min(dcap, n-1-8b) its
+// first row can have (rounded up to whole tiles), its tiles follow each other by diagonal:
+//     arch(d, i) = rowblk_off[(i-1) >> 3] + ((i-1) & 7) + 8 (d - 4),      rowblk_off[b] = 8 * sum of arch_nd over the blocks below b.
+// The epilogue's accesses are runs along a row (partner scans), along a column (multiloop splits), along a helix (i+l, j-l) and the exterior
+// sweep's (row block x all diagonals) streams; in a diagonal-major triangle each of those touched one line per cell.  The fill kernel writes one
+// diagonal per interval: 16-byte runs that the L2 merges into whole lines over the next seven diagonals.
+#define ARCH_RB ((LCAP + 7) / 8)
+__host__ __device__ constexpr int arch_nd(int b, int n, int dcap) {
+    int m = n - 1 - 8 * b;
+    if (m > dcap) m = dcap;
+    m -= 3;
+    return m > 0 ? (m + 7) & ~7 : 0;
+}
+__host__ __device__ inline int arch_rowblk_off(int b, int n, int dcap) {
+    int o = 0;
+    for (int x = 0; x < b; x++) o += 8 * arch_nd(x, n, dcap);
+    return o;
+}
+
 struct LdsLayout {
     unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total;
 };
@@ -137,7 +159,7 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.qb2 = o; o += lds_al(LCAP + 8);
     L.list = o; o += lds_al(3 * LSEG * 2);
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
-    L.misc = o; o += lds_al(48 * 4);
+    L.misc = o; o += lds_al((48 + ARCH_RB) * 4);
     L.total = o;
     return L;
 }
@@ -475,6 +497,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
     int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16..21: list lengths
     int* lcnt = misc + 16;                                          // [6]: entries in the list of diagonal d at d % 6
+    int* rbt = misc + 48;                                           // [ARCH_RB]: row-block offsets of the window's archive slabs (arch_rowblk_off)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nc = CSTR;
@@ -553,6 +576,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             misc[1] = 0;
             for (int x = 0; x < 6; x++) lcnt[x] = 0;
         }
+        if (tid >= 64 && tid < 64 + ARCH_RB) rbt[tid - 64] = arch_rowblk_off(tid - 64, n, span);
         __syncthreads();
         if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
         for (int x = tid; x <= n; x += LNT) {
@@ -587,6 +611,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // split loop state carried across diagonals (see splits below)
         int sp_ncpad = 0, sp_nsub = 0, sp_pair = 0, sp_sub = 0, sp_so1 = 0, sp_si1 = 0, sp_so2 = 0, sp_si2 = 0;
         int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
+        const int abase = tid < 8 * ARCH_RB ? rbt[tid >> 3] + (tid & 7) - 32 : 0;   // archive offset of (d, i = tid + 1) is abase + 8 d
         int a1_ncp = __builtin_amdgcn_readfirstlane(lcnt[0]);   // phase A1: length of the next diagonal's list (first: diagonal 6)
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
@@ -942,8 +967,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     cring[(d & 31) * CSTR + i] = g16;
                     if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
                 }
-                carch[od + i] = c16;
-                tb_out[od + i] = (unsigned short)tb;
+                carch[abase + 8 * d] = c16;
+                tb_out[abase + 8 * d] = (unsigned short)tb;
                 fml[od + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 ckey[i] = KEY_NONE; mdec[i] = INF;
@@ -964,17 +989,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int x = tid;
             int lt = 0, lbase = 0;
             unsigned long long lbal = 0;
-            if (d + 3 <= D && wave < 6) {
-                if (x + 1 + d + 3 <= n) lt = pair_type(S[x + 1], S[x + 1 + d + 3]);
-                lbal = __ballot(lt != 0);
-                if (lbal && lane == 0) lbase = atomicAdd(&lcnt[(d + 3) % 6], (int)__popcll(lbal));
-            }
+            const bool do_list = d + 3 <= D && !(dbg_flags & 32768);
             if (tid == 0) lcnt[(d + 4) % 6] = 0;
-            if (x < ncell) {
+            if (x < ncell && !(dbg_flags & 131072)) {
                 const int i = x + 1, j = i + d, u = d - 1;
                 // ---- round 1
                 lds_vu8 Sv = (lds_vu8)S;
                 const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
+                const int s_j3 = Sv[j + 3 <= n ? j + 3 : n];          // far end of cell (i, j+3): the paired-cell list of diagonal d+3
                 const int md = mdec[i];
                 const unsigned kk = ckey[i];
                 const int dmlv = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1];
@@ -982,6 +1004,17 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 if (d > 4) { fa = fml[od1 + i]; fb = fml[od1 + i + 1]; }
                 int sv = -32768;
                 if (u == 4) sv = spec[nc + i]; else if (u == 6) sv = spec[2 * nc + i]; else if (u == 3) sv = spec[i];
+                // the list range is claimed here, between the two rounds: the atomic's return is first looked at after the cell's stores, so its
+                // round trip is not in front of anything (issued ahead of round 1 it put two LDS round trips in front of the whole chain)
+                if (do_list) {
+                    if (j + 3 <= n) lt = pair_type(s_i, s_j3);
+                    lbal = __ballot(lt != 0);
+                    // hand-issued: the compiler's atomic optimizer wraps atomicAdd in a wave reduction whose readfirstlane waits right here
+                    if (lbal && lane == 0) {
+                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&lcnt[(d + 3) % 6];
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(lbase) : "v"(la), "v"((int)__popcll(lbal)) : "memory");
+                    }
+                }
                 // ---- pair type (arithmetic) and round 2: parameter tables; a type-0 row of a table is valid memory, its value is never used
                 const int type = pair_type(s_i, s_j);
                 const int rt = rtype_of(type);
@@ -1026,12 +1059,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const unsigned short g16 = cv < INF ? (unsigned short)(cv + mmI + 32768) : (unsigned short)65535;
                 cring[(d & 31) * CSTR + i] = g16;
                 if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
-                carch[od + i] = c16;
-                tb_out[od + i] = (unsigned short)tb;
+                if (!(dbg_flags & 65536)) { carch[abase + 8 * d] = c16; tb_out[abase + 8 * d] = (unsigned short)tb; }
                 fml[od + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 ckey[i] = KEY_NONE; mdec[i] = INF;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lbase) : : "memory");   // the atomic's return is first needed here
             const int lb = __builtin_amdgcn_readfirstlane(lbase);
             if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
         };
@@ -1054,12 +1087,21 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (overflow) {   // int16 range exceeded: hand the window to the generic kernel
             if (tid == 0) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0; }
         } else {
-            // hand the tables to the epilogue kernel: c was archived on the fly, fML is copied out now (coalesced dwords)
-            int tri = 0;
-            if (Dm >= 4) tri = tri_off(Dm + 1, n) + 1;
-            const unsigned int* src = reinterpret_cast<const unsigned int*>(fml);
-            unsigned int* dst = reinterpret_cast<unsigned int*>(fml_out);
-            for (int x = tid; x < (tri + 1) / 2; x += LNT) dst[x] = src[x];
+            // hand the tables to the epilogue kernel: c and the trace-back codes were archived on the fly, fML is copied out now into the same tiled
+            // layout (a wave per diagonal: conflict-free LDS reads, 16-byte runs in HBM that its neighbours in d complete)
+            constexpr int NK = (LCAP + 63) / 64;
+            int rb[NK];
+#pragma unroll
+            for (int k = 0; k < NK; k++) rb[k] = (lane + 64 * k < 8 * ARCH_RB ? rbt[(lane + 64 * k) >> 3] : 0) + (lane & 7) - 32;
+            for (int d = 4 + wave; d <= Dm; d += LNW) {
+                const int o = tri_off(d, n) + lane + 1;
+                unsigned short v[NK];
+#pragma unroll
+                for (int k = 0; k < NK; k++) v[k] = fml[o + 64 * k];          // past the diagonal's end: some other cell of the triangle, not stored
+#pragma unroll
+                for (int k = 0; k < NK; k++)
+                    if (lane + 64 * k < n - d) fml_out[rb[k] + 8 * d] = (short)v[k];
+            }
             if (tid == 0) win_state[win] = 1;
         }
         }   // window fits this kernel
@@ -1081,7 +1123,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 // fill kernel's one-workgroup-per-CU geometry.
 // ------------------------------------------------------------------------------------------
 #define ENT 256
-__global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
+#ifndef MIRP_EPI_WGS
+#define MIRP_EPI_WGS 8
+#endif
+__global__ void __launch_bounds__(ENT, MIRP_EPI_WGS) fold_lds_epilogue_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int span, const short* __restrict__ slabs, size_t slab_shorts, const int* __restrict__ win_state, unsigned int* __restrict__ work_counter,
     int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss, int* __restrict__ out_nlines,
@@ -1099,9 +1144,14 @@ __global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
     unsigned char* seq = S + nc;                                     // nc
     char* btbuf = (char*)(seq + nc);                                 // (ENT/64)*nc
     EpiTables* EP = (EpiTables*)(smem + ((((size_t)(btbuf - (char*)smem) + (ENT / 64) * nc) + 15) & ~(size_t)15));
+    short* xtab = (short*)(EP + 1);                                  // XTAB_N
+    unsigned char* pq2 = (unsigned char*)(xtab + XTAB_N);            // nc
+    short* ppart = (short*)(pq2 + nc);                               // nc
     const int tid = threadIdx.x;
     fill_epi_tables(EP, P, tid, ENT);
+    fill_ext_table(xtab, P, tid, ENT);
     __syncthreads();
+    EPI_INIT();
     for (;;) {
         if (tid == 0) misc[0] = (int)atomicAdd(work_counter, 1u);
         __syncthreads();
@@ -1122,13 +1172,14 @@ __global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
                 seq[x] = ch;
                 S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
             }
-            if (tid == 0) fill_tri_off(off, n);
+            if (tid < ARCH_RB) off[tid] = arch_rowblk_off(tid, n, span);
             __syncthreads();
             if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
+            for (int x = tid + 1; x <= n; x += ENT) pq2[x] = (unsigned char)((S[x] * 6 + (x < n ? (int)S[x + 1] : 5)) * 2);
             special_hairpins(P, seq, n, spec, nc, tid, ENT);
             __syncthreads();
             WinCtx X;
-            X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D; X.E = EP;
+            X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D; X.E = EP; X.xtab = xtab; X.pq2 = pq2; X.pp = ppart;
             LTab TB;
             TB.carch = slabs + (size_t)win * 3 * slab_shorts; TB.fml = TB.carch + slab_shorts; TB.off = off;
             TB.tb = reinterpret_cast<const unsigned short*>(TB.carch + 2 * slab_shorts);
@@ -1137,6 +1188,7 @@ __global__ void __launch_bounds__(ENT, 8) fold_lds_epilogue_kernel(
         }
         __syncthreads();
     }
+    EPI_FLUSH();
 }
 
 // Epilogue of the vienna-1.8.5 model on the slabs of fold_lds_kernel<1>: exterior sweep, enumeration, full backtracks (interior loops follow the
@@ -1145,21 +1197,22 @@ struct LTab185 {
     const short* carch;
     const short* fml;
     const unsigned short* tb;
-    const int* off;
+    const int* off;         // LDS: rowblk_off of the tiled archive layout
     int n, D, Dm;
+    __device__ __forceinline__ int at(int d, int i) const { return off[(i - 1) >> 3] + ((i - 1) & 7) + 8 * (d - 4); }
     __device__ __forceinline__ int C(int i, int j) const {
         const int d = j - i;
         if (d <= TURN || d > D || i < 1 || j > n) return V_INF;
-        const int v = carch[off[d] + i];
+        const int v = carch[at(d, i)];
         return v == I16_INF ? V_INF : v;
     }
     __device__ __forceinline__ int Mm(int i, int j) const {
         const int d = j - i;
         if (d <= TURN || d > Dm || i < 1 || j > n) return V_INF;
-        const int v = (unsigned short)fml[off[d] + i];
+        const int v = (unsigned short)fml[at(d, i)];
         return v == 65535 ? V_INF : v - FML_BIAS;
     }
-    __device__ __forceinline__ int TB(int i, int j) const { return tb[off[j - i] + i]; }
+    __device__ __forceinline__ int TB(int i, int j) const { return tb[at(j - i, i)]; }
 };
 
 __global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
@@ -1201,7 +1254,7 @@ __global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
                 S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
             }
             for (int x = tid; x < nc + 8; x += ENT) f3[x] = 0;
-            if (tid == 0) fill_tri_off(off, n);
+            if (tid < ARCH_RB) off[tid] = arch_rowblk_off(tid, n, span);
             __syncthreads();
             if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
             for (int x = tid; x <= n; x += ENT) {
@@ -1239,7 +1292,7 @@ size_t fold_lds_epilogue_bytes(int max_lines) {
     const int nc = LCAP + 8;
     size_t b = sizeof(int) * (nc + 2 * (size_t)max_lines + (ENT / 64) * 3 * BT_STACK + 16 + LDMAX + 2) + sizeof(short) * 3 * nc + 2 * (size_t)nc + (ENT / 64) * (size_t)nc;
     b = (b + 15) & ~(size_t)15;
-    return b + sizeof(EpiTables) + 16;
+    return b + sizeof(EpiTables) + 16 + sizeof(short) * XTAB_N + nc + sizeof(short) * nc;
 }
 
 size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout<1>().total; }
@@ -1282,20 +1335,21 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
 
 #ifdef MIRP_EPI_CLOCKS
 void fold_lds_epi_clocks_print() {
-    unsigned long long h[16];
+    unsigned long long h[32];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_epi_clk), sizeof(h));
-    const char* nm[8] = {"f3 sweep", "enumeration", "partner scan", "backtrack", "output", "loop tail", "barrier", "containment"};
-    for (int k = 0; k < 8; k++) std::fprintf(stderr, "[mirp epi clocks] %-14s %llu\n", nm[k], h[k]);
-    unsigned long long z[16] = {0};
+    const char* nm[14] = {"f3 sweep", "enumeration", "partner scan", "backtrack", "output", "loop tail", "barrier", "containment",
+                          "sweep: issue+init+barrier", "sweep: load wait", "sweep: step 1", "sweep: barrier 2", "sweep: step 2", "sweep: barrier 3"};
+    for (int k = 0; k < 14; k++) std::fprintf(stderr, "[mirp epi clocks] %-14s %llu\n", nm[k], h[k]);
+    const char* cn[10] = {"ext partner scan rounds", "ml segment pops", "ml pair checks", "ml split rounds (segment)", "helix line fetches", "line-end c fetches",
+                          "line-end code fetches", "ml split rounds (closing)", "short-backtrack scan rounds", "structures"};
+    for (int k = 0; k < 10; k++) std::fprintf(stderr, "[mirp epi counts] %-28s %llu\n", cn[k], h[16 + k]);
+    unsigned long long z[32] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_epi_clk), z, sizeof(z));
 }
 #endif
 
-size_t fold_lds_slab_shorts(int n_cap) {   // triangle of d = 4..LDMAX for windows up to n_cap (+ slack for the dword copy)
-    size_t tri = 0;
-    tri = 1;
-    for (int d = 4; d <= LDMAX; d++) tri += (size_t)tri_len(d, n_cap);
-    return (tri + 8 + 7) & ~(size_t)7;
+size_t fold_lds_slab_shorts(int n_cap) {   // tiled archive of one table for windows up to n_cap at the largest span (whole 128-byte tiles)
+    return (size_t)arch_rowblk_off(ARCH_RB, n_cap < LCAP ? n_cap : LCAP, LDMAX + 1) + 64;
 }
 
 }  // namespace mirp
