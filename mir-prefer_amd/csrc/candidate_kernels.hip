@@ -58,8 +58,12 @@ __global__ void __launch_bounds__(256) cov_unscatter_kernel(const MirpAln* __res
 // a2 (first half): single-pass scan of both difference arrays -> depth, threshold, run starts.
 // Decoupled look-back over 64-bit {flag, d+, d-} and {flag, n_starts, n_above} tile descriptors.
 // ------------------------------------------------------------------------------------------
+#ifndef SCAN_NT
 #define SCAN_NT 256
+#endif
+#ifndef SCAN_IPT
 #define SCAN_IPT 32
+#endif
 #define SCAN_TILE (SCAN_NT * SCAN_IPT)
 
 __device__ __forceinline__ unsigned long long ld_status(const unsigned long long* p) {

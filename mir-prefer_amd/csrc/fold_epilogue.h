@@ -374,13 +374,15 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
 }
 
 // Backtrack over a TILED archive with trace-back codes (Tab::kTiled).  Same search orders and results as backtrack_wave; what changes is how often
-// it goes to memory: the walk is a chain of dependent round trips (~2 us each under load), so every fetch brings an 8 x 8 PATCH of the archive
-// anchored at the current pair or segment (i, j) -- lane (a, b) holds cell (i + a, j - b), a handful of 128-byte tiles -- and the walk continues
-// in registers (v_readlane) until it leaves the patch:
-//   * helix: trace-back codes and c of the patch; stacked pairs, bulges and interior loops are followed inside it (an asymmetric loop no longer
-//     costs a fetch), the closing pair's c is already there for the hairpin test;
-//   * multiloop segment: fML and c of the patch; the run of unpaired bases that the reference trims one pop at a time (j first, then i) is walked
-//     inside it, the pair test of the segment's final (i, j) needs no further fetch;
+// it goes to memory: the walk is a chain of dependent round trips (~1 us each under load), so every fetch brings an 8 x 8 PATCH of the archive
+// anchored at the current pair or segment (i, j) -- lane (a, b) holds cell (i + a, j - b): trace-back code, c and (for a multiloop segment) fML,
+// a handful of 128-byte tiles per table -- and the walk continues in registers (v_readlane) until it leaves the patch:
+//   * exterior segment: the top four partner candidates (the caller's j is its own hit + 2) are row 0 of the patch, so the partner scan and the
+//     first stretch of the helix are one fetch;
+//   * helix: stacked pairs, bulges and interior loops are followed inside the patch (an asymmetric loop does not cost a fetch), the closing
+//     pair's c is already there for the hairpin test;
+//   * multiloop segment: the run of unpaired bases that the reference trims one pop at a time (j first, then i) is walked inside the patch, the
+//     pair test of the segment's final (i, j) needs no further fetch, and the helix starts in the same patch;
 //   * multiloop splits: all split points of the segment are fetched at once (two fML reads per lane and 64 points), first match ascending.
 template <class Tab>
 __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, int jend, int span, char* buf, int* stk) {
@@ -401,6 +403,8 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
         i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j); ml = __builtin_amdgcn_readfirstlane(ml);
         if (j < i + TURN + 1) continue;
         if (sp + 3 >= BT_STACK) return -20;
+        int tbv = 0, cv = INF;          // the current patch: trace-back codes and c of the cells (i + pa, j - pb) at fetch time
+        int r = 0, c = 0;               // the walk's position inside it
         if (ml == 0) {
             // unpaired 5' bases: the reference pops (i + 1, j) while f3[i] == f3[i + 1]; here 64 positions per step
             for (;;) {
@@ -413,19 +417,32 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
             }
             if (j < i + TURN + 1) continue;
             const int fij = X.f3[i];
+            EPI_CNT(16);
+            {
+                const int ia = i + pa, jb = j - pb, dd = jb - ia;
+                if (dd >= TURN + 1) { const int o = T.at(dd, ia); tbv = T.TBat(o); cv = T.Cat(o); }
+            }
+            // partners descending.  The caller's j is its own hit + 2 for a structure's first segment: the top four candidates are row 0 of the patch
             int found = -1;
-            // partners descending.  The caller's j is its own hit + 2 for a structure's first segment, so the top four candidates are probed alone first
-            // (one or two tiles); a full round of 64 is a row of the archive = 8 tiles
-            for (int kb = j, width = 4; kb >= i + TURN + 1 && found < 0; kb -= width, width = 64) {
-                EPI_CNT(16);
+            {
+                const int k = j - pb;
+                bool ok = false;
+                if (pa == 0 && pb < 4 && k >= i + TURN + 1) {
+                    const int type = ptype_at(X, i, k);
+                    if (type) ok = (fij == cv + ext_term(X, i, k, type) + X.f3[k + 1]);
+                }
+                const int fl = first_lane(__ballot(ok));
+                if (fl >= 0) { found = j - fl; c = fl; }
+            }
+            for (int kb = j - 4; kb >= i + TURN + 1 && found < 0; kb -= 64) {      // rare: a full round of 64 is a row of the archive = 8 tiles
                 const int k = kb - lane;
                 bool ok = false;
-                if (lane < width && k >= i + TURN + 1) {
+                if (k >= i + TURN + 1) {
                     const int type = ptype_at(X, i, k);
                     if (type) ok = (fij == T.C(k - i, i) + ext_term(X, i, k, type) + X.f3[k + 1]);
                 }
                 const int fl = first_lane(__ballot(ok));
-                if (fl >= 0) found = kb - fl;
+                if (fl >= 0) { found = kb - fl; c = 8; }       // outside the patch: the helix fetches its own
             }
             if (found < 0) return -21;
             const int k = found;
@@ -444,10 +461,11 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
             for (;;) {      // trim unpaired bases inside patches of fML: j first, then i (the reference's order), until neither matches
                 EPI_CNT(17);
                 const int ia = i + pa, jb = j - pb, dd = jb - ia;
-                int mv = INF, cv = INF;
-                if (dd >= TURN + 1) { mv = T.M(dd, ia); cv = T.C(dd, ia); }
+                int mv = INF;
+                tbv = 0; cv = INF;
+                if (dd >= TURN + 1) { const int o = T.at(dd, ia); mv = T.Mat(o); cv = T.Cat(o); tbv = T.TBat(o); }
                 fij = __builtin_amdgcn_readlane(mv, 0);
-                int r = 0, c = 0;
+                r = 0; c = 0;
                 bool edge = false;
                 for (;;) {
                     if (r == 7 || c == 7) { edge = true; break; }
@@ -471,15 +489,19 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
                 const int k0 = i + 1 + TURN, k1 = j - 2 - TURN;
 #pragma unroll
                 for (int q = 0; q < NSR; q++) {
-                    const int k = k0 + 64 * q + lane;
                     m1[q] = INF; m2[q] = INF;
-                    if (k <= k1) { m1[q] = T.M(k - i, i); m2[q] = T.M(j - k - 1, k + 1); }
+                    if (k0 + 64 * q <= k1) {                    // wave-uniform: most segments need one round
+                        const int k = k0 + 64 * q + lane;
+                        if (k <= k1) { m1[q] = T.M(k - i, i); m2[q] = T.M(j - k - 1, k + 1); }
+                    }
                 }
                 int found = -1;
 #pragma unroll
                 for (int q = 0; q < NSR; q++) {
-                    const int fl = first_lane(__ballot(fij == m1[q] + m2[q]));
-                    if (fl >= 0 && found < 0) found = k0 + 64 * q + fl;
+                    if (k0 + 64 * q <= k1 && found < 0) {
+                        const int fl = first_lane(__ballot(fij == m1[q] + m2[q]));
+                        if (fl >= 0) found = k0 + 64 * q + fl;
+                    }
                 }
                 if (found < 0) return -22;
                 if (lane == 0) {
@@ -491,14 +513,15 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
             }
             if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
         }
-        // (i,j) is a traced pair: follow the trace-back codes through patches until a hairpin or a multiloop
+        // (i,j) is a traced pair at position (r, c) of the current patch (c > 7: not in it): follow the trace-back codes until a hairpin or a multiloop
         for (;;) {
-            EPI_CNT(20);
-            const int ia = i + pa, jb = j - pb, dd = jb - ia;
-            int tbv = 0, cv = INF;
-            if (dd >= TURN + 1) { tbv = T.TB(dd, ia); cv = T.C(dd, ia); }
-            int r = 0, c = 0;
-            bool off_patch = false;
+            if (r > 7 || c > 7) {       // left the patch: fetch the one anchored at the current pair
+                EPI_CNT(20);
+                const int ia = i + pa, jb = j - pb, dd = jb - ia;
+                tbv = 0; cv = INF;
+                if (dd >= TURN + 1) { const int o = T.at(dd, ia); tbv = T.TBat(o); cv = T.Cat(o); }
+                r = 0; c = 0;
+            }
             for (;;) {
                 const int code = __builtin_amdgcn_readlane(tbv, r * 8 + c);
                 if (code <= 0) break;                               // hairpin or multiloop closes here
@@ -506,9 +529,9 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
                 i += 1 + n1; j -= 1 + n2;
                 if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
                 r += 1 + n1; c += 1 + n2;
-                if (r > 7 || c > 7) { off_patch = true; break; }
+                if (r > 7 || c > 7) break;
             }
-            if (off_patch) continue;
+            if (r > 7 || c > 7) continue;
             const int cij = __builtin_amdgcn_readlane(cv, r * 8 + c);
             const int type = ptype_at(X, i, j);
             if (cij == e_hairpin(X, i, j, type)) break;
@@ -518,15 +541,19 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
             const int k0 = i + 2 + TURN, k1 = j - 3 - TURN;
 #pragma unroll
             for (int q = 0; q < NSR; q++) {
-                const int k = k0 + 64 * q + lane;
                 m1[q] = INF; m2[q] = INF;
-                if (k <= k1) { m1[q] = T.M(k - i - 1, i + 1); m2[q] = T.M(j - k - 2, k + 1); }
+                if (k0 + 64 * q <= k1) {                        // wave-uniform
+                    const int k = k0 + 64 * q + lane;
+                    if (k <= k1) { m1[q] = T.M(k - i - 1, i + 1); m2[q] = T.M(j - k - 2, k + 1); }
+                }
             }
             int found = -1;
 #pragma unroll
             for (int q = 0; q < NSR; q++) {
-                const int fl = first_lane(__ballot(cij == m1[q] + m2[q] + mm));
-                if (fl >= 0 && found < 0) found = k0 + 64 * q + fl;
+                if (k0 + 64 * q <= k1 && found < 0) {
+                    const int fl = first_lane(__ballot(cij == m1[q] + m2[q] + mm));
+                    if (fl >= 0) found = k0 + 64 * q + fl;
+                }
             }
             if (found < 0) return -23;
             if (lane == 0) {

@@ -69,6 +69,10 @@ struct LTab {               // table accessors for the shared epilogue/backtrack
     __device__ __forceinline__ int at(int d, int i) const { return off[(i - 1) >> 3] + ((i - 1) & 7) + 8 * (d - 4); }
     __device__ __forceinline__ int TB(int d, int i) const { return tb[at(d, i)]; }
     __device__ __forceinline__ int C(int d, int i) const { int v = carch[at(d, i)]; return v == I16_INF ? INF : v; }
+    // the three tables share their offsets: a patch computes at() once
+    __device__ __forceinline__ int TBat(int o) const { return tb[o]; }
+    __device__ __forceinline__ int Cat(int o) const { int v = carch[o]; return v == I16_INF ? INF : v; }
+    __device__ __forceinline__ int Mat(int o) const { const int v = (unsigned short)fml[o]; return v == 65535 ? INF : v - FML_BIAS; }
     __device__ __forceinline__ int M(int d, int i) const {
         if (d < 4) return INF;
         const int v = (unsigned short)fml[at(d, i)];
@@ -1088,19 +1092,31 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             if (tid == 0) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0; }
         } else {
             // hand the tables to the epilogue kernel: c and the trace-back codes were archived on the fly, fML is copied out now into the same tiled
-            // layout (a wave per diagonal: conflict-free LDS reads, 16-byte runs in HBM that its neighbours in d complete)
-            constexpr int NK = (LCAP + 63) / 64;
-            int rb[NK];
+            // layout.  A wave takes whole row blocks; lane = diagonal, so the 8 rows of a row block on one diagonal are one 16-byte store and a
+            // wave stores contiguous kilobytes; all of a row block's LDS reads are issued before the first store.
+            if (Dm >= 4 && !(dbg_flags & 262144)) {
+                constexpr int NGD = (LDMAX + 1 - 4) / 64 + 1;
+                for (int rb = wave; 8 * rb + 1 + 4 <= n; rb += LNW) {
+                    const int dmax_rb = Dm < n - 1 - 8 * rb ? Dm : n - 1 - 8 * rb;      // the block's first row reaches furthest
+                    short* dst = fml_out + rbt[rb] - 32;
+                    unsigned v[NGD][8];
 #pragma unroll
-            for (int k = 0; k < NK; k++) rb[k] = (lane + 64 * k < 8 * ARCH_RB ? rbt[(lane + 64 * k) >> 3] : 0) + (lane & 7) - 32;
-            for (int d = 4 + wave; d <= Dm; d += LNW) {
-                const int o = tri_off(d, n) + lane + 1;
-                unsigned short v[NK];
+                    for (int g = 0; g < NGD; g++) {
+                        const int d = 4 + 64 * g + lane;
+                        const int o = tri_off(d <= dmax_rb ? d : 4, n) + 8 * rb + 1;
 #pragma unroll
-                for (int k = 0; k < NK; k++) v[k] = fml[o + 64 * k];          // past the diagonal's end: some other cell of the triangle, not stored
+                        for (int k = 0; k < 8; k++) v[g][k] = fml[o + k];      // past a diagonal's end: some other cell, never read back
+                    }
 #pragma unroll
-                for (int k = 0; k < NK; k++)
-                    if (lane + 64 * k < n - d) fml_out[rb[k] + 8 * d] = (short)v[k];
+                    for (int g = 0; g < NGD; g++) {
+                        const int d = 4 + 64 * g + lane;
+                        if (d <= dmax_rb) {
+                            uint4 w;
+                            w.x = v[g][0] | v[g][1] << 16; w.y = v[g][2] | v[g][3] << 16; w.z = v[g][4] | v[g][5] << 16; w.w = v[g][6] | v[g][7] << 16;
+                            *reinterpret_cast<uint4*>(dst + 8 * d) = w;
+                        }
+                    }
+                }
             }
             if (tid == 0) win_state[win] = 1;
         }
