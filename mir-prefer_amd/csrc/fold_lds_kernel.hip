@@ -475,6 +475,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 #ifdef MIRP_DIAG
     const int dbg_flags = dbg_flags_arg;
     long long* const dbg_cycles = dbg_cycles_arg;
+#elif defined(MIRP_LITE_CLOCKS)      // dev build: product code + per-wave busy / barrier-wait clocks only (two clock reads per wave and interval)
+    constexpr int dbg_flags = 1 << 20;
+    long long* const dbg_cycles = dbg_cycles_arg;
+    (void)dbg_flags_arg;
 #else
 #ifndef MIRP_ABLATE
 #define MIRP_ABLATE 0      // dev builds only (make ABLATE=<flags>): phases removed at compile time, to time product-like code without them
@@ -718,7 +722,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             // so the two halves even out the LDS load of the interval (the phases are independent: both only feed phase B of this diagonal).
             const bool swap_order = (wave & 1) && !(dbg_flags & 2048);
             if (swap_order) splits();
-            if (dbg_cycles && lane == 0) wt = clock64();
+            if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
             if (!(dbg_flags & (1 | 64)) && d >= 6 && d <= D) {
                 const unsigned short* clist = list + (d % 3) * LSEG;
@@ -859,13 +863,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     a1_small<0, 0>(a, i, j, type, S[i + 1], S[j - 1], res);
                     if (act && res != KEY_NONE) atomicMin(&ckey[i], res);
                 }
-                if (dbg_cycles && lane == 0 && wave == 9) {   // diagnostics: interior-loop time of one wave by number of blocks
+                if (dbg_cycles && lane == 0 && wave == 9 && !(dbg_flags & (1 << 20))) {   // diagnostics: interior-loop time of one wave by number of blocks
                     const int b = nblk < 3 ? nblk : 3;
                     atomicAdd((unsigned long long*)&dbg_cycles[68 + b], (unsigned long long)(clock64() - wt));
                     atomicAdd((unsigned long long*)&dbg_cycles[72 + b], 1ull);
                 }
             }
-            if (dbg_cycles && lane == 0) { const long long t = clock64(); wA1 += t - wt; wt = t; }
+            if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) { const long long t = clock64(); wA1 += t - wt; wt = t; }
             if (!swap_order) splits();
         };
         auto phaseB = [&](const int d) {
@@ -1078,12 +1082,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         for (int d = 4; d <= Dm; d++) {
             if (dbg_cycles && lane == 0) wt = clock64();
             if constexpr (MODEL == 0) { if (dbg_flags & 4096) phaseB(d); else phaseB0(d); } else phaseB(d);
-            if (dbg_cycles && lane == 0) { const long long t = clock64(); wB += t - wt; wt = t; }
+            if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) { const long long t = clock64(); wB += t - wt; wt = t; }   // bit 20: light mode, busy / barrier only
             if (d + 1 <= Dm) phaseA(d + 1);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA2 += t - wt; wt = t; }
             __syncthreads();
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wW += t - wt; wt = t; }
-            if (dbg_cycles && tid == 0) { long long t = clock64(); tB += t - t0; t0 = t; }
+            if (dbg_cycles && tid == 0 && !(dbg_flags & (1 << 20))) { long long t = clock64(); tB += t - t0; t0 = t; }
         }
         const int overflow = misc[1];
         __syncthreads();

@@ -258,10 +258,12 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         unsigned int* ctl = (unsigned int*)c->fctl.p;
         // diagnostics exist only in a -DMIRP_DIAG build (`make DIAG=1`, profiles/tools/): MIRP_FOLD_DEBUG=<flags> ablates phases (results then
         // wrong), MIRP_FOLD_CLOCKS=1 prints phase clocks, MIRP_FOLD_DUMP=<path> dumps slabs.  The shipped library reads no environment.
-#ifdef MIRP_DIAG
+#if defined(MIRP_DIAG) || defined(MIRP_LITE_CLOCKS)
         const char* dbg_env = std::getenv("MIRP_FOLD_DEBUG");
-        const int dbg_flags = dbg_env ? std::atoi(dbg_env) : 0;
-        long long* dbg_cycles = std::getenv("MIRP_FOLD_CLOCKS") ? (long long*)(ctl + 8) : nullptr;
+        int dbg_flags = dbg_env ? std::atoi(dbg_env) : 0;
+        const char* clk_env = std::getenv("MIRP_FOLD_CLOCKS");
+        long long* dbg_cycles = clk_env ? (long long*)(ctl + 8) : nullptr;
+        if (clk_env && std::atoi(clk_env) == 2) dbg_flags |= 1 << 20;      // light mode: per wave only busy (reported as splits) and barrier wait
 #else
         const int dbg_flags = 0;
         long long* dbg_cycles = nullptr;
@@ -294,7 +296,7 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             (void)hipEventElapsedTime(&b, c->fold_ev[3 * k + 1], c->fold_ev[3 * k + 2]);
             c->fold_kernel_ms[0] += a; c->fold_kernel_ms[1] += b;
         }
-#ifdef MIRP_DIAG
+#if defined(MIRP_DIAG) || defined(MIRP_LITE_CLOCKS)
         if (const char* dump = std::getenv("MIRP_FOLD_DUMP")) {   // diagnostics: c / fML slabs of the first window of the last sub-batch
             std::vector<short> h(3 * slab);
             HIPCHK(c, hipMemcpy(h.data(), c->carch.p, 6 * slab, hipMemcpyDeviceToHost));

@@ -9,7 +9,7 @@ ctx = capi.Context(0)
 ctx.load_genome(ds.contigs); ctx.load_alignments(ds.sorted_alns())
 ctx.candidate(10, 100, 300, np.zeros(1, dtype=np.int32))
 ctx.fold(300)
-os.environ["MIRP_FOLD_CLOCKS"] = "1"
+os.environ["MIRP_FOLD_CLOCKS"] = os.environ.get("CLOCKS_MODE", "1")   # 2: light mode (busy + barrier wait per wave only)
 for f in (sys.argv[1:] or ["0"]):
     os.environ["MIRP_FOLD_DEBUG"] = f
     print("==== MIRP_FOLD_DEBUG=%s" % f, flush=True)
