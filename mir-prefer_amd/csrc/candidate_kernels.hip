@@ -58,11 +58,13 @@ __global__ void __launch_bounds__(256) cov_unscatter_kernel(const MirpAln* __res
 // a2 (first half): single-pass scan of both difference arrays -> depth, threshold, run starts.
 // Decoupled look-back over 64-bit {flag, d+, d-} and {flag, n_starts, n_above} tile descriptors.
 // ------------------------------------------------------------------------------------------
+// 512 threads x 16 positions: the same 8192-position tile as 256 x 32, but 96 instead of 187 VGPRs, so twice the waves hide the two look-backs
+// (measured on config[1] and on a cfg[4] shard: 0.50 / 0.26 of 8 TB/s against 0.46 / 0.256)
 #ifndef SCAN_NT
-#define SCAN_NT 256
+#define SCAN_NT 512
 #endif
 #ifndef SCAN_IPT
-#define SCAN_IPT 32
+#define SCAN_IPT 16
 #endif
 #define SCAN_TILE (SCAN_NT * SCAN_IPT)
 

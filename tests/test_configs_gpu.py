@@ -19,9 +19,13 @@ MSU7 = [43300000, 35900000, 36400000, 35500000, 30000000, 31200000, 29700000, 28
 
 
 def _mem_used_gb():
-    import torch
-    free, total = torch.cuda.mem_get_info(0)
-    return (total - free) / 2.0 ** 30
+    """Device memory in use, straight from the HIP runtime the library itself runs on (hipMemGetInfo)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+    assert rc == 0, "hipMemGetInfo failed (%d)" % rc
+    return (total.value - free.value) / 2.0 ** 30
 
 
 def _brute_depth(alns, key, tid, pos, cut):
