@@ -20,6 +20,20 @@ def test_fold_small_windows(gpu_ctx, oracle):
     _compare(gpu_ctx, oracle, seqgen.windows(11, 200, 5, 120), 300)
 
 
+def test_fold_every_window_length(gpu_ctx, oracle):
+    """One window of every length 5..350: every row-block / tile-edge case of the tiled archive the fill kernel hands to the epilogue (8 x 8 tiles over
+    (row, diagonal): partial last row block, partial last tile of a row block, blocks of 32 rows in the exterior sweep that end past the window)."""
+    import random
+    r = random.Random(2024)
+    seqs = []
+    for n in range(5, 351):
+        w = seqgen.window(r, n, n)
+        seqs.append(w[:n] if len(w) >= n else w + "A" * (n - len(w)))
+    assert sorted(set(len(s) for s in seqs)) == list(range(5, 351))
+    _compare(gpu_ctx, oracle, seqs, 300)
+    _compare(gpu_ctx, oracle, seqs[60:], 64)
+
+
 def test_fold_span_shorter_than_window(gpu_ctx, oracle):
     _compare(gpu_ctx, oracle, seqgen.windows(12, 100, 60, 200), 40)
 
