@@ -10,6 +10,14 @@
 namespace mirp {
 namespace v185 {
 
+#if defined(MIRP_EPI_CLOCKS) && defined(EPI_T)      // phase clocks of the LDS-path epilogue (dev build; fold_epilogue.h defines the macros)
+#define V185_T0() EPI_T0()
+#define V185_T(k) EPI_T(k)
+#else
+#define V185_T0() do {} while (0)
+#define V185_T(k) do {} while (0)
+#endif
+
 #define V_TURN 3
 #define V_MAXLOOP 30
 #define V_INF 1000000
@@ -35,7 +43,12 @@ struct Ctx {
     const short* tetra;         // LDS: tetraloop bonus of the hairpin closed at i (0 = none)
     const int* f3;              // LDS
     int n, M;
+    const short* dg = nullptr;  // optional LDS copy: dangle5[t * 5 + base] at [0, 40), dangle3 at [40, 80) (the global tables cost a round trip per read)
 };
+template <class PT>
+__device__ __forceinline__ int D5(const Ctx<PT>& X, int t, int b) { return X.dg ? (int)X.dg[t * 5 + b] : X.P->dangle5[t][b]; }
+template <class PT>
+__device__ __forceinline__ int D3(const Ctx<PT>& X, int t, int b) { return X.dg ? (int)X.dg[40 + t * 5 + b] : X.P->dangle3[t][b]; }
 
 template <class PT>
 __device__ __forceinline__ int ptype(const Ctx<PT>& X, int i, int j) {
@@ -112,15 +125,15 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
                 if (k <= j) {
                     int t = ptype(X, i + 1, k);
                     if (t) {
-                        const int cc = T.C(i + 1, k) + P->dangle5[t][X.S[i]] + AU(X, t);
+                        const int cc = T.C(i + 1, k) + D5(X, t, X.S[i]) + AU(X, t);
                         if (fij == cc + X.f3[k + 1]) traced = i + 1;
-                        if (k < n && fij == cc + X.f3[k + 2] + P->dangle3[t][X.S[k + 1]]) { traced = i + 1; jj = k + 2; }
+                        if (k < n && fij == cc + X.f3[k + 2] + D3(X, t, X.S[k + 1])) { traced = i + 1; jj = k + 2; }
                     }
                     t = ptype(X, i, k);
                     if (t) {
                         const int cc = T.C(i, k) + AU(X, t);
                         if (fij == cc + X.f3[k + 1]) traced = i;
-                        if (k < n && fij == cc + X.f3[k + 2] + P->dangle3[t][X.S[k + 1]]) { traced = i; jj = k + 2; }
+                        if (k < n && fij == cc + X.f3[k + 2] + D3(X, t, X.S[k + 1])) { traced = i; jj = k + 2; }
                     }
                 }
                 const int fl = first_lane(__ballot(traced != 0));
@@ -152,11 +165,11 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
             int t = ptype(X, i, j);
             const int cij = T.C(i, j) + MLi(X, t);
             t = ptype(X, i + 1, j);
-            const int ci1j = T.C(i + 1, j) + P->dangle5[t][X.S[i]] + MLi(X, t);
+            const int ci1j = T.C(i + 1, j) + D5(X, t, X.S[i]) + MLi(X, t);
             t = ptype(X, i, j - 1);
-            const int cij1 = T.C(i, j - 1) + P->dangle3[t][X.S[j]] + MLi(X, t);
+            const int cij1 = T.C(i, j - 1) + D3(X, t, X.S[j]) + MLi(X, t);
             t = ptype(X, i + 1, j - 1);
-            const int ci1j1 = T.C(i + 1, j - 1) + P->dangle5[t][X.S[i]] + P->dangle3[t][X.S[j]] + MLi(X, t);
+            const int ci1j1 = T.C(i + 1, j - 1) + D5(X, t, X.S[i]) + D3(X, t, X.S[j]) + MLi(X, t);
             if (fij == cij || fij == ci1j || fij == cij1 || fij == ci1j1) {
                 if (fij == ci1j) i++;
                 else if (fij == cij1) j--;
@@ -231,7 +244,7 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
             }
             const int tt = rtype_of(type);
             const int mm = P->ML_closing + MLi(X, tt);
-            const int e5 = P->dangle5[tt][X.S[j - 1]], e3 = P->dangle3[tt][X.S[i + 1]];
+            const int e5 = D5(X, tt, X.S[j - 1]), e3 = D3(X, tt, X.S[i + 1]);
             int fk = -1, fv = 0;
             for (int kb = i + 2 + V_TURN; kb <= j - 3 - V_TURN && fk < 0; kb += 64) {
                 const int k = kb + lane;
@@ -278,6 +291,7 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
     const int n = X.n, M = X.M;
     const PT* __restrict__ P = X.P;
     const unsigned char* S = X.S;
+    V185_T0();
         // ---- exterior sweep: f3[i] = min(f3[i+1], min_j { c(i,j), c(i+1,j) + dangle5 } + AU, continued by f3[j+1] or dangle3 + f3[j+2]) is sequential in i only
         // through f3, so rows go in blocks of RB.  Step 1 (all waves): a half-wave holds the rows of the block (lane = row) and walks the partners
         // diagonal by diagonal -- its 32 cells of one archived diagonal are one contiguous read.  Partners at or above the block top have
@@ -295,30 +309,44 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
                 {
                     const int r = lane & (RB - 1), i = i_hi - r;
                     int best = V_INF;
-                    if (i >= 1) {
-                        const int jmax = (i + M < n) ? i + M : n;
-                        for (int d = V_TURN + 1 + 2 * wave + (lane >> 5); i + d <= jmax; d += 2 * NW) {
-                            const int j = i + d;
-                            int a = V_INF, b = V_INF;
-                            int t = ptype(X, i, j);
-                            if (t) {
-                                const int e = T.C(i, j) + AU(X, t);
-                                a = e;
-                                if (j < n) b = e + P->dangle3[t][S[j + 1]];
+                    {
+                        const int jmax = i >= 1 ? ((i + M < n) ? i + M : n) : 0;
+                        constexpr int UNR = 4;      // archive reads in flight per lane (two rows each): the sweep is a chain of memory round trips otherwise
+                        for (int d0 = V_TURN + 1 + 2 * wave + (lane >> 5); d0 <= M; d0 += 2 * NW * UNR) {
+                            int ca[UNR], cb[UNR];
+#pragma unroll
+                            for (int u = 0; u < UNR; u++) {
+                                const int j = i + d0 + u * 2 * NW;
+                                const bool in = i >= 1 && j <= jmax;
+                                ca[u] = in ? T.C(i, j) : V_INF;
+                                cb[u] = in ? T.C(i + 1, j) : V_INF;
                             }
-                            t = ptype(X, i + 1, j);
-                            if (t) {
-                                const int e = T.C(i + 1, j) + P->dangle5[t][S[i]] + AU(X, t);
-                                a = e < a ? e : a;
-                                if (j < n) { const int v = e + P->dangle3[t][S[j + 1]]; b = v < b ? v : b; }
-                            }
-                            if (a < V_INF) {
-                                if (j >= i_hi) {        // f3[j+1], f3[j+2] final (f3[n+1] = f3[n+2] = 0)
-                                    int v = f3[j + 1] + a; best = v < best ? v : best;
-                                    if (j < n) { v = f3[j + 2] + b; best = v < best ? v : best; }
-                                } else {
-                                    innerA[r * RB + d - V_TURN - 1] = a;
-                                    innerB[r * RB + d - V_TURN - 1] = b;
+#pragma unroll
+                            for (int u = 0; u < UNR; u++) {
+                                const int d = d0 + u * 2 * NW, j = i + d;
+                                if (!(i >= 1 && j <= jmax)) continue;
+                                int a = V_INF, b = V_INF;
+                                int t = ptype(X, i, j);
+                                if (t) {
+                                    const int e = ca[u] + AU(X, t);
+                                    a = e;
+                                    if (j < n) b = e + D3(X, t, S[j + 1]);
+                                }
+                                t = ptype(X, i + 1, j);
+                                if (t) {
+                                    const int e = cb[u] + D5(X, t, S[i]) + AU(X, t);
+                                    a = e < a ? e : a;
+                                    if (j < n) { const int v = e + D3(X, t, S[j + 1]); b = v < b ? v : b; }
+                                }
+                                if (a < V_INF) {
+                                    if (j >= i_hi) {        // f3[j+1], f3[j+2] final (f3[n+1] = f3[n+2] = 0)
+                                        int v = f3[j + 1] + a; best = v < best ? v : best;
+                                        if (j < n) { v = f3[j + 2] + b; best = v < best ? v : best; }
+                                    } else {                // continued by rows of this block: parked transposed, by the row whose f3 they wait for
+                                        innerA[(i_hi - j - 1) * RB + r] = a;
+                                        if (j + 2 > i_hi) { const int v = f3[j + 2] + b; best = v < best ? v : best; }
+                                        else innerB[(i_hi - j - 2) * RB + r] = b;
+                                    }
                                 }
                             }
                         }
@@ -327,31 +355,27 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
                 }
                 __syncthreads();
                 if (wave == 0) {
-                    const int i_lo = (i_hi - RB + 1 > 1) ? i_hi - RB + 1 : 1;
-                    for (int r = i_hi; r >= i_lo; r--) {
-                        const int w = i_hi - r;
-                        int best = f3[r + 1];
-                        const int p = part[w];
-                        best = p < best ? p : best;
-                        if (lane < RB) {
-                            const int a = innerA[w * RB + lane];
-                            if (a < V_INF) {
-                                const int j = r + V_TURN + 1 + lane;
-                                int v = a + f3[j + 1]; best = v < best ? v : best;
-                                v = innerB[w * RB + lane] + f3[j + 2]; best = v < best ? v : best;
-                            }
-                        }
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(best, o); best = t < best ? t : best; }
-                        if (lane == 0) f3[r] = best;
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_wave_barrier();
+                    // the sequential chain through the block in registers (lane = row r, i = i_hi - r): when f3 of row x becomes final, every row that
+                    // parked a term waiting for it takes it (one v_readlane + two adds + two mins per row; the LDS reads do not depend on the chain)
+                    const int r = lane & (RB - 1);
+                    int best = part[r];
+                    int fx = f3[i_hi + 1], fo = 0;
+#pragma unroll 4
+                    for (int xr = 0; xr < RB; xr++) {
+                        const int bx = __builtin_amdgcn_readlane(best, xr);
+                        fx = bx < fx ? bx : fx;                            // f3 of row i_hi - xr
+                        fo = lane == xr ? fx : fo;
+                        const int ea = innerA[xr * RB + r], eb = innerB[xr * RB + r];
+                        int v = ea + fx; v = ea < V_INF ? v : V_INF; best = v < best ? v : best;
+                        v = eb + fx; v = eb < V_INF ? v : V_INF; best = v < best ? v : best;
                     }
+                    if (lane < RB && i_hi - lane >= 1) f3[i_hi - lane] = fo;
                 }
                 __syncthreads();
             }
         }
 
+        V185_T(0);
         // ---- structure starts, descending: l >= 2 with f3[l] != f3[l+1] && f3[l-1] == f3[l]; l == 1 with f3[1] != f3[2], or when there is
         // no other start at all (probed on the binary: a structure-free window still prints the start-1 backtrack ".")
         if (wave == 0) {
@@ -373,11 +397,13 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
         }
         __syncthreads();
         const int nst = red[8];
+        V185_T(1);
         char* mybuf = btbuf + wave * (nc + 8);
         int* mystk = btstk + wave * 3 * V_BT_STACK;
         for (int k = wave; k < nst; k += NT / 64) {
             const int lind = starts[k];
             const int L = backtrack(X, T, lind, lind == 1 ? M : M + 1, mybuf, nc + 8, mystk);
+            V185_T(3);
             if (L < 0) { if (lane == 0) { red[10] = L; lens[k] = 0; } continue; }
             if (L + 1 > ss_stride) { if (lane == 0) { red[10] = -30; lens[k] = 0; } continue; }
             char* dst = out_ss + ((size_t)win * max_lines + k) * ss_stride;
@@ -389,8 +415,11 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
                 ln.start = lind; ln.len = L; ln.energy = f3[lind] - f3[lind + L]; ln.printed = 1;
                 out_lines[(size_t)win * max_lines + k] = ln;
             }
+            V185_T(4);
         }
+        V185_T(5);
         __syncthreads();
+        V185_T(6);
         // ---- RNALfold prints `prev` unless it is contained in `new` (the next start); the start-1 structure never takes part as `new`
         for (int k = wave; k + 1 < nst; k += NT / 64) {
             const int prev_i = starts[k], new_i = starts[k + 1];

@@ -1253,7 +1253,11 @@ __global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
     unsigned char* S = (unsigned char*)(tetra + nc);                 // nc
     unsigned char* seq = S + nc;                                     // nc
     char* btbuf = (char*)(seq + nc);                                 // (ENT/64) * (nc + 8)
+    short* dg = (short*)(smem + ((((size_t)(btbuf - (char*)smem) + (ENT / 64) * (nc + 8)) + 15) & ~(size_t)15));   // 80: dangle5 | dangle3
     const int tid = threadIdx.x;
+    if (tid < 40) { dg[tid] = (short)P->dangle5[tid / 5][tid % 5]; dg[40 + tid] = (short)P->dangle3[tid / 5][tid % 5]; }
+    __syncthreads();
+    EPI_INIT();
     for (;;) {
         if (tid == 0) misc[0] = (int)atomicAdd(work_counter, 1u);
         __syncthreads();
@@ -1289,7 +1293,7 @@ __global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
             }
             __syncthreads();
             v185::Ctx<FoldParams> X;
-            X.P = P; X.S = S; X.tetra = tetra; X.f3 = f3; X.n = n; X.M = span;
+            X.P = P; X.S = S; X.tetra = tetra; X.f3 = f3; X.n = n; X.M = span; X.dg = dg;
             LTab185 T;
             T.carch = slabs + (size_t)win * 3 * slab_shorts; T.fml = T.carch + slab_shorts;
             T.tb = reinterpret_cast<const unsigned short*>(T.carch + 2 * slab_shorts);
@@ -1299,13 +1303,14 @@ __global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
         }
         __syncthreads();
     }
+    EPI_FLUSH();
 }
 
 size_t fold185_lds_epilogue_bytes(int max_lines) {
     const size_t nc = LCAP + 8;
     size_t b = sizeof(int) * (nc + 8 + 2 * (size_t)max_lines + (ENT / 64) * 3 * V_BT_STACK + ENT / 64 + 8 + 4 + LDMAX + 2);
     b += sizeof(short) * nc + 2 * nc + (ENT / 64) * (nc + 8);
-    return (b + 15) & ~(size_t)15;
+    return ((b + 15) & ~(size_t)15) + 16 + 80 * sizeof(short);
 }
 
 size_t fold_lds_epilogue_bytes(int max_lines) {
