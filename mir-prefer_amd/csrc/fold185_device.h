@@ -24,6 +24,7 @@ namespace v185 {
 #define V_NT 256
 #define V_G 8
 #define V_BT_STACK 192
+#define V_BT_LINE 16     // cells of a helix line fetched per round trip (every further cell is one more tile of the archive)
 
 struct GTab185 {   // int32 tables in a global workspace (fold185_kernel)
     int* __restrict__ c;
@@ -198,7 +199,7 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
             // with trace-back codes the chain is followed a whole helix per memory round trip (see backtrack_wave in fold_epilogue.h)
             {
                 const int il = i + lane, jl = j - lane;
-                int cl = (jl - il >= V_TURN + 1) ? T.TB(il, jl) : 0;
+                int cl = (lane < V_BT_LINE && jl - il >= V_TURN + 1) ? T.TB(il, jl) : 0;
                 if (__builtin_amdgcn_readfirstlane(cl) > 0) {
                     int pos = 0;
                     for (;;) {
@@ -207,7 +208,7 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
                         const int n1 = (c - 1) >> 5, n2 = (c - 1) & 31;
                         i += 1 + n1; j -= 1 + n2;
                         if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
-                        if (n1 != n2 || pos + 1 + n1 > 63) { pos = -1; break; }
+                        if (n1 != n2 || pos + 1 + n1 >= V_BT_LINE) { pos = -1; break; }
                         pos += 1 + n1;
                     }
                     if (pos < 0) continue;
