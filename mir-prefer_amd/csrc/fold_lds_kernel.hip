@@ -161,7 +161,7 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.seq = o; o += lds_al(LCAP + 8);
     L.pax = o; o += lds_al((LCAP + 8) * 2);
     L.qb2 = o; o += lds_al(LCAP + 8);
-    L.list = o; o += lds_al(3 * LSEG * 2);
+    L.list = o; o += lds_al(3 * LSEG * (MODEL ? 2 : 4));      // 32-bit entries in the default model (see `list` in the kernel); the vienna-1.8.5 layout has no room for them
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
     L.misc = o; o += lds_al((48 + ARCH_RB) * 4);
     L.total = o;
@@ -501,7 +501,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     // special-hairpin energies by start position (tri-, tetra-, hexaloops): only read on diagonals 4, 5 and 7, so they borrow the ring rows
     // of diagonals 29-31, which are first written on diagonal 29
     short* spec = (short*)(cring + 29 * CSTR);
-    unsigned short* list = (unsigned short*)(smem + LY.list);       // [3][LSEG]: i | type << 9, paired cells of diagonal d in buffer d % 3 (compact, unordered)
+    // [3][LSEG]: i | type << 9 | oi << 16, paired cells of diagonal d in buffer d % 3 (compact, unordered).  oi = type * 25 + S[i+1] * 5 + S[j-1]
+    // indexes the outer pair's mismatch tables: it rides in the entry so that phase A1 goes from the entry straight to the tables (reading the two
+    // bases first was one more LDS round trip in front of every block of every wave)
+    using list_t = std::conditional_t<MODEL == 0, unsigned, unsigned short>;     // vienna-1.8.5: 16-bit entries, phase A1 reads the two bases itself
+    list_t* list = (list_t*)(smem + LY.list);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
     int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16..21: list lengths
     int* lcnt = misc + 16;                                          // [6]: entries in the list of diagonal d at d % 6
@@ -512,13 +516,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     // Appends this thread's cell (i, pair type t; t = 0: none) to the paired-cell list of diagonal dd: ballot compaction inside the wave, one
     // LDS atomic per wave for its range.  The order of the ranges depends on which wave arrives first; nothing depends on the order of a
     // list, only on it staying fixed once built.
-    auto list_append = [&](int dd, int i, int t) {
+    auto list_append = [&](int dd, int i, int t, int oi) {
         const unsigned long long bal = __ballot(t != 0);
         if (bal) {      // wave-uniform
             int base = 0;
             if (lane == 0) base = atomicAdd(&lcnt[dd % 6], (int)__popcll(bal));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (t) list[(dd % 3) * LSEG + base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(i | (t << 9));
+            if (t) list[(dd % 3) * LSEG + base + __popcll(bal & ((1ull << lane) - 1ull))] = (list_t)(i | (t << 9) | (oi << 16));
         }
     };
 
@@ -607,9 +611,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         }
         // paired-cell lists of the first three diagonals (list of diagonal d lives in buffer d % 3, its length in lcnt[d % 6])
         for (int dd = 4; dd <= 6 && dd <= D; dd++) {
-            int t = 0;
-            if (tid < n - dd) t = pair_type(S[tid + 1], S[tid + 1 + dd]);
-            list_append(dd, tid + 1, t);
+            int t = 0, oi = 0;
+            if (tid < n - dd) { t = pair_type(S[tid + 1], S[tid + 1 + dd]); oi = t * 25 + S[tid + 2] * 5 + S[tid + dd]; }
+            list_append(dd, tid + 1, t, oi);
         }
         __syncthreads();
 
@@ -725,7 +729,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
             if (!(dbg_flags & (1 | 64)) && d >= 6 && d <= D) {
-                const unsigned short* clist = list + (d % 3) * LSEG;
+                const list_t* clist = list + (d % 3) * LSEG;
                 // Lane fill: the blocks of 64 paired cells of diagonal d are topped up with the first cells of diagonal d+1.  All candidates of
                 // a cell of d+1 except the stacked pair have their inner pair on diagonals <= d-2, which are final in this interval; the stacked
                 // pair follows one interval later (`done` cells below).  Such a lane differs only in j = i + d + 1 and in its ring rows, which
@@ -765,8 +769,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int k = blk * 64 + lane;
                     const bool own = k < rem, ahead = !own && aent != 0;       // k >= rem only happens in the last block
                     const bool act = own || ahead;
-                    const unsigned ent = own ? (unsigned)clist[done + k] : ahead ? aent : (1u | (1u << 9));   // idle lanes: harmless dummy cell
-                    const int i = ent & 511, type = ent >> 9, j = i + d + (ahead ? 1 : 0);
+                    const unsigned ent = own ? clist[done + k] : ahead ? aent : (1u | (1u << 9));   // idle lanes: harmless dummy cell
+                    const int i = ent & 511, type = (ent >> 9) & 7, j = i + d + (ahead ? 1 : 0);
                     a.cring = cring + (ahead ? CSTR : 0);
                     unsigned* ck = ahead ? ckey2 : ckey;
                     unsigned res = KEY_NONE;
@@ -774,8 +778,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     // their two round trips (bases, then tables) overlap the job's own reads instead of following them
                     int au1 = 0, mmo = 0, mm1 = 0;
                     if (role < 14) {
-                        lds_vu8 Sv = (lds_vu8)S;
-                        const int oi = type * 25 + (int)Sv[i + 1] * 5 + (int)Sv[j - 1];
+                        int oi = ent >> 16;
+                        if constexpr (MODEL != 0) { lds_vu8 Sv = (lds_vu8)S; oi = type * 25 + (int)Sv[i + 1] * 5 + (int)Sv[j - 1]; }
                         au1 = type > 2 ? (int)T.TerminalAU : 0;
                         mmo = T.mismatchI[oi]; mm1 = T.mismatch1nI[oi];
                     }
@@ -854,8 +858,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 }
                 if (role == 14 && done > 0 && !(dbg_flags & 32)) {   // stacked pairs of the cells that went ahead in the previous interval (done <= 63)
                     const bool act = lane < done;
-                    const unsigned ent = act ? (unsigned)clist[lane] : (1u | (1u << 9));
-                    const int i = ent & 511, type = ent >> 9, j = i + d;
+                    const unsigned ent = act ? clist[lane] : (1u | (1u << 9));
+                    const int i = ent & 511, type = (ent >> 9) & 7, j = i + d;
                     int r0 = d - 2, um = MAXLOOP;
                     asm volatile("" : "+s"(r0), "+s"(um));
                     a.r0 = r0; a.um = um; a.cring = cring;
@@ -881,10 +885,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int x = tid;
             // paired-cell list of diagonal d+3 (phase A1 of this interval reads those of d+1 and d+2): the range is claimed first, the entry is
             // written at the end, so that the atomic's latency is covered by the cell work in between
-            int lt = 0, lbase = 0;
+            int lt = 0, lbase = 0, loi = 0;
             unsigned long long lbal = 0;
             if (d + 3 <= D && wave < 6) {
-                if (x + 1 + d + 3 <= n) lt = pair_type(S[x + 1], S[x + 1 + d + 3]);
+                if (x + 1 + d + 3 <= n) { lt = pair_type(S[x + 1], S[x + 1 + d + 3]); loi = lt * 25 + S[x + 2] * 5 + S[x + d + 3]; }
                 lbal = __ballot(lt != 0);
                 if (lbal && lane == 0) lbase = atomicAdd(&lcnt[(d + 3) % 6], (int)__popcll(lbal));
             }
@@ -982,7 +986,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 ckey[i] = KEY_NONE; mdec[i] = INF;
             }
             const int lb = __builtin_amdgcn_readfirstlane(lbase);      // lane 0 holds the claimed range
-            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((x + 1) | (lt << 9) | (loi << 16));
         };
         // Phase B of the default model, written as two rounds of loads and then arithmetic: every LDS read whose address depends on (i, j, d)
         // only is issued first (round 1), the parameter-table reads that need the pair type and the neighbouring bases follow together
@@ -995,7 +999,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             const int od = tri_off(d, n), od1 = tri_off(d - 1, n);
             const int x = tid;
-            int lt = 0, lbase = 0;
+            int lt = 0, lbase = 0, loi = 0;
             unsigned long long lbal = 0;
             const bool do_list = d + 3 <= D && !(dbg_flags & 32768);
             if (tid == 0) lcnt[(d + 4) % 6] = 0;
@@ -1005,6 +1009,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 lds_vu8 Sv = (lds_vu8)S;
                 const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
                 const int s_j3 = Sv[j + 3 <= n ? j + 3 : n];          // far end of cell (i, j+3): the paired-cell list of diagonal d+3
+                const int s_j2 = Sv[j + 2 <= n ? j + 2 : n];          // its 5' neighbour, for the entry's outer-pair table index
                 const int md = mdec[i];
                 const unsigned kk = ckey[i];
                 const int dmlv = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1];
@@ -1015,7 +1020,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 // the list range is claimed here, between the two rounds: the atomic's return is first looked at after the cell's stores, so its
                 // round trip is not in front of anything (issued ahead of round 1 it put two LDS round trips in front of the whole chain)
                 if (do_list) {
-                    if (j + 3 <= n) lt = pair_type(s_i, s_j3);
+                    if (j + 3 <= n) { lt = pair_type(s_i, s_j3); loi = lt * 25 + s_ip1 * 5 + s_j2; }
                     lbal = __ballot(lt != 0);
                     // hand-issued: the compiler's atomic optimizer wraps atomicAdd in a wave reduction whose readfirstlane waits right here
                     if (lbal && lane == 0) {
@@ -1074,7 +1079,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lbase) : : "memory");   // the atomic's return is first needed here
             const int lb = __builtin_amdgcn_readfirstlane(lbase);
-            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (unsigned short)((x + 1) | (lt << 9));
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((x + 1) | (lt << 9) | (loi << 16));
         };
         if (Dm >= 4) phaseA(4);
         __syncthreads();
