@@ -27,6 +27,7 @@ namespace v185 {
 #define V_BT_LINE 16     // cells of a helix line fetched per round trip (every further cell is one more tile of the archive)
 
 struct GTab185 {   // int32 tables in a global workspace (fold185_kernel)
+    static constexpr bool kTiled = false;
     int* __restrict__ c;
     int* __restrict__ m;
     int* __restrict__ dm;
@@ -282,6 +283,215 @@ __device__ int backtrack(const Ctx<PT>& X, const TabT& T, int start, int maxdist
     return L;
 }
 
+// The same backtrack over the TILED archive of the LDS-resident fill kernel (TabT::kTiled, trace-back codes present): identical search orders
+// and results, fewer trips to memory -- see backtrack_wave_tiled in fold_epilogue.h.  Every fetch is an 8 x 8 patch anchored at the current pair or
+// segment (lane (a, b) holds cell (i + a, j - b): trace-back code, c and, for a multiloop segment, fML).  The run of unpaired bases of a
+// multiloop segment (j first, then i, one pop each in the reference) is walked inside the fML patch, the four dangle variants of the segment's
+// closing pair are the patch cells (r, c), (r+1, c), (r, c+1), (r+1, c+1), the helix follows the codes inside the patch, and all split points of a
+// multiloop are fetched at once.
+template <class PT, class TabT>
+__device__ int backtrack_tiled(const Ctx<PT>& X, const TabT& T, int start, int maxdist, char* buf, int bufcap, int* stk) {
+    const int lane = threadIdx.x & 63;
+    const int n = X.n;
+    const PT* __restrict__ P = X.P;
+    const int pa = lane >> 3, pb = lane & 7;
+    constexpr int NSR = 5;      // rounds of 64 split points that cover any segment (pair distances <= 300)
+    const int len0 = (n - start < maxdist ? n - start : maxdist) + 1;
+    if (len0 + 3 > bufcap) return -9;
+    for (int x = lane; x < len0 + 3; x += 64) buf[x] = x < len0 ? '-' : (char)0;
+    int sp = 0;
+    if (lane == 0) { stk[0] = start; stk[1] = (n < start + maxdist + 1 ? n : start + maxdist + 1); stk[2] = 0; }
+    sp = 1;
+    __builtin_amdgcn_wave_barrier();
+    while (sp > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        sp--;
+        int i = __builtin_amdgcn_readfirstlane(stk[3 * sp]), j = __builtin_amdgcn_readfirstlane(stk[3 * sp + 1]), ml = __builtin_amdgcn_readfirstlane(stk[3 * sp + 2]);
+        if (j < i + V_TURN + 1) continue;
+        if (sp + 3 >= V_BT_STACK) return -20;
+        int tbv = 0, cv = V_INF;        // the current patch
+        int r = 8, c = 8;               // the walk's position inside it (8: none fetched)
+        if (ml == 0) {
+            for (;;) {                  // unpaired 5' bases, 64 positions per step (the reference pops (i + 1, j) while f3[i] == f3[i + 1])
+                const int x = i + lane;
+                const bool diff = x <= n ? (X.f3[x] != X.f3[x + 1]) : true;
+                const int fl = first_lane(__ballot(diff));
+                if (fl < 0) { i += 64; continue; }
+                i += fl;
+                break;
+            }
+            if (j < i + V_TURN + 1) continue;
+            const int fij = X.f3[i];
+            // ascending scan over the partner k; inside one k the four tests run in the original order and later hits overwrite earlier ones
+            int fk = -1, ftr = 0, fjj = 0;
+            for (int kb = i + V_TURN + 1; kb <= j && fk < 0; kb += 64) {
+                const int k = kb + lane;
+                int traced = 0, jj = k + 1;
+                if (k <= j) {
+                    const int c1 = T.C(i + 1, k), c0 = T.C(i, k);
+                    int t = ptype(X, i + 1, k);
+                    if (t) {
+                        const int cc = c1 + D5(X, t, X.S[i]) + AU(X, t);
+                        if (fij == cc + X.f3[k + 1]) traced = i + 1;
+                        if (k < n && fij == cc + X.f3[k + 2] + D3(X, t, X.S[k + 1])) { traced = i + 1; jj = k + 2; }
+                    }
+                    t = ptype(X, i, k);
+                    if (t) {
+                        const int cc = c0 + AU(X, t);
+                        if (fij == cc + X.f3[k + 1]) traced = i;
+                        if (k < n && fij == cc + X.f3[k + 2] + D3(X, t, X.S[k + 1])) { traced = i; jj = k + 2; }
+                    }
+                }
+                const int fl = first_lane(__ballot(traced != 0));
+                if (fl >= 0) { fk = kb + fl; ftr = __shfl(traced, fl); fjj = __shfl(jj, fl); }
+            }
+            if (fk < 0) return -21;
+            if (j == n) {
+                if (lane == 0) { stk[3 * sp] = fjj; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 0; }
+                sp++;
+            }
+            i = ftr; j = fk;
+            if (lane == 0) {
+                buf[i - start] = '(';
+                buf[j - start] = ')';
+                if (fjj == fk + 2) buf[fk + 1 - start] = '.';
+            }
+        } else {
+            int fij;
+            for (;;) {      // trim unpaired bases inside patches of fML: j first, then i, until neither matches
+                const int ia = i + pa, jb = j - pb;
+                const int mv = T.Mm(ia, jb);
+                cv = T.C(ia, jb);
+                tbv = (jb - ia >= V_TURN + 1 && jb - ia <= T.D) ? T.TB(ia, jb) : 0;
+                fij = __builtin_amdgcn_readlane(mv, 0);
+                r = 0; c = 0;
+                bool edge = false;
+                for (;;) {
+                    if (r == 7 || c == 7) { edge = true; break; }
+                    if (__builtin_amdgcn_readlane(mv, r * 8 + c + 1) == fij) { c++; continue; }
+                    if (__builtin_amdgcn_readlane(mv, (r + 1) * 8 + c) == fij) { r++; continue; }
+                    break;
+                }
+                i += r; j -= c;
+                if (edge && (r | c)) continue;      // left the patch: fetch again at the new segment
+                if (edge) return -24;
+                break;
+            }
+            // the segment's closing pair with its four dangle variants: patch cells (r, c), (r+1, c), (r, c+1), (r+1, c+1)   (r, c <= 6 here)
+            int t = ptype(X, i, j);
+            const int cij = __builtin_amdgcn_readlane(cv, r * 8 + c) + MLi(X, t);
+            t = ptype(X, i + 1, j);
+            const int ci1j = __builtin_amdgcn_readlane(cv, (r + 1) * 8 + c) + D5(X, t, X.S[i]) + MLi(X, t);
+            t = ptype(X, i, j - 1);
+            const int cij1 = __builtin_amdgcn_readlane(cv, r * 8 + c + 1) + D3(X, t, X.S[j]) + MLi(X, t);
+            t = ptype(X, i + 1, j - 1);
+            const int ci1j1 = __builtin_amdgcn_readlane(cv, (r + 1) * 8 + c + 1) + D5(X, t, X.S[i]) + D3(X, t, X.S[j]) + MLi(X, t);
+            if (fij == cij || fij == ci1j || fij == cij1 || fij == ci1j1) {
+                if (fij == ci1j) { i++; r++; }                 // the reference's order of preference
+                else if (fij == cij1) { j--; c++; }
+                else if (fij == ci1j1) { i++; j--; r++; c++; }
+                if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+            } else {
+                // all split points at once, first match ascending
+                int m1[NSR], m2[NSR];
+                const int k0 = i + 1 + V_TURN, k1 = j - 2 - V_TURN;
+#pragma unroll
+                for (int q = 0; q < NSR; q++) {
+                    m1[q] = V_INF; m2[q] = V_INF;
+                    if (k0 + 64 * q <= k1) {
+                        const int k = k0 + 64 * q + lane;
+                        if (k <= k1) { m1[q] = T.Mm(i, k); m2[q] = T.Mm(k + 1, j); }
+                    }
+                }
+                int found = -1;
+#pragma unroll
+                for (int q = 0; q < NSR; q++) {
+                    if (k0 + 64 * q <= k1 && found < 0) {
+                        const int fl = first_lane(__ballot(fij == m1[q] + m2[q]));
+                        if (fl >= 0) found = k0 + 64 * q + fl;
+                    }
+                }
+                if (found < 0) return -22;
+                if (lane == 0) {
+                    stk[3 * sp] = i; stk[3 * sp + 1] = found; stk[3 * sp + 2] = 1;
+                    stk[3 * sp + 3] = found + 1; stk[3 * sp + 4] = j; stk[3 * sp + 5] = 1;
+                }
+                sp += 2;
+                continue;
+            }
+        }
+        // (i,j) is a traced pair at position (r, c) of the current patch (> 7: not in it): follow the trace-back codes until a hairpin or a multiloop
+        for (;;) {
+            if (r > 7 || c > 7) {
+                const int ia = i + pa, jb = j - pb;
+                cv = T.C(ia, jb);
+                tbv = (jb - ia >= V_TURN + 1 && jb - ia <= T.D) ? T.TB(ia, jb) : 0;
+                r = 0; c = 0;
+            }
+            for (;;) {
+                const int code = __builtin_amdgcn_readlane(tbv, r * 8 + c);
+                if (code <= 0) break;
+                const int n1 = (code - 1) >> 5, n2 = (code - 1) & 31;
+                i += 1 + n1; j -= 1 + n2;
+                if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+                r += 1 + n1; c += 1 + n2;
+                if (r > 7 || c > 7) break;
+            }
+            if (r > 7 || c > 7) continue;
+            const int cij = __builtin_amdgcn_readlane(cv, r * 8 + c);
+            const int type = ptype(X, i, j);
+            if (cij == hairpin(X, i, j, type)) break;
+            const int tt = rtype_of(type);
+            const int mm = P->ML_closing + MLi(X, tt);
+            const int e5 = D5(X, tt, X.S[j - 1]), e3 = D3(X, tt, X.S[i + 1]);
+            // all split points at once; per point the four variants in the original order, first point ascending
+            int fk = -1, fv = 0;
+            {
+                int a1[NSR], a2[NSR], b1[NSR], b2[NSR];
+                const int k0 = i + 2 + V_TURN, k1 = j - 3 - V_TURN;
+#pragma unroll
+                for (int q = 0; q < NSR; q++) {
+                    a1[q] = V_INF; a2[q] = V_INF; b1[q] = V_INF; b2[q] = V_INF;
+                    if (k0 + 64 * q <= k1) {
+                        const int k = k0 + 64 * q + lane;
+                        if (k <= k1) { a1[q] = T.Mm(i + 1, k); a2[q] = T.Mm(i + 2, k); b1[q] = T.Mm(k + 1, j - 1); b2[q] = T.Mm(k + 1, j - 2); }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NSR; q++) {
+                    if (k0 + 64 * q <= k1 && fk < 0) {
+                        int v = 0;      // 1: plain, 2: i1 = i+2, 3: j1 = j-2, 4: both (first in this order)
+                        if (cij == a1[q] + b1[q] + mm) v = 1;
+                        else if (cij == a2[q] + b1[q] + mm + e3) v = 2;
+                        else if (cij == a1[q] + b2[q] + mm + e5) v = 3;
+                        else if (cij == a2[q] + b2[q] + mm + e3 + e5) v = 4;
+                        const int fl = first_lane(__ballot(v != 0));
+                        if (fl >= 0) { fk = k0 + 64 * q + fl; fv = __shfl(v, fl); }
+                    }
+                }
+            }
+            if (fk < 0) return -23;
+            const int i1 = (fv == 2 || fv == 4) ? i + 2 : i + 1, j1 = (fv == 3 || fv == 4) ? j - 2 : j - 1;
+            if (lane == 0) {
+                stk[3 * sp] = i1; stk[3 * sp + 1] = fk; stk[3 * sp + 2] = 1;
+                stk[3 * sp + 3] = fk + 1; stk[3 * sp + 4] = j1; stk[3 * sp + 5] = 1;
+            }
+            sp += 2;
+            break;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int L = len0;
+    while (L < len0 + 2 && buf[L] != 0) L++;
+    while (L > 1 && buf[L - 1] == '-') L--;
+    for (int x = lane; x < L; x += 64)
+        if (buf[x] == '-') buf[x] = '.';
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return L;
+}
+
 // Exterior sweep (sequential in i, partners reduced in parallel), enumeration of the structure starts, one backtrack per start and wave,
 // RNALfold's "print prev unless contained in new" rule, output records.  Called by all NT threads of the workgroup; f3 must be zero-filled.
 template <class PT, class TabT, int NT>
@@ -403,7 +613,9 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
         int* mystk = btstk + wave * 3 * V_BT_STACK;
         for (int k = wave; k < nst; k += NT / 64) {
             const int lind = starts[k];
-            const int L = backtrack(X, T, lind, lind == 1 ? M : M + 1, mybuf, nc + 8, mystk);
+            int L;
+            if constexpr (TabT::kTiled) L = backtrack_tiled(X, T, lind, lind == 1 ? M : M + 1, mybuf, nc + 8, mystk);
+            else L = backtrack(X, T, lind, lind == 1 ? M : M + 1, mybuf, nc + 8, mystk);
             V185_T(3);
             if (L < 0) { if (lane == 0) { red[10] = L; lens[k] = 0; } continue; }
             if (L + 1 > ss_stride) { if (lane == 0) { red[10] = -30; lens[k] = 0; } continue; }

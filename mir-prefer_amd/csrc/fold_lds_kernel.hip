@@ -1219,6 +1219,7 @@ __global__ void __launch_bounds__(ENT, MIRP_EPI_WGS) fold_lds_epilogue_kernel(
 // Epilogue of the vienna-1.8.5 model on the slabs of fold_lds_kernel<1>: exterior sweep, enumeration, full backtracks (interior loops follow the
 // trace-back codes), output.  Shares its device code with the generic vienna-1.8.5 kernel (fold185_device.h).
 struct LTab185 {
+    static constexpr bool kTiled = true;     // 8 x 8-tiled archive with trace-back codes: the patch backtrack applies
     const short* carch;
     const short* fml;
     const unsigned short* tb;
