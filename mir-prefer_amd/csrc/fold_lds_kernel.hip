@@ -21,444 +21,9 @@
 //     INF is >= 65535 and can never beat the 65535 start value of a running minimum;
 //   * windows whose energies leave the 16-bit ranges are flagged and re-run by the generic kernel.
 // No MFMA: integer min-plus DP with irregular table lookups.
-#include <hip/hip_runtime.h>
-#include <type_traits>
-#include <cstdio>
-#include "fold_epilogue.h"
-#include "fold185_device.h"
+#include "fold_lds_common.h"
 
 namespace mirp {
-
-#define LNT 1024
-#define LNW (LNT / 64)
-#define LCAP 352            // window length capacity
-#define LDMAX 300           // diagonals 4..LDMAX are allocated: pair distances up to span-1 = 299, plus the fML-only diagonal d = span of the vienna-1.8.5 model
-#define LSPAN 300           // largest span (-L) this kernel supports
-#define I16_INF 0x7fff
-#define FIN_LIMIT 28000      // finite c must stay in [-28000, 28000]: G0 + 32768 + any loop term then stays below 65535
-#define FML_BIAS 31500       // fML is kept in LDS as uint16 (value + FML_BIAS), 65535 = INF; finite fML must stay in [-31500, 1267] so that the sum of
-#define FML_MAX 1267         // two finite entries (<= 65534) can never be mistaken for a sum that involves INF (>= 65535)
-#define LSEG 384             // paired-cell list: 6 producer waves x 64 entries
-#define KEY_BIAS 40000        // candidate keys: (energy + KEY_BIAS) << 10 | n1 << 5 | n2, 0xffffffff = none
-#define KEY_NONE 0xffffffffu
-#define KEY_INF (65535u << 10) // running-minimum start inside a job: any key that involves an INF ring entry is >= this
-#define OTH_BIAS 2048        // keeps (table delta + size term) of a bulge / 1xn candidate non-negative (the FoldParams key tables carry it)
-
-struct LdsTables {          // int16 copies of the hot parameter tables
-    short stack[64];
-    short bulge[32];
-    short internal_loop[32];
-    short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200];
-    // inner-pair terms by combined pair code idx = PA(p)*25 + QB(q), PA = S[p]*5 + S[p-1], QB = S[q]*5 + S[q+1]; relative to G0:
-    short XB[628];          // TerminalAU(inner) - mismatchI(inner)           (bulges of size >= 2)
-    short X1[628];          // mismatch1nI(inner) - mismatchI(inner)          (1 x n loops, n >= 3)
-    short dangle5[40], dangle3[40];   // [type*5 + base], clamped <= 0 (vienna-1.8.5 model)
-    unsigned char rt2[28];  // rtype(pair_type(a, b)) at [a*5+b]
-    short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
-};
-#define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
-#define MIRP_CK(d) ((d) % 3)
-#define CRING_ROWS 33       // diagonal dd lives in row dd & 31; row 32 mirrors row 0, so "the row after row r" is always r + 1 (phase A1 mixes lanes of two diagonals)
-
-struct LTab {               // table accessors for the shared epilogue/backtrack
-    static constexpr bool kTiled = true;   // 8 x 8 tiles over (row, diagonal): see the archive layout below
-    const short* fml;       // fML slab (per-window, global), tiled like the other two
-    const int* off;         // LDS: rowblk_off of the tiled archive layout (arch_rowblk_off)
-    const short* carch;     // global archive of c
-    const unsigned short* tb;   // trace-back codes written by the fill kernel
-    __device__ __forceinline__ int at(int d, int i) const { return off[(i - 1) >> 3] + ((i - 1) & 7) + 8 * (d - 4); }
-    __device__ __forceinline__ int TB(int d, int i) const { return tb[at(d, i)]; }
-    __device__ __forceinline__ int C(int d, int i) const { int v = carch[at(d, i)]; return v == I16_INF ? INF : v; }
-    // the three tables share their offsets: a patch computes at() once
-    __device__ __forceinline__ int TBat(int o) const { return tb[o]; }
-    __device__ __forceinline__ int Cat(int o) const { int v = carch[o]; return v == I16_INF ? INF : v; }
-    __device__ __forceinline__ int Mat(int o) const { const int v = (unsigned short)fml[o]; return v == 65535 ? INF : v - FML_BIAS; }
-    __device__ __forceinline__ int M(int d, int i) const {
-        if (d < 4) return INF;
-        const int v = (unsigned short)fml[at(d, i)];
-        return v == 65535 ? INF : v - FML_BIAS;
-    }
-};
-
-__device__ __forceinline__ int lds_mlstem(const LdsTables& T, const FoldParams* __restrict__ P, int type, int a, int b) {
-    int e = T.ML_intern + (type > 2 ? T.TerminalAU : 0);
-    if (a >= 0 && b >= 0) e += T.mismatchM[type * 25 + a * 5 + b];
-    else if (a >= 0) e += P->dangle5[type][a];
-    else if (b >= 0) e += P->dangle3[type][b];
-    return e;
-}
-
-// interior-loop energy with LDS tables for the common classes; type2 already rtype'd
-__device__ __forceinline__ int lds_intloop(const LdsTables& T, const FoldParams* __restrict__ P, int n1, int n2, int type, int type2,
-                                           int si1, int sj1, int sp1, int sq1) {
-    int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;
-    if (nl == 0) return T.stack[type * 8 + type2];
-    if (ns == 0) {
-        int e = T.bulge[nl];
-        if (nl == 1) e += T.stack[type * 8 + type2];
-        else e += (type > 2 ? T.TerminalAU : 0) + (type2 > 2 ? T.TerminalAU : 0);
-        return e;
-    }
-    if (ns == 1) {
-        if (nl == 1) return P->int11[type][type2][si1][sj1];
-        if (nl == 2) return (n1 == 1) ? P->int21[type][type2][si1][sq1][sj1] : P->int21[type2][type][sq1][si1][sp1];
-        int x = (nl - 1) * T.ninio;
-        return T.internal_loop[nl + 1] + (x < T.MAX_NINIO ? x : T.MAX_NINIO) + T.mismatch1nI[type * 25 + si1 * 5 + sj1] +
-               T.mismatch1nI[type2 * 25 + sq1 * 5 + sp1];
-    }
-    if (ns == 2) {
-        if (nl == 2) return P->int22[type][type2][si1][sp1][sq1][sj1];
-        if (nl == 3) return T.internal_loop[5] + T.ninio + T.mismatch23I[type * 25 + si1 * 5 + sj1] + T.mismatch23I[type2 * 25 + sq1 * 5 + sp1];
-    }
-    int x = (nl - ns) * T.ninio;
-    return T.internal_loop[nl + ns] + (x < T.MAX_NINIO ? x : T.MAX_NINIO) + T.mismatchI[type * 25 + si1 * 5 + sj1] +
-           T.mismatchI[type2 * 25 + sq1 * 5 + sp1];
-}
-
-// Diagonal-major triangle of fML / c / trace-back: cell (d, i), i = 1..n-d, lives at off(d) + i.  Every diagonal starts at an ODD offset and
-// is padded to an even length, so a pair of cells (i, i+1) with odd i is one naturally aligned 32-bit word (the split loop reads pairs; a
-// misaligned 32-bit DS read is replayed on gfx950).  off(d) = 1 + (d-4) n - (d(d-1)/2 - 6) + #{odd lengths among diagonals 4..d-1}.
-__host__ __device__ constexpr int tri_off(int d, int n) { return 1 + (d - 4) * n - (d * (d - 1) / 2 - 6) + (((d - 4) + (n & 1)) >> 1); }
-__host__ __device__ constexpr int tri_len(int d, int n) { return n - d > 0 ? (n - d) + ((n - d) & 1) : 0; }
-// tri_off(d + 1, n) - tri_off(d, n) of the closed form, for any d (also below the first diagonal, where tri_len is cut off)
-__host__ __device__ constexpr int tri_len_any(int d, int n) { return (n - d) + ((n - d) & 1); }
-__device__ inline void fill_tri_off(int* off, int n) {
-    int o = 1;
-    for (int d = 4; d <= LDMAX + 1; d++) { off[d] = o; o += tri_len(d, n); }
-}
-
-// Archive layout in HBM (the c, fML and trace-back slabs a window hands to its epilogue): 8 x 8 tiles over (row i, diagonal d), one tile =
-// one 128-byte line.  Rows are cut into row blocks of 8 (block b = rows 8b+1 .. 8b+8); a block holds the diagonals 4 .. min(dcap, n-1-8b) its
-// first row can have (rounded up to whole tiles), its tiles follow each other by diagonal:
-//     arch(d, i) = rowblk_off[(i-1) >> 3] + ((i-1) & 7) + 8 (d - 4),      rowblk_off[b] = 8 * sum of arch_nd over the blocks below b.
-// The epilogue's accesses are runs along a row (partner scans), along a column (multiloop splits), along a helix (i+l, j-l) and the exterior
-// sweep's (row block x all diagonals) streams; in a diagonal-major triangle each of those touched one line per cell.  The fill kernel writes one
-// diagonal per interval: 16-byte runs that the L2 merges into whole lines over the next seven diagonals.
-#define ARCH_RB ((LCAP + 7) / 8)
-__host__ __device__ constexpr int arch_nd(int b, int n, int dcap) {
-    int m = n - 1 - 8 * b;
-    if (m > dcap) m = dcap;
-    m -= 3;
-    return m > 0 ? (m + 7) & ~7 : 0;
-}
-__host__ __device__ inline int arch_rowblk_off(int b, int n, int dcap) {
-    int o = 0;
-    for (int x = 0; x < b; x++) o += 8 * arch_nd(x, n, dcap);
-    return o;
-}
-
-struct LdsLayout {
-    unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total;
-};
-__host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
-template <int MODEL>
-__host__ __device__ constexpr LdsLayout lds_layout() {
-    LdsLayout L{};
-    unsigned o = 0;
-    L.fml = o; o += lds_al((tri_off(LDMAX + 1, LCAP) + 2) * 2);                           // fML triangle, d = 4..LDMAX at n = LCAP
-    L.aux = o; o += lds_al(CRING_ROWS * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + 5 * LCAP * 4);   // c ring (32 diagonals + mirror row), DML ring (3; 5 in the vienna-1.8.5 model), 3 x ckey, 2 x mdec
-    L.S = o; o += lds_al(LCAP + 8);
-    L.seq = o; o += lds_al(LCAP + 8);
-    L.pax = o; o += lds_al((LCAP + 8) * 2);
-    L.qb2 = o; o += lds_al(LCAP + 8);
-    L.list = o; o += lds_al(3 * LSEG * (MODEL ? 2 : 4));      // 32-bit entries in the default model (see `list` in the kernel); the vienna-1.8.5 layout has no room for them
-    L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
-    L.misc = o; o += lds_al((48 + ARCH_RB) * 4);
-    L.total = o;
-    return L;
-}
-static_assert(lds_layout<0>().total <= 160 * 1024 && lds_layout<1>().total <= 160 * 1024, "fill kernel LDS budget");
-
-// ---- phase A1 building blocks.  All take the lane's paired cell (i, j = i + d) and wave-uniform d; r0 = d - 2 (ring row of the
-// stacked pair), um = largest admissible n1 + n2 (inner pair keeps q - p >= TURN + 1).  Running minima are biased uint (65535 = none).
-typedef const volatile __attribute__((address_space(3))) unsigned short* lds_vu16;   // LDS reads that must stay narrow (see a1_gen_row)
-typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8;
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-struct A1 {
-    const FoldParams* __restrict__ P;
-    const LdsTables* T;
-    const unsigned char* S;
-    const unsigned short* cring;
-    const unsigned short* pax;     // PA(x) * 50: byte offset of row PA in XB / X1
-    const unsigned char* qbr;      // QB(n + 1 - y) * 2 at y: the q side is walked downwards, so it is stored reversed (ascending immediates)
-    int r0, um, n;
-};
-
-// generic loops (n1, n2 >= 2) of size U: one contiguous run of ring row r0 - U.  The reads stay 16-bit on purpose (volatile keeps the
-// compiler from fusing neighbours into b64/b128 reads): a lane's run starts at an arbitrary 2-byte boundary, and a wide DS read off its
-// natural alignment is replayed at 64 cycles per wave-instruction on gfx950, against 2 cycles for a 16-bit read.
-template <bool CHECK, int U>
-__device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb, unsigned& bg) {
-    if (!CHECK || U <= a.um) {
-        lds_vu16 rp = (lds_vu16)(rb + ((a.r0 - U) & 31) * CSTR);
-        unsigned v[U - 3];      // all reads of the run in flight before the first use
-#pragma unroll
-        for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = rp[n1];
-#pragma unroll
-        for (int n1 = 2; n1 <= U - 2; n1++) {
-            const unsigned e = (v[n1 - 2] << 10) + a.P->gen_key[U - 6][n1];
-            bg = e < bg ? e : bg;
-        }
-    }
-}
-// job-local key (term << 10 | code) -> cell key ((energy + KEY_BIAS) << 10 | code); `adj` turns the job's term into the loop energy
-__device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
-    return b >= KEY_INF ? KEY_NONE : ((unsigned)((int)(b >> 10) + adj + KEY_BIAS) << 10) | (b & 1023u);
-}
-template <bool CHECK, int... Us>
-__device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int mm_outer) {
-    unsigned bg = KEY_INF;
-    const unsigned short* rb = a.cring + i + 1;
-    (a1_gen_row<CHECK, Us>(a, rb, bg), ...);
-    return a1_key(bg, -32768 + mm_outer);      // mm_outer = mismatchI of the outer pair (i, j), fetched by the caller ahead of the rows
-}
-
-// bulges, n1 = 0, n2 = U in [LO, HI]: p = i+1, q = j-1-U
-template <bool CHECK, int LO, int HI>
-__device__ __forceinline__ void a1_b0(const A1& a, int i, int j, unsigned& best) {
-    const unsigned idxp = a.pax[i + 1];
-    lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
-    const unsigned short* rb = a.cring + i + 1;
-    const char* xb = reinterpret_cast<const char*>(a.T->XB);
-#pragma unroll
-    for (int U = LO; U <= HI; U++) {
-        if (!CHECK || U <= a.um) {
-            const unsigned idx2 = idxp + ql[U];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
-            const unsigned g = rb[((a.r0 - U) & 31) * CSTR];
-            const unsigned e = ((g + (unsigned)x) << 10) + a.P->kb0_key[U];
-            best = e < best ? e : best;
-        }
-    }
-}
-// bulges, n2 = 0, n1 = U: p = i+1+U, q = j-1
-template <bool CHECK, int LO, int HI>
-__device__ __forceinline__ void a1_b1(const A1& a, int i, int j, unsigned& best) {
-    const unsigned idxq = a.qbr[a.n + 2 - j];
-    lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
-    const unsigned short* rb = a.cring + i + 1;
-    const char* xb = reinterpret_cast<const char*>(a.T->XB);
-#pragma unroll
-    for (int U = LO; U <= HI; U++) {
-        if (!CHECK || U <= a.um) {
-            const unsigned idx2 = idxq + pl[U];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
-            const unsigned g = rb[((a.r0 - U) & 31) * CSTR + U];
-            const unsigned e = ((g + (unsigned)x) << 10) + a.P->kb1_key[U];
-            best = e < best ? e : best;
-        }
-    }
-}
-// 1 x K loops, n1 = 1, n2 = K in [LO, HI]: p = i+2, q = j-1-K
-template <bool CHECK, int LO, int HI>
-__device__ __forceinline__ void a1_i0(const A1& a, int i, int j, unsigned& best) {
-    const unsigned idxp = a.pax[i + 2];
-    lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
-    const unsigned short* rb = a.cring + i + 2;
-    const char* xb = reinterpret_cast<const char*>(a.T->X1);
-#pragma unroll
-    for (int K = LO; K <= HI; K++) {
-        if (!CHECK || K + 1 <= a.um) {
-            const unsigned idx2 = idxp + ql[K];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
-            const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR];
-            const unsigned e = ((g + (unsigned)x) << 10) + a.P->k1n0_key[K];
-            best = e < best ? e : best;
-        }
-    }
-}
-// K x 1 loops, n2 = 1, n1 = K: p = i+1+K, q = j-2
-template <bool CHECK, int LO, int HI>
-__device__ __forceinline__ void a1_i1(const A1& a, int i, int j, unsigned& best) {
-    const unsigned idxq = a.qbr[a.n + 3 - j];
-    lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
-    const unsigned short* rb = a.cring + i + 1;
-    const char* xb = reinterpret_cast<const char*>(a.T->X1);
-#pragma unroll
-    for (int K = LO; K <= HI; K++) {
-        if (!CHECK || K + 1 <= a.um) {
-            const unsigned idx2 = idxq + pl[K];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
-            const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR + K];
-            const unsigned e = ((g + (unsigned)x) << 10) + a.P->k1n1_key[K];
-            best = e < best ? e : best;
-        }
-    }
-}
-
-// the nine small shapes: full energy function, branch-free so the global table loads of one wave are issued together
-template <int N1, int N2>
-__device__ __forceinline__ void a1_small(const A1& a, int i, int j, int type, int si1, int sj1, unsigned& best) {
-    if (N1 + N2 <= a.um) {
-        const int p = i + 1 + N1, q = j - 1 - N2;
-        const unsigned g = a.cring[((a.r0 - N1 - N2) & 31) * CSTR + p];
-        const int sp1 = a.S[p - 1], sq1 = a.S[q + 1];
-        const int t2 = a.T->rt2[a.S[p] * 5 + a.S[q]];
-        const int c = (int)g - 32768 - (int)a.T->mismatchI[t2 * 25 + sq1 * 5 + sp1];
-        const int e = lds_intloop(*a.T, a.P, N1, N2, type, t2, si1, sj1, sp1, sq1) + c;
-        const unsigned k = g == 65535u ? KEY_NONE : ((unsigned)(e + KEY_BIAS) << 10) | (unsigned)(N1 << 5 | N2);
-        best = k < best ? k : best;
-    }
-}
-
-// the four shapes whose energies come from the big int11 / int21 / int22 tables in global memory: the load is issued here and consumed
-// by the caller after its LDS-only shapes, so the L2 latency is covered
-template <int N1, int N2>
-__device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, int si1, int sj1, int& raw, int& cc) {
-    raw = 0; cc = INF;
-    if (N1 + N2 <= a.um) {
-        const int p = i + 1 + N1, q = j - 1 - N2;
-        const unsigned g = a.cring[((a.r0 - N1 - N2) & 31) * CSTR + p];
-        const int sp1 = a.S[p - 1], sq1 = a.S[q + 1];
-        const int t2 = a.T->rt2[a.S[p] * 5 + a.S[q]];
-        cc = g == 65535u ? INF : (int)g - 32768 - (int)a.T->mismatchI[t2 * 25 + sq1 * 5 + sp1];
-        if (N1 == 1 && N2 == 1) raw = a.P->int11[type][t2][si1][sj1];
-        else if (N1 == 1 && N2 == 2) raw = a.P->int21[type][t2][si1][sq1][sj1];
-        else if (N1 == 2 && N2 == 1) raw = a.P->int21[t2][type][sq1][si1][sp1];
-        else raw = a.P->int22[type][t2][si1][sp1][sq1][sj1];
-    }
-}
-
-// ---- "fast" variants of the jobs above for the steady state (every loop size admissible: um = MAXLOOP).  Same candidates, same keys; the
-// difference is the order of the loads: everything whose address is known up front (pair codes, ring entries, bases) is issued as one batch,
-// the table reads that depend on it as a second one, then the arithmetic.  The straightforward versions interleave a volatile read (kept
-// narrow on purpose, see a1_gen_row) with the reads that depend on it, and a volatile access is an ordering point for the scheduler: they
-// compile to one LDS round trip per candidate.
-#define A1_CHUNK 10
-template <int LO, int HI>
-__device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best) {
-    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_b0f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_b0f<LO + A1_CHUNK, HI>(a, i, j, best); }
-    else {
-        constexpr int N = HI - LO + 1;
-        const unsigned idxp = a.pax[i + 1];
-        lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
-        const unsigned short* rb = a.cring + i + 1;
-        const char* xb = reinterpret_cast<const char*>(a.T->XB);
-        unsigned code[N], g[N];
-        int x[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR];
-#pragma unroll
-        for (int k = 0; k < N; k++) code[k] = ql[LO + k];
-#pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
-#pragma unroll
-        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb0_key[LO + k]; best = e < best ? e : best; }
-    }
-}
-template <int LO, int HI>
-__device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best) {
-    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_b1f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_b1f<LO + A1_CHUNK, HI>(a, i, j, best); }
-    else {
-        constexpr int N = HI - LO + 1;
-        const unsigned idxq = a.qbr[a.n + 2 - j];
-        lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
-        const unsigned short* rb = a.cring + i + 1;
-        const char* xb = reinterpret_cast<const char*>(a.T->XB);
-        unsigned code[N], g[N];
-        int x[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR + (LO + k)];
-#pragma unroll
-        for (int k = 0; k < N; k++) code[k] = pl[LO + k];
-#pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
-#pragma unroll
-        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb1_key[LO + k]; best = e < best ? e : best; }
-    }
-}
-template <int LO, int HI>
-__device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best) {
-    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_i0f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_i0f<LO + A1_CHUNK, HI>(a, i, j, best); }
-    else {
-        constexpr int N = HI - LO + 1;
-        const unsigned idxp = a.pax[i + 2];
-        lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
-        const unsigned short* rb = a.cring + i + 2;
-        const char* xb = reinterpret_cast<const char*>(a.T->X1);
-        unsigned code[N], g[N];
-        int x[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR];
-#pragma unroll
-        for (int k = 0; k < N; k++) code[k] = ql[LO + k];
-#pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
-#pragma unroll
-        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n0_key[LO + k]; best = e < best ? e : best; }
-    }
-}
-template <int LO, int HI>
-__device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best) {
-    if constexpr (HI - LO + 1 > A1_CHUNK) { a1_i1f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_i1f<LO + A1_CHUNK, HI>(a, i, j, best); }
-    else {
-        constexpr int N = HI - LO + 1;
-        const unsigned idxq = a.qbr[a.n + 3 - j];
-        lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
-        const unsigned short* rb = a.cring + i + 1;
-        const char* xb = reinterpret_cast<const char*>(a.T->X1);
-        unsigned code[N], g[N];
-        int x[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR + (LO + k)];
-#pragma unroll
-        for (int k = 0; k < N; k++) code[k] = pl[LO + k];
-#pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
-#pragma unroll
-        for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n1_key[LO + k]; best = e < best ? e : best; }
-    }
-}
-
-// key of one small shape from its ring entry g (G0 + 32768, 65535 = none), the inner pair's mismatchI term (G0 = c + that term) and the loop energy
-__device__ __forceinline__ unsigned a1_small_key(unsigned g, int mm_inner, int e_loop, unsigned code) {
-    const int e = e_loop + (int)g - 32768 - mm_inner;
-    return g == 65535u ? KEY_NONE : ((unsigned)(e + KEY_BIAS) << 10) | code;
-}
-// stack, the two 1-bulges, 1x1, 1x2 of the lane's cell (i, j): the seven bases and five ring entries first, pair types by arithmetic, then the table reads
-__device__ __forceinline__ unsigned a1_small14f(const A1& a, int i, int j, int type, bool ahead, bool noglobal = false) {
-    lds_vu8 Sv = (lds_vu8)a.S;
-    const int s_i = Sv[i], s_i1 = Sv[i + 1], s_i2 = Sv[i + 2], s_j3 = Sv[j - 3], s_j2 = Sv[j - 2], s_j1 = Sv[j - 1], s_j = Sv[j];
-    const unsigned short* rb = a.cring;
-    const unsigned g00 = rb[((a.r0) & 31) * CSTR + i + 1], g01 = rb[((a.r0 - 1) & 31) * CSTR + i + 1], g10 = rb[((a.r0 - 1) & 31) * CSTR + i + 2];
-    const unsigned g11 = rb[((a.r0 - 2) & 31) * CSTR + i + 2], g12 = rb[((a.r0 - 3) & 31) * CSTR + i + 2];
-    const int t00 = rtype_of(pair_type(s_i1, s_j1)), t01 = rtype_of(pair_type(s_i1, s_j2)), t10 = rtype_of(pair_type(s_i2, s_j1));
-    const int t11 = rtype_of(pair_type(s_i2, s_j2)), t12 = rtype_of(pair_type(s_i2, s_j3));
-    const LdsTables& T = *a.T;
-    const int m00 = T.mismatchI[t00 * 25 + s_j * 5 + s_i], m01 = T.mismatchI[t01 * 25 + s_j1 * 5 + s_i], m10 = T.mismatchI[t10 * 25 + s_j * 5 + s_i1];
-    const int m11 = T.mismatchI[t11 * 25 + s_j1 * 5 + s_i1], m12 = T.mismatchI[t12 * 25 + s_j2 * 5 + s_i1];
-    const int st00 = T.stack[type * 8 + t00], st01 = T.stack[type * 8 + t01], st10 = T.stack[type * 8 + t10], b1 = T.bulge[1];
-    const int r11 = noglobal ? 0 : a.P->int11[type][t11][s_i1][s_j1];
-    const int r12 = noglobal ? 0 : a.P->int21[type][t12][s_i1][s_j2][s_j1];
-    unsigned res = a1_small_key(g01, m01, b1 + st01, 0u << 5 | 1u);
-    unsigned k = a1_small_key(g10, m10, b1 + st10, 1u << 5 | 0u); res = k < res ? k : res;
-    k = a1_small_key(g00, m00, st00, 0u); if (!ahead) res = k < res ? k : res;     // the stacked pair of a lane of diagonal d+1 is not final yet
-    k = a1_small_key(g11, m11, r11, 1u << 5 | 1u); res = k < res ? k : res;
-    k = a1_small_key(g12, m12, r12, 1u << 5 | 2u); res = k < res ? k : res;
-    return res;
-}
-// 2x1, 2x2, 2x3, 3x2
-__device__ __forceinline__ unsigned a1_small15f(const A1& a, int i, int j, int type, bool noglobal = false) {
-    lds_vu8 Sv = (lds_vu8)a.S;
-    const int s_i1 = Sv[i + 1], s_i2 = Sv[i + 2], s_i3 = Sv[i + 3], s_i4 = Sv[i + 4], s_j4 = Sv[j - 4], s_j3 = Sv[j - 3], s_j2 = Sv[j - 2], s_j1 = Sv[j - 1];
-    const unsigned short* rb = a.cring;
-    const unsigned g21 = rb[((a.r0 - 3) & 31) * CSTR + i + 3], g22 = rb[((a.r0 - 4) & 31) * CSTR + i + 3], g23 = rb[((a.r0 - 5) & 31) * CSTR + i + 3];
-    const unsigned g32 = rb[((a.r0 - 5) & 31) * CSTR + i + 4];
-    // (n1, n2): p = i + 1 + n1, q = j - 1 - n2; sp1 = S[p - 1], sq1 = S[q + 1]
-    const int t21 = rtype_of(pair_type(s_i3, s_j2)), t22 = rtype_of(pair_type(s_i3, s_j3)), t23 = rtype_of(pair_type(s_i3, s_j4)), t32 = rtype_of(pair_type(s_i4, s_j3));
-    const LdsTables& T = *a.T;
-    const int m21 = T.mismatchI[t21 * 25 + s_j1 * 5 + s_i2], m22 = T.mismatchI[t22 * 25 + s_j2 * 5 + s_i2], m23 = T.mismatchI[t23 * 25 + s_j3 * 5 + s_i2];
-    const int m32 = T.mismatchI[t32 * 25 + s_j2 * 5 + s_i3];
-    const int o23 = T.mismatch23I[type * 25 + s_i1 * 5 + s_j1], i23 = T.mismatch23I[t23 * 25 + s_j3 * 5 + s_i2], i32 = T.mismatch23I[t32 * 25 + s_j2 * 5 + s_i3];
-    const int base23 = T.internal_loop[5] + T.ninio;
-    const int r21 = noglobal ? 0 : a.P->int21[t21][type][s_j1][s_i1][s_i2];
-    const int r22 = noglobal ? 0 : a.P->int22[type][t22][s_i1][s_i2][s_j2][s_j1];
-    unsigned res = a1_small_key(g23, m23, base23 + o23 + i23, 2u << 5 | 3u);
-    unsigned k = a1_small_key(g32, m32, base23 + o23 + i32, 3u << 5 | 2u); res = k < res ? k : res;
-    k = a1_small_key(g21, m21, r21, 2u << 5 | 1u); res = k < res ? k : res;
-    k = a1_small_key(g22, m22, r22, 2u << 5 | 2u); res = k < res ? k : res;
-    return res;
-}
 
 // MODEL 0: vienna-2.1.2 (Turner-2004, dangles 2).  MODEL 1: vienna-1.8.5 (Turner-1999 values in the same parameter layout, dangles 1: four-way
 // dangle minima in the multiloop closing and the fML pair terms, fML also on the diagonal d = span; SURVEY.md Appendix B, d1 column).
@@ -1341,9 +906,18 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
     if (model)
         hipLaunchKernelGGL(fold_lds_kernel<1>, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
                            fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
-    else
+    else {
+#if !defined(MIRP_FILL2)
+        // product: the one-diagonal-per-interval fill kernel.  -DMIRP_FILL2 (dev builds, make VARIANT=...) selects the two-diagonal schedule of
+        // fold_lds2_kernel.hip, which is parity-green but measured no faster
         hipLaunchKernelGGL(fold_lds_kernel<0>, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
                            fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+#else
+        e = launch_fold_lds2_fill(stream, grid, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter, fallback_list, fallback_count,
+                                  out_nlines, out_mfe, out_status);
+        if (e != hipSuccess) return e;
+#endif
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_between) { e = hipEventRecord(ev_between, stream); if (e != hipSuccess) return e; }   // fill | epilogue boundary (mirp_last_fold_kernel_ms)

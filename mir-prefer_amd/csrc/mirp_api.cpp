@@ -317,6 +317,9 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
 #ifdef MIRP_EPI_CLOCKS
         mirp::fold_lds_epi_clocks_print();
 #endif
+#ifdef MIRP_L2_CLOCKS
+        if (!m185) mirp::fold_lds2_clocks_print();
+#endif
         if (nfb == 0) return 0;
         work_list = (const int*)c->flist.p;
         n_generic = (int)nfb;

@@ -43,6 +43,15 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
                            int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between = nullptr);
 
+// fold_lds2_kernel.hip: fill kernel of the default model, two diagonals per barrier interval
+size_t fold_lds2_bytes();
+#ifdef MIRP_L2_CLOCKS
+void fold_lds2_clocks_print();
+#endif
+hipError_t launch_fold_lds2_fill(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens, int n_work,
+                                 int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
+                                 unsigned int* fallback_count, int* out_nlines, int* out_mfe, int* out_status);
+
 // candidate_kernels.hip
 void launch_cov_scatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int cutoff, int* diff_p, int* diff_m);
 void launch_cov_unscatter(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, int* diff_p, int* diff_m);
