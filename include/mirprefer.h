@@ -203,15 +203,33 @@ int mirp_last_fold_kernel_ms(mirp_ctx* ctx, double ms[2]);
 int mirp_microbench(mirp_ctx* ctx, double out[4]);
 
 /* ------------------------------------------------------------------------------------------------
- * Multi-GPU: there is deliberately NO mirp_gather_loci entry point (SURVEY.md 8b item 4 proposed one).  The path shards by contig, one context
- * per GPU and process, with no data-path collective; the one exchange step is the gather of the final loci list (MirpMirna records + structure
- * text, a few MB at most, latency-bound) to rank 0, the analogue of the reference's `multiprocessing.Queue.put(list)` per piece (MP:2461-2499).
- * That gather runs over RCCL in the host binding (mir-prefer_amd/dist.py: all_gather of the counts + gather of max-padded 64-byte records, through
- * the `nccl` backend of torch.distributed, which IS RCCL on ROCm): the host process already owns that communicator, and a C entry point would
- * need either a second RCCL communicator inside this library (a ncclUniqueId exchange of its own, and two RCCL instances in one process) or a
- * torch type in its signature.  What the boundary provides for sharding is mirp_set_contig_shard (the one quirk of the reference that crosses
- * shard boundaries) and records that are plain 64-byte PODs, ready to be sent as they are.
+ * Multi-GPU: one process and one context per GPU, whole contigs per rank, no collective on the data path except
+ * the ONE exchange step: the gather of the final loci list to rank 0 -- the analogue of the reference's `multiprocessing.Queue.put(list)` per
+ * piece that the parent collects (MP:2461-2499) -- and, in the sharded ingest, the routing of parsed records to the rank that owns their contig
+ * (mirp_ingest_sams_shard).  Both run over RCCL on the context's stream.  librccl.so.1 is resolved with dlopen at the first mirp_dist_* call: a
+ * single-GPU run never loads it, and the process holds one HIP runtime and one RCCL instance (no torch type or torch communicator is involved;
+ * the host binding only has to carry the 128-byte id from rank 0 to the other ranks, through a file or any CPU-side store).
  * ---------------------------------------------------------------------------------------------- */
+#define MIRP_DIST_ID_BYTES 128
+/* ncclGetUniqueId: called by one rank, the bytes are handed to every rank's mirp_dist_init. */
+int mirp_dist_unique_id(uint8_t id[MIRP_DIST_ID_BYTES]);
+/* ncclCommInitRank on the context's device (collective over all `world` ranks).  world = 1 is valid (every exchange is then a local copy). */
+int mirp_dist_init(mirp_ctx* ctx, const uint8_t id[MIRP_DIST_ID_BYTES], int32_t rank, int32_t world);
+/* The same rank / world bookkeeping without RCCL, for ranks that SHARE one GPU (RCCL refuses two ranks on one device): every exchange is staged
+ * through the host and files in `dir`, a directory all ranks see.  For tests and for debugging a sharded run on a single-GPU machine. */
+int mirp_dist_init_local(mirp_ctx* ctx, const char* dir, int32_t rank, int32_t world);
+int mirp_dist_finalize(mirp_ctx* ctx);
+int mirp_dist_rank(const mirp_ctx* ctx);
+int mirp_dist_world(const mirp_ctx* ctx);
+/* Sum over the ranks of a small int64 vector, in place (n <= 1024); every rank gets the sums.  mirp_dist_barrier = one such reduction. */
+int mirp_dist_allreduce_sum(mirp_ctx* ctx, int64_t* v, int32_t n);
+int mirp_dist_barrier(mirp_ctx* ctx);
+/* Replaces the result queue of gen_miRNA_loci_nopredict (MP:2461-2499): the result of the last mirp_predict of every rank (records + structure
+ * text, as mirp_predict returns them), concatenated in rank order on rank dst straight from the device-resident arrays; n_result = 0 elsewhere.
+ * tids are genome-wide contig indices on every rank, so the records need no translation. */
+int mirp_gather_loci(mirp_ctx* ctx, int32_t dst, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride);
+/* The same gather for arbitrary fixed-size host records (per-rank counts may differ); out = NULL and n_out = 0 on ranks other than dst. */
+int mirp_gather_records(mirp_ctx* ctx, const void* rec, int64_t n, int32_t rec_bytes, int32_t dst, void** out, int64_t* n_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side native ingest (no device involved).
@@ -238,6 +256,22 @@ typedef struct { int32_t tid, start, end; } MirpRegion;
  * returned in *out.  seconds (optional): {tokenize, upload + filter, sort, download}.  Errors: mirp_last_error. */
 int mirp_ingest_sams_gpu(mirp_ctx* ctx, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
                          int64_t n_regions, MirpSamData* out, double seconds[4]);
+
+/* The same ingest sharded over the ranks of the context's communicator (mirp_dist_init; without one, or with one rank, it equals
+ * mirp_ingest_sams_gpu): every rank tokenizes its own byte range of every SAM file, the records are routed to the rank that owns their
+ * contig -- owner_of_tid[n_contigs], the same whole-contig partition the later stages use -- with one all-to-all over RCCL, and every rank
+ * filters and sorts what it owns.  Each rank's result is the (tid, pos)-stable subsequence of the single-process result for its contigs
+ * (the blocks are laid out in file-then-offset order before the sort), so the two ingests are interchangeable.  Replaces the serial
+ * prepare_data of the reference (MP:772-874). */
+int mirp_ingest_sams_shard(mirp_ctx* ctx, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
+                           int64_t n_regions, const int32_t* owner_of_tid, MirpSamData* out, double seconds[4]);
+
+/* FASTA file -> sequences (replaces the genome access of `samtools faidx`, MP:1100-1105; names are the first word of the header line as
+ * faidx has them, bytes and case kept).  names: n_contigs NUL-terminated names back to back in file order; len[k] = length of sequence k or
+ * -1 when it was not wanted; seq: the wanted sequences back to back (n_bytes).  want / n_want: keep only these names (n_want = 0: all). */
+typedef struct { int32_t n_contigs; char* names; int64_t* len; uint8_t* seq; int64_t n_bytes; } MirpFastaData;
+int mirp_read_fasta(const char* path, const char* const* want, int32_t n_want, MirpFastaData* out, char* errbuf, size_t errbuf_len);
+void mirp_free_fasta_data(MirpFastaData* data);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIRP_LIB") or os.path.join(_HERE, "libmirprefer.so")   # MIRP_LIB: dev tools load the diagnostics build (make DIAG=1)
+ABI_VERSION = 5      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
 
 
 class MirpError(RuntimeError):
@@ -25,6 +26,36 @@ class SamData(C.Structure):
 
 class Region(C.Structure):
     _fields_ = [("tid", C.c_int32), ("start", C.c_int32), ("end", C.c_int32)]
+
+
+class FastaData(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("names", C.c_void_p), ("len", C.POINTER(C.c_int64)), ("seq", C.c_void_p), ("n_bytes", C.c_int64)]
+
+
+def read_fasta(path, want=None):
+    """Native FASTA reader (mirp_read_fasta): -> list of (name, uint8 array) in file order; with `want` (names) only those sequences are
+    materialised, the others come back as None."""
+    lib = load_library()
+    d = FastaData()
+    err = C.create_string_buffer(512)
+    nw = len(want) if want else 0
+    arr = (C.c_char_p * max(nw, 1))(*[str(w).encode() for w in (want or [])])
+    if lib.mirp_read_fasta(str(path).encode(), arr, nw, C.byref(d), err, 512) != 0:
+        raise ValueError(err.value.decode())
+    try:
+        blob = np.frombuffer((C.c_char * d.n_bytes).from_address(d.seq), dtype=np.uint8, count=d.n_bytes).copy() if d.n_bytes else np.zeros(0, np.uint8)
+        out, off, o = [], 0, 0
+        for k in range(d.n_contigs):
+            nm = C.string_at(d.names + off)
+            off += len(nm) + 1
+            L = d.len[k]
+            if L < 0:
+                out.append((nm.decode(), None))
+            else:
+                out.append((nm.decode(), blob[o:o + L])); o += L
+    finally:
+        lib.mirp_free_fasta_data(C.byref(d))
+    return out
 
 
 def _unpack_sam_data(lib, d):
@@ -83,6 +114,13 @@ def load_library():
         raise MirpError("libmirprefer.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU fallback for the product path)")
     lib = C.CDLL(LIB_PATH)
+    lib.mirp_abi_version.argtypes = []
+    lib.mirp_abi_version.restype = C.c_int
+    if lib.mirp_abi_version() != ABI_VERSION:      # a stale build (or a stale MIRP_LIB variant) would be called through the wrong signatures
+        raise MirpError("%s has ABI version %d, this binding needs %d: rebuild it (make -C mir-prefer_amd/csrc)" % (LIB_PATH, lib.mirp_abi_version(), ABI_VERSION))
+    if os.environ.get("MIRP_LIB"):
+        import sys
+        sys.stderr.write("[mirp] using the library named by MIRP_LIB: %s\n" % LIB_PATH)
     vp = C.c_void_p
     lib.mirp_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.mirp_create.restype = C.c_int
@@ -146,6 +184,27 @@ def load_library():
     lib.mirp_ingest_sams_gpu.restype = C.c_int
     lib.mirp_load_coverage_segments.argtypes = [vp, vp, C.c_int64]
     lib.mirp_load_coverage_segments.restype = C.c_int
+    lib.mirp_ingest_sams_shard.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, vp, C.c_int64, vp, C.POINTER(SamData), C.POINTER(C.c_double)]
+    lib.mirp_ingest_sams_shard.restype = C.c_int
+    lib.mirp_read_fasta.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(FastaData), C.c_char_p, C.c_size_t]
+    lib.mirp_read_fasta.restype = C.c_int
+    lib.mirp_free_fasta_data.argtypes = [C.POINTER(FastaData)]
+    lib.mirp_free_fasta_data.restype = None
+    lib.mirp_dist_unique_id.argtypes = [vp]
+    lib.mirp_dist_unique_id.restype = C.c_int
+    lib.mirp_dist_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    lib.mirp_dist_init.restype = C.c_int
+    lib.mirp_dist_init_local.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+    lib.mirp_dist_init_local.restype = C.c_int
+    for f in ("mirp_dist_finalize", "mirp_dist_barrier", "mirp_dist_rank", "mirp_dist_world"):
+        getattr(lib, f).argtypes = [vp]
+        getattr(lib, f).restype = C.c_int
+    lib.mirp_dist_allreduce_sum.argtypes = [vp, vp, C.c_int32]
+    lib.mirp_dist_allreduce_sum.restype = C.c_int
+    lib.mirp_gather_loci.argtypes = [vp, C.c_int32, C.POINTER(vp), i64p, C.POINTER(vp), i32p]
+    lib.mirp_gather_loci.restype = C.c_int
+    lib.mirp_gather_records.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp), i64p]
+    lib.mirp_gather_records.restype = C.c_int
     _lib = lib
     return lib
 
@@ -277,6 +336,77 @@ class Context:
             raise ValueError(self.lib.mirp_last_error(self.h).decode())
         cn, lens, sn, alns, segs = _unpack_sam_data(self.lib, d)
         return cn, lens, sn, alns, segs, {"tokenize_s": sec[0], "upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3]}
+
+    def ingest_sams_shard(self, paths, owner_of_tid, regions=None, n_threads=0):
+        """Sharded ingest (mirp_ingest_sams_shard): this rank tokenizes its byte range of every file, records travel to the rank that owns their
+        contig over RCCL (dist_init first), this rank filters / sorts / keeps its own.  Same return as ingest_sams, records of this rank's contigs."""
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        nreg = len(regions) if regions else 0
+        reg = (Region * max(nreg, 1))()
+        for k in range(nreg):
+            reg[k].tid, reg[k].start, reg[k].end = int(regions[k][0]), int(regions[k][1]), int(regions[k][2])
+        own = np.ascontiguousarray(owner_of_tid, dtype=np.int32) if owner_of_tid is not None else None
+        d = SamData()
+        sec = (C.c_double * 4)()
+        rc = self.lib.mirp_ingest_sams_shard(self.h, arr, len(paths), int(n_threads), C.cast(reg, C.c_void_p), nreg,
+                                             own.ctypes.data if own is not None else None, C.byref(d), sec)
+        if rc != 0:
+            raise ValueError(self.lib.mirp_last_error(self.h).decode())
+        cn, lens, sn, alns, segs = _unpack_sam_data(self.lib, d)
+        return cn, lens, sn, alns, segs, {"tokenize_s": sec[0], "exchange_upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3]}
+
+    # ---- multi-GPU: RCCL communicator of this context (one process per GPU) -------------------
+    def dist_unique_id(self):
+        """128 bytes of ncclGetUniqueId: rank 0 calls this and hands the bytes to every rank's dist_init."""
+        buf = (C.c_uint8 * 128)()
+        if self.lib.mirp_dist_unique_id(buf) != 0:
+            raise MirpError("mirp_dist_unique_id failed (librccl.so.1 not loadable?)")
+        return bytes(buf)
+
+    def dist_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.mirp_dist_init(self.h, buf, int(rank), int(world)), "mirp_dist_init")
+
+    def dist_init_local(self, directory, rank, world):
+        """Ranks that share one GPU: exchanges staged through files in `directory` (mirp_dist_init_local)."""
+        self._check(self.lib.mirp_dist_init_local(self.h, str(directory).encode(), int(rank), int(world)), "mirp_dist_init_local")
+
+    def dist_finalize(self):
+        self._check(self.lib.mirp_dist_finalize(self.h), "mirp_dist_finalize")
+
+    def dist_world(self):
+        return int(self.lib.mirp_dist_world(self.h))
+
+    def dist_barrier(self):
+        self._check(self.lib.mirp_dist_barrier(self.h), "mirp_dist_barrier")
+
+    def dist_allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, dtype=np.int64).copy()
+        self._check(self.lib.mirp_dist_allreduce_sum(self.h, v.ctypes.data, len(v)), "mirp_dist_allreduce_sum")
+        return v
+
+    def gather_loci(self, dst=0):
+        """The result of the last predict() of every rank on rank dst (rank order): {"result": MIRNA records, "ss": [str]}; empty elsewhere."""
+        from . import records
+        r, t = C.c_void_p(), C.c_void_p()
+        n, stride = C.c_int64(), C.c_int32()
+        self._check(self.lib.mirp_gather_loci(self.h, int(dst), C.byref(r), C.byref(n), C.byref(t), C.byref(stride)), "mirp_gather_loci")
+        res = _copy_out(self.lib, r, records.MIRNA_DTYPE, n.value) if r.value else np.zeros(0, dtype=records.MIRNA_DTYPE)
+        txt = _copy_out(self.lib, t, np.uint8, n.value * stride.value).reshape(n.value, stride.value) if t.value else np.zeros((0, max(stride.value, 1)), np.uint8)
+        ss = [txt[k, :res[k]["ss_len"]].tobytes().decode() for k in range(n.value)]
+        return {"result": res, "ss": ss}
+
+    def gather_records(self, rec, dst=0):
+        """Fixed-size records (a C-contiguous numpy array, first axis = records) of every rank on rank dst, in rank order; None elsewhere."""
+        rec = np.ascontiguousarray(rec)
+        rb = int(rec.dtype.itemsize * (rec.size // max(len(rec), 1))) if len(rec) else int(rec.dtype.itemsize * int(np.prod(rec.shape[1:], dtype=np.int64)))
+        o, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.mirp_gather_records(self.h, rec.ctypes.data if len(rec) else None, len(rec), max(rb, 1), int(dst), C.byref(o), C.byref(n)),
+                    "mirp_gather_records")
+        if not o.value:
+            return None
+        flat = _copy_out(self.lib, o, np.uint8, n.value * max(rb, 1))
+        return flat.view(rec.dtype).reshape((n.value,) + rec.shape[1:])
 
     def candidate(self, cutoff, max_gap, precursor_len, contig_order, min_peak_len=19):
         pp = (C.c_int32 * 4)(int(cutoff), int(min_peak_len), int(max_gap), int(precursor_len))

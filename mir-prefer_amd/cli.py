@@ -57,22 +57,32 @@ def main(argv=None):
                                                                 opt["NAME_PREFIX"] + "_recover"))
         print("Last finished stage: %s" % last)
         return 0
-    # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m mir_prefer_amd.cli ...`): contigs are sharded over the ranks,
-    # only file names, counts and the final loci list are exchanged (RCCL / `nccl` by default, MIRP_DIST_BACKEND=gloo for CPU-side exchange)
+    # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m mir_prefer_amd.cli ...`): contigs are sharded over the ranks.  Host
+    # objects (file names, counts, report payloads) travel over a CPU-side `gloo` group; the data path's exchanges (record routing of the ingest,
+    # gather of the loci list) run over RCCL on the library's own communicator, one rank per GPU (dist.init_context).  MIRP_DIST_BACKEND=gloo
+    # keeps everything on the host channel (ranks that share one GPU, as in the tests).
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("MIRP_DIST_BACKEND", "rccl")
     if world > 1:
-        import torch
         import torch.distributed as tdist
-        backend = os.environ.get("MIRP_DIST_BACKEND", "nccl")
-        if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tdist.init_process_group("gloo")
+        if backend not in ("gloo", "local"):
             o["device"] = int(os.environ.get("LOCAL_RANK", str(rank)))
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            torch.cuda.set_device(o["device"])
-            tdist.init_process_group("nccl", device_id=torch.device("cuda", o["device"]))
-        else:
-            tdist.init_process_group(backend)
     try:
-        p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"], rank=rank, world=world)
+        dctx = None
+        if world > 1 and backend == "local":        # ranks that share one GPU: the library's exchanges go through files (mirp_dist_init_local)
+            xdir = os.path.join(opt["TMPFOLDER"] or os.path.join(opt["OUTFOLDER"], opt["NAME_PREFIX"] + "_tmp"), "dist_xchg")
+            if rank == 0:
+                shutil.rmtree(xdir, ignore_errors=True)
+                os.makedirs(xdir)
+            tdist.barrier()
+            dctx = capi.Context(o["device"])
+            dctx.dist_init_local(xdir, rank, world)
+        elif world > 1 and backend != "gloo":
+            from . import dist
+            dctx = dist.init_context(capi.Context(o["device"]), rank, world)
+        p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"], rank=rank, world=world, ctx=dctx)
         def removetmp():                        # run_removetmp (MP:3630-3639): unless -k; DELETE_IF_SUCCESS is parsed but unused, as in the reference
             if not o["keeptmp"]:
                 if world > 1:

@@ -10,7 +10,7 @@
 #include <vector>
 #include "mirp_internal.h"
 
-#define MIRP_ABI_VERSION 4   // 4: MirpSamData.segs, mirp_ingest_sams_gpu, mirp_load_coverage_segments; 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
+#define MIRP_ABI_VERSION 5   // 5: mirp_dist_*, mirp_gather_loci / mirp_gather_records, mirp_read_fasta, mirp_ingest_sams_shard; 4: MirpSamData.segs, mirp_ingest_sams_gpu, mirp_load_coverage_segments; 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
 #define MIRP_NMAX 3096
 
 #include "mirp_ctx.h"
@@ -71,13 +71,15 @@ extern "C" int mirp_set_fold_model(mirp_ctx* c, int32_t model) {
         delete hp;
     }
     c->fold_model = model;
-    c->have_fold = false;
+    c->have_fold = false; c->have_result = false;
     return 0;
 }
 
 extern "C" void mirp_destroy(mirp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)mirp_dist_finalize(c);
+    c->dist_tmp.release();
     c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
     c->nlines.release(); c->mfe.release(); c->status.release(); c->carch.release(); c->fctl.release(); c->flist.release(); c->wstate.release();
     for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,

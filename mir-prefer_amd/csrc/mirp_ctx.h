@@ -70,6 +70,14 @@ struct mirp_ctx {
     double fold_kernel_ms[2] = {0, 0};   // fill / epilogue kernels of the last mirp_run_fold (LDS-resident path)
     std::vector<hipEvent_t> fold_ev;     // 3 events per sub-batch, created on demand
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // ---- multi-GPU (mirp_dist.cpp): RCCL communicator of this context's device, one process per GPU
+    void* comm = nullptr;
+    int dist_rank = 0, dist_world = 1;
+    std::string dist_dir;             // local transport (mirp_dist_init_local): ranks that share a GPU exchange through files in this directory
+    long long dist_seq = 0;
+    DevBuf dist_tmp;
+    long long n_result = 0;           // records of the last mirp_predict (p_res / p_text), what mirp_gather_loci sends
+    bool have_result = false;
 };
 
 static inline int fail(mirp_ctx* c, int code, const std::string& msg) {
@@ -89,6 +97,15 @@ static inline int fail(mirp_ctx* c, int code, const std::string& msg) {
 int mirp_device_sort_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long n, int posbits, int tidbits);
 int mirp_device_mask_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long* n_io, MirpAln* d_segs, MirpAln* d_segtmp, const int* d_owner, long long* nseg_io,
                           const long long* d_rfirst, const int* d_rstart, const int* d_remax);
+
+namespace mirp {
+// mirp_dist.cpp: collectives on the context's communicator (no-ops / local copies without one)
+int dist_all_counts(mirp_ctx* c, long long mine, std::vector<long long>& counts);
+int dist_gatherv_bytes(mirp_ctx* c, const void* d_src, long long mine, int dst, void* d_dst, const std::vector<long long>& counts);
+int dist_alltoallv_bytes(mirp_ctx* c, const void* d_send, const std::vector<long long>& send_off, const std::vector<long long>& send_cnt, void* d_recv,
+                         const std::vector<long long>& recv_off, const std::vector<long long>& recv_cnt);
+int dist_allgather_ll(mirp_ctx* c, const long long* mine, int n, std::vector<long long>& out);
+}  // namespace mirp
 
 int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,
                   int max_lines, int stride, MirpFoldLine* d_lines, char* d_ss, int* d_nlines, int* d_mfe, int* d_status);

@@ -1,0 +1,341 @@
+// Multi-GPU exchange step of the path behind the C-ABI: one process per GPU, contigs sharded over the ranks, and ONE collective on the data
+// path -- the gather of the final loci list to one rank (the reference's analogue is `multiprocessing.Queue.put(list)` per piece,
+// /root/reference/miR_PREFeR.py:2461-2499) -- plus the record exchange of the sharded SAM ingest (mirp_ingest.cpp).  RCCL (librccl.so.1 of the
+// ROCm installation this library's HIP runtime comes from) is resolved with dlopen on first use: a single-GPU run never loads it, and the
+// process holds exactly one HIP runtime and one RCCL instance (the host binding exchanges the 128-byte ncclUniqueId through whatever channel it
+// has: a file, or a CPU-side store).
+#include <dlfcn.h>
+#include <time.h>
+#include <cstdio>
+#include <cstring>
+#include <rccl/rccl.h>
+#include "mirp_ctx.h"
+
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (h) return true;
+        for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) { err = std::string("cannot load librccl.so.1: ") + dlerror(); return false; }
+#define MIRP_SYM(field, sym)                                                                   \
+    field = reinterpret_cast<decltype(field)>(dlsym(h, sym));                                  \
+    if (!field) { err = std::string("librccl has no symbol ") + sym; dlclose(h); h = nullptr; return false; }
+        MIRP_SYM(GetUniqueId, "ncclGetUniqueId") MIRP_SYM(CommInitRank, "ncclCommInitRank") MIRP_SYM(CommDestroy, "ncclCommDestroy")
+        MIRP_SYM(AllGather, "ncclAllGather") MIRP_SYM(AllReduce, "ncclAllReduce") MIRP_SYM(Send, "ncclSend") MIRP_SYM(Recv, "ncclRecv")
+        MIRP_SYM(GroupStart, "ncclGroupStart") MIRP_SYM(GroupEnd, "ncclGroupEnd") MIRP_SYM(GetErrorString, "ncclGetErrorString")
+#undef MIRP_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+
+// ---- local transport: ranks that share one GPU (RCCL refuses two ranks on one device) exchange through files in a directory they all see.
+// Every collective draws the next sequence number; rank s leaves its block for rank q in <dir>/x<seq>.<s>.<q> (written under a temporary
+// name, then renamed) and polls for the blocks addressed to itself.  Host-staged, for tests and single-GPU debugging of a sharded run.
+int local_exchange(mirp_ctx* c, const std::vector<std::pair<const void*, long long>>& send, std::vector<std::vector<char>>& recv) {
+    const int W = c->dist_world, me = c->dist_rank;
+    const long long seq = c->dist_seq++;
+    recv.assign((size_t)W, {});
+    auto name = [&](int s2, int q) { return c->dist_dir + "/x" + std::to_string(seq) + "." + std::to_string(s2) + "." + std::to_string(q); };
+    for (int q = 0; q < W; q++) {
+        if (q == me) { recv[me].assign((const char*)send[q].first, (const char*)send[q].first + send[q].second); continue; }
+        const std::string fn = name(me, q), tmp = fn + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f) return fail(c, -7, "local transport: cannot write " + tmp);
+        if (send[q].second && std::fwrite(send[q].first, 1, (size_t)send[q].second, f) != (size_t)send[q].second) { std::fclose(f); return fail(c, -7, "local transport: short write"); }
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), fn.c_str()) != 0) return fail(c, -7, "local transport: rename failed");
+    }
+    for (int s2 = 0; s2 < W; s2++) {
+        if (s2 == me) continue;
+        const std::string fn = name(s2, me);
+        FILE* f = nullptr;
+        for (long long spin = 0; !(f = std::fopen(fn.c_str(), "rb")); spin++) {
+            if (spin > 600000) return fail(c, -7, "local transport: timed out waiting for rank " + std::to_string(s2));
+            struct timespec ts = {0, 1000000};
+            nanosleep(&ts, nullptr);
+        }
+        std::fseek(f, 0, SEEK_END);
+        const long sz = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        recv[s2].resize((size_t)sz);
+        if (sz && std::fread(recv[s2].data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); return fail(c, -7, "local transport: short read"); }
+        std::fclose(f);
+        std::remove(fn.c_str());
+    }
+    return 0;
+}
+}  // namespace
+
+#define NCCLCHK(c, call)                                                                                                      \
+    do {                                                                                                                      \
+        ncclResult_t r_ = (call);                                                                                             \
+        if (r_ != ncclSuccess) return fail((c), -7, std::string(#call) + ": " + g_rccl.GetErrorString(r_));                  \
+    } while (0)
+
+extern "C" int mirp_dist_unique_id(uint8_t* id) {
+    if (!id) return -1;
+    static_assert(MIRP_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!g_rccl.load()) return -7;
+    ncclUniqueId u;
+    if (g_rccl.GetUniqueId(&u) != ncclSuccess) return -7;
+    std::memcpy(id, u.internal, MIRP_DIST_ID_BYTES);
+    return 0;
+}
+
+extern "C" int mirp_dist_init(mirp_ctx* c, const uint8_t* id, int32_t rank, int32_t world) {
+    if (!c) return -1;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(c, -1, "mirp_dist_init: bad argument");
+    if (c->comm) return fail(c, -1, "mirp_dist_init: the context already has a communicator");
+    if (!g_rccl.load()) return fail(c, -7, g_rccl.err);
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, MIRP_DIST_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(c, g_rccl.CommInitRank(&comm, world, u, rank));
+    c->comm = comm; c->dist_rank = rank; c->dist_world = world;
+    return 0;
+}
+
+extern "C" int mirp_dist_init_local(mirp_ctx* c, const char* dir, int32_t rank, int32_t world) {
+    if (!c) return -1;
+    if (!dir || !*dir || world < 1 || rank < 0 || rank >= world) return fail(c, -1, "mirp_dist_init_local: bad argument");
+    if (c->comm || c->dist_world > 1) return fail(c, -1, "mirp_dist_init_local: the context already has a communicator");
+    c->dist_dir = dir; c->dist_rank = rank; c->dist_world = world; c->dist_seq = 0;
+    return 0;
+}
+
+extern "C" int mirp_dist_finalize(mirp_ctx* c) {
+    if (!c) return -1;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    c->dist_rank = 0; c->dist_world = 1; c->dist_dir.clear();
+    return 0;
+}
+
+extern "C" int mirp_dist_rank(const mirp_ctx* c) { return c ? c->dist_rank : 0; }
+extern "C" int mirp_dist_world(const mirp_ctx* c) { return c ? c->dist_world : 1; }
+
+// all ranks: sum of a small int64 vector (in place, host memory); doubles as the barrier
+extern "C" int mirp_dist_allreduce_sum(mirp_ctx* c, int64_t* v, int32_t n) {
+    if (!c) return -1;
+    if (n < 0 || n > 1024 || (n > 0 && !v)) return fail(c, -1, "mirp_dist_allreduce_sum: bad argument");
+    if (c->dist_world == 1 || n == 0) return 0;
+    if (!c->comm) {
+        std::vector<long long> all;
+        if (int rc = mirp::dist_allgather_ll(c, (const long long*)v, n, all)) return rc;
+        for (int k = 0; k < n; k++) { long long t = 0; for (int r = 0; r < c->dist_world; r++) t += all[(size_t)r * n + k]; v[k] = t; }
+        return 0;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->dist_tmp.ensure(8 * 1024)) return fail(c, -6, "device allocation failed (dist)");
+    HIPCHK(c, hipMemcpyAsync(c->dist_tmp.p, v, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, g_rccl.AllReduce(c->dist_tmp.p, c->dist_tmp.p, (size_t)n, ncclInt64, ncclSum, (ncclComm_t)c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(v, c->dist_tmp.p, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int mirp_dist_barrier(mirp_ctx* c) {
+    int64_t one = 1;
+    return mirp_dist_allreduce_sum(c, &one, 1);
+}
+
+namespace mirp {
+// counts[world] (records of `rec_bytes` bytes each) of every rank, on every rank
+int dist_all_counts(mirp_ctx* c, long long mine, std::vector<long long>& counts) { return dist_allgather_ll(c, &mine, 1, counts); }
+
+// Gather of device-resident byte blocks of different sizes to rank dst (rank order): every rank sends `mine` bytes from d_src; on dst, d_dst
+// receives sum(counts) bytes.  Grouped ncclSend / ncclRecv on the context's stream (the caller synchronises).
+int dist_gatherv_bytes(mirp_ctx* c, const void* d_src, long long mine, int dst, void* d_dst, const std::vector<long long>& counts) {
+    if (c->dist_world == 1) {
+        if (mine) HIPCHK(c, hipMemcpyAsync(d_dst, d_src, (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    if (!c->comm) {      // local transport, host-staged
+        std::vector<char> h((size_t)std::max<long long>(mine, 1));
+        if (mine) HIPCHK(c, hipMemcpyAsync(h.data(), d_src, (size_t)mine, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<std::pair<const void*, long long>> send((size_t)c->dist_world, {h.data(), 0});
+        send[dst].second = mine;
+        std::vector<std::vector<char>> recv;
+        if (int rc = local_exchange(c, send, recv)) return rc;
+        if (c->dist_rank == dst) {
+            long long off = 0;
+            for (int r = 0; r < c->dist_world; r++) {
+                if ((long long)recv[r].size() != counts[r]) return fail(c, -7, "local transport: block size mismatch");
+                if (counts[r]) HIPCHK(c, hipMemcpy((char*)d_dst + off, recv[r].data(), (size_t)counts[r], hipMemcpyHostToDevice));
+                off += counts[r];
+            }
+        }
+        return 0;
+    }
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(c, g_rccl.GroupStart());
+    if (c->dist_rank == dst) {
+        long long off = 0;
+        for (int r = 0; r < c->dist_world; r++) {
+            if (r != dst && counts[r]) NCCLCHK(c, g_rccl.Recv((char*)d_dst + off, (size_t)counts[r], ncclUint8, r, comm, c->stream));
+            off += counts[r];
+        }
+    } else if (mine) {
+        NCCLCHK(c, g_rccl.Send(d_src, (size_t)mine, ncclUint8, dst, comm, c->stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+    if (c->dist_rank == dst && mine) {
+        long long off = 0;
+        for (int r = 0; r < dst; r++) off += counts[r];
+        HIPCHK(c, hipMemcpyAsync((char*)d_dst + off, d_src, (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
+}
+
+// All-to-all of device-resident byte blocks: send_off / send_cnt[world] into d_send (bytes), received blocks land in d_recv in source-rank
+// order; recv_cnt is filled.  Used by the sharded SAM ingest to route records to the rank that owns their contig.
+int dist_alltoallv_bytes(mirp_ctx* c, const void* d_send, const std::vector<long long>& send_off, const std::vector<long long>& send_cnt, void* d_recv,
+                         const std::vector<long long>& recv_off, const std::vector<long long>& recv_cnt) {
+    const int W = c->dist_world, me = c->dist_rank;
+    if (W == 1) {
+        if (send_cnt[0]) HIPCHK(c, hipMemcpyAsync((char*)d_recv + recv_off[0], (const char*)d_send + send_off[0], (size_t)send_cnt[0], hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
+    if (!c->comm) {      // local transport, host-staged
+        long long tot = 0;
+        for (int r = 0; r < W; r++) tot = std::max(tot, send_off[r] + send_cnt[r]);
+        std::vector<char> h((size_t)std::max<long long>(tot, 1));
+        if (tot) HIPCHK(c, hipMemcpyAsync(h.data(), d_send, (size_t)tot, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<std::pair<const void*, long long>> send((size_t)W);
+        for (int r = 0; r < W; r++) send[r] = {h.data() + send_off[r], send_cnt[r]};
+        std::vector<std::vector<char>> recv;
+        if (int rc = local_exchange(c, send, recv)) return rc;
+        for (int r = 0; r < W; r++) {
+            if ((long long)recv[r].size() != recv_cnt[r]) return fail(c, -7, "local transport: block size mismatch");
+            if (recv_cnt[r]) HIPCHK(c, hipMemcpy((char*)d_recv + recv_off[r], recv[r].data(), (size_t)recv_cnt[r], hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(c, g_rccl.GroupStart());
+    for (int r = 0; r < W; r++) {
+        if (r == me) continue;
+        if (send_cnt[r]) NCCLCHK(c, g_rccl.Send((const char*)d_send + send_off[r], (size_t)send_cnt[r], ncclUint8, r, comm, c->stream));
+        if (recv_cnt[r]) NCCLCHK(c, g_rccl.Recv((char*)d_recv + recv_off[r], (size_t)recv_cnt[r], ncclUint8, r, comm, c->stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+    if (send_cnt[me]) HIPCHK(c, hipMemcpyAsync((char*)d_recv + recv_off[me], (const char*)d_send + send_off[me], (size_t)send_cnt[me], hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// every rank's `mine[n]` int64 vector on every rank: out[r * n + k]
+int dist_allgather_ll(mirp_ctx* c, const long long* mine, int n, std::vector<long long>& out) {
+    const int W = c->dist_world;
+    out.assign((size_t)W * n, 0);
+    if (W == 1) { for (int k = 0; k < n; k++) out[k] = mine[k]; return 0; }
+    if (!c->comm) {
+        std::vector<std::pair<const void*, long long>> send((size_t)W, {mine, 8LL * n});
+        std::vector<std::vector<char>> recv;
+        if (int rc = local_exchange(c, send, recv)) return rc;
+        for (int r = 0; r < W; r++) {
+            if ((long long)recv[r].size() != 8LL * n) return fail(c, -7, "local transport: block size mismatch");
+            std::memcpy(out.data() + (size_t)r * n, recv[r].data(), 8 * (size_t)n);
+        }
+        return 0;
+    }
+    if (c->dist_tmp.ensure(8 * (size_t)(W + 1) * n + 64)) return fail(c, -6, "device allocation failed (dist)");
+    long long* d = (long long*)c->dist_tmp.p;
+    HIPCHK(c, hipMemcpyAsync(d + (size_t)W * n, mine, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, g_rccl.AllGather(d + (size_t)W * n, d, (size_t)n, ncclInt64, (ncclComm_t)c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out.data(), d, 8 * (size_t)W * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+}  // namespace mirp
+
+// Generic gather of fixed-size host records to rank dst, in rank order (host buffers in and out; staged through the device for RCCL).
+extern "C" int mirp_gather_records(mirp_ctx* c, const void* rec, int64_t n, int32_t rec_bytes, int32_t dst, void** out, int64_t* n_out) {
+    if (!c) return -1;
+    if (n < 0 || rec_bytes < 1 || (n > 0 && !rec) || !out || !n_out || dst < 0 || dst >= c->dist_world) return fail(c, -1, "mirp_gather_records: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    *out = nullptr; *n_out = 0;
+    std::vector<long long> counts;
+    if (int rc = mirp::dist_all_counts(c, (long long)n * rec_bytes, counts)) return rc;
+    long long total = 0;
+    for (long long x : counts) total += x;
+    TmpDevice T;
+    void* d_src = T.get((size_t)n * rec_bytes + 16);
+    void* d_dst = c->dist_rank == dst ? T.get((size_t)total + 16) : nullptr;
+    if (!d_src || (c->dist_rank == dst && !d_dst)) return fail(c, -6, "device allocation failed (gather)");
+    if (n) HIPCHK(c, hipMemcpyAsync(d_src, rec, (size_t)n * rec_bytes, hipMemcpyHostToDevice, c->stream));
+    if (int rc = mirp::dist_gatherv_bytes(c, d_src, (long long)n * rec_bytes, dst, d_dst, counts)) return rc;
+    if (c->dist_rank == dst) {
+        void* h = std::malloc((size_t)std::max<long long>(total, 1));
+        if (!h) return fail(c, -6, "host allocation failed (gather)");
+        if (total) HIPCHK(c, hipMemcpyAsync(h, d_dst, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *out = h; *n_out = total / rec_bytes;
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// The exchange step of the path: the loci list of the last mirp_predict of every rank, gathered to rank dst in rank order straight
+// out of the device-resident result arrays (64-byte MirpMirna records + structure text rows).  Ranks other than dst get n_result = 0.
+extern "C" int mirp_gather_loci(mirp_ctx* c, int32_t dst, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride) {
+    if (!c) return -1;
+    if (!result || !n_result || !ss_text || !ss_stride || dst < 0 || dst >= c->dist_world) return fail(c, -1, "mirp_gather_loci: bad argument");
+    if (!c->have_result) return fail(c, -1, "mirp_gather_loci: run mirp_predict first");
+    HIPCHK(c, hipSetDevice(c->device));
+    *result = nullptr; *n_result = 0; *ss_text = nullptr; *ss_stride = c->fold_stride;
+    const long long mine = c->n_result;
+    long long v[2] = {mine, c->fold_stride};
+    std::vector<long long> all;
+    if (int rc = mirp::dist_allgather_ll(c, v, 2, all)) return rc;
+    std::vector<long long> crec((size_t)c->dist_world), ctxt((size_t)c->dist_world);
+    long long total = 0;
+    for (int r = 0; r < c->dist_world; r++) {
+        if (all[2 * r + 1] != c->fold_stride) return fail(c, -1, "mirp_gather_loci: the ranks folded with different PRECURSOR_LEN (structure text stride differs)");
+        crec[r] = all[2 * r] * (long long)sizeof(MirpMirna); ctxt[r] = all[2 * r] * c->fold_stride; total += all[2 * r];
+    }
+    TmpDevice T;
+    const bool root = c->dist_rank == dst;
+    void* d_rec = root ? T.get((size_t)total * sizeof(MirpMirna) + 16) : nullptr;
+    void* d_txt = root ? T.get((size_t)total * c->fold_stride + 16) : nullptr;
+    if (root && (!d_rec || !d_txt)) return fail(c, -6, "device allocation failed (gather)");
+    if (int rc = mirp::dist_gatherv_bytes(c, c->p_res.p, mine * (long long)sizeof(MirpMirna), dst, d_rec, crec)) return rc;
+    if (int rc = mirp::dist_gatherv_bytes(c, c->p_text.p, mine * c->fold_stride, dst, d_txt, ctxt)) return rc;
+    if (root) {
+        MirpMirna* hr = (MirpMirna*)std::calloc((size_t)std::max<long long>(total, 1), sizeof(MirpMirna));
+        char* ht = (char*)std::calloc((size_t)std::max<long long>(total, 1), (size_t)c->fold_stride);
+        if (!hr || !ht) { std::free(hr); std::free(ht); return fail(c, -6, "host allocation failed (gather)"); }
+        if (total) {
+            HIPCHK(c, hipMemcpyAsync(hr, d_rec, (size_t)total * sizeof(MirpMirna), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(ht, d_txt, (size_t)total * c->fold_stride, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *result = hr; *n_result = total; *ss_text = ht;
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}

@@ -210,7 +210,9 @@ struct Parsed {
 };
 
 // header + threaded tokenizer over every file; records stay in per-chunk vectors (sample, then file order)
-int parse_all(const char* const* paths, int32_t n_paths, int32_t n_threads, Parsed* P, std::string* err) {
+// (part, n_parts): this caller tokenizes the part-th of n_parts equal byte ranges of every file's body (cut at line starts): the sharded ingest
+// of one process per GPU; (0, 1) = the whole file.
+int parse_all(const char* const* paths, int32_t n_paths, int32_t n_threads, Parsed* P, std::string* err, int part = 0, int n_parts = 1) {
     if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     NameTable tab;
     P->per_file.resize(n_paths);
@@ -254,6 +256,20 @@ int parse_all(const char* const* paths, int32_t n_paths, int32_t n_threads, Pars
             for (size_t k = 0; k < id.size(); k++) if (id[k] == '_') us.push_back(k);
             if (us.size() >= 2) sname = id.substr(0, us[us.size() - 2]);
             P->samples.push_back(sname);
+        }
+        if (n_parts > 1) {      // this rank's byte range of the body, cut at line starts
+            const size_t whole = (size_t)(e - s);
+            auto cut_at = [&](int k) -> const char* {
+                if (k <= 0) return s;
+                if (k >= n_parts) return e;
+                const char* c = s + whole / n_parts * k;
+                if (c <= s) return s;
+                const char* le = (const char*)memchr(c - 1, '\n', (size_t)(e - (c - 1)));      // c itself is a line start if c[-1] is the newline
+                return le ? le + 1 : e;
+            };
+            const char* s2 = cut_at(part);
+            e = cut_at(part + 1);
+            s = s2;
         }
         // split the body at line starts
         const size_t body = (size_t)(e - s);
@@ -363,40 +379,139 @@ extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32
 // Device path: host threads tokenize, the records go to the GPU in (sample, file) order, the optional keep-region filter
 // (`samtools view -L`, MP:817-859) and the stable radix sort run there, and the sorted records stay resident as the context's alignments
 // (as after mirp_load_alignments + mirp_load_coverage_segments) besides being returned to the host.
-extern "C" int mirp_ingest_sams_gpu(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
-                                    int64_t n_regions, MirpSamData* out, double seconds[4]) {
+//
+// Sharded form (one process per GPU, mirp_dist_init done): every rank tokenizes its own byte range of every file, routes each record to the
+// rank that owns its contig (owner_of_tid) with one all-to-all over RCCL, and filters / sorts what it receives.  The receiver lays the blocks
+// out by (file, source rank), i.e. in (sample, file offset) order, so the stable sort sees exactly the sequence the single-process ingest sees for
+// those contigs and ties resolve identically (first-seen maximum, MP:1457).
+static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions, int64_t n_regions,
+                       bool shard, const int32_t* owner_of_tid, MirpSamData* out, double seconds[4], const char* who) {
     if (!c) return -1;
-    if (!paths || n_paths < 1 || !out) return fail(c, -1, "mirp_ingest_sams_gpu: bad argument");
-    if (n_paths > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_ingest_sams_gpu: too many samples");
+    if (!paths || n_paths < 1 || !out) return fail(c, -1, std::string(who) + ": bad argument");
+    if (n_paths > MIRP_MAX_SAMPLES) return fail(c, -1, std::string(who) + ": too many samples");
     std::memset(out, 0, sizeof(*out));
     HIPCHK(c, hipSetDevice(c->device));
+    const int W = shard ? c->dist_world : 1, me = shard ? c->dist_rank : 0;
+    if (shard && W > 1 && !owner_of_tid) return fail(c, -1, std::string(who) + ": owner_of_tid is required with more than one rank");
     const double t0 = now_s();
     Parsed P;
     std::string err;
-    if (parse_all(paths, n_paths, n_threads, &P, &err)) return fail(c, -1, err);
+    if (parse_all(paths, n_paths, n_threads, &P, &err, me, W)) return fail(c, -1, err);
+    const int nc = (int)P.names.size();
+    if (W > 1)
+        for (int t = 0; t < nc; t++)
+            if (owner_of_tid[t] < 0 || owner_of_tid[t] >= W) return fail(c, -1, std::string(who) + ": owner_of_tid out of range");
+    // a record past the end of its contig would overflow the position bits of the sort key (and the reference's samtools rejects it)
+    for (auto& f : P.per_file)
+        for (auto& ch : f)
+            for (const MirpAln& r : ch.recs)
+                if ((int64_t)r.pos > P.lens[r.tid] + 1) return fail(c, -1, "alignment position " + std::to_string(r.pos) + " is beyond the end of sequence " + P.names[r.tid] + " (LN:" + std::to_string(P.lens[r.tid]) + ")");
     const double t1 = now_s();
-    long long n = (long long)P.n_recs, ns = (long long)P.n_segs;
-    if (n > 0x7fffffffLL) return fail(c, -5, "mirp_ingest_sams_gpu: more than 2^31 records");
-    MirpAln* all = (MirpAln*)std::malloc(std::max<size_t>((size_t)n, 1) * sizeof(MirpAln));
-    MirpAln* segs = (MirpAln*)std::malloc(std::max<size_t>((size_t)ns, 1) * sizeof(MirpAln));
-    std::vector<int32_t> owner(std::max<size_t>((size_t)ns, 1));
-    auto bail = [&](int code, const std::string& m) { std::free(all); std::free(segs); mirp_free_sam_data(out); return fail(c, code, m); };
-    if (!all || !segs) return bail(-6, "out of memory");
-    concat(P, all, segs, owner.data());
+    MirpAln* all = nullptr;
+    MirpAln* segs = nullptr;
+    std::vector<int32_t> owner;
+    long long n = 0, ns = 0;
+    auto bail = [&](int code, const std::string& m) { std::free(all); std::free(segs); all = segs = nullptr; mirp_free_sam_data(out); return fail(c, code, m); };
+    if (W == 1) {
+        n = (long long)P.n_recs; ns = (long long)P.n_segs;
+        if (n > 0x7fffffffLL) return fail(c, -5, std::string(who) + ": more than 2^31 records");
+        all = (MirpAln*)std::malloc(std::max<size_t>((size_t)n, 1) * sizeof(MirpAln));
+        segs = (MirpAln*)std::malloc(std::max<size_t>((size_t)ns, 1) * sizeof(MirpAln));
+        owner.resize(std::max<size_t>((size_t)ns, 1));
+        if (!all || !segs) return bail(-6, "out of memory");
+        concat(P, all, segs, owner.data());
+        if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
+            c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1)))
+            return bail(-6, "device allocation failed (ingest)");
+        if (n && hipMemcpyAsync(c->alns.p, all, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(-2, "H2D failed");
+        if (ns && hipMemcpyAsync(c->segs.p, segs, sizeof(MirpAln) * (size_t)ns, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(-2, "H2D failed");
+    } else {
+        // ---- bucket by destination rank, per file: records, segments, and for every segment the index of its record inside the (file, destination) block
+        const int F = n_paths;
+        std::vector<std::vector<MirpAln>> brec((size_t)F * W), bseg((size_t)F * W);
+        std::vector<std::vector<int32_t>> bown((size_t)F * W);
+        std::vector<int32_t> newidx;
+        for (int f = 0; f < F; f++)
+            for (auto& ch : P.per_file[f]) {
+                newidx.resize(ch.recs.size());
+                for (size_t k = 0; k < ch.recs.size(); k++) {
+                    auto& b = brec[(size_t)f * W + owner_of_tid[ch.recs[k].tid]];
+                    newidx[k] = (int32_t)b.size();
+                    b.push_back(ch.recs[k]);
+                }
+                for (size_t k = 0; k < ch.segs.size(); k++) {
+                    const size_t q = (size_t)f * W + owner_of_tid[ch.segs[k].tid];
+                    bseg[q].push_back(ch.segs[k]);
+                    bown[q].push_back(newidx[(size_t)ch.seg_owner[k]]);
+                }
+                std::vector<MirpAln>().swap(ch.recs); std::vector<MirpAln>().swap(ch.segs); std::vector<int32_t>().swap(ch.seg_owner);
+            }
+        // counts of every (source, file, destination): cnt[(s * F + f) * W + q] records, then the same for segments
+        std::vector<long long> mine((size_t)2 * F * W), cnt;
+        for (int f = 0; f < F; f++)
+            for (int q = 0; q < W; q++) { mine[(size_t)f * W + q] = (long long)brec[(size_t)f * W + q].size(); mine[(size_t)F * W + (size_t)f * W + q] = (long long)bseg[(size_t)f * W + q].size(); }
+        if (int rc = mirp::dist_allgather_ll(c, mine.data(), 2 * F * W, cnt)) return rc;
+        auto nrec = [&](int s, int f, int q) { return cnt[(size_t)s * 2 * F * W + (size_t)f * W + q]; };
+        auto nseg = [&](int s, int f, int q) { return cnt[(size_t)s * 2 * F * W + (size_t)F * W + (size_t)f * W + q]; };
+        // one blob per destination: [records of file 0..F-1][segments of file 0..F-1][owner indices of file 0..F-1]
+        auto blob_bytes = [&](int s, int q) { long long r = 0, g = 0; for (int f = 0; f < F; f++) { r += nrec(s, f, q); g += nseg(s, f, q); } return r * 16 + g * 16 + g * 4; };
+        std::vector<long long> soff(W), scnt(W), roff(W), rcnt(W);
+        long long stot = 0, rtot = 0;
+        for (int q = 0; q < W; q++) { soff[q] = stot; scnt[q] = blob_bytes(me, q); stot += (scnt[q] + 15) & ~15LL; }
+        for (int s2 = 0; s2 < W; s2++) { roff[s2] = rtot; rcnt[s2] = blob_bytes(s2, me); rtot += (rcnt[s2] + 15) & ~15LL; }
+        for (int s2 = 0; s2 < W; s2++) for (int f = 0; f < F; f++) { n += nrec(s2, f, me); ns += nseg(s2, f, me); }
+        if (n > 0x7fffffffLL) return fail(c, -5, std::string(who) + ": more than 2^31 records on one rank");
+        std::vector<char> sendbuf((size_t)std::max<long long>(stot, 16));
+        for (int q = 0; q < W; q++) {
+            char* w = sendbuf.data() + soff[q];
+            for (int f = 0; f < F; f++) { auto& b = brec[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 16); w += b.size() * 16; }
+            for (int f = 0; f < F; f++) { auto& b = bseg[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 16); w += b.size() * 16; }
+            for (int f = 0; f < F; f++) { auto& b = bown[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 4); w += b.size() * 4; }
+        }
+        brec.clear(); bseg.clear(); bown.clear();
+        TmpDevice T;
+        char* d_send = (char*)T.get((size_t)stot + 16);
+        char* d_recv = (char*)T.get((size_t)rtot + 16);
+        if (!d_send || !d_recv) return fail(c, -6, "device allocation failed (ingest exchange)");
+        if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
+            c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1)))
+            return fail(c, -6, "device allocation failed (ingest)");
+        if (stot) HIPCHK(c, hipMemcpyAsync(d_send, sendbuf.data(), (size_t)stot, hipMemcpyHostToDevice, c->stream));
+        if (int rc = mirp::dist_alltoallv_bytes(c, d_send, soff, scnt, d_recv, roff, rcnt)) return rc;
+        // unpack into (file, source) order; segment owners are re-based to the record's index in this rank's array
+        owner.resize(std::max<size_t>((size_t)ns, 1));
+        std::vector<char> hrecv;        // owner indices come back to the host (tiny unless the input is mostly gapped)
+        std::vector<long long> rbase((size_t)F * W), sbase((size_t)F * W);
+        { long long a = 0, b = 0; for (int f = 0; f < F; f++) for (int s2 = 0; s2 < W; s2++) { rbase[(size_t)f * W + s2] = a; sbase[(size_t)f * W + s2] = b; a += nrec(s2, f, me); b += nseg(s2, f, me); } }
+        std::vector<int32_t> own_tmp;
+        for (int s2 = 0; s2 < W; s2++) {
+            long long ro = roff[s2];
+            long long rsum = 0, gsum = 0;
+            for (int f = 0; f < F; f++) { rsum += nrec(s2, f, me); gsum += nseg(s2, f, me); }
+            long long o_rec = ro, o_seg = ro + rsum * 16, o_own = ro + rsum * 16 + gsum * 16;
+            if (gsum) { own_tmp.resize((size_t)gsum); HIPCHK(c, hipMemcpyAsync(own_tmp.data(), d_recv + o_own, (size_t)gsum * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+            long long go = 0;
+            for (int f = 0; f < F; f++) {
+                const long long r = nrec(s2, f, me), g = nseg(s2, f, me);
+                if (r) HIPCHK(c, hipMemcpyAsync((char*)c->alns.p + rbase[(size_t)f * W + s2] * 16, d_recv + o_rec, (size_t)r * 16, hipMemcpyDeviceToDevice, c->stream));
+                if (g) HIPCHK(c, hipMemcpyAsync((char*)c->segs.p + sbase[(size_t)f * W + s2] * 16, d_recv + o_seg, (size_t)g * 16, hipMemcpyDeviceToDevice, c->stream));
+                for (long long k = 0; k < g; k++) owner[(size_t)(sbase[(size_t)f * W + s2] + k)] = (int32_t)(rbase[(size_t)f * W + s2] + own_tmp[(size_t)(go + k)]);
+                o_rec += r * 16; o_seg += g * 16; go += g;
+            }
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        all = (MirpAln*)std::malloc(std::max<size_t>((size_t)n, 1) * sizeof(MirpAln));
+        segs = (MirpAln*)std::malloc(std::max<size_t>((size_t)ns, 1) * sizeof(MirpAln));
+        if (!all || !segs) return bail(-6, "out of memory");
+    }
     // contig count / lengths decide the key width
     int64_t maxlen = 1;
     for (int64_t l : P.lens) maxlen = std::max(maxlen, l);
     int posbits = 1, tidbits = 1;
     while ((1LL << posbits) <= maxlen + 65536 && posbits < 31) posbits++;
     while ((1LL << tidbits) < (long long)P.names.size() && tidbits < 31) tidbits++;
-    if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
-        c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1)))
-        return bail(-6, "device allocation failed (ingest)");
-    if (n && hipMemcpyAsync(c->alns.p, all, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(-2, "H2D failed");
-    if (ns && hipMemcpyAsync(c->segs.p, segs, sizeof(MirpAln) * (size_t)ns, hipMemcpyHostToDevice, c->stream) != hipSuccess) return bail(-2, "H2D failed");
     if (n_regions > 0 && keep_regions && n > 0) {
         // per-contig slices of the regions, sorted by start, with the running maximum of the ends
-        const int nc = (int)P.names.size();
         std::vector<std::vector<std::pair<int, int>>> by(nc);
         for (int64_t k = 0; k < n_regions; k++)
             if (keep_regions[k].tid >= 0 && keep_regions[k].tid < nc && keep_regions[k].end > keep_regions[k].start)
@@ -436,8 +551,97 @@ extern "C" int mirp_ingest_sams_gpu(mirp_ctx* c, const char* const* paths, int32
     if (fill_meta(P, out)) return bail(-6, "out of memory");
     out->alns = all; out->n_alns = n; out->segs = segs; out->n_segs = ns;
     c->n_alns = n; c->n_segs = ns;
-    c->have_candidate = c->have_fold = false;
+    c->have_candidate = c->have_fold = c->have_result = false;
     c->ingest_resident = true; c->ingest_n_contigs = (int)P.names.size();
     if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = t3 - t2; seconds[3] = t4 - t3; }
+    return 0;
+}
+
+extern "C" int mirp_ingest_sams_gpu(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
+                                    int64_t n_regions, MirpSamData* out, double seconds[4]) {
+    return ingest_impl(c, paths, n_paths, n_threads, keep_regions, n_regions, false, nullptr, out, seconds, "mirp_ingest_sams_gpu");
+}
+
+extern "C" int mirp_ingest_sams_shard(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
+                                      int64_t n_regions, const int32_t* owner_of_tid, MirpSamData* out, double seconds[4]) {
+    return ingest_impl(c, paths, n_paths, n_threads, keep_regions, n_regions, true, owner_of_tid, out, seconds, "mirp_ingest_sams_shard");
+}
+
+// ---- FASTA reader (the host side of `samtools faidx`, MP:1100-1105): name = first word of the header line, sequence lines joined with their
+// surrounding white space stripped, bytes kept as they are (case preserved).  With a `want` list only those sequences are materialised (a rank of
+// a sharded run keeps the contigs it owns); the others are skipped at memchr speed.
+extern "C" void mirp_free_fasta_data(MirpFastaData* d) {
+    if (!d) return;
+    std::free(d->names); std::free(d->len); std::free(d->seq);
+    std::memset(d, 0, sizeof(*d));
+}
+
+extern "C" int mirp_read_fasta(const char* path, const char* const* want, int32_t n_want, MirpFastaData* out, char* errbuf, size_t errbuf_len) {
+    auto failf = [&](const std::string& m) {
+        if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "%s", m.c_str());
+        return -1;
+    };
+    if (!path || !out || n_want < 0 || (n_want > 0 && !want)) return failf("mirp_read_fasta: bad argument");
+    std::memset(out, 0, sizeof(*out));
+    Mapped m;
+    if (!m.open(path)) return failf(std::string("cannot open ") + path);
+    NameTable wt;
+    for (int k = 0; k < n_want; k++) wt.names.push_back(want[k]);
+    if (n_want) wt.build();
+    const char* b = m.p;
+    const char* e = m.p + m.n;
+    // pass 1: record boundaries ('>' at a line start)
+    struct Rec { const char* name; size_t name_len; const char* body; const char* end; bool keep; };
+    std::vector<Rec> recs;
+    const char* s = b;
+    while (s < e) {
+        if (*s == '>') {
+            const char* le = (const char*)memchr(s, '\n', (size_t)(e - s));
+            if (!le) le = e;
+            const char* nb = s + 1;
+            const char* ne = nb;
+            while (ne < le && *ne != ' ' && *ne != '\t' && *ne != '\r' && *ne != '\v' && *ne != '\f') ne++;
+            if (!recs.empty()) recs.back().end = s;
+            Rec r; r.name = nb; r.name_len = (size_t)(ne - nb); r.body = le < e ? le + 1 : e; r.end = e;
+            r.keep = n_want == 0 || wt.find(nb, r.name_len) >= 0;
+            recs.push_back(r);
+            s = r.body;
+        } else {      // next line start that begins with '>': memchr over '>' and check the byte before
+            const char* g = (const char*)memchr(s, '>', (size_t)(e - s));
+            while (g && g > b && g[-1] != '\n') g = (const char*)memchr(g + 1, '>', (size_t)(e - (g + 1)));
+            s = g ? g : e;
+        }
+    }
+    size_t cap = 0, nb = 0;
+    for (auto& r : recs) { nb += r.name_len + 1; if (r.keep) cap += (size_t)(r.end - r.body); }
+    out->names = (char*)std::malloc(std::max<size_t>(nb, 1));
+    out->len = (int64_t*)std::malloc(std::max<size_t>(recs.size(), 1) * sizeof(int64_t));
+    out->seq = (uint8_t*)std::malloc(std::max<size_t>(cap, 1));
+    if (!out->names || !out->len || !out->seq) { mirp_free_fasta_data(out); return failf("out of memory"); }
+    char* w = out->names;
+    uint8_t* q = out->seq;
+    for (size_t k = 0; k < recs.size(); k++) {
+        const Rec& r = recs[k];
+        std::memcpy(w, r.name, r.name_len); w[r.name_len] = 0; w += r.name_len + 1;
+        int64_t L = -1;      // -1: skipped (not wanted)
+        if (r.keep) {
+            const uint8_t* q0 = q;
+            const char* p = r.body;
+            while (p < r.end) {
+                const char* le = (const char*)memchr(p, '\n', (size_t)(r.end - p));
+                if (!le) le = r.end;
+                const char* a = p;
+                const char* z = le;
+                while (a < z && (*a == ' ' || *a == '\t' || *a == '\r' || *a == '\v' || *a == '\f')) a++;
+                while (z > a && (z[-1] == ' ' || z[-1] == '\t' || z[-1] == '\r' || z[-1] == '\v' || z[-1] == '\f')) z--;
+                if (z > a) { std::memcpy(q, a, (size_t)(z - a)); q += z - a; }
+                p = le + 1;
+            }
+            L = (int64_t)(q - q0);
+        }
+        out->len[k] = L;
+    }
+    out->n_contigs = (int32_t)recs.size();
+    out->n_bytes = (int64_t)(q - out->seq);
     return 0;
 }

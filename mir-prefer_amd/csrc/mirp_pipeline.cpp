@@ -97,7 +97,7 @@ extern "C" int mirp_load_genome(mirp_ctx* c, int32_t n_contigs, const int64_t* c
     HIPCHK(c, hipMemcpy(c->clen.p, c->h_clen.data(), 8 * (size_t)n_contigs, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->goff.p, c->h_goff.data(), 8 * (size_t)(n_contigs + 1), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->gboff.p, c->h_gboff.data(), 8 * (size_t)(n_contigs + 1), hipMemcpyHostToDevice));
-    c->have_candidate = c->have_fold = false;
+    c->have_candidate = c->have_fold = c->have_result = false;
     return 0;
 }
 
@@ -115,7 +115,7 @@ extern "C" int mirp_load_alignments(mirp_ctx* c, const MirpAln* alns, int64_t n)
     if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<int64_t>(n, 1))) return fail(c, -6, "device allocation failed (alignments)");
     if (n) HIPCHK(c, hipMemcpy(c->alns.p, alns, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice));
     c->n_alns = n; c->n_segs = 0; c->ingest_resident = false;
-    c->have_candidate = c->have_fold = false;
+    c->have_candidate = c->have_fold = c->have_result = false;
     return 0;
 }
 
@@ -129,7 +129,7 @@ extern "C" int mirp_load_coverage_segments(mirp_ctx* c, const MirpAln* segs, int
     if (c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<int64_t>(n, 1))) return fail(c, -6, "device allocation failed (segments)");
     if (n) HIPCHK(c, hipMemcpy(c->segs.p, segs, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice));
     c->n_segs = n;
-    c->have_candidate = c->have_fold = false;
+    c->have_candidate = c->have_fold = c->have_result = false;
     return 0;
 }
 
@@ -180,7 +180,7 @@ static int clean_coverage(mirp_ctx* c) {
 extern "C" int mirp_set_contig_shard(mirp_ctx* c, int32_t preceded_by_coverage_elsewhere) {
     if (!c) return -1;
     c->shard_first_run_double = preceded_by_coverage_elsewhere ? 1 : 0;
-    c->have_candidate = false; c->have_fold = false;
+    c->have_candidate = false; c->have_fold = false; c->have_result = false;
     return 0;
 }
 
@@ -194,7 +194,7 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
     if (params->cutoff < 2) return fail(c, -1, "Error: READS_DEPTH_CUTOFF should >=2.");
     HIPCHK(c, hipSetDevice(c->device));
     c->cand = *params;
-    c->have_candidate = c->have_fold = false;
+    c->have_candidate = c->have_fold = c->have_result = false;
     const int nc = c->n_contigs;
     if (c->order.ensure(4 * (size_t)nc)) return fail(c, -6, "device allocation failed");
     HIPCHK(c, hipMemcpyAsync(c->order.p, contig_order, 4 * (size_t)nc, hipMemcpyHostToDevice, c->stream));
@@ -598,6 +598,7 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
     int32_t* hst = host_copy<int32_t>(c, c->p_status.p, (size_t)nw);
     if (!hr || !ht || !hn || !hst) { std::free(hr); std::free(ht); std::free(hn); std::free(hst); return fail(c, -2, "D2H failed"); }
     *result = hr; *n_result = nres; *ss_text = ht; *ss_stride = c->fold_stride; *n_passed = hn; *status = hst; *n_windows = nw;
+    c->n_result = nres; c->have_result = true;
     return 0;
 }
 

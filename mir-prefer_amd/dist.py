@@ -1,7 +1,20 @@
 """Contig sharding across ranks and the one exchange step of the path: the gather of the final loci list to rank 0
 (the reference's analogue is `multiprocessing.Queue.put(list)` per piece, /root/reference/miR_PREFeR.py:2461-2499).
-Works over RCCL (`nccl` backend, device tensors) on MI355X and over `gloo` (CPU tensors) in tests."""
+On MI355X the gather runs over RCCL inside libmirprefer.so (mirp_gather_loci / mirp_gather_records on the context's own communicator,
+init_context below); `gather_records` over a `gloo` group is the CPU-side stand-in the tests use."""
 import numpy as np
+
+
+def init_context(ctx, rank, world):
+    """Gives `ctx` its RCCL communicator: rank 0 draws the ncclUniqueId (mirp_dist_unique_id) and the host's own process group -- any backend,
+    `gloo` in the CLI and the bench -- carries the 128 bytes to the other ranks; every rank then joins with mirp_dist_init.  No torch tensor
+    ever touches the GPU here: the process keeps the one HIP runtime and the one RCCL instance of the library."""
+    import torch.distributed as tdist
+    box = [ctx.dist_unique_id() if rank == 0 else None]
+    if world > 1:
+        tdist.broadcast_object_list(box, src=0)
+    ctx.dist_init(box[0], rank, world)
+    return ctx
 
 
 def partition_contigs(contig_lens, world):

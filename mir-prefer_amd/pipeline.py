@@ -61,7 +61,7 @@ class Pipeline:
     """One device context + the option dict; the stage methods can run in one process (pipeline verb) or one per process
     (stage verbs): a stage that finds no device-resident state re-creates it from the previous stages' artefacts."""
 
-    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2", rank=0, world=1):
+    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2", rank=0, world=1, ctx=None):
         """rank / world: contig sharding over one process per GPU (`torch.distributed` initialised by the caller, see cli.py).  Every rank
         runs the stages on its own contigs (dist.partition_contigs); rank 0 merges the artefacts and writes the result files."""
         self.rank, self.world = rank, world
@@ -70,10 +70,13 @@ class Pipeline:
         os.makedirs(dict_option["OUTFOLDER"], exist_ok=True)
         os.makedirs(self.tmp, exist_ok=True)
         self.recovername = os.path.join(self.tmp, dict_option["NAME_PREFIX"] + "_recover")
-        self.ctx = capi.Context(device)
+        self.ctx = ctx if ctx is not None else capi.Context(device)      # ctx: a context that already holds the ranks' RCCL communicator
         self.ctx.set_fold_model(fold_model)
         self.state = None  # None / "candidate" / "fold"
         self.data = None
+        # the context's own RCCL communicator (cli.py / bench.py: mirp_dist_init) carries the data-path exchanges of a sharded run: the record routing
+        # of the ingest and the gather of the loci list.  Without one (ranks that share a GPU in tests) those go through the host's object channel.
+        self.rccl = world > 1 and self.ctx.dist_world() == world
 
     def _p(self, name):
         return os.path.join(self.tmp, name)
@@ -111,16 +114,61 @@ class Pipeline:
         sys.exit(-1)
 
     # ---- prepare (MP:3320-3358): SAM/FASTA ingest replaces sam2bam / cat / sort / expand / strand split
+    def _keep_regions(self, names, lens):
+        """GFF masking (MP:817-859): keep regions as the reference's BED file, applied like `samtools view -L` on the combined records."""
+        gff_ex, gff_in = self.opt.get("GFF_FILE_EXCLUDE", ""), self.opt.get("GFF_FILE_INCLUDE", "")
+        regions = None
+        if gff_ex and os.path.exists(gff_ex):
+            self._say("Removing reads that are overlapped with features in the GFF file.")
+            regions = gffmask.keep_regions_exclude(gff_ex, {n: int(l) for n, l in zip(names, lens)}, 55)
+            if not regions:
+                self._say("!!! No regions need to analyze after excluding regions in the GFF file, stop analyze!")
+                sys.exit(-1)
+        elif gff_in and os.path.exists(gff_in):
+            self._say("GFF_FILE_INCLUDE specified, removing reads that are not overlap with features in the GFF file.")
+            regions = gffmask.keep_regions_include(gff_in, 55)
+            if not regions:
+                self._say("!!! No regions in the GFF_FILE_INCLUDE file or all regions are shorter than 55, stop analyze!")
+                sys.exit(-1)
+        if regions is not None:
+            regions = gffmask.regions_by_tid(regions, names)
+        return regions
+
     def run_prepare(self):
-        """Rank 0 ingests; the other ranks wait on a token FILE, not inside a collective (a cfg5-sized ingest outlasts the NCCL watchdog)."""
+        """One rank: ingest everything.  Several ranks with their own RCCL communicator: every rank tokenizes its byte range of every SAM file, the
+        records travel to the rank that owns their contig (mirp_ingest_sams_shard) and every rank keeps `prepared_<rank>.npz`.  Ranks without a
+        communicator (or compressed inputs): rank 0 ingests, the others wait on a token FILE, not inside a collective (a cfg5-sized ingest outlasts
+        a collective's watchdog), with a liveness check on rank 0."""
+        paths = self.opt["ALIGNMENT_FILE"]
+        if getattr(self, "rccl", False) and not any(str(p).endswith(".gz") for p in paths):
+            return self._prepare_sharded()
         token = self._all_gather("%d.%d" % (os.getpid(), int(time.time() * 1e3)))[0]      # rank 0's token names this run
-        done, failed = self._p("prepare.done." + token), self._p("prepare.failed." + token)
+        done, failed, beat = self._p("prepare.done." + token), self._p("prepare.failed." + token), self._p("prepare.alive." + token)
         if self.rank != 0:
+            # the temporary folder must be shared by all ranks (one node, or a shared file system).  Rank 0 touches the heartbeat file while it
+            # works; a rank 0 that died (OOM kill, SIGKILL) stops doing so and the waiting ranks leave instead of waiting forever.
+            t_start = time.time()
             while not (os.path.exists(done) or os.path.exists(failed)):
                 time.sleep(0.2)
+                try:
+                    age = time.time() - os.path.getmtime(beat)
+                except OSError:
+                    age = time.time() - t_start
+                if age > float(os.environ.get("MIRP_PREPARE_TIMEOUT", "600")):
+                    sys.stderr.write("Error: rank 0 gave no sign of life for %.0f s during the prepare stage (is %s shared by all ranks?); stopping.\n" % (age, self.tmp))
+                    sys.exit(-1)
             if os.path.exists(failed):
                 sys.exit(-1)
             return
+        import threading
+        stop = threading.Event()
+
+        def heartbeat():
+            while not stop.is_set():
+                open(beat, "w").close()
+                stop.wait(5.0)
+        hb = threading.Thread(target=heartbeat, daemon=True)
+        hb.start()
         try:
             self._prepare_rank0()
         except SystemExit:
@@ -129,40 +177,53 @@ class Pipeline:
         except BaseException:
             open(failed, "w").close()
             raise
+        finally:
+            stop.set()
+            hb.join()
         for old in os.listdir(self.tmp):
-            if old.startswith("prepare.done.") or old.startswith("prepare.failed."):
+            if old.startswith("prepare.done.") or old.startswith("prepare.failed.") or old.startswith("prepare.alive."):
                 os.remove(os.path.join(self.tmp, old))
         open(done, "w").close()
+
+    def _prepare_sharded(self):
+        self._say("Starting preparing data for the 'candidate' stage.")
+        paths = self.opt["ALIGNMENT_FILE"]
+        names, lens = ingest.read_sam_header(paths[0])
+        regions = self._keep_regions(names, lens)
+        owner = np.zeros(len(names), dtype=np.int32)
+        for r, part in enumerate(dist.partition_contigs(lens, self.world)):
+            owner[part] = r
+        ok, res = True, None
+        try:
+            res = self.ctx.ingest_sams_shard(paths, owner, regions=regions)
+        except ValueError as e:
+            sys.stderr.write(str(e) + "\n")
+            ok = False
+        self._agree_ok(ok, "prepare")
+        names, lens, samples, alns, segs, self.ingest_seconds = res
+        prepared = self._p("prepared_%d.npz" % self.rank)
+        np.savez(prepared, contig_names=np.array(names, dtype=object), contig_lens=lens, sample_names=np.array(samples, dtype=object), alns=alns,
+                 segs=segs, allow_pickle=True)
+        files = self._all_gather(prepared)
+        if self.rank == 0:
+            d = {"last_stage": "prepare", "finished_stages": {"prepare": {"preparedname": files}}, "files": {"prepare": files}, "world": self.world}
+            _save_recover(self.recovername, d)
+        self._say("Done (prepare stage)\n")
+        self._barrier()
 
     def _prepare_rank0(self):
         _msg("Starting preparing data for the 'candidate' stage.")
         paths = self.opt["ALIGNMENT_FILE"]
         names, lens = ingest.read_sam_header(paths[0])
-        # GFF masking (MP:817-859): keep regions as the reference's BED file, applied like `samtools view -L` on the combined records
-        gff_ex, gff_in = self.opt.get("GFF_FILE_EXCLUDE", ""), self.opt.get("GFF_FILE_INCLUDE", "")
-        regions = None
-        if gff_ex and os.path.exists(gff_ex):
-            _msg("Removing reads that are overlapped with features in the GFF file.")
-            regions = gffmask.keep_regions_exclude(gff_ex, {n: int(l) for n, l in zip(names, lens)}, 55)
-            if not regions:
-                _msg("!!! No regions need to analyze after excluding regions in the GFF file, stop analyze!")
-                sys.exit(-1)
-        elif gff_in and os.path.exists(gff_in):
-            _msg("GFF_FILE_INCLUDE specified, removing reads that are not overlap with features in the GFF file.")
-            regions = gffmask.keep_regions_include(gff_in, 55)
-            if not regions:
-                _msg("!!! No regions in the GFF_FILE_INCLUDE file or all regions are shorter than 55, stop analyze!")
-                sys.exit(-1)
-        if regions is not None:
-            regions = gffmask.regions_by_tid(regions, names)
-        if any(str(p).endswith(".gz") for p in paths):        # compressed inputs: host parser (same rules), host filter and sort
-            names, lens, samples, alns, segs = ingest.read_sams(paths, regions=regions, with_segments=True)
-        else:       # tokenizer on the host threads; keep-region filter and the stable (tid, pos) sort on the GPU (mirp_ingest_sams_gpu)
-            try:
+        regions = self._keep_regions(names, lens)
+        try:
+            if any(str(p).endswith(".gz") for p in paths):        # compressed inputs: host parser (same rules), host filter and sort
+                names, lens, samples, alns, segs = ingest.read_sams(paths, regions=regions, with_segments=True)
+            else:       # tokenizer on the host threads; keep-region filter and the stable (tid, pos) sort on the GPU (mirp_ingest_sams_gpu)
                 names, lens, samples, alns, segs, self.ingest_seconds = self.ctx.ingest_sams(paths, regions=regions)
-            except ValueError as e:
-                sys.stderr.write(str(e) + "\n")
-                sys.exit(-1)
+        except ValueError as e:
+            sys.stderr.write(str(e) + "\n")
+            sys.exit(-1)
         prepared = self._p("prepared.npz")
         np.savez(prepared, contig_names=np.array(names, dtype=object), contig_lens=lens, sample_names=np.array(samples, dtype=object), alns=alns,
                  segs=segs, allow_pickle=True)
@@ -179,23 +240,37 @@ class Pipeline:
                 sys.stderr.write("Error: the stage files in %s were written by a run with %d rank(s); this run has %d. Run the stages with the same "
                                  "number of ranks, or start again from 'prepare'.\n" % (self.tmp, d.get("world", 1), self.world))
             sys.exit(-1)
-        z = np.load(d["finished_stages"]["prepare"]["preparedname"], allow_pickle=True)
+        prep = d["finished_stages"]["prepare"]["preparedname"]
+        sharded = isinstance(prep, (list, tuple))          # one file per rank, each with the records of the rank's own contigs
+        z = np.load(prep[self.rank] if sharded else prep, allow_pickle=True)
         names = [str(x) for x in z["contig_names"]]
-        fa = dict(ingest.read_fasta(self.opt["FASTA_FILE"]))
-        missing = [n for n in names if n not in fa]
+        lens = z["contig_lens"]
+        mine = np.ones(len(names), dtype=bool)
+        if self.world > 1:          # contig sharding: whole contigs per rank, balanced by length
+            mine[:] = False
+            mine[dist.partition_contigs(lens, self.world)[self.rank]] = True
+        # genome: only this rank's contigs are read and uploaded; the others stay in the contig table with length 0 (tids are genome-wide)
+        fasta = self.opt["FASTA_FILE"]
+        if str(fasta).endswith(".gz"):
+            fa = dict(ingest.read_fasta(fasta))
+            have = set(fa)
+        else:
+            got = capi.read_fasta(fasta, want=[n for n, m_ in zip(names, mine) if m_] if self.world > 1 else None)
+            have = set(n for n, _ in got)
+            fa = {n: a for n, a in got if a is not None}
+        missing = [n for n in names if n not in have]
         if missing:          # every rank reads the same files and leaves together
             if self.rank == 0:
                 sys.stderr.write("Error: sequence %s of the SAM header is not in the FASTA file\n" % missing[0])
             sys.exit(-1)
         alns = z["alns"]
         segs = z["segs"] if "segs" in z.files else alns[:0]
-        self.data = {"names": names, "lens": z["contig_lens"], "samples": [str(x) for x in z["sample_names"]], "alns": alns, "alns_all": alns,
-                     "contigs": [(n, fa[n]) for n in names]}
-        if self.world > 1:          # contig sharding: whole contigs per rank, balanced by length
-            mine = np.zeros(len(names), dtype=bool)
-            mine[dist.partition_contigs(self.data["lens"], self.world)[self.rank]] = True
-            self.data["alns"] = alns[mine[alns["tid"]]]
+        if self.world > 1 and not sharded:
+            alns = alns[mine[alns["tid"]]]
             segs = segs[mine[segs["tid"]]]
+        empty = np.zeros(0, dtype=np.uint8)
+        self.data = {"names": names, "lens": lens, "samples": [str(x) for x in z["sample_names"]], "alns": alns,
+                     "contigs": [(n, fa[n] if m_ else empty) for n, m_ in zip(names, mine)]}
         self.ctx.load_genome(self.data["contigs"])
         self.ctx.load_alignments(self.data["alns"])
         if len(segs):
@@ -352,12 +427,27 @@ class Pipeline:
                         for rr in range(self.world):
                             with open(rname + ".part%d" % rr) as fi:
                                 fo.write(fi.read())
-            failed = [m for part in self._all_gather(failed) for m in part]
+            fpay = locus_payloads(failed, dict(self.data["contigs"]), self.data["names"], self.data["alns"], self.data["samples"])
+            gathered = self._all_gather((failed, fpay))
             if self.rank == 0 and os.path.getsize(rname):          # `if failed_reasons:` (MP:3534): the folder exists even when it stays empty
-                fcounts = mirna_read_counts(failed, self.data["names"], self.data["alns_all"], ns)
-                write_readmapping(failed, dict(self.data["contigs"]), self.data["names"], self.data["alns_all"], self.data["samples"], fcounts,
-                                  os.path.join(outdir, "failed_readmapping"))
-        result = [m for part in self._all_gather(result_records(out, self.data["names"])) for m in part]   # rank order, as pieces in the reference
+                failed = [m for part in gathered for m in part[0]]
+                fpay = [x for part in gathered for x in part[1]]
+                write_readmapping(failed, fpay, None, None, self.data["samples"], None, os.path.join(outdir, "failed_readmapping"))
+        # the exchange step of the path (the reference's result queue, MP:2461-2499): the loci list of every rank on rank 0, in rank
+        # order -- over the context's RCCL communicator straight from the device-resident result, or as host objects when the ranks have none.
+        # The rank that owns a locus' contig also prepares what the report files need from the genome and the reads (locus_payloads).
+        local = result_records(out, self.data["names"])
+        adjust_mature_star(local)
+        pay = locus_payloads(local, dict(self.data["contigs"]), self.data["names"], self.data["alns"], self.data["samples"])
+        if self.rccl:
+            g = self.ctx.gather_loci(0)
+            result = result_records(g, self.data["names"]) if self.rank == 0 else []
+            adjust_mature_star(result)
+            payloads = [x for part in self._all_gather(pay) for x in part]
+        else:
+            parts = self._all_gather((local, pay))
+            result = [m for part in parts for m in part[0]]     # rank order, as pieces in the reference
+            payloads = [x for part in parts for x in part[1]]
         if self.rank != 0:
             self._barrier()
             return []
@@ -365,19 +455,20 @@ class Pipeline:
             _msg("0 miRNA identified. No result files generated.")
             self._barrier()
             return result
-        adjust_mature_star(result)
+        order = sorted(range(len(result)), key=lambda k: result[k][:10])      # resultlist.sort() of gen_gff_from_result (MP:2622) names the loci
+        result = [result[k] for k in order]
+        payloads = [payloads[k] for k in order]
         gffname = os.path.join(outdir, prefix + "_miRNA.gff3")
         write_gff(result, gffname)
         maturename = os.path.join(outdir, prefix + "_miRNA.mature.fa")
         stemloopname = os.path.join(outdir, prefix + "_miRNA.precursor.fa")
         ssname = os.path.join(outdir, prefix + "_miRNA.precursor.ss")
-        contigs = dict(self.data["contigs"])
-        write_fasta_ss(result, contigs, maturename, stemloopname, ssname)
-        counts = mirna_read_counts(result, self.data["names"], self.data["alns_all"], ns)
-        write_csv_and_stat(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
+        write_fasta_ss(result, payloads, maturename, stemloopname, ssname)
+        counts = np.stack([x["counts"] for x in payloads])
+        write_csv_and_stat(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
                            os.path.join(outdir, "miRNA.stat.txt"))
-        write_html(result, contigs, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"))
-        write_readmapping(result, contigs, self.data["names"], self.data["alns_all"], self.data["samples"], counts, os.path.join(outdir, "readmapping"))
+        write_html(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"))
+        write_readmapping(result, payloads, None, None, self.data["samples"], counts, os.path.join(outdir, "readmapping"))
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         d = load_recover_file(self.recovername)
@@ -472,6 +563,28 @@ def _revcomp(seq):
     return seq.encode().translate(_RC)[::-1].decode()
 
 
+def _seq(seqs, idx, m, s, e_incl):
+    """Sequence chrom:s-e of locus idx for the report writers.  `seqs` is the genome ({name: uint8 array}) or, in a sharded run, the list of
+    locus payloads (locus_payloads) that the ranks owning the contigs computed: every coordinate the writers ask for lies inside the precursor."""
+    if isinstance(seqs, dict):
+        return _faidx(seqs, m[0], s, e_incl)
+    return seqs[idx]["pre"][s - m[1]:e_incl - m[1] + 1]
+
+
+def locus_payloads(resultlist, contigs, names, alns, samples):
+    """What the report files need from the genome and the reads of every locus of `resultlist`, computed where the locus' contig lives (a rank of
+    a sharded run holds only its own contigs and records): the forward-strand precursor text, the read counts per sample (gen_mirna_info,
+    MP:2644-2728) and the body of the locus' read-mapping file (gen_map_result, MP:2907-2959).  Rank 0 formats the files from these."""
+    counts = mirna_read_counts(resultlist, names, alns, len(samples))
+    tid_of = {n: t for t, n in enumerate(names)}
+    key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
+    out = []
+    for idx, m in enumerate(resultlist):
+        pre = _faidx(contigs, m[0], m[1], m[2] - 1)
+        out.append({"pre": pre, "counts": counts[idx], "map": _readmapping_body(m, pre, contigs[m[0]], tid_of[m[0]], key, alns, samples, counts[idx])})
+    return out
+
+
 def write_fasta_ss(resultlist, contigs, maturename, stemloopname, ssname):
     """gen_mirna_fasta_ss_from_result (MP:2963-3019): mature / precursor FASTA and the structure file with its M/S annotation line."""
     with open(maturename, "w") as fm, open(stemloopname, "w") as fp, open(ssname, "w") as fs:
@@ -479,8 +592,8 @@ def write_fasta_ss(resultlist, contigs, maturename, stemloopname, ssname):
             mirname = "miRNA-precursor_%d" % idx
             matureid = ">%s:%d-%d %s %s" % (m[0], m[3], m[4] - 1, m[8], mirname)
             stemloopid = ">%s:%d-%d %s %s" % (m[0], m[1], m[2] - 1, m[8], mirname)
-            matureseq = _faidx(contigs, m[0], m[3], m[4] - 1)
-            stemloopseq = _faidx(contigs, m[0], m[1], m[2] - 1)
+            matureseq = _seq(contigs, idx, m, m[3], m[4] - 1)
+            stemloopseq = _seq(contigs, idx, m, m[1], m[2] - 1)
             ms, me, ss_, se = m[3] - m[1], m[4] - m[1], m[5] - m[1], m[6] - m[1]
             if ms < ss_:
                 seq_dot = "." * ms + "M" * (me - ms) + "." * (ss_ - me) + "S" * (se - ss_) + "." * (len(stemloopseq) - se)
@@ -517,48 +630,57 @@ def mirna_read_counts(resultlist, names, alns, n_samples):
     return out
 
 
+def _readmapping_body(m, pre_fwd, seq, t, key, alns, samples, counts_k):
+    """Lines of one locus' read-mapping file after its header line (gen_map_result, MP:2907-2959).  The read text is the reference sequence under
+    the alignment (upper case): exact for perfect-match alignments, which is what the reference's own aligner script produces (bowtie -v 0);
+    the ingest keeps coordinates, not read sequences."""
+    pre = _revcomp(pre_fwd) if m[8] == "-" else pre_fwd
+    mlen, slen = m[4] - m[3], m[6] - m[5]
+    out = []
+    lo = np.searchsorted(key, (t << 32) | m[1], side="left")
+    hi = np.searchsorted(key, (t << 32) | m[2], side="left")
+    a = alns[lo:hi]
+    a = a[(a["pos"].astype(np.int64) + a["len"].astype(np.int64) <= m[2]) & (a["strand"] == (1 if m[8] == "-" else 0))]
+    for s, sample in enumerate(samples):
+        out += [">> Read mappings for sample: " + sample, "5'->3'", pre + "\ttotal_mapped_reads=" + str(int(counts_k[s, 0])), m[7]]
+        rs = a[a["sample"] == s]
+        starts = sorted(set(int(p) for p in rs["pos"]), reverse=(m[8] == "-"))
+        for startpos in starts:
+            here = rs[rs["pos"] == startpos]
+            for r in sorted(here, key=lambda r: int(r["len"])):          # stable: alignment order among equal lengths
+                rl = int(r["len"])
+                read = seq[startpos - 1:startpos - 1 + rl].tobytes().decode().upper()
+                pad = "m" if (startpos == m[3] and rl == mlen) else ("s" if (startpos == m[5] and rl == slen) else ".")
+                line = pad * (startpos - m[1]) + read
+                line += pad * (len(pre) - len(line))
+                if m[8] == "-":
+                    line = _revcomp(line).replace("U", "T")
+                line += "\tdepth=%d, length=%d" % (int(r["depth"]), rl)
+                if pad == "m":
+                    line += " [mature]"
+                if pad == "s":
+                    line += " [star]"
+                out.append(line)
+    return out
+
+
 def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder):
     """gen_map_result (MP:2907-2959): one <precursor id>.map.txt per locus with the reads of every sample laid out under the precursor.
-    The read text is the reference sequence under the alignment (upper case): exact for perfect-match alignments, which is what the
-    reference's own aligner script produces (bowtie -v 0); the ingest keeps coordinates, not read sequences."""
+    `contigs` = the genome dict (names / alns / counts are then used) or the list of locus payloads of a sharded run (bodies come ready)."""
     os.makedirs(folder, exist_ok=True)
-    tid_of = {n: t for t, n in enumerate(names)}
-    key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
+    payload = not isinstance(contigs, dict)
+    if not payload:
+        tid_of = {n: t for t, n in enumerate(names)}
+        key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
     for idx, m in enumerate(resultlist):
         mirname = "miRNA-precursor_%d" % idx
-        pre = _faidx(contigs, m[0], m[1], m[2] - 1)
-        mlen, slen = m[4] - m[3], m[6] - m[5]
-        if m[8] == "-":
-            pre = _revcomp(pre)
-        out = [">%s %s:%d-%d %s" % (mirname, m[0], m[1], m[2], m[8])]
-        t = tid_of[m[0]]
-        lo = np.searchsorted(key, (t << 32) | m[1], side="left")
-        hi = np.searchsorted(key, (t << 32) | m[2], side="left")
-        a = alns[lo:hi]
-        a = a[(a["pos"].astype(np.int64) + a["len"].astype(np.int64) <= m[2]) & (a["strand"] == (1 if m[8] == "-" else 0))]
-        seq = contigs[m[0]]
-        for s, sample in enumerate(samples):
-            out += [">> Read mappings for sample: " + sample, "5'->3'", pre + "\ttotal_mapped_reads=" + str(int(counts[idx, s, 0])), m[7]]
-            rs = a[a["sample"] == s]
-            starts = sorted(set(int(p) for p in rs["pos"]), reverse=(m[8] == "-"))
-            for startpos in starts:
-                here = rs[rs["pos"] == startpos]
-                for r in sorted(here, key=lambda r: int(r["len"])):          # stable: alignment order among equal lengths
-                    rl = int(r["len"])
-                    read = seq[startpos - 1:startpos - 1 + rl].tobytes().decode().upper()
-                    pad = "m" if (startpos == m[3] and rl == mlen) else ("s" if (startpos == m[5] and rl == slen) else ".")
-                    line = pad * (startpos - m[1]) + read
-                    line += pad * (len(pre) - len(line))
-                    if m[8] == "-":
-                        line = _revcomp(line).replace("U", "T")
-                    line += "\tdepth=%d, length=%d" % (int(r["depth"]), rl)
-                    if pad == "m":
-                        line += " [mature]"
-                    if pad == "s":
-                        line += " [star]"
-                    out.append(line)
+        head = ">%s %s:%d-%d %s" % (mirname, m[0], m[1], m[2], m[8])
+        if payload:
+            body = contigs[idx]["map"]
+        else:
+            body = _readmapping_body(m, _faidx(contigs, m[0], m[1], m[2] - 1), contigs[m[0]], tid_of[m[0]], key, alns, samples, counts[idx])
         with open(os.path.join(folder, mirname + ".map.txt"), "w") as f:
-            f.write("\n".join(out) + "\n")
+            f.write("\n".join([head] + body) + "\n")
 
 
 def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
@@ -569,9 +691,9 @@ def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
         f.write(head + "".join(s + "," + s + "," + s + "," + s + "," for s in samples) + "\n")
         f.write(head + "reads mapped to precursor, reads mapped to mature, reads mapped to star, reads mapped to antisense region," * len(samples) + "\n")
         for idx, m in enumerate(resultlist):
-            pre = _faidx(contigs, m[0], m[1], m[2] - 1)
-            mat = _faidx(contigs, m[0], m[3], m[4] - 1)
-            star = _faidx(contigs, m[0], m[5], m[6] - 1)
+            pre = _seq(contigs, idx, m, m[1], m[2] - 1)
+            mat = _seq(contigs, idx, m, m[3], m[4] - 1)
+            star = _seq(contigs, idx, m, m[5], m[6] - 1)
             dict_len[len(mat)] = dict_len.get(len(mat), 0) + 1                     # gen_miRNA_stat (MP:2731-2741) uses the forward-strand text
             dict_first[mat[0]] = dict_first.get(mat[0], 0) + 1
             if m[8] == "-":
@@ -607,9 +729,9 @@ def write_html(resultlist, contigs, samples, counts, htmlname):
     dict_len, dict_first = {}, {}
     rows = []
     for idx, m in enumerate(resultlist):
-        pre = _faidx(contigs, m[0], m[1], m[2] - 1)
-        mat = _faidx(contigs, m[0], m[3], m[4] - 1)
-        star = _faidx(contigs, m[0], m[5], m[6] - 1)
+        pre = _seq(contigs, idx, m, m[1], m[2] - 1)
+        mat = _seq(contigs, idx, m, m[3], m[4] - 1)
+        star = _seq(contigs, idx, m, m[5], m[6] - 1)
         dict_len[len(mat)] = dict_len.get(len(mat), 0) + 1                         # forward-strand text, as in the stat file
         dict_first[mat[0]] = dict_first.get(mat[0], 0) + 1
         if m[8] == "-":

@@ -89,10 +89,10 @@ def test_stage_verbs_and_recover(tmp_path):
     assert open(out / "mini_miRNA.gff3").read() == exp["gff3"]
 
 
-def _run_ranks(world, args, port):
+def _run_ranks(world, args, port, backend="gloo"):
     import subprocess
     import sys
-    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MIRP_DIST_BACKEND="gloo")
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MIRP_DIST_BACKEND=backend)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = [subprocess.Popen([sys.executable, "-m", "mir_prefer_amd.cli"] + args, cwd=root,
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -100,12 +100,15 @@ def _run_ranks(world, args, port):
     return [p.returncode for p in procs], logs
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipeline_verb_sharded_over_ranks(world, tmp_path):
-    """Contig sharding: one process per rank (here all on GPU 0, exchanging the small host objects over gloo) must produce the files of the
-    single-process run, -d output included -- and with it the strand-vote quirk at the first run of a shard (mirp_set_contig_shard)."""
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (2, "local"), (3, "local")])
+def test_pipeline_verb_sharded_over_ranks(world, backend, tmp_path):
+    """Contig sharding: one process per rank (here all on GPU 0) must produce the files of the single-process run, -d output included -- and with
+    it the strand-vote quirk at the first run of a shard (mirp_set_contig_shard).  backend gloo: rank 0 ingests, every exchange is a host object;
+    backend local: the library's own exchanges -- the sharded ingest (every rank tokenizes a byte range of every SAM file, records are routed
+    to the contig's owner: mirp_ingest_sams_shard) and the gather of the loci list (mirp_gather_loci) -- over the transport for ranks that share
+    a GPU (on a multi-GPU node the same calls run over RCCL)."""
     exp, cfg, out = _setup("mini", tmp_path)
-    codes, logs = _run_ranks(world, ["-k", "-d", "--device", "0", "pipeline", cfg], 29517 + world)
+    codes, logs = _run_ranks(world, ["-k", "-d", "--device", "0", "pipeline", cfg], 29517 + world + (10 if backend == "local" else 0), backend)
     assert all(c == 0 for c in codes), logs
     prefix = exp["config"]["NAME_PREFIX"]
     tmp = out / (prefix + "_tmp")
@@ -129,7 +132,21 @@ def test_pipeline_verb_sharded_over_ranks(world, tmp_path):
         got += open(tmp / (prefix + ".rnalfold.in_%d.fa" % r)).read().splitlines()
     want = [x for p in exp["pieces"] for e in p["fasta"] for x in e]
     assert sorted(got) == sorted(want) and len(got) == len(want)
-    assert pipeline.load_recover_file(str(tmp / (prefix + "_recover")))["world"] == world
+    rec = pipeline.load_recover_file(str(tmp / (prefix + "_recover")))
+    assert rec["world"] == world
+    if backend == "local":          # one prepared file per rank, each holding only the records of the rank's own contigs
+        import numpy as np
+        from mir_prefer_amd import dist
+        files = rec["finished_stages"]["prepare"]["preparedname"]
+        assert len(files) == world
+        z0 = np.load(files[0], allow_pickle=True)
+        parts = dist.partition_contigs(z0["contig_lens"], world)
+        total = 0
+        for r, fn in enumerate(files):
+            a = np.load(fn, allow_pickle=True)["alns"]
+            assert set(np.unique(a["tid"]).tolist()) <= set(parts[r])
+            total += len(a)
+        assert total == sum(len(gu.load_pipeline_case("mini")["alns"]) for _ in range(1))
 
 
 def test_sharded_run_fails_on_every_rank_together(tmp_path):

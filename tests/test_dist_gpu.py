@@ -1,0 +1,134 @@
+"""GPU tests of the multi-GPU entry points of the C-ABI (include/mirprefer.h, "Multi-GPU"): the library's own RCCL communicator (first execution of
+librccl through mirp_dist_init on the one GPU of the box), the gather of the loci list (mirp_gather_loci, the reference's result queue
+MP:2461-2499) and the sharded SAM ingest (mirp_ingest_sams_shard, replaces the serial prepare_data MP:772-874) with several ranks on one GPU
+over the local transport."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mir_prefer_amd import capi, dist, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dataset(tmp_path, seed=5):
+    ds = synth.make_dataset([90000, 40000, 70000, 20000, 55000], 90, n_samples=3, seed=seed, contig_names=["c3", "c1", "c5", "c2", "c4"], edge_cases=True)
+    return ds, ds.write_sams(str(tmp_path))
+
+
+def test_rccl_communicator_world1_gather_and_ingest(tmp_path):
+    """ncclGetUniqueId / ncclCommInitRank / all-reduce / all-gather / grouped send-recv paths of the library at world = 1 on the GPU, and the
+    loci gather straight from the device-resident result: equal to what mirp_predict returned."""
+    ds, sams = _dataset(tmp_path)
+    ctx = capi.Context(0)
+    ctx.dist_init(ctx.dist_unique_id(), 0, 1)
+    assert ctx.dist_world() == 1
+    ctx.dist_barrier()
+    assert ctx.dist_allreduce_sum([3, -4, 1 << 40]).tolist() == [3, -4, 1 << 40]
+    rec = np.arange(35, dtype=np.int32).reshape(7, 5)
+    assert (ctx.gather_records(rec) == rec).all()
+    assert len(ctx.gather_records(rec[:0])) == 0
+    # sharded ingest with one rank == plain device ingest
+    names, lens, samples, alns, segs, _ = ctx.ingest_sams_shard(sams, np.zeros(len(ds.contig_names), dtype=np.int32))
+    ref = capi.Context(0)
+    n2, l2, s2, a2, g2, _ = ref.ingest_sams(sams)
+    assert names == n2 and samples == s2 and (lens == l2).all() and alns.tobytes() == a2.tobytes() and segs.tobytes() == g2.tobytes()
+    ref.close()
+    ctx.load_genome(ds.contigs)
+    order = np.argsort(np.array(names, dtype=object), kind="stable").astype(np.int32)
+    ctx.candidate(10, 100, 300, order)
+    ctx.fold(300)
+    out = ctx.predict(3, 18, 23, False, True)
+    g = ctx.gather_loci(0)
+    assert len(out["result"]) > 3
+    assert g["result"].tobytes() == out["result"].tobytes() and g["ss"] == out["ss"]
+    ctx.dist_finalize()
+    ctx.close()
+
+
+_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from mir_prefer_amd import capi, dist, synth
+rank, world, xdir, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+sams = sys.argv[6:]
+ctx = capi.Context(0)
+ctx.dist_init_local(xdir, rank, world)
+names, lens = None, None
+from mir_prefer_amd import ingest
+names, lens = ingest.read_sam_header(sams[0])
+owner = np.zeros(len(names), dtype=np.int32)
+for r, part in enumerate(dist.partition_contigs(lens, world)):
+    owner[part] = r
+regions = json.load(open(os.path.join(out, "regions.json")))
+cn, cl, sn, alns, segs, sec = ctx.ingest_sams_shard(sams, owner, regions=regions or None)
+np.savez(os.path.join(out, "shard_%d.npz" % rank), alns=alns, segs=segs, owner=owner)
+tot = ctx.dist_allreduce_sum([len(alns), rank])
+g = ctx.gather_records(np.full((rank + 2, 3), rank, dtype=np.int32), dst=world - 1)
+if rank == world - 1:
+    np.save(os.path.join(out, "gathered.npy"), g)
+np.save(os.path.join(out, "tot_%d.npy" % rank), tot)
+ctx.dist_barrier()
+ctx.close()
+"""
+
+
+@pytest.mark.parametrize("world,with_regions", [(2, False), (3, True), (4, False)])
+def test_sharded_ingest_equals_single_rank_ingest(world, with_regions, tmp_path):
+    """Every rank tokenizes its own byte range of every SAM file; after the all-to-all each rank holds exactly the single-process ingest's
+    records of its contigs, in the same order (ties included: the stable sort sees file-then-offset order), with gapped reads' coverage
+    segments following their records -- with and without GFF keep regions."""
+    rng = np.random.default_rng(3)
+    ds, sams = _dataset(tmp_path, seed=11)
+    # a few gapped alignments, so that segments and their owner indices travel too
+    extra = tmp_path / "s_gapped.sam"
+    lines = open(sams[0]).read().splitlines()
+    head = [l for l in lines if l.startswith("@")]
+    body = [l for l in lines if not l.startswith("@")]
+    sname = body[0].split("\t")[0].rsplit("_", 2)[0]
+    gl = []
+    for k in range(200):
+        t = int(rng.integers(0, len(ds.contig_names)))
+        pos = int(rng.integers(1, ds.contig_lens[t] - 200))
+        gl.append("%s_r%d_x%d\t%d\t%s\t%d\t255\t10M%dN11M\t*\t0\t0\t%s\t*" % (sname, 900000 + k, int(rng.integers(1, 30)), 16 if k % 3 == 0 else 0,
+                                                                             ds.contig_names[t], pos, int(rng.integers(1, 90)), "A" * 21))
+    mixed = body + gl
+    perm = rng.permutation(len(mixed))
+    extra.write_text("\n".join(head + [mixed[k] for k in perm]) + "\n")
+    sams = [str(extra)] + sams[1:]
+    regions = []
+    if with_regions:
+        regions = [[0, 1000, 30000], [0, 50000, 51000], [2, 0, 70000], [4, 100, 25000], [3, 5000, 5100]]
+    import json
+    (tmp_path / "regions.json").write_text(json.dumps(regions))
+    xdir = tmp_path / "x"
+    xdir.mkdir()
+    wk = tmp_path / "worker.py"
+    wk.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(wk), ROOT, str(r), str(world), str(xdir), str(tmp_path)] + sams, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    ctx = capi.Context(0)
+    _, lens, _, alns, segs, _ = ctx.ingest_sams(sams, regions=regions or None)
+    ctx.close()
+    assert len(segs) > 100
+    parts = dist.partition_contigs(lens, world)
+    seen = 0
+    for r in range(world):
+        z = np.load(tmp_path / ("shard_%d.npz" % r))
+        mine = np.isin(alns["tid"], parts[r])
+        assert z["alns"].tobytes() == alns[mine].tobytes(), r
+        want_segs = segs[np.isin(segs["tid"], parts[r])]
+        key = lambda a: sorted(a.tolist())        # segments are an unordered side array
+        assert key(z["segs"]) == key(want_segs), r
+        seen += len(z["alns"])
+        assert np.load(tmp_path / ("tot_%d.npy" % r)).tolist() == [len(alns), world * (world - 1) // 2]
+    assert seen == len(alns)
+    g = np.load(tmp_path / "gathered.npy")
+    assert g.tolist() == [[r] * 3 for r in range(world) for _ in range(r + 2)]

@@ -272,3 +272,22 @@ def test_prepare_stage_applies_gff_exclude_mask(tmp_path):
     assert np.array_equal(z["alns"], want) and 0 < len(want) < len(alns)
     inside = (z["alns"]["tid"] == names.index("cB")) & (z["alns"]["pos"] > 2100) & (z["alns"]["pos"] + z["alns"]["len"] < 11900)
     assert not inside.any()                               # nothing survives strictly inside the merged excluded block
+
+
+def test_native_fasta_reader_matches_the_python_reader(tmp_path):
+    """mirp_read_fasta (host-only entry point of the library; replaces the genome access of `samtools faidx`, MP:1100-1105): names = first word
+    of the header, lines joined with surrounding white space stripped, case kept; with a want list the other sequences are skipped."""
+    from mir_prefer_amd import capi, ingest
+    fa = tmp_path / "g.fa"
+    fa.write_bytes(b">chrB some description\nACGTacgtNN\r\n  ACGT  \n\nTT\n>chrA\n>chrC\tx\nGGGG>notaheader\nCC\n>last\nA")
+    py = ingest.read_fasta(str(fa))
+    nat = capi.read_fasta(str(fa))
+    assert [n for n, _ in nat] == [n for n, _ in py] == ["chrB", "chrA", "chrC", "last"]
+    for (_, a), (_, b) in zip(nat, py):
+        assert a.tobytes() == b.tobytes()
+    assert nat[0][1].tobytes() == b"ACGTacgtNNACGTTT" and nat[1][1].tobytes() == b"" and nat[2][1].tobytes() == b"GGGG>notaheaderCC"
+    part = capi.read_fasta(str(fa), want=["chrC", "chrB"])
+    assert [n for n, _ in part] == ["chrB", "chrA", "chrC", "last"]
+    assert part[0][1].tobytes() == b"ACGTacgtNNACGTTT" and part[1][1] is None and part[2][1].tobytes() == b"GGGG>notaheaderCC" and part[3][1] is None
+    with pytest.raises(ValueError):
+        capi.read_fasta(str(tmp_path / "missing.fa"))
