@@ -2,21 +2,31 @@
 """Benchmark of the candidate -> fold -> predict hot path on MI355X.
 
 Metric (BASELINE.json): precursor windows folded+filtered per second at L = 300, inputs resident in HBM; end-to-end wall-clock beside it.
-A step = one pass of the whole hot path (coverage scan -> peaks -> windows -> payload -> local fold -> filter -> loci list) over one
-synthetic batch.  Workload at N = 1: BASELINE config[1], an A. thaliana chr1-sized contig (30,427,671 bp), 1 sample, L = 300,
-12,000 synthetic loci (~20 k windows), SURVEY.md 8d.  For N > 1 every rank owns one such contig (contig sharding, weak scaling) and the
-final loci lists are gathered to rank 0 over RCCL.
+A step = one pass of the whole hot path (coverage scan -> peaks -> windows -> payload -> local fold -> filter -> loci list -> gather of the loci
+list) over one synthetic batch.  Workloads (`--workload`, numbered like BASELINE.json `configs`):
+  config1 (default, the headline) A. thaliana chr1-sized contig (30,427,671 bp), 1 sample, 12,000 synthetic loci (~20 k windows) PER GPU:
+          weak scaling, rank r owns contig Chr<r+1>;
+  config2 TAIR10-sized genome, 5 contigs, 3 samples (~72 k windows);
+  config3 MSU7-sized genome, 12 contigs (373 Mb), 4 samples (~240 k windows), contigs dealt to the ranks longest-first;
+  config4 64 contigs x 31.25 Mb = 2 Gb, 2 x 10^8 packed alignment records, ~2 M windows (meant for 8 GPUs: a rank's shard is 8 contigs).
+config2-4 are fixed-size jobs sharded by contig ("strong" scaling); every rank generates and holds only its own contigs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: re-launches itself under torch.distributed.run before any GPU call)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload configX]      (N > 1: re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU; host objects and the timing barrier go over a CPU-side `gloo` group, the data path's one exchange step (the
+gather of the loci list, mirp_gather_loci) over RCCL on the library's own communicator.  torch never touches the GPU in this process, so it
+holds a single HIP runtime; every C-ABI call returns after its stream has drained, which is the device synchronisation of the timed region.
 
 The JSON line carries, beside the contract's keys:
   roofline       the dominant kernel (fold_lds_kernel, the dynamic program) against the roof that bounds it -- integer min-plus relaxations
-                 out of LDS, LDS-read / VALU-issue bound, both roofs micro-benchmarked on this GPU in this run (mirp_microbench);
+                 out of LDS: `peak` is the measured conflict-free ds_read_b32 rate of this GPU (mirp_microbench), `peak_guide` the figure of
+                 MI355X_MICROARCH.md (75 TB/s of ds_read_b32 = 9.4e12 relaxations/s at 8 B per relaxation), fractions against both;
   roofline_hbm   the HBM view north_star asks for (algorithmic bytes / measured time / 8 TB/s), expected << 1 for an LDS-resident DP;
-  roofline_coverage  the one HBM-bound stage (memset + scatter + scan);
-  cpu_baseline   the CPU oracle (the build's own restatement of the reference, "port") timed on this box AFTER the GPU timing: 1-thread and
-                 one-process-per-physical-core legs over candidate + fold + filter;
+  roofline_coverage  the one HBM-bound stage (scatter + scan + clearing of the written positions);
+  configs        (N = 1, default workload) config2 on the same GPU, the vienna-1.8.5 model, and the fold micro-benchmark of SURVEY.md 8d
+                 (2^16 windows, n = L = 300: uniform / 50 % planted hairpins / GC = 0.65) with generic-fallback counts per family;
+  cpu_baseline   the CPU oracle (the build's own restatement of the reference, "port") timed on this box AFTER the GPU timing;
   e2e            the CLI `pipeline` verb on files of the same workload (SAM + FASTA in -> gff3 and reports out), wall-clock by stage.
 """
 import argparse
@@ -33,6 +43,58 @@ CHR1_LEN = 30427671
 N_LOCI = 12000
 CUT, GAP, L = 10, 100, 300
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDS_GUIDE_RELAX_PER_S = 75e12 / 8.0      # MI355X_MICROARCH.md (LDS): ~75 TB/s aggregate for ds_read_b32; one relaxation = two 4-byte reads
+LOCI_PER_BP = N_LOCI / float(CHR1_LEN)   # every workload plants loci at the density of the headline one
+TAIR10 = [30427671, 19698289, 23459830, 18585056, 26975502]
+MSU7 = [43300000, 35900000, 36400000, 35500000, 30000000, 31200000, 29700000, 28400000, 23000000, 23200000, 29000000, 27500000]
+
+
+def workload_specs(name, world, genome=CHR1_LEN, loci=N_LOCI):
+    """-> (contig specs [(name, length, loci, seed)], n_samples, background records per contig, scaling, description)"""
+    if name == "config1":
+        return ([("Chr%d" % (r + 1), genome, loci, 2 + r) for r in range(world)], 1, 0, "weak",
+                "BASELINE config[1]: A. thaliana chr1-sized contig per GPU (%d bp), 1 sample, L=300, %d synthetic loci per contig" % (genome, loci))
+    if name == "config2":
+        return ([("Chr%d" % (t + 1), l, int(round(l * LOCI_PER_BP)), 30 + t) for t, l in enumerate(TAIR10)], 3, 0, "strong",
+                "BASELINE config[2]: TAIR10-sized genome (5 contigs, 119,146,348 bp), 3 samples, L=300")
+    if name == "config3":
+        return ([("Chr%d" % (t + 1), l, int(round(l * LOCI_PER_BP)), 50 + t) for t, l in enumerate(MSU7)], 4, 0, "strong",
+                "BASELINE config[3]: MSU7-sized genome (12 contigs, 373 Mb), 4 samples, L=300, contigs dealt to the ranks longest-first")
+    if name == "config4":
+        return ([("ctg%02d" % t, 31250000, 19000, 100 + t) for t in range(64)], 1, 3125000, "strong",
+                "BASELINE config[4]: 64 contigs x 31.25 Mb = 2 Gb, 2e8 packed alignment records, L=300, contigs dealt to the ranks")
+    raise SystemExit("unknown workload " + name)
+
+
+def build_shard(specs, owned, n_samples, background):
+    """The contigs `owned` of a workload as this rank holds them: contig table over ALL contigs (the others with length 0, tids are genome-wide),
+    records of the owned contigs sorted by (tid, pos) in sample order.  Every contig is generated from its own seed, so the union over the ranks
+    does not depend on how many ranks there are."""
+    import numpy as np
+    from mir_prefer_amd import synth
+    contigs, parts = [], []
+    for t, (name, length, loci, seed) in enumerate(specs):
+        if t not in owned:
+            contigs.append((name, np.zeros(0, dtype=np.uint8)))
+            continue
+        ds = synth.make_dataset([length], loci, n_samples=n_samples, seed=seed, contig_names=[name])
+        a = ds.alns
+        if background:      # config4: packed records generated directly -- single reads scattered over the contig, far below the depth cutoff
+            rng = np.random.RandomState(seed + 7919)
+            b = np.zeros(background - len(a), dtype=synth.ALN_DTYPE)
+            b["pos"] = rng.randint(1, length - 30, size=len(b))
+            b["depth"] = 1
+            b["len"] = rng.randint(18, 26, size=len(b))
+            b["strand"] = rng.randint(0, 2, size=len(b))
+            b["sample"] = rng.randint(0, n_samples, size=len(b))
+            a = np.concatenate([a, b])
+        a = a[np.lexsort((np.arange(len(a)), a["sample"]))]
+        a = a[np.argsort(a["pos"], kind="stable")]
+        a["tid"] = t
+        parts.append(a)
+        contigs.append((name, ds.contigs[0][1]))
+    alns = np.concatenate(parts) if parts else np.zeros(0, dtype=synth.ALN_DTYPE)
+    return contigs, alns, ["S%d" % (k + 1) for k in range(n_samples)]
 
 
 def parse_args():
@@ -40,8 +102,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--loci", type=int, default=N_LOCI)
-    ap.add_argument("--genome", type=int, default=CHR1_LEN)
+    ap.add_argument("--workload", default="config1", choices=["config1", "config2", "config3", "config4", "cfg1", "cfg2", "cfg3", "cfg4"],
+                    help="BASELINE.json configs[k] (cfgK = configK); config1 is the headline and the default")
+    ap.add_argument("--loci", type=int, default=N_LOCI, help="config1: loci per contig")
+    ap.add_argument("--genome", type=int, default=CHR1_LEN, help="config1: contig length")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (config2, vienna-1.8.5, fold micro-benchmark)")
+    ap.add_argument("--micro-windows", type=int, default=1 << 16, help="windows per family of the fold micro-benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of wall-clock per CPU-baseline leg")
@@ -278,8 +344,57 @@ def ingest_leg(ctx, n_records):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
+def micro_families(n_windows, n=300, seed=99):
+    """The three sequence families of the fold micro-benchmark: uint8 ASCII matrices [n_windows, n]."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    acgu = np.frombuffer(b"ACGU", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGU", b"UGCA"):
+        comp[a] = b
+    uni = acgu[rng.randint(0, 4, size=(n_windows, n))]
+    hp = acgu[rng.randint(0, 4, size=(n_windows, n))]
+    for w in range(0, n_windows, 2):          # every second window carries one planted imperfect hairpin (arm 24-34, loop 6-40, 0-4 arm mismatches)
+        arm, loop = int(rng.randint(24, 35)), int(rng.randint(6, 41))
+        a = acgu[rng.randint(0, 4, size=arm)]
+        b = comp[a[::-1]].copy()
+        for _ in range(int(rng.randint(0, 5))):
+            b[rng.randint(0, arm)] = acgu[rng.randint(0, 4)]
+        h = np.concatenate([a, acgu[rng.randint(0, 4, size=loop)], b])
+        o = int(rng.randint(0, n - len(h) + 1))
+        hp[w, o:o + len(h)] = h
+    gc = acgu[rng.choice(4, size=(n_windows, n), p=[0.175, 0.325, 0.325, 0.175])]
+    return [("uniform", uni), ("planted_hairpins_50pct", hp), ("gc_0.65", gc)]
+
+
+def fold_microbench(ctx, n_windows):
+    import numpy as np
+    out = {}
+    for name, mat in micro_families(n_windows):
+        nw, n = mat.shape
+        offs = np.arange(nw + 1, dtype=np.int64) * n
+        blob = np.ascontiguousarray(mat).reshape(-1)
+        ctx.fold_batch_summary(blob[:n * 512], offs[:513], L)          # warm-up
+        t = time.time()
+        nl, mfe, st = ctx.fold_batch_summary(blob, offs, L)
+        wall = time.time() - t
+        km = ctx.last_fold_kernel_ms()
+        ns = min(nw, 4096)
+        R = relaxation_count(blob, offs[:ns], np.full(ns, n, dtype=np.int64), L)
+        r_tot = R["total"] * nw / ns
+        fb = int(ctx.last_fold_fallbacks())
+        out[name] = {"windows": int(nw), "windows_per_s": nw / wall, "wall_s": wall, "fill_kernel_ms": km[0], "epilogue_kernel_ms": km[1],
+                     "relaxations": r_tot, "T_relaxations_per_s_fill": (r_tot / (km[0] / 1e3) / 1e12) if km[0] > 0 else None,
+                     "generic_fallback_windows": fb, "line_overflow_windows": int((st == 1).sum()), "failed_windows": int((st < 0).sum()),
+                     "mean_mfe_kcal": float(mfe.mean()) / 100.0, "mean_structure_lines": float(nl.mean())}
+    out["note"] = ("mirp_fold_batch_summary on 2^16 windows of n = L = 300 per family, sequences uploaded from the host, structure text left on the device; wall includes "
+                   "the upload and the generic re-fold of the windows the LDS-resident kernel hands back (16-bit energy range); relaxations counted on the first 4096 windows")
+    return out
+
+
 def main():
     a = parse_args()
+    a.workload = a.workload.replace("cfg", "config")
     if a.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start one worker process per GPU under torch.distributed.run BEFORE anything touches the GPU
         # (no HIP call has happened in this process; it only waits for the child and passes its exit code on)
@@ -291,42 +406,36 @@ def main():
         sys.exit(subprocess.call(cmd, env=env))
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
     from mir_prefer_amd import capi, synth
     from mir_prefer_amd import dist as mdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    tdist = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        world = dist.get_world_size()
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    # ---- synthetic workload: one chr1-sized contig per rank (contig sharding)
-    ds = synth.make_dataset([a.genome], a.loci, n_samples=1, seed=2 + rank, contig_names=["Chr%d" % (rank + 1)])
-    alns = ds.sorted_alns()
-    order = np.zeros(1, dtype=np.int32)
-    ctx = capi.Context(local_rank)
+        tdist = mdist.init_host_group()          # CPU-side gloo group only: host objects and the timing barrier (torch never touches the GPU here)
+        world = tdist.get_world_size()
+    share_dir = os.environ.get("MIRP_BENCH_SHARE_GPU")      # dev: all ranks on GPU 0, the library's exchanges over its local transport (a directory)
+    ctx = capi.Context(0 if share_dir else local_rank)
+    if world > 1 and share_dir:
+        ctx.dist_init_local(share_dir, rank, world)
+    elif world > 1:
+        mdist.init_context(ctx, rank, world)        # the library's RCCL communicator, one rank per GPU
     ctx.set_fold_model(a.fold_model)
-    ctx.load_genome(ds.contigs)
-    ctx.load_alignments(alns)
 
-    def gather_loci(out):
-        """Final loci list to rank 0 over RCCL (mir_prefer_amd.dist.gather_records: all_gather of counts, gather of padded 64-B records)."""
-        rec = np.zeros((len(out["result"]), 16), dtype=np.int32)
-        if len(out["result"]):
-            rec[:] = np.frombuffer(out["result"].tobytes(), dtype=np.int32).reshape(-1, 16)
-        if world == 1:
-            return rec.shape[0]
-        allrec = mdist.gather_records(rec, device=dev, dst=0)
-        n_all = torch.tensor([0 if allrec is None else allrec.shape[0]], device=dev, dtype=torch.int64)
-        dist.broadcast(n_all, src=0)
-        return int(n_all.item())
+    # ---- synthetic workload: every rank generates and holds only the contigs it owns
+    specs, n_samples, background, scaling, desc = workload_specs(a.workload, world, a.genome, a.loci)
+    if a.workload == "config1":
+        owned = [rank]
+    else:
+        owned = mdist.partition_contigs([sp[1] for sp in specs], world)[rank]
+    contigs, alns, sample_names = build_shard(specs, set(owned), n_samples, background)
+    names = [n for n, _ in contigs]
+    order = np.argsort(np.array(names, dtype=object), kind="stable").astype(np.int32)
+    ctx.load_genome(contigs)
+    ctx.load_alignments(alns)
 
     fb = [0, 0]
 
@@ -334,15 +443,20 @@ def main():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)
         ctx.fold(L)
         fb[0], fb[1] = ctx.last_fold_fallbacks(), ctx.last_fold_overflow()
-        out = ctx.predict(1, 18, 23, False, True)
-        total = gather_loci(out)
+        out = ctx.predict(n_samples, 18, 23, False, True)
+        if world > 1:          # the exchange step of the path: loci lists of all ranks on rank 0, over RCCL from the device-resident result
+            g = ctx.gather_loci(0)
+            total = len(g["result"])
+        else:
+            total = len(out["result"])
         return nwin, total, ctx.last_timings(), ctx.last_fold_kernel_ms()
 
     def sync():
-        torch.cuda.synchronize()
+        # every C-ABI call above returns after its stream has drained; across ranks: a RCCL reduction on the library's communicator and the
+        # CPU-side barrier
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            ctx.dist_barrier()
+            tdist.barrier()
 
     for _ in range(a.warmup):
         step()
@@ -354,14 +468,18 @@ def main():
         nwin, nres, tm, km = step()
         fold_ms.append(tm["fold_ms"]); cov_ms.append(tm["coverage_ms"]); rest_ms.append(tm["candidate_rest_ms"]); pred_ms.append(tm["predict_ms"])
         fill_ms.append(km[0]); epi_ms.append(km[1])
+    t_own = time.time() - t0          # this rank's own K steps (before waiting for the others)
     sync()
     elapsed = time.time() - t0
+    ranks = None
     if world > 1:
-        t = torch.tensor([elapsed, float(nwin)], device=dev, dtype=torch.float64)
-        tl = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(tl, t)
-        elapsed = max(float(x[0].item()) for x in tl)
-        total_windows = sum(float(x[1].item()) for x in tl)
+        box = [None] * world
+        tdist.all_gather_object(box, (elapsed, float(nwin), t_own, len(alns), len(owned)))
+        elapsed = max(x[0] for x in box)
+        total_windows = sum(x[1] for x in box)
+        ranks = {"own_ms_per_step": [1e3 * x[2] / a.steps for x in box], "windows": [int(x[1]) for x in box], "alignments": [int(x[3]) for x in box],
+                 "contigs": [int(x[4]) for x in box]}
+        ranks["max_over_mean_time"] = max(ranks["own_ms_per_step"]) / (sum(ranks["own_ms_per_step"]) / world)
     else:
         total_windows = float(nwin)
 
@@ -374,9 +492,13 @@ def main():
         W = wins["windows"]
         lens = W["seq_len"].astype(np.int64)
         # ---- dominant kernel: the fill kernel (dynamic program).  Unit of algorithmic work = one relaxation; R is counted
-        # exactly for this batch from its pair-type counts.  Roofs measured on this GPU now: LDS = 2 reads per relaxation at the measured
-        # conflict-free ds_read rate, VALU = 3 integer lane-operations per relaxation at the measured 32-bit issue rate.
-        R = relaxation_count(wins["seq"], W["seq_off"].astype(np.int64), lens, L)
+        # exactly for this rank's batch from its pair-type counts (a sample of 20,000 windows, scaled, when the batch is larger).  Roofs:
+        # LDS = 2 reads per relaxation at the ds_read_b32 rate -- measured on this GPU now, and the microarchitecture guide's figure beside it;
+        # VALU = 3 integer lane-operations per relaxation at the measured 32-bit issue rate.
+        nsmp = min(len(W), 20000)
+        R = relaxation_count(wins["seq"], W["seq_off"].astype(np.int64)[:nsmp], lens[:nsmp], L)
+        if nsmp < len(W):
+            R = {k: v * len(W) / nsmp for k, v in R.items()}
         mb = ctx.microbench()
         lds_roof = mb["ds_read_b32_per_s"] * 64.0 / 2.0
         valu_roof = mb["valu_u32_per_s"] * 64.0 / 3.0
@@ -390,50 +512,104 @@ def main():
             prof = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
         except Exception:
             pass
-        same_workload = a.genome == CHR1_LEN and a.loci == N_LOCI and a.fold_model == "vienna-2.1.2"
+        headline = a.workload == "config1" and a.genome == CHR1_LEN and a.loci == N_LOCI
+        same_workload = headline and a.fold_model == "vienna-2.1.2"
         traffic = prof.get("fold_fill_hbm_bytes_per_launch") if same_workload else None
-        g_tot = float(a.genome + 1)
+        g_tot = float(sum(len(sq) + 1 for _, sq in contigs))
         b_cov = 16.0 * len(alns) + 16.0 * g_tot
-        line = {
+        b_cov_moved = 48.0 * len(alns) + 8.0 * g_tot      # what the stage moves since the clearing pass is gone: the scan reads 8 B per position; a record is
+        line = {                                           # read by the scatter and by the un-scatter (16 B each) and touches 2 x 2 x 4 B of the arrays
             "metric": "precursor windows folded+filtered/sec (L=300)", "value": total_windows * a.steps / elapsed, "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int16/int32 (energies in 0.01 kcal/mol)", "data": "synthetic",
-            "config": {"workload": "BASELINE config[1]: A. thaliana chr1-sized contig per GPU (%d bp), 1 sample, L=300, %d synthetic loci -> %d windows/GPU; "
-                                   "candidate+fold+predict, inputs resident in HBM" % (a.genome, a.loci, nwin),
-                       "windows_per_gpu": int(nwin), "loci_found": int(nres), "alignments_per_gpu": int(len(alns)),
+            "scaling": scaling, "vs_baseline": None, "dtype": "int16/int32 (energies in 0.01 kcal/mol)", "data": "synthetic",
+            "config": {"workload": desc + "; candidate+fold+predict(+gather of the loci list), inputs resident in HBM",
+                       "name": a.workload, "windows_total": int(total_windows), "windows_rank0": int(nwin), "loci_found": int(nres),
+                       "alignments_rank0": int(len(alns)), "contigs_rank0": len(owned), "samples": n_samples,
                        "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)" if a.fold_model == "vienna-2.1.2" else "vienna-1.8.5 (Turner-1999, d1)",
-                       "fold_generic_fallback_windows": int(fb[0]), "fold_line_overflow_windows": int(fb[1])},
+                       "fold_generic_fallback_windows": int(fb[0]), "fold_line_overflow_windows": int(fb[1]),
+                       "exchange": ("none (1 GPU)" if world == 1 else "mirp_gather_loci over the local transport (ranks share GPU 0: dev run)" if share_dir
+                                    else "mirp_gather_loci over RCCL (library-owned communicator), host objects over gloo")},
             "roofline": {"kernel": "fold_lds_kernel<%d>" % (0 if a.fold_model == "vienna-2.1.2" else 1),
                          "bound": "lds" if lds_roof <= valu_roof else "valu", "achieved": achieved / 1e12, "peak": roof / 1e12, "unit": "T relaxations/s",
-                         "frac": achieved / roof if roof > 0 else None, "avg_launch_ms": fill_s * 1e3,
+                         "frac": achieved / roof if roof > 0 else None, "peak_guide": LDS_GUIDE_RELAX_PER_S / 1e12,
+                         "frac_guide": achieved / LDS_GUIDE_RELAX_PER_S, "avg_launch_ms": fill_s * 1e3,
                          "relaxations_per_launch": R, "lds_roof_T": lds_roof / 1e12, "valu_roof_T": valu_roof / 1e12, "microbench_wave_insts_per_s": mb,
                          "traffic": traffic, "traffic_source": prof.get("source") if traffic is not None else None,
                          "note": "integer min-plus dynamic program out of LDS: bounded by LDS reads (2 per relaxation) or VALU issue (3 lane-ops per relaxation), "
-                                 "SURVEY.md 8d; both roofs micro-benchmarked on this GPU in this run; traffic = HBM bytes per launch from the committed rocprofv3 PMC passes"},
+                                 "SURVEY.md 8d; peak = roofs micro-benchmarked on this GPU in this run, peak_guide = 75 TB/s of ds_read_b32 (MI355X_MICROARCH.md) / 8 B; "
+                                 "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes"},
             "roofline_hbm": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": fold_s * 1e3,
                              "note": "HBM view of the fold (algorithmic bytes / time / 8 TB/s); << 1 is expected: the tables are LDS-resident"},
-            "roofline_coverage": {"kernel": "memset + cov_scatter_kernel + cov_scan_kernel", "bound": "hbm", "achieved": b_cov / cov_s / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cov / cov_s / 1e9 / HBM_PEAK_GBS, "avg_ms": cov_s * 1e3},
+            "roofline_coverage": {"kernel": "cov_scatter_kernel + cov_scan_kernel + cov_unscatter_kernel", "bound": "hbm", "achieved": b_cov / cov_s / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cov / cov_s / 1e9 / HBM_PEAK_GBS, "avg_ms": cov_s * 1e3,
+                                  "bytes_algorithmic": b_cov, "bytes_moved_model": b_cov_moved, "achieved_moved": b_cov_moved / cov_s / 1e9,
+                                  "frac_moved": b_cov_moved / cov_s / 1e9 / HBM_PEAK_GBS,
+                                  "note": "achieved / frac price SURVEY 8d's algorithmic bytes 16 A + 16 G; the stage no longer clears the whole difference arrays, so "
+                                          "the bytes it actually moves are ~ 8 G + 48 A (achieved_moved / frac_moved): part of the gain is work not done, not bandwidth"},
             "stage_ms": {"coverage": cov_s * 1e3, "candidate_rest": float(np.mean(rest_ms)), "fold": fold_s * 1e3, "fold_fill_kernel": fill_s * 1e3,
                          "fold_epilogue_kernel": epi_s * 1e3, "predict": float(np.mean(pred_ms))},
         }
-        if world == 1:      # reported baselines: rank 0 at N = 1 only, AFTER the GPU timing
-            if not a.no_e2e:
+        if ranks:
+            line["ranks"] = ranks
+        if world == 1:      # reported side lines and baselines: rank 0 at N = 1 only, AFTER the GPU timing
+            if headline and not a.no_configs:
+                cfgs = {}
+                other = "vienna-1.8.5" if a.fold_model == "vienna-2.1.2" else "vienna-2.1.2"
+                ctx.set_fold_model(other)
+                step()
+                t = time.time()
+                k3 = [step() for _ in range(3)]
+                el = time.time() - t
+                cfgs["config1_" + other] = {"windows_per_s": k3[-1][0] * 3 / el, "ms_per_step": 1e3 * el / 3, "windows": int(k3[-1][0]), "loci_found": int(k3[-1][1]),
+                                            "fold_fill_kernel_ms": float(np.mean([x[3][0] for x in k3])), "fold_epilogue_kernel_ms": float(np.mean([x[3][1] for x in k3])),
+                                            "fold_generic_fallback_windows": int(fb[0])}
+                ctx.set_fold_model(a.fold_model)
+                cfgs["fold_microbench"] = fold_microbench(ctx, a.micro_windows)
+                sp2, ns2, bg2, _, d2 = workload_specs("config2", 1)
+                c2, a2, _ = build_shard(sp2, set(range(len(sp2))), ns2, bg2)
+                o2 = np.argsort(np.array([n for n, _ in c2], dtype=object), kind="stable").astype(np.int32)
+                ctx.load_genome(c2)
+                ctx.load_alignments(a2)
+
+                def step2():
+                    _, _, nw2 = ctx.candidate(CUT, GAP, L, o2)
+                    ctx.fold(L)
+                    f2 = ctx.last_fold_fallbacks()
+                    r2 = ctx.predict(ns2, 18, 23, False, True)
+                    return nw2, len(r2["result"]), f2, ctx.last_timings(), ctx.last_fold_kernel_ms()
+                step2()
+                t = time.time()
+                k2 = [step2() for _ in range(3)]
+                el = time.time() - t
+                cfgs["config2"] = {"workload": d2, "windows_per_s": k2[-1][0] * 3 / el, "ms_per_step": 1e3 * el / 3, "windows": int(k2[-1][0]), "loci_found": int(k2[-1][1]),
+                                   "alignments": int(len(a2)), "fold_generic_fallback_windows": int(k2[-1][2]),
+                                   "stage_ms": {"coverage": float(np.mean([x[3]["coverage_ms"] for x in k2])), "candidate_rest": float(np.mean([x[3]["candidate_rest_ms"] for x in k2])),
+                                                "fold_fill_kernel": float(np.mean([x[4][0] for x in k2])), "fold_epilogue_kernel": float(np.mean([x[4][1] for x in k2])),
+                                                "predict": float(np.mean([x[3]["predict_ms"] for x in k2]))}}
+                cfgs["note"] = ("config3 / config4 are multi-GPU workloads: `python bench.py --gpus 8 --workload config3|config4` (a rank's shard of either is covered at "
+                                "full size by tests/test_configs_gpu.py); the headline above stays config1")
+                line["configs"] = cfgs
+                ctx.load_genome(contigs)          # back to the headline workload for the baselines below
+                ctx.load_alignments(alns)
+            ds = synth.Dataset(contigs, sample_names, alns, [])
+            if not a.no_e2e and headline:
                 try:
                     line["e2e"] = e2e_cli(ds, a.fold_model)
                     line["e2e_wall_s"] = line["e2e"]["wall_s"]
                 except SystemExit as e:
                     line["e2e"] = {"error": "CLI exited with %r" % (e.code,)}
-            if not a.no_ingest:
+            if not a.no_ingest and headline:
                 line["ingest"] = ingest_leg(ctx, a.ingest_records)
             if not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(ds, alns, order, a.cpu_budget)
         print(json.dumps(line))
+    if world > 1:
+        tdist.barrier()
+        ctx.dist_finalize()
     ctx.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

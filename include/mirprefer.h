@@ -94,6 +94,10 @@ int mirp_fold_batch(mirp_ctx* ctx, const char* seqs, const int64_t* offsets, int
                     int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t** n_lines,
                     int32_t** mfe, int32_t** status);
 
+/* The same fold, returning the per-sequence summary only (number of structure lines, minimum free energy, status): the structure text stays
+ * on the device and no line is copied back.  mirp_last_fold_kernel_ms / mirp_last_fold_fallbacks then cover the whole call. */
+int mirp_fold_batch_summary(mirp_ctx* ctx, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span, int32_t max_lines,
+                            int32_t** n_lines, int32_t** mfe, int32_t** status);
 
 /*
  * Replaces: the per-window loop of filter_next_loci / check_loci (MP:2350-2432, 2206-2347) with its two
@@ -167,6 +171,17 @@ int mirp_get_fold_summary(mirp_ctx* ctx, int32_t** n_lines, int32_t** mfe, int32
  * for every resident window the `>` header line taken from fasta_path (the candidate stage's FASTA), the printed structure lines
  * "%s (%6.2f) %4d", the upper-cased T->U sequence and " (%6.2f)". */
 int mirp_write_fold_text(mirp_ctx* ctx, const char* fasta_path, const char* out_path);
+/* The same file, written behind the caller: the call returns once the fold output has been copied off the device; formatting and writing run in
+ * worker threads on host copies only, so the next stage (mirp_predict) may start.  mirp_wait_text joins every pending writer of the context and
+ * returns the first error (mirp_destroy waits too). */
+int mirp_write_fold_text_async(mirp_ctx* ctx, const char* fasta_path, const char* out_path);
+int mirp_wait_text(mirp_ctx* ctx);
+/* The candidate stage's text artefacts, formatted by native worker threads from the resident state (contig_names: n_names NUL-terminated names
+ * back to back, @SQ order): the thresholded depth file `bam.depth.cut<CUT>` -- `chr\tpos\td+\td-` per position with d+ + d- > cutoff
+ * (MP:937-949) -- and the folder's input FASTA `<prefix>.rnalfold.in_<i>.fa`: per resident window the header
+ * `>chr:ws-we strand locS-locE {0|L|R} s,e,strand;... M:s-e/strand/depth ...` and the sequence (MP:1124-1142, 1162-1178). */
+int mirp_write_depth_text(mirp_ctx* ctx, const char* path, const char* contig_names, int32_t n_names);
+int mirp_write_window_fasta(mirp_ctx* ctx, const char* path, const char* contig_names, int32_t n_names);
 /* Replaces gen_miRNA_loci_nopredict (MP:2435-2502) for the resident windows: per-window check_loci, the 0/(L,R) pairing
  * of filter_next_loci (MP:2373-2432) and the "first mature only" rule (MP:2494).  Out: result[n_result] in window order,
  * ss_text[n_result*ss_stride] NUL-terminated structure strings, n_passed[n_windows] = len(miRNAs) per FASTA entry, status[n_windows] = 0 or the
@@ -272,6 +287,16 @@ int mirp_ingest_sams_shard(mirp_ctx* ctx, const char* const* paths, int32_t n_pa
 typedef struct { int32_t n_contigs; char* names; int64_t* len; uint8_t* seq; int64_t n_bytes; } MirpFastaData;
 int mirp_read_fasta(const char* path, const char* const* want, int32_t n_want, MirpFastaData* out, char* errbuf, size_t errbuf_len);
 void mirp_free_fasta_data(MirpFastaData* data);
+
+/* Report side, host only: the bodies of the per-locus read-mapping files of gen_map_result (MP:2907-2959) -- per sample the
+ * precursor with `total_mapped_reads=`, the structure, and every read of the locus' strand that lies inside the precursor laid out under it
+ * (`m` / `s` padding and the [mature] / [star] marks for the exact mature / star reads) -- from the position-sorted records and the genome
+ * instead of one `samtools view` + `samtools faidx` per locus.  loci[n][8] = {tid, fold_s, fold_e, mat_s, mat_e, star_s, star_e, strand};
+ * ss = n NUL-terminated structure strings back to back; contig_seq[t] may be NULL for contigs this process does not hold (a locus there is
+ * an error, -2); counts[n][n_samples] = reads on the precursor.  Out: text (bodies back to back) and offsets[n+1], released with mirp_free. */
+int mirp_report_readmapping(const int32_t* loci, int64_t n_loci, const char* ss, const MirpAln* alns, int64_t n_alns, const uint8_t* const* contig_seq,
+                            const int64_t* contig_len, int32_t n_contigs, const char* sample_names, int32_t n_samples, const int64_t* counts,
+                            char** text, int64_t** offsets);
 
 #ifdef __cplusplus
 }

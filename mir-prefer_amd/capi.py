@@ -32,6 +32,33 @@ class FastaData(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("names", C.c_void_p), ("len", C.POINTER(C.c_int64)), ("seq", C.c_void_p), ("n_bytes", C.c_int64)]
 
 
+def report_readmapping(loci, ss_list, alns, contig_arrays, sample_names, counts0):
+    """Bodies of the per-locus read-mapping files (mirp_report_readmapping, host only): loci = int32 [n, 8] {tid, fold_s, fold_e, mat_s, mat_e,
+    star_s, star_e, strand}, ss_list = n structure strings, contig_arrays[t] = uint8 bases of contig t (None / empty where not held),
+    counts0 = int64 [n, n_samples] reads on the precursor.  -> list of n strings (the lines after the header line)."""
+    lib = load_library()
+    loci = np.ascontiguousarray(loci, dtype=np.int32).reshape(-1, 8)
+    n = len(loci)
+    if n == 0:
+        return []
+    alns = np.ascontiguousarray(alns)
+    keep = [np.ascontiguousarray(a, dtype=np.uint8) if a is not None and len(a) else None for a in contig_arrays]
+    ptrs = (C.c_void_p * len(keep))(*[a.ctypes.data if a is not None else None for a in keep])
+    lens = np.array([len(a) if a is not None else 0 for a in keep], dtype=np.int64)
+    ssb = b"".join(x.encode() + b"\0" for x in ss_list)
+    snb = b"".join(x.encode() + b"\0" for x in sample_names)
+    cnt = np.ascontiguousarray(counts0, dtype=np.int64)
+    text, offs = C.c_void_p(), C.c_void_p()
+    rc = lib.mirp_report_readmapping(loci.ctypes.data, n, ssb, alns.ctypes.data if len(alns) else None, len(alns), ptrs, lens.ctypes.data, len(keep), snb,
+                                     len(sample_names), cnt.ctypes.data, C.byref(text), C.byref(offs))
+    if rc != 0:
+        raise MirpError("mirp_report_readmapping failed (%d): a locus lies on a contig this process does not hold" % rc)
+    o = _copy_out(lib, offs, np.int64, n + 1)
+    blob = C.string_at(text.value, int(o[-1]))
+    lib.mirp_free(text)
+    return [blob[o[k]:o[k + 1]].decode() for k in range(n)]
+
+
 def read_fasta(path, want=None):
     """Native FASTA reader (mirp_read_fasta): -> list of (name, uint8 array) in file order; with `want` (names) only those sequences are
     materialised, the others come back as None."""
@@ -136,6 +163,8 @@ def load_library():
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(vp),
                                     C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_fold_batch.restype = C.c_int
+    lib.mirp_fold_batch_summary.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.mirp_fold_batch_summary.restype = C.c_int
     lib.mirp_predict_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict_batch.restype = C.c_int
@@ -171,6 +200,13 @@ def load_library():
     lib.mirp_last_fold_overflow.restype = C.c_int64
     lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mirp_write_fold_text.restype = C.c_int
+    lib.mirp_write_fold_text_async.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.mirp_write_fold_text_async.restype = C.c_int
+    lib.mirp_wait_text.argtypes = [vp]
+    lib.mirp_wait_text.restype = C.c_int
+    for f in ("mirp_write_depth_text", "mirp_write_window_fasta"):
+        getattr(lib, f).argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int32]
+        getattr(lib, f).restype = C.c_int
     lib.mirp_get_fold_summary.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64p]
     lib.mirp_get_fold_summary.restype = C.c_int
     for f in ("mirp_load_genome", "mirp_load_alignments", "mirp_candidate", "mirp_get_depth", "mirp_get_peaks", "mirp_get_loci",
@@ -186,6 +222,8 @@ def load_library():
     lib.mirp_load_coverage_segments.restype = C.c_int
     lib.mirp_ingest_sams_shard.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int32, C.c_int32, vp, C.c_int64, vp, C.POINTER(SamData), C.POINTER(C.c_double)]
     lib.mirp_ingest_sams_shard.restype = C.c_int
+    lib.mirp_report_readmapping.argtypes = [vp, C.c_int64, C.c_char_p, vp, C.c_int64, vp, vp, C.c_int32, C.c_char_p, C.c_int32, vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.mirp_report_readmapping.restype = C.c_int
     lib.mirp_read_fasta.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(FastaData), C.c_char_p, C.c_size_t]
     lib.mirp_read_fasta.restype = C.c_int
     lib.mirp_free_fasta_data.argtypes = [C.POINTER(FastaData)]
@@ -256,6 +294,18 @@ class Context:
                 ls.append((raw["ss"][w, k, :int(ln["len"])].tobytes().decode(), int(ln["energy"]), int(ln["start"])))
             out.append({"lines": ls, "mfe": int(raw["mfe"][w]), "status": int(raw["status"][w])})
         return out
+
+    def fold_batch_summary(self, blob, offsets, span, max_lines=96):
+        """Folds the sequences blob[offsets[k]:offsets[k+1]] and returns only (n_lines, mfe, status) per sequence: nothing of the structure text
+        is copied back (mirp_fold_batch_summary).  blob: bytes / uint8 array, offsets: int64 array of n + 1 entries."""
+        blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else blob, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offs) - 1
+        vp = C.c_void_p
+        nl, mfe, st = vp(), vp(), vp()
+        self._check(self.lib.mirp_fold_batch_summary(self.h, C.cast(blob.ctypes.data, C.c_char_p), offs.ctypes.data_as(C.POINTER(C.c_int64)), n, int(span),
+                                                     int(max_lines), C.byref(nl), C.byref(mfe), C.byref(st)), "mirp_fold_batch_summary")
+        return _copy_out(self.lib, nl, np.int32, n), _copy_out(self.lib, mfe, np.int32, n), _copy_out(self.lib, st, np.int32, n)
 
     def fold_batch_raw(self, seqs, span, max_lines=96):
         """As fold_batch but returns the C-ABI arrays: lines[n,max_lines], ss[n,max_lines,stride], n_lines, mfe, status."""
@@ -481,8 +531,24 @@ class Context:
     def fold_status(self):
         return self.fold_summary()["status"]
 
-    def write_fold_text(self, fasta_path, out_path):
-        self._check(self.lib.mirp_write_fold_text(self.h, str(fasta_path).encode(), str(out_path).encode()), "mirp_write_fold_text")
+    def write_fold_text(self, fasta_path, out_path, wait=True):
+        """RNALfold-format text of the resident fold output.  wait=False: returns once the output is off the device; formatting and writing go on
+        in the library's worker threads (wait_text joins them)."""
+        fn = self.lib.mirp_write_fold_text if wait else self.lib.mirp_write_fold_text_async
+        self._check(fn(self.h, str(fasta_path).encode(), str(out_path).encode()), "mirp_write_fold_text")
+
+    def wait_text(self):
+        self._check(self.lib.mirp_wait_text(self.h), "mirp_wait_text")
+
+    def write_depth_text(self, path, contig_names):
+        """bam.depth.cut<CUT> of the last candidate() (MP:937-949), written by the library's worker threads."""
+        blob = b"".join(n.encode() + b"\0" for n in contig_names)
+        self._check(self.lib.mirp_write_depth_text(self.h, str(path).encode(), blob, len(contig_names)), "mirp_write_depth_text")
+
+    def write_window_fasta(self, path, contig_names):
+        """<prefix>.rnalfold.in_<i>.fa of the last candidate(): header + sequence of every window (MP:1124-1142)."""
+        blob = b"".join(n.encode() + b"\0" for n in contig_names)
+        self._check(self.lib.mirp_write_window_fasta(self.h, str(path).encode(), blob, len(contig_names)), "mirp_write_window_fasta")
 
     def get_fold(self):
         vp = C.c_void_p

@@ -64,9 +64,9 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("MIRP_DIST_BACKEND", "rccl")
     if world > 1:
-        import torch.distributed as tdist
+        from . import dist as mdist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        tdist.init_process_group("gloo")
+        tdist = mdist.init_host_group()
         if backend not in ("gloo", "local"):
             o["device"] = int(os.environ.get("LOCAL_RANK", str(rank)))
     try:

@@ -78,6 +78,7 @@ extern "C" int mirp_set_fold_model(mirp_ctx* c, int32_t model) {
 extern "C" void mirp_destroy(mirp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)mirp_wait_text(c);
     (void)mirp_dist_finalize(c);
     c->dist_tmp.release();
     c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
@@ -100,12 +101,14 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
 extern "C" const char* mirp_last_error(const mirp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 extern "C" void mirp_free(void* p) { std::free(p); }
 
-extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
-                               int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride_out,
-                               int32_t** n_lines, int32_t** mfe, int32_t** status) {
+static int fold_batch_impl(mirp_ctx* c, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
+                           int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride_out,
+                           int32_t** n_lines, int32_t** mfe, int32_t** status, bool want_text) {
     if (!c) return -1;
-    if (!seqs || !offsets || n_seqs < 0 || !lines || !ss || !ss_stride_out || !n_lines || !mfe || !status)
+    if (!seqs || !offsets || n_seqs < 0 || (want_text && (!lines || !ss || !ss_stride_out)) || !n_lines || !mfe || !status)
         return fail(c, -1, "mirp_fold_batch: null argument");
+    int32_t stride_dummy = 0;
+    if (!ss_stride_out) ss_stride_out = &stride_dummy;
     if (span < 1 || max_lines < 1) return fail(c, -1, "mirp_fold_batch: bad span/max_lines");
     HIPCHK(c, hipSetDevice(c->device));
     int n_max = 1;
@@ -118,8 +121,8 @@ extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* off
     const int stride = ((n_max + 3 + 7) / 8) * 8;
     *ss_stride_out = stride;
     const size_t nl = (size_t)n_seqs * max_lines;
-    MirpFoldLine* h_lines = (MirpFoldLine*)std::calloc(std::max<size_t>(nl, 1), sizeof(MirpFoldLine));
-    char* h_ss = (char*)std::calloc(std::max<size_t>(nl * stride, 1), 1);
+    MirpFoldLine* h_lines = (MirpFoldLine*)std::calloc(want_text ? std::max<size_t>(nl, 1) : 1, sizeof(MirpFoldLine));
+    char* h_ss = (char*)std::calloc(want_text ? std::max<size_t>(nl * stride, 1) : 1, 1);
     int32_t* h_nl = (int32_t*)std::calloc(std::max(n_seqs, 1), sizeof(int32_t));
     int32_t* h_mfe = (int32_t*)std::calloc(std::max(n_seqs, 1), sizeof(int32_t));
     int32_t* h_st = (int32_t*)std::calloc(std::max(n_seqs, 1), sizeof(int32_t));
@@ -143,25 +146,42 @@ extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* off
         if (c->lines.ensure(sizeof(MirpFoldLine) * (size_t)batch * max_lines) || c->ss.ensure((size_t)batch * per_win) ||
             c->nlines.ensure(4 * (size_t)n_seqs) || c->mfe.ensure(4 * (size_t)n_seqs) || c->status.ensure(4 * (size_t)n_seqs))
             return bail(-6, "device allocation failed (outputs)");
+        double kms[2] = {0, 0};
+        long long fallbacks = 0;
         for (int b0 = 0; b0 < n_seqs; b0 += batch) {
             const int nb = std::min(batch, n_seqs - b0);
             // windows of this batch are addressed relative to b0: shift the pointers
             int rc = mirp_run_fold(c, (const unsigned char*)c->seqs.p, (const long long*)c->offs.p + b0, nullptr, nb, n_max, span, max_lines, stride,
                                    (MirpFoldLine*)c->lines.p, (char*)c->ss.p, (int*)c->nlines.p + b0, (int*)c->mfe.p + b0, (int*)c->status.p + b0);
             if (rc) return bail(rc, c->err);
-            if (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->lines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
-                               hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipMemcpyAsync(h_ss + (size_t)b0 * per_win, c->ss.p, (size_t)nb * per_win, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            kms[0] += c->fold_kernel_ms[0]; kms[1] += c->fold_kernel_ms[1]; fallbacks += c->last_fallback;
+            if (want_text &&
+                (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->lines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
+                                hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                 hipMemcpyAsync(h_ss + (size_t)b0 * per_win, c->ss.p, (size_t)nb * per_win, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
                 return bail(-2, "D2H copy failed");
             if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(-2, "fold kernel execution failed");
         }
+        c->fold_kernel_ms[0] = kms[0]; c->fold_kernel_ms[1] = kms[1]; c->last_fallback = fallbacks;      // over all batches of this call
         if (hipMemcpy(h_nl, c->nlines.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(h_mfe, c->mfe.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(h_st, c->status.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess)
             return bail(-2, "D2H copy failed");
     }
-    *lines = h_lines; *ss = h_ss; *n_lines = h_nl; *mfe = h_mfe; *status = h_st;
+    if (want_text) { *lines = h_lines; *ss = h_ss; } else { std::free(h_lines); std::free(h_ss); }
+    *n_lines = h_nl; *mfe = h_mfe; *status = h_st;
     return 0;
+}
+
+extern "C" int mirp_fold_batch(mirp_ctx* c, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
+                               int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride_out,
+                               int32_t** n_lines, int32_t** mfe, int32_t** status) {
+    return fold_batch_impl(c, seqs, offsets, n_seqs, span, max_lines, lines, ss, ss_stride_out, n_lines, mfe, status, true);
+}
+
+extern "C" int mirp_fold_batch_summary(mirp_ctx* c, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span, int32_t max_lines,
+                                       int32_t** n_lines, int32_t** mfe, int32_t** status) {
+    return fold_batch_impl(c, seqs, offsets, n_seqs, span, max_lines, nullptr, nullptr, nullptr, n_lines, mfe, status, false);
 }
 
 // ------------------------------------------------------------------------------------------

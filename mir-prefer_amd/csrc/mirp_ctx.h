@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include "mirp_internal.h"
 
@@ -76,6 +78,8 @@ struct mirp_ctx {
     std::string dist_dir;             // local transport (mirp_dist_init_local): ranks that share a GPU exchange through files in this directory
     long long dist_seq = 0;
     DevBuf dist_tmp;
+    struct TextJob { std::thread th; int rc = 0; std::string err; };
+    std::vector<std::shared_ptr<TextJob>> text_jobs;      // text artefacts still being formatted / written behind the caller (mirp_wait_text)
     long long n_result = 0;           // records of the last mirp_predict (p_res / p_text), what mirp_gather_loci sends
     bool have_result = false;
 };

@@ -27,8 +27,20 @@ struct Rccl {
     std::string err;
     bool load() {
         if (h) return true;
-        for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // The RCCL that belongs to the HIP runtime THIS library is bound to: a process can hold two ROCm stacks with the same sonames (a Python
+        // package that bundles its own libamdhip64.so.7 / librccl.so.1 next to the system installation; whichever was loaded first serves the
+        // soname).  A collective must see the device pointers of the runtime that allocated them, so librccl is taken from the directory the
+        // resolved hipMalloc lives in, by absolute path, before any by-name lookup.
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) { dir.resize(slash); names.push_back(dir + "/librccl.so.1"); names.push_back(dir + "/librccl.so"); }
+        }
+        names.push_back("librccl.so.1"); names.push_back("/opt/rocm/lib/librccl.so.1"); names.push_back("librccl.so");
+        for (const std::string& name : names) {
+            h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (h) break;
         }
         if (!h) { err = std::string("cannot load librccl.so.1: ") + dlerror(); return false; }

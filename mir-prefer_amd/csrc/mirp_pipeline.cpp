@@ -484,54 +484,6 @@ extern "C" int mirp_get_fold_overflow(mirp_ctx* c, int32_t** windows, int64_t* n
     return 0;
 }
 
-extern "C" int mirp_write_fold_text(mirp_ctx* c, const char* fasta_path, const char* out_path) {
-    if (!c) return -1;
-    if (!fasta_path || !out_path) return fail(c, -1, "mirp_write_fold_text: null argument");
-    if (!c->have_fold) return fail(c, -1, "mirp_write_fold_text: run mirp_fold first");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t nw = (size_t)c->n_windows, ml = (size_t)c->fold_max_lines, stride = (size_t)c->fold_stride;
-    MirpFoldLine* hl = host_copy<MirpFoldLine>(c, c->lines.p, nw * ml);
-    char* hs = host_copy<char>(c, c->ss.p, nw * ml * stride);
-    int32_t* hn = host_copy<int32_t>(c, c->nlines.p, nw);
-    int32_t* hm = host_copy<int32_t>(c, c->mfe.p, nw);
-    // windows folded again at full line capacity: their lines come from the side buffers
-    const size_t ns = (size_t)c->n_side, ml2 = (size_t)c->side_max_lines;
-    int32_t* hsi = ns ? host_copy<int32_t>(c, c->side_idx.p, nw) : nullptr;
-    MirpFoldLine* hl2 = ns ? host_copy<MirpFoldLine>(c, c->lines2.p, ns * ml2) : nullptr;
-    char* hs2 = ns ? host_copy<char>(c, c->ss2.p, ns * ml2 * stride) : nullptr;
-    auto done = [&](int rc, const char* msg) { std::free(hl); std::free(hs); std::free(hn); std::free(hm); std::free(hsi); std::free(hl2); std::free(hs2); return rc ? fail(c, rc, msg) : 0; };
-    if (!hl || !hs || !hn || !hm || (ns && (!hsi || !hl2 || !hs2))) return done(-2, "D2H failed");
-    FILE* fin = std::fopen(fasta_path, "r");
-    if (!fin) return done(-8, "mirp_write_fold_text: cannot open the FASTA file");
-    FILE* fo = std::fopen(out_path, "w");
-    if (!fo) { std::fclose(fin); return done(-8, "mirp_write_fold_text: cannot open the output file"); }
-    std::vector<char> head(1 << 16), seq(1 << 16);
-    int rc = 0;
-    for (size_t w = 0; w < nw; w++) {
-        if (!std::fgets(head.data(), (int)head.size(), fin) || !std::fgets(seq.data(), (int)seq.size(), fin)) { rc = -8; break; }
-        std::fputs(head.data(), fo);
-        const bool side = ns && hsi[w] >= 0;
-        const MirpFoldLine* wl = side ? hl2 + (size_t)hsi[w] * ml2 : hl + w * ml;
-        const char* wt = side ? hs2 + (size_t)hsi[w] * ml2 * stride : hs + w * ml * stride;
-        for (int k = 0; k < hn[w]; k++) {
-            const MirpFoldLine& ln = wl[k];
-            if (!ln.printed) continue;
-            std::fwrite(wt + (size_t)k * stride, 1, (size_t)ln.len, fo);
-            std::fprintf(fo, " (%6.2f) %4d\n", ln.energy / 100., ln.start);
-        }
-        for (char* p = seq.data(); *p && *p != '\n' && *p != '\r'; p++) {
-            char ch = *p;
-            if (ch >= 'a' && ch <= 'z') ch -= 32;
-            if (ch == 'T') ch = 'U';
-            std::fputc(ch, fo);
-        }
-        std::fprintf(fo, "\n (%6.2f)\n", hm[w] / 100.);
-    }
-    std::fclose(fin);
-    if (std::fclose(fo) != 0) rc = -8;
-    return done(rc, "mirp_write_fold_text: I/O error or FASTA shorter than the window list");
-}
-
 // the filter kernel over the resident windows: the main launch (fold output at the default line capacity) and, when windows were folded
 // again at full capacity, a second launch over those with the side buffers
 static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride) {

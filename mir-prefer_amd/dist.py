@@ -5,6 +5,26 @@ init_context below); `gather_records` over a `gloo` group is the CPU-side stand-
 import numpy as np
 
 
+def init_host_group():
+    """The CPU-side `gloo` process group of a multi-rank run (host objects, barriers).  gloo announces its connections on the process' stdout
+    file descriptor; for the duration of the rendezvous that descriptor points at stderr, so stdout stays what the caller prints (the bench's
+    one JSON line, the CLI's messages)."""
+    import os
+    import sys
+    import torch.distributed as tdist
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        tdist.init_process_group("gloo")
+        tdist.barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep, 1)
+        os.close(keep)
+    return tdist
+
+
 def init_context(ctx, rank, world):
     """Gives `ctx` its RCCL communicator: rank 0 draws the ncclUniqueId (mirp_dist_unique_id) and the host's own process group -- any backend,
     `gloo` in the CLI and the bench -- carries the 128 bytes to the other ranks; every rank then joins with mirp_dist_init.  No torch tensor

@@ -302,11 +302,10 @@ class Pipeline:
         self._ensure_candidate()
         names, prefix, r = self.data["names"], self.opt["NAME_PREFIX"], self.rank
         depthname = self._p("bam.depth.cut%d" % self.opt["READS_DEPTH_CUTOFF"])
-        depth = self.ctx.get_depth()
         if self.world == 1:
-            with open(depthname, "w") as f:
-                f.write(records.depth_text(depth, names))
+            self.ctx.write_depth_text(depthname, names)          # formatted by the library's worker threads
         else:       # every rank writes the lines of its contigs; rank 0 stitches the parts back together in @SQ order
+            depth = self.ctx.get_depth()
             part = depthname + ".part%d" % r
             spans = {}
             with open(part, "w") as f:
@@ -341,10 +340,7 @@ class Pipeline:
                 f.write(records.exregion_gff_text(dict_loci))
         w = self.ctx.get_windows()
         fastaname = self._p(prefix + ".rnalfold.in_%d.fa" % r)       # one piece per rank, like the reference's pieces per process
-        with open(fastaname, "w") as f:
-            for win in w["windows"]:
-                f.write(records.fasta_header(win, w["wpeaks"], w["matures"], names) + "\n")
-                f.write(w["seq"][win["seq_off"]:win["seq_off"] + win["seq_len"]].tobytes().decode() + "\n")
+        self.ctx.write_window_fasta(fastaname, names)                # headers (MP:1124-1140) + sequences, formatted by the library's worker threads
         dumpname = self._p(prefix + ".alndump_%d.npz" % r)
         np.savez(dumpname, windows=w["windows"], wpeaks=w["wpeaks"], matures=w["matures"])
         parts = self._all_gather((fastaname, dumpname, int(self.counts[1]), int(self.counts[2])))
@@ -368,7 +364,9 @@ class Pipeline:
         return self.ctx.fold_status()
 
     # ---- fold (MP:3441-3495)
-    def run_fold(self, write_text=True):
+    def run_fold(self, write_text=True, defer=False):
+        """defer (the `pipeline` verb): the RNALfold-format text is formatted and written behind the predict stage's device work; the fold
+        stage is recorded in the checkpoint file once that file is complete (run_predict joins the writer first)."""
         if not previous_stage_saved(self.recovername, "candidate"):
             self._fail_stage()
         self._say("Starting folding candidate sequences.")
@@ -383,22 +381,28 @@ class Pipeline:
         self._agree_ok(len(bad) == 0, "fold")
         if write_text:
             d = load_recover_file(self.recovername)
-            self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][self.rank], foldname)
+            self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][self.rank], foldname, wait=not defer)
         else:
             open(foldname, "w").close()
         foldnames = self._all_gather(foldname)
+        self._pending_fold = foldnames if defer else None
+        if not defer:
+            self._record_fold(foldnames)
+        self._say("Done (fold stage)\n")
+        self._barrier()
+
+    def _record_fold(self, foldnames):
         if self.rank == 0:
             d = load_recover_file(self.recovername)
             d["last_stage"] = "fold"
             d["finished_stages"]["fold"] = {"foldnames": foldnames}
             d["files"]["fold"] = foldnames
             _save_recover(self.recovername, d)
-        self._say("Done (fold stage)\n")
-        self._barrier()
 
     # ---- predict (MP:3498-3627): the loci list, gff3, fasta / ss / csv / html / stat / readmapping files
     def run_predict(self):
-        if not previous_stage_saved(self.recovername, "fold"):
+        pending = getattr(self, "_pending_fold", None)
+        if pending is None and not previous_stage_saved(self.recovername, "fold"):
             self._fail_stage()
         self._say("Starting predicting miRNAs.")
         if self.state != "fold":
@@ -411,6 +415,11 @@ class Pipeline:
         if len(bad):      # a capacity of the filter kernel was exceeded (structure pieces / candidate matures of one window): never truncate silently
             sys.stderr.write("Error occurred when predicting miRNAs: window %d exceeds the capacity of the filter kernel (status %d).\n" % (bad[0], out["status"][bad[0]]))
         self._agree_ok(len(bad) == 0, "predict")
+        if pending is not None:          # the fold stage's text file was being written behind the filter kernel: complete it, then record the stage
+            self.ctx.wait_text()
+            self._barrier()
+            self._record_fold(pending)
+            self._pending_fold = None
         prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
         if self.opt.get("OUTPUT_DETAILS_FOR_DEBUG"):          # -d: why the other regions are not miRNAs (MP:3532-3543)
             rec = self.ctx.predict_reasons(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"],
@@ -458,19 +467,20 @@ class Pipeline:
         order = sorted(range(len(result)), key=lambda k: result[k][:10])      # resultlist.sort() of gen_gff_from_result (MP:2622) names the loci
         result = [result[k] for k in order]
         payloads = [payloads[k] for k in order]
+        counts = np.stack([x["counts"] for x in payloads])
+        rm_thread = write_readmapping(result, payloads, None, None, self.data["samples"], counts, os.path.join(outdir, "readmapping"), background=True)
         gffname = os.path.join(outdir, prefix + "_miRNA.gff3")
         write_gff(result, gffname)
         maturename = os.path.join(outdir, prefix + "_miRNA.mature.fa")
         stemloopname = os.path.join(outdir, prefix + "_miRNA.precursor.fa")
         ssname = os.path.join(outdir, prefix + "_miRNA.precursor.ss")
         write_fasta_ss(result, payloads, maturename, stemloopname, ssname)
-        counts = np.stack([x["counts"] for x in payloads])
         write_csv_and_stat(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
                            os.path.join(outdir, "miRNA.stat.txt"))
         write_html(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"))
-        write_readmapping(result, payloads, None, None, self.data["samples"], counts, os.path.join(outdir, "readmapping"))
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
+        rm_thread.join()
         d = load_recover_file(self.recovername)
         d["last_stage"] = "predict"
         d["finished_stages"]["predict"] = {"gffname": gffname, "maturename": maturename, "stemloopname": stemloopname}
@@ -485,7 +495,7 @@ class Pipeline:
     def run_pipeline(self):
         self.run_prepare()
         self.run_candidate()
-        self.run_fold()
+        self.run_fold(defer=True)
         return self.run_predict()
 
     def run_recover(self):
@@ -574,15 +584,17 @@ def _seq(seqs, idx, m, s, e_incl):
 def locus_payloads(resultlist, contigs, names, alns, samples):
     """What the report files need from the genome and the reads of every locus of `resultlist`, computed where the locus' contig lives (a rank of
     a sharded run holds only its own contigs and records): the forward-strand precursor text, the read counts per sample (gen_mirna_info,
-    MP:2644-2728) and the body of the locus' read-mapping file (gen_map_result, MP:2907-2959).  Rank 0 formats the files from these."""
+    MP:2644-2728) and the body of the locus' read-mapping file (gen_map_result, MP:2907-2959; native, mirp_report_readmapping).  Rank 0
+    formats the files from these."""
     counts = mirna_read_counts(resultlist, names, alns, len(samples))
+    bodies = readmapping_bodies(resultlist, contigs, names, alns, samples, counts)
+    return [{"pre": _faidx(contigs, m[0], m[1], m[2] - 1), "counts": counts[idx], "map": bodies[idx]} for idx, m in enumerate(resultlist)]
+
+
+def readmapping_bodies(resultlist, contigs, names, alns, samples, counts):
     tid_of = {n: t for t, n in enumerate(names)}
-    key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
-    out = []
-    for idx, m in enumerate(resultlist):
-        pre = _faidx(contigs, m[0], m[1], m[2] - 1)
-        out.append({"pre": pre, "counts": counts[idx], "map": _readmapping_body(m, pre, contigs[m[0]], tid_of[m[0]], key, alns, samples, counts[idx])})
-    return out
+    loci = np.array([[tid_of[m[0]], m[1], m[2], m[3], m[4], m[5], m[6], 1 if m[8] == "-" else 0] for m in resultlist], dtype=np.int32).reshape(-1, 8)
+    return capi.report_readmapping(loci, [m[7] for m in resultlist], alns, [contigs.get(n) for n in names], samples, counts[:, :, 0])
 
 
 def write_fasta_ss(resultlist, contigs, maturename, stemloopname, ssname):
@@ -608,79 +620,65 @@ def write_fasta_ss(resultlist, contigs, maturename, stemloopname, ssname):
 
 def mirna_read_counts(resultlist, names, alns, n_samples):
     """Per locus and sample: reads on the precursor / exactly the mature / exactly the star / antisense (gen_mirna_info, MP:2644-2728),
-    from the position-sorted alignment records instead of one `samtools view` per locus.  -> int64 array [n_loci, n_samples, 4]."""
-    tid_of = {n: t for t, n in enumerate(names)}
+    from the position-sorted alignment records instead of one `samtools view` per locus.  -> int64 array [n_loci, n_samples, 4].
+    All loci at once: the (locus, record) pairs of the loci's record ranges are flattened and binned."""
+    n = len(resultlist)
+    out = np.zeros((n, n_samples, 4), dtype=np.int64)
+    if n == 0 or len(alns) == 0:
+        return out
+    tid_of = {nm: t for t, nm in enumerate(names)}
+    L = np.array([[tid_of[m[0]], m[1], m[2], m[3], m[4], m[5], m[6], 1 if m[8] == "-" else 0] for m in resultlist], dtype=np.int64)
     key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
-    out = np.zeros((len(resultlist), n_samples, 4), dtype=np.int64)
-    for k, m in enumerate(resultlist):
-        t = tid_of[m[0]]
-        lo = np.searchsorted(key, (t << 32) | m[1], side="left")
-        hi = np.searchsorted(key, (t << 32) | m[2], side="left")
-        a = alns[lo:hi]
-        a = a[a["pos"].astype(np.int64) + a["len"].astype(np.int64) <= m[2]]       # startpos >= locus_start and startpos + readlen <= locus_end
-        sense = a["strand"] == (1 if m[8] == "-" else 0)
-        depth = a["depth"].astype(np.int64)
-        for s in range(n_samples):
-            of = a["sample"] == s
-            out[k, s, 3] = depth[of & ~sense].sum()
-            on = of & sense
-            out[k, s, 0] = depth[on].sum()
-            out[k, s, 1] = depth[on & (a["pos"] == m[3]) & (a["len"] == m[4] - m[3])].sum()
-            out[k, s, 2] = depth[on & (a["pos"] == m[5]) & (a["len"] == m[6] - m[5])].sum()
+    lo = np.searchsorted(key, (L[:, 0] << 32) | L[:, 1], side="left")
+    hi = np.searchsorted(key, (L[:, 0] << 32) | L[:, 2], side="left")
+    cnt = hi - lo
+    tot = int(cnt.sum())
+    if tot == 0:
+        return out
+    loc = np.repeat(np.arange(n), cnt)
+    ridx = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(lo, cnt)
+    a = alns[ridx]
+    pos, ln, depth = a["pos"].astype(np.int64), a["len"].astype(np.int64), a["depth"].astype(np.int64)
+    inside = pos + ln <= L[loc, 2]                                   # startpos >= locus_start and startpos + readlen <= locus_end
+    sense = a["strand"].astype(np.int64) == L[loc, 7]
+    smp = a["sample"].astype(np.int64)
+    cat = [inside & sense, inside & sense & (pos == L[loc, 3]) & (ln == L[loc, 4] - L[loc, 3]), inside & sense & (pos == L[loc, 5]) & (ln == L[loc, 6] - L[loc, 5]),
+           inside & ~sense]
+    for c, msk in enumerate(cat):
+        if msk.any():
+            np.add.at(out, (loc[msk], smp[msk], c), depth[msk])
     return out
 
 
-def _readmapping_body(m, pre_fwd, seq, t, key, alns, samples, counts_k):
-    """Lines of one locus' read-mapping file after its header line (gen_map_result, MP:2907-2959).  The read text is the reference sequence under
-    the alignment (upper case): exact for perfect-match alignments, which is what the reference's own aligner script produces (bowtie -v 0);
-    the ingest keeps coordinates, not read sequences."""
-    pre = _revcomp(pre_fwd) if m[8] == "-" else pre_fwd
-    mlen, slen = m[4] - m[3], m[6] - m[5]
-    out = []
-    lo = np.searchsorted(key, (t << 32) | m[1], side="left")
-    hi = np.searchsorted(key, (t << 32) | m[2], side="left")
-    a = alns[lo:hi]
-    a = a[(a["pos"].astype(np.int64) + a["len"].astype(np.int64) <= m[2]) & (a["strand"] == (1 if m[8] == "-" else 0))]
-    for s, sample in enumerate(samples):
-        out += [">> Read mappings for sample: " + sample, "5'->3'", pre + "\ttotal_mapped_reads=" + str(int(counts_k[s, 0])), m[7]]
-        rs = a[a["sample"] == s]
-        starts = sorted(set(int(p) for p in rs["pos"]), reverse=(m[8] == "-"))
-        for startpos in starts:
-            here = rs[rs["pos"] == startpos]
-            for r in sorted(here, key=lambda r: int(r["len"])):          # stable: alignment order among equal lengths
-                rl = int(r["len"])
-                read = seq[startpos - 1:startpos - 1 + rl].tobytes().decode().upper()
-                pad = "m" if (startpos == m[3] and rl == mlen) else ("s" if (startpos == m[5] and rl == slen) else ".")
-                line = pad * (startpos - m[1]) + read
-                line += pad * (len(pre) - len(line))
-                if m[8] == "-":
-                    line = _revcomp(line).replace("U", "T")
-                line += "\tdepth=%d, length=%d" % (int(r["depth"]), rl)
-                if pad == "m":
-                    line += " [mature]"
-                if pad == "s":
-                    line += " [star]"
-                out.append(line)
-    return out
-
-
-def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder):
+def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder, background=False):
     """gen_map_result (MP:2907-2959): one <precursor id>.map.txt per locus with the reads of every sample laid out under the precursor.
-    `contigs` = the genome dict (names / alns / counts are then used) or the list of locus payloads of a sharded run (bodies come ready)."""
+    `contigs` = the genome dict (names / alns / counts are then used) or the list of locus payloads of a sharded run (bodies come ready).
+    background: the files are written by a thread that is returned (join it) while the caller formats the other report files."""
     os.makedirs(folder, exist_ok=True)
-    payload = not isinstance(contigs, dict)
-    if not payload:
-        tid_of = {n: t for t, n in enumerate(names)}
-        key = alns["tid"].astype(np.int64) << 32 | alns["pos"].astype(np.int64)
+    if isinstance(contigs, dict):
+        bodies = readmapping_bodies(resultlist, contigs, names, alns, samples, counts)
+    else:
+        bodies = [x["map"] for x in contigs]
+    jobs = []
     for idx, m in enumerate(resultlist):
         mirname = "miRNA-precursor_%d" % idx
-        head = ">%s %s:%d-%d %s" % (mirname, m[0], m[1], m[2], m[8])
-        if payload:
-            body = contigs[idx]["map"]
-        else:
-            body = _readmapping_body(m, _faidx(contigs, m[0], m[1], m[2] - 1), contigs[m[0]], tid_of[m[0]], key, alns, samples, counts[idx])
-        with open(os.path.join(folder, mirname + ".map.txt"), "w") as f:
-            f.write("\n".join([head] + body) + "\n")
+        jobs.append((os.path.join(folder, mirname + ".map.txt"), ">%s %s:%d-%d %s\n" % (mirname, m[0], m[1], m[2], m[8]) + bodies[idx]))
+
+    def put_all():          # thousands of small files: creating them is the cost, and the system calls release the interpreter lock
+        flags = os.O_WRONLY | os.O_CREAT | os.O_TRUNC
+        for path, text in jobs:
+            fd = os.open(path, flags, 0o644)
+            try:
+                os.write(fd, text.encode())
+            finally:
+                os.close(fd)
+    if not background:
+        put_all()
+        return None
+    import threading
+    th = threading.Thread(target=put_all)
+    th.start()
+    return th
 
 
 def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
