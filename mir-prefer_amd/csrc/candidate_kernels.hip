@@ -17,22 +17,34 @@ namespace mirp {
 // ------------------------------------------------------------------------------------------
 // a1: per-record weight min(N, CUT) scattered into the strand's difference array (MP:734-738, 870-873)
 // ------------------------------------------------------------------------------------------
+// The two slots of the strand's difference array that a record (or coverage segment) touches: its clamped interval [s, e) adds at s - 1 and takes back
+// at e - 1 of the contig's guarded slice.  ONE definition for the pass that writes them and the pass that clears them again (the arrays must be
+// all zero between passes: a clamp that differed between the two would leave stale counts behind).
+struct CovSlots { int* d; long long i0, i1; bool ok; };
+__device__ __forceinline__ CovSlots cov_slots(const MirpAln& r, const long long* __restrict__ goff, const long long* __restrict__ clen, int* diff_p, int* diff_m) {
+    const long long L = clen[r.tid];
+    long long s = r.pos, e = (long long)r.pos + r.len;
+    if (s < 1) s = 1;
+    if (e > L + 1) e = L + 1;
+    CovSlots c;
+    c.ok = s < e;
+    c.d = (r.strand & 1) ? diff_m : diff_p;
+    const long long base = goff[r.tid];
+    c.i0 = base + s - 1; c.i1 = base + e - 1;
+    return c;
+}
+
 __global__ void __launch_bounds__(256) cov_scatter_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
                                                           const long long* __restrict__ clen, int cutoff, int* __restrict__ diff_p,
                                                           int* __restrict__ diff_m) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-        MirpAln r = alns[k];
+        const MirpAln r = alns[k];
         int w = (int)(r.depth > (unsigned)cutoff ? (unsigned)cutoff : r.depth);
-        long long L = clen[r.tid];
-        long long s = r.pos, e = (long long)r.pos + r.len;
-        if (s < 1) s = 1;
-        if (e > L + 1) e = L + 1;
-        if (s >= e || w == 0) continue;
+        const CovSlots c = cov_slots(r, goff, clen, diff_p, diff_m);
+        if (!c.ok || w == 0) continue;
         if (r.strand & 2) w = -w;          // coverage segment that takes a gapped alignment's own interval back out (mirp_load_coverage_segments)
-        int* d = (r.strand & 1) ? diff_m : diff_p;
-        long long base = goff[r.tid];
-        atomicAdd(&d[base + s - 1], w);
-        atomicAdd(&d[base + e - 1], -w);
+        atomicAdd(&c.d[c.i0], w);
+        atomicAdd(&c.d[c.i1], -w);
     }
 }
 
@@ -41,16 +53,10 @@ __global__ void __launch_bounds__(256) cov_scatter_kernel(const MirpAln* __restr
 __global__ void __launch_bounds__(256) cov_unscatter_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
                                                             const long long* __restrict__ clen, int* __restrict__ diff_p, int* __restrict__ diff_m) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-        MirpAln r = alns[k];
-        long long L = clen[r.tid];
-        long long s = r.pos, e = (long long)r.pos + r.len;
-        if (s < 1) s = 1;
-        if (e > L + 1) e = L + 1;
-        if (s >= e) continue;
-        int* d = (r.strand & 1) ? diff_m : diff_p;
-        long long base = goff[r.tid];
-        d[base + s - 1] = 0;
-        d[base + e - 1] = 0;
+        const CovSlots c = cov_slots(alns[k], goff, clen, diff_p, diff_m);
+        if (!c.ok) continue;
+        c.d[c.i0] = 0;
+        c.d[c.i1] = 0;
     }
 }
 

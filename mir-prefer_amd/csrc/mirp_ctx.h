@@ -99,7 +99,8 @@ static inline int fail(mirp_ctx* c, int code, const std::string& msg) {
 // Uses the LDS-resident kernel when span allows and re-runs flagged windows (length / int16 range) with the generic kernel.
 // sort_kernels.hip: stable device sort by (tid, pos) / keep-region filter of the resident record array
 int mirp_device_sort_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long n, int posbits, int tidbits);
-int mirp_device_mask_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long* n_io, MirpAln* d_segs, MirpAln* d_segtmp, const int* d_owner, long long* nseg_io,
+int mirp_device_mask_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long* n_io, MirpAln* d_segs, MirpAln* d_segtmp, const int* d_owner, const int* d_seg_span,
+                          long long* nseg_io,
                           const long long* d_rfirst, const int* d_rstart, const int* d_remax);
 
 namespace mirp {

@@ -78,6 +78,7 @@ struct NameTable {
 struct ChunkOut {
     std::vector<MirpAln> recs, segs;
     std::vector<int32_t> seg_owner;      // index of the owning record inside this chunk
+    std::vector<int32_t> seg_span;       // for the subtract segment of a gapped record: its reference span + 1 (bam_calend - POS: what `samtools view -L` tests); else 0
     std::string err;
 };
 
@@ -157,7 +158,8 @@ void parse_chunk(const char* b, const char* e, const NameTable* tab, int sample,
                         const int32_t owner = (int32_t)out->recs.size();
                         MirpAln sg = r;
                         sg.strand = (uint8_t)(r.strand | 2);                 // bit 1: subtract (takes the record's own interval back out)
-                        out->segs.push_back(sg); out->seg_owner.push_back(owner);
+                        out->segs.push_back(sg); out->seg_owner.push_back(owner); out->seg_span.push_back(0);
+                        const size_t sub_idx = out->seg_span.size() - 1;
                         // Two passes over the CIGAR.  The bundled samtools 0.1.18 piles a read up only below its bam_calend(), which adds up the
                         // M, D and N lengths but not = and X: blocks are cut at pos + sum(M, D, N) (probed against the binary with
                         // tests/golden/tools/gen_gapped_golden.py; an alignment written with = / X loses its tail there, as in the reference run).
@@ -172,6 +174,7 @@ void parse_chunk(const char* b, const char* e, const NameTable* tab, int sample,
                             if (op == 'M' || op == 'D' || op == 'N') calend += len;
                             else if (!(op == 'I' || op == 'S' || op == 'H' || op == 'P' || op == '=' || op == 'X')) { out->err = "malformed CIGAR " + std::string(c, ce); return; }
                         }
+                        out->seg_span[sub_idx] = (int32_t)std::min<long>(calend - pos, 0x7ffffff0L) + 1;
                         long ref = pos;
                         p = c;
                         while (p < ce) {
@@ -185,7 +188,7 @@ void parse_chunk(const char* b, const char* e, const NameTable* tab, int sample,
                                     const long part = std::min<long>(stop - off, 65535);
                                     MirpAln bsg = r;
                                     bsg.pos = (int32_t)off; bsg.len = (uint16_t)part;
-                                    out->segs.push_back(bsg); out->seg_owner.push_back(owner);
+                                    out->segs.push_back(bsg); out->seg_owner.push_back(owner); out->seg_span.push_back(0);
                                     off += part;
                                 }
                                 ref += len;
@@ -293,7 +296,7 @@ int parse_all(const char* const* paths, int32_t n_paths, int32_t n_threads, Pars
 }
 
 // concatenation in (sample, file) order; segment owners become indices into the concatenated record array
-void concat(Parsed& P, MirpAln* all, MirpAln* segs, int32_t* owner) {
+void concat(Parsed& P, MirpAln* all, MirpAln* segs, int32_t* owner, int32_t* span = nullptr) {
     size_t o = 0, so = 0;
     for (auto& f : P.per_file)
         for (auto& c : f) {
@@ -301,10 +304,11 @@ void concat(Parsed& P, MirpAln* all, MirpAln* segs, int32_t* owner) {
             if (!c.segs.empty()) {
                 std::memcpy(segs + so, c.segs.data(), c.segs.size() * sizeof(MirpAln));
                 for (size_t k = 0; k < c.segs.size(); k++) owner[so + k] = (int32_t)(o + (size_t)c.seg_owner[k]);
+                if (span) std::memcpy(span + so, c.seg_span.data(), c.segs.size() * sizeof(int32_t));
                 so += c.segs.size();
             }
             o += c.recs.size();
-            std::vector<MirpAln>().swap(c.recs); std::vector<MirpAln>().swap(c.segs); std::vector<int32_t>().swap(c.seg_owner);
+            std::vector<MirpAln>().swap(c.recs); std::vector<MirpAln>().swap(c.segs); std::vector<int32_t>().swap(c.seg_owner); std::vector<int32_t>().swap(c.seg_span);
         }
 }
 
@@ -409,7 +413,7 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
     const double t1 = now_s();
     MirpAln* all = nullptr;
     MirpAln* segs = nullptr;
-    std::vector<int32_t> owner;
+    std::vector<int32_t> owner, span;
     long long n = 0, ns = 0;
     auto bail = [&](int code, const std::string& m) { std::free(all); std::free(segs); all = segs = nullptr; mirp_free_sam_data(out); return fail(c, code, m); };
     if (W == 1) {
@@ -417,9 +421,9 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         if (n > 0x7fffffffLL) return fail(c, -5, std::string(who) + ": more than 2^31 records");
         all = (MirpAln*)std::malloc(std::max<size_t>((size_t)n, 1) * sizeof(MirpAln));
         segs = (MirpAln*)std::malloc(std::max<size_t>((size_t)ns, 1) * sizeof(MirpAln));
-        owner.resize(std::max<size_t>((size_t)ns, 1));
+        owner.resize(std::max<size_t>((size_t)ns, 1)); span.resize(std::max<size_t>((size_t)ns, 1));
         if (!all || !segs) return bail(-6, "out of memory");
-        concat(P, all, segs, owner.data());
+        concat(P, all, segs, owner.data(), span.data());
         if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
             c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1)))
             return bail(-6, "device allocation failed (ingest)");
@@ -429,7 +433,7 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         // ---- bucket by destination rank, per file: records, segments, and for every segment the index of its record inside the (file, destination) block
         const int F = n_paths;
         std::vector<std::vector<MirpAln>> brec((size_t)F * W), bseg((size_t)F * W);
-        std::vector<std::vector<int32_t>> bown((size_t)F * W);
+        std::vector<std::vector<int32_t>> bown((size_t)F * W), bspan((size_t)F * W);
         std::vector<int32_t> newidx;
         for (int f = 0; f < F; f++)
             for (auto& ch : P.per_file[f]) {
@@ -443,6 +447,7 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
                     const size_t q = (size_t)f * W + owner_of_tid[ch.segs[k].tid];
                     bseg[q].push_back(ch.segs[k]);
                     bown[q].push_back(newidx[(size_t)ch.seg_owner[k]]);
+                    bspan[q].push_back(ch.seg_span[k]);
                 }
                 std::vector<MirpAln>().swap(ch.recs); std::vector<MirpAln>().swap(ch.segs); std::vector<int32_t>().swap(ch.seg_owner);
             }
@@ -453,8 +458,8 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         if (int rc = mirp::dist_allgather_ll(c, mine.data(), 2 * F * W, cnt)) return rc;
         auto nrec = [&](int s, int f, int q) { return cnt[(size_t)s * 2 * F * W + (size_t)f * W + q]; };
         auto nseg = [&](int s, int f, int q) { return cnt[(size_t)s * 2 * F * W + (size_t)F * W + (size_t)f * W + q]; };
-        // one blob per destination: [records of file 0..F-1][segments of file 0..F-1][owner indices of file 0..F-1]
-        auto blob_bytes = [&](int s, int q) { long long r = 0, g = 0; for (int f = 0; f < F; f++) { r += nrec(s, f, q); g += nseg(s, f, q); } return r * 16 + g * 16 + g * 4; };
+        // one blob per destination: [records of file 0..F-1][segments of file 0..F-1][owner indices of file 0..F-1][reference spans of file 0..F-1]
+        auto blob_bytes = [&](int s, int q) { long long r = 0, g = 0; for (int f = 0; f < F; f++) { r += nrec(s, f, q); g += nseg(s, f, q); } return r * 16 + g * 16 + g * 8; };
         std::vector<long long> soff(W), scnt(W), roff(W), rcnt(W);
         long long stot = 0, rtot = 0;
         for (int q = 0; q < W; q++) { soff[q] = stot; scnt[q] = blob_bytes(me, q); stot += (scnt[q] + 15) & ~15LL; }
@@ -467,8 +472,9 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
             for (int f = 0; f < F; f++) { auto& b = brec[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 16); w += b.size() * 16; }
             for (int f = 0; f < F; f++) { auto& b = bseg[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 16); w += b.size() * 16; }
             for (int f = 0; f < F; f++) { auto& b = bown[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 4); w += b.size() * 4; }
+            for (int f = 0; f < F; f++) { auto& b = bspan[(size_t)f * W + q]; if (!b.empty()) std::memcpy(w, b.data(), b.size() * 4); w += b.size() * 4; }
         }
-        brec.clear(); bseg.clear(); bown.clear();
+        brec.clear(); bseg.clear(); bown.clear(); bspan.clear();
         TmpDevice T;
         char* d_send = (char*)T.get((size_t)stot + 16);
         char* d_recv = (char*)T.get((size_t)rtot + 16);
@@ -479,7 +485,7 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         if (stot) HIPCHK(c, hipMemcpyAsync(d_send, sendbuf.data(), (size_t)stot, hipMemcpyHostToDevice, c->stream));
         if (int rc = mirp::dist_alltoallv_bytes(c, d_send, soff, scnt, d_recv, roff, rcnt)) return rc;
         // unpack into (file, source) order; segment owners are re-based to the record's index in this rank's array
-        owner.resize(std::max<size_t>((size_t)ns, 1));
+        owner.resize(std::max<size_t>((size_t)ns, 1)); span.resize(std::max<size_t>((size_t)ns, 1));
         std::vector<char> hrecv;        // owner indices come back to the host (tiny unless the input is mostly gapped)
         std::vector<long long> rbase((size_t)F * W), sbase((size_t)F * W);
         { long long a = 0, b = 0; for (int f = 0; f < F; f++) for (int s2 = 0; s2 < W; s2++) { rbase[(size_t)f * W + s2] = a; sbase[(size_t)f * W + s2] = b; a += nrec(s2, f, me); b += nseg(s2, f, me); } }
@@ -489,13 +495,20 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
             long long rsum = 0, gsum = 0;
             for (int f = 0; f < F; f++) { rsum += nrec(s2, f, me); gsum += nseg(s2, f, me); }
             long long o_rec = ro, o_seg = ro + rsum * 16, o_own = ro + rsum * 16 + gsum * 16;
-            if (gsum) { own_tmp.resize((size_t)gsum); HIPCHK(c, hipMemcpyAsync(own_tmp.data(), d_recv + o_own, (size_t)gsum * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+            if (gsum) {      // owner indices and spans of this source's segments (both int32, back to back)
+                own_tmp.resize((size_t)gsum * 2);
+                HIPCHK(c, hipMemcpyAsync(own_tmp.data(), d_recv + o_own, (size_t)gsum * 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
             long long go = 0;
             for (int f = 0; f < F; f++) {
                 const long long r = nrec(s2, f, me), g = nseg(s2, f, me);
                 if (r) HIPCHK(c, hipMemcpyAsync((char*)c->alns.p + rbase[(size_t)f * W + s2] * 16, d_recv + o_rec, (size_t)r * 16, hipMemcpyDeviceToDevice, c->stream));
                 if (g) HIPCHK(c, hipMemcpyAsync((char*)c->segs.p + sbase[(size_t)f * W + s2] * 16, d_recv + o_seg, (size_t)g * 16, hipMemcpyDeviceToDevice, c->stream));
-                for (long long k = 0; k < g; k++) owner[(size_t)(sbase[(size_t)f * W + s2] + k)] = (int32_t)(rbase[(size_t)f * W + s2] + own_tmp[(size_t)(go + k)]);
+                for (long long k = 0; k < g; k++) {
+                    owner[(size_t)(sbase[(size_t)f * W + s2] + k)] = (int32_t)(rbase[(size_t)f * W + s2] + own_tmp[(size_t)(go + k)]);
+                    span[(size_t)(sbase[(size_t)f * W + s2] + k)] = own_tmp[(size_t)(gsum + go + k)];
+                }
                 o_rec += r * 16; o_seg += g * 16; go += g;
             }
         }
@@ -530,14 +543,16 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         int* d_rs = (int*)T.get(4 * std::max<size_t>(rs.size(), 1));
         int* d_rm = (int*)T.get(4 * std::max<size_t>(rm.size(), 1));
         int* d_own = (int*)T.get(4 * (size_t)std::max<long long>(ns, 1));
+        int* d_span = (int*)T.get(4 * (size_t)std::max<long long>(ns, 1));
         MirpAln* d_segtmp = (MirpAln*)T.get(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1));
-        if (!d_rf || !d_rs || !d_rm || !d_own || !d_segtmp) return bail(-6, "device allocation failed (regions)");
+        if (!d_rf || !d_rs || !d_rm || !d_own || !d_span || !d_segtmp) return bail(-6, "device allocation failed (regions)");
         if (hipMemcpy(d_rf, rfirst.data(), 8 * rfirst.size(), hipMemcpyHostToDevice) != hipSuccess ||
             (!rs.empty() && (hipMemcpy(d_rs, rs.data(), 4 * rs.size(), hipMemcpyHostToDevice) != hipSuccess ||
                              hipMemcpy(d_rm, rm.data(), 4 * rm.size(), hipMemcpyHostToDevice) != hipSuccess)) ||
-            (ns && hipMemcpy(d_own, owner.data(), 4 * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess))
+            (ns && (hipMemcpy(d_own, owner.data(), 4 * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d_span, span.data(), 4 * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess)))
             return bail(-2, "H2D failed");
-        if (int rc = mirp_device_mask_alns(c, (MirpAln*)c->alns.p, (MirpAln*)c->sort_tmp.p, &n, (MirpAln*)c->segs.p, d_segtmp, d_own, &ns, d_rf, d_rs, d_rm)) {
+        if (int rc = mirp_device_mask_alns(c, (MirpAln*)c->alns.p, (MirpAln*)c->sort_tmp.p, &n, (MirpAln*)c->segs.p, d_segtmp, d_own, d_span, &ns, d_rf, d_rs, d_rm)) {
             std::free(all); std::free(segs); mirp_free_sam_data(out); return rc;
         }
     }

@@ -97,10 +97,11 @@ __global__ void __launch_bounds__(64 * SORT_WAVES) sort_scatter_kernel(const Mir
 // `samtools view -L bed` on the record array: keep[k] = 1 iff record k overlaps one of the (merged, per-contig sorted) regions.
 // Regions: starts[r], ends[r] 0-based half-open, emax[r] = running maximum of the ends inside the contig, rfirst[tid] .. rfirst[tid+1] the contig's slice.
 __global__ void mask_keep_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ rfirst, const int* __restrict__ rstart,
-                                 const int* __restrict__ remax, int* __restrict__ keep) {
+                                 const int* __restrict__ remax, const int* __restrict__ rspan, int* __restrict__ keep) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
         const MirpAln r = alns[k];
-        const long long a0 = (long long)r.pos - 1, a1 = a0 + r.len;
+        // `samtools view -L` tests [POS - 1, bam_calend): the reference span (M + D + N) of a gapped alignment, len(SEQ) of a plain one
+        const long long a0 = (long long)r.pos - 1, a1 = a0 + ((rspan && rspan[k]) ? (long long)rspan[k] - 1 : (long long)r.len);
         long long lo = rfirst[r.tid], hi = rfirst[r.tid + 1];
         const long long f = lo;
         while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)rstart[mid] < a1) lo = mid + 1; else hi = mid; }   // regions with start < a1
@@ -111,6 +112,11 @@ __global__ void mask_compact_kernel(const MirpAln* __restrict__ in, const int* _
                                     MirpAln* __restrict__ out) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x)
         if (keep[k]) out[kscan[k]] = in[k];
+}
+// reference span + 1 of the gapped records: carried by their subtract segment (seg_span != 0), scattered to the record's slot
+__global__ void mask_span_kernel(const int* __restrict__ owner, const int* __restrict__ seg_span, long long n, int* __restrict__ rspan) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x)
+        if (seg_span[k]) rspan[owner[k]] = seg_span[k];
 }
 // coverage segments of gapped alignments follow their owner (index into the unfiltered record array)
 __global__ void mask_seg_keep_kernel(const int* __restrict__ owner, long long n, const int* __restrict__ keep_rec, int* __restrict__ keep) {
@@ -147,14 +153,24 @@ int mirp_device_sort_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long lon
 }
 
 // keep[] + stable compaction of records (and of the coverage segments through their owners).  Regions arrive per contig, sorted by start.
-int mirp_device_mask_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long* n_io, MirpAln* d_segs, MirpAln* d_segtmp, const int* d_owner, long long* nseg_io,
+int mirp_device_mask_alns(mirp_ctx* c, MirpAln* d_alns, MirpAln* d_tmp, long long* n_io, MirpAln* d_segs, MirpAln* d_segtmp, const int* d_owner, const int* d_seg_span,
+                          long long* nseg_io,
                           const long long* d_rfirst, const int* d_rstart, const int* d_remax) {
     const long long n = *n_io, ns = *nseg_io;
     if (n <= 0) return 0;
     if (c->keep.ensure(4 * (size_t)std::max<long long>(n, 1)) || c->kscan.ensure(8 * (size_t)(n + 1))) return fail(c, -6, "device allocation failed (mask)");
     int* keep = (int*)c->keep.p;
     long long* kscan = (long long*)c->kscan.p;
-    hipLaunchKernelGGL(mirp::mask_keep_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, c->stream, (const MirpAln*)d_alns, n, d_rfirst, d_rstart, d_remax, keep);
+    TmpDevice TS;
+    int* rspan = nullptr;
+    if (ns > 0 && d_seg_span) {
+        rspan = (int*)TS.get(4 * (size_t)n);
+        if (!rspan) return fail(c, -6, "device allocation failed (mask)");
+        HIPCHK(c, hipMemsetAsync(rspan, 0, 4 * (size_t)n, c->stream));
+        hipLaunchKernelGGL(mirp::mask_span_kernel, dim3(grid_for(ns, 256, 8192)), dim3(256), 0, c->stream, d_owner, d_seg_span, ns, rspan);
+    }
+    hipLaunchKernelGGL(mirp::mask_keep_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, c->stream, (const MirpAln*)d_alns, n, d_rfirst, d_rstart, d_remax,
+                       (const int*)rspan, keep);
     mirp::launch_excl_scan(c->stream, keep, kscan, n);
     long long kept = 0;
     HIPCHK(c, hipMemcpyAsync(&kept, kscan + n, 8, hipMemcpyDeviceToHost, c->stream));

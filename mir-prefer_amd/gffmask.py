@@ -72,12 +72,13 @@ def keep_regions_include(path, minlen=55):
     return out
 
 
-def keep_mask(alns, regions):
+def keep_mask(alns, regions, span=None):
     """`samtools view -L bed` as a boolean mask: True for the records that overlap any keep region.  regions: [(tid, start0, end0)] 0-based
-    half-open; alns: ALN_DTYPE in any order, pos 1-based."""
+    half-open; alns: ALN_DTYPE in any order, pos 1-based.  The bundled samtools 0.1.18 tests [POS - 1, bam_calend): span = the reference span
+    (sum of the M / D / N lengths) per record; None = len(SEQ), which is the same thing for ungapped alignments."""
     keep = np.zeros(len(alns), dtype=bool)
     a0 = alns["pos"].astype(np.int64) - 1
-    a1 = a0 + alns["len"].astype(np.int64)
+    a1 = a0 + (alns["len"].astype(np.int64) if span is None else np.asarray(span, dtype=np.int64))
     by_tid = {}
     for t, s, e in regions:
         if e > s:

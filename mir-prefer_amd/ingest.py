@@ -93,7 +93,7 @@ def read_sams(paths, native=True, regions=None, with_segments=False):
     names, lens = read_sam_header(paths[0])
     tid_of = {n: i for i, n in enumerate(names)}
     sample_names = []
-    recs, segs, owner = [], [], []
+    recs, segs, owner, span = [], [], [], []
     for si, p in enumerate(paths):
         sname = None
         with _open(p) as f:
@@ -112,17 +112,19 @@ def read_sams(paths, native=True, regions=None, with_segments=False):
                 cigar = sp[5]
                 rl = len(sp[9])
                 rec = (tid_of[sp[2]], int(sp[3]), int(m.group(1)), rl, 1 if flag & 16 else 0, si)
+                sp_ref = rl
                 if cigar != "%dM" % rl:
                     for sg in cigar_segments(rec, cigar):
                         segs.append(sg); owner.append(len(recs))
-                recs.append(rec)
+                    sp_ref = sum(int(ln) for ln, op in _CIGAR_RE.findall(cigar) if op in "MDN")      # bam_calend - POS: what `samtools view -L` tests
+                recs.append(rec); span.append(sp_ref)
         sample_names.append(sname)
     dt = [("tid", "<i4"), ("pos", "<i4"), ("depth", "<u4"), ("len", "<u2"), ("strand", "u1"), ("sample", "u1")]
     a = np.array(recs, dtype=dt).astype(ALN_DTYPE)
     sg = np.array(segs, dtype=dt).astype(ALN_DTYPE) if segs else np.zeros(0, dtype=ALN_DTYPE)
     if regions is not None:
         from . import gffmask
-        keep = gffmask.keep_mask(a, regions)
+        keep = gffmask.keep_mask(a, regions, span=np.array(span, dtype=np.int64))
         if len(sg):
             sg = sg[keep[np.array(owner, dtype=np.int64)]]
         a = a[keep]

@@ -64,11 +64,31 @@ def main():
         subprocess.check_call([ST, "view", "-b", "-F", "16", "-o", p("plus.bam"), p("exp.bam")])
         subprocess.check_call([ST, "view", "-b", "-f", "16", "-o", p("minus.bam"), p("exp.bam")])
         depth = subprocess.run("%s depth %s %s | awk '$3+$4>%d'" % (ST, p("plus.bam"), p("minus.bam"), cut), shell=True, capture_output=True, text=True, check=True).stdout
+        # `samtools view -L <bed>` on the gapped reads (the GFF masking of prepare_data, MP:817-859): 0.1.18 tests [POS-1, bam_calend) -- the M / D / N
+        # span, not len(SEQ) -- so a region inside an intron keeps the read and a soft-clipped read just before a region does not reach it.
+        # Regions: seeded ones plus, for a sample of gapped reads, a region just past POS-1+len(SEQ) or inside the first D / N gap.
+        import re
+        regions = []
+        recs = [l.split("\t") for l in text.splitlines() if not l.startswith("@")]
+        for f in recs[::7]:
+            pos0, cg, sl = int(f[3]) - 1, f[5], len(f[9])
+            span = sum(int(n) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", cg) if o in "MDN")
+            if cg != "%dM" % sl and span != sl:
+                lo, hi = sorted((pos0 + span, pos0 + sl))
+                regions.append((f[2], lo, hi))                               # between the reference span and the SEQ length: only one of the two rules sees it
+        for _ in range(12):
+            c, L = r.choice(contigs)
+            a = r.randint(0, L - 40)
+            regions.append((c, a, a + r.randint(1, 30)))
+        open(p("k.bed"), "w").write("".join("%s\t%d\t%d\n" % x for x in regions))
+        kept = subprocess.run([ST, "view", "-L", p("k.bed"), p("in.bam")], capture_output=True, text=True, check=True).stdout
+        kept_ids = sorted(l.split("\t")[0] for l in kept.splitlines())
     path = os.path.join(GOLD, "gapped.json.gz")
     with gzip.open(path, "wt", compresslevel=9) as f:
         json.dump({"generator": "bundled samtools 0.1.18: view -bS, sort, expand (x min(N, CUT)), strand split, depth | awk (miR_PREFeR.py:716-746, 759-769, 937-941)",
-                   "sam": text, "contigs": [list(c) for c in contigs], "cutoff": cut, "depth_cut": depth}, f)
-    print("wrote", path, os.path.getsize(path), len(sam), "SAM lines,", len(depth.splitlines()), "depth lines")
+                   "sam": text, "contigs": [list(c) for c in contigs], "cutoff": cut, "depth_cut": depth,
+                   "view_L": {"bed": [list(x) for x in regions], "kept_ids": kept_ids}}, f)
+    print("wrote", path, os.path.getsize(path), len(sam), "SAM lines,", len(depth.splitlines()), "depth lines,", len(kept_ids), "of", len(recs), "reads kept by view -L")
 
 
 if __name__ == "__main__":

@@ -291,3 +291,25 @@ def test_native_fasta_reader_matches_the_python_reader(tmp_path):
     assert part[0][1].tobytes() == b"ACGTacgtNNACGTTT" and part[1][1] is None and part[2][1].tobytes() == b"GGGG>notaheaderCC" and part[3][1] is None
     with pytest.raises(ValueError):
         capi.read_fasta(str(tmp_path / "missing.fa"))
+
+
+def test_host_keep_mask_uses_the_reference_span_of_gapped_reads(tmp_path):
+    """gffmask.keep_mask / ingest.read_sams(regions=...) against the reads the bundled samtools 0.1.18 `view -L` keeps on the gapped fixture:
+    the overlap test runs on [POS - 1, bam_calend), the M / D / N span (gen_gapped_golden.py, `view_L`)."""
+    from mir_prefer_amd import gffmask, ingest
+    from tests import golden_util as gu
+    g = gu.load_json("gapped.json.gz")
+    sam = tmp_path / "S1.sam"
+    sam.write_text(g["sam"])
+    names = [c[0] for c in g["contigs"]]
+    regions = gffmask.regions_by_tid([tuple(x) for x in g["view_L"]["bed"]], names)
+    _, _, _, alns = ingest.read_sams([str(sam)], native=False, regions=regions)
+    lines = [l.split("\t") for l in g["sam"].splitlines() if not l.startswith("@")]
+    kept = set(g["view_L"]["kept_ids"])
+    want = sorted((names.index(f[2]), int(f[3]), int(f[0].rsplit("_x", 1)[1]), len(f[9])) for f in lines if f[0] in kept)
+    got = sorted((int(r["tid"]), int(r["pos"]), int(r["depth"]), int(r["len"])) for r in alns)
+    assert got == want and 5 < len(want) < len(lines)
+    # the len(SEQ) rule (round 2) disagrees with the binary on this fixture: the test has teeth
+    _, _, _, a0 = ingest.read_sams([str(sam)], native=False)
+    old = sorted((int(r["tid"]), int(r["pos"]), int(r["depth"]), int(r["len"])) for r in a0[gffmask.keep_mask(a0, regions)])
+    assert old != want

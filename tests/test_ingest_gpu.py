@@ -166,3 +166,36 @@ def test_cli_with_gff_exclude_on_the_device_path(tmp_path):
         assert open(out_d / fn).read() == open(out_h / fn).read()
     dd = open(out_d / (prefix + "_tmp") / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read()
     assert dd == open(out_h / (prefix + "_tmp") / ("bam.depth.cut%d" % exp["config"]["READS_DEPTH_CUTOFF"])).read() and dd != exp["depth_cut"]
+
+
+def test_keep_regions_on_gapped_alignments_match_samtools_view_L(gpu_ctx, tmp_path):
+    """`samtools view -L` of the bundled 0.1.18 tests [POS - 1, bam_calend) -- the M / D / N span of a gapped alignment, not len(SEQ): a region inside
+    an intron keeps the read, a region next to a soft-clipped read does not (golden: gen_gapped_golden.py, `view_L`).  Device filter
+    (mask_keep_kernel) and host filter (gffmask.keep_mask) both keep exactly the reads the binary keeps, and the segments of the dropped ones go."""
+    g = gu.load_json("gapped.json.gz")
+    sam = tmp_path / "S1.sam"
+    sam.write_text(g["sam"])
+    names = [c[0] for c in g["contigs"]]
+    regions = gffmask.regions_by_tid([tuple(x) for x in g["view_L"]["bed"]], names)
+    ids = [l.split("\t")[0] for l in g["sam"].splitlines() if not l.startswith("@")]
+    want = sorted(g["view_L"]["kept_ids"])
+    assert 5 < len(want) < len(ids)
+
+    def kept_ids(alns):
+        # a record is identified by (contig, pos, depth, len, strand): map back to the read ids of the input
+        key = {}
+        for l in g["sam"].splitlines():
+            if l.startswith("@"):
+                continue
+            f = l.split("\t")
+            key.setdefault((names.index(f[2]), int(f[3]), int(f[0].rsplit("_x", 1)[1]), len(f[9]), 1 if int(f[1]) & 16 else 0), []).append(f[0])
+        out = []
+        for r in alns:
+            out.append(key[(int(r["tid"]), int(r["pos"]), int(r["depth"]), int(r["len"]), int(r["strand"]))].pop(0))
+        return sorted(out)
+    _, _, _, a_dev, s_dev, _ = gpu_ctx.ingest_sams([str(sam)], regions=regions)
+    _, _, _, a_host, s_host = ingest.read_sams([str(sam)], native=False, regions=regions, with_segments=True)
+    assert kept_ids(a_dev) == want and kept_ids(a_host) == want
+    assert np.array_equal(a_dev, a_host) and sorted(map(tuple, s_dev.tolist())) == sorted(map(tuple, s_host.tolist()))
+    _, _, _, a_all, s_all, _ = gpu_ctx.ingest_sams([str(sam)])
+    assert len(s_dev) < len(s_all)
