@@ -110,6 +110,14 @@ int mirp_predict_batch(mirp_ctx* ctx, const MirpWindow* windows, int32_t n_windo
                        int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* params, MirpMirna** mirnas,
                        int32_t** n_mirnas, int32_t** status);
 
+/* The same filter with the -d bookkeeping of check_loci (dict_why_not_miRNA_reasons, MP:2206-2347): besides the miRNA lists, one int32 record per
+ * window and per evaluated (mature, structure) pair -- the get_maturestar_info code (MP:1876-1999) and the expression numbers of the pair; layout
+ * and flags as documented at mirp_predict_reasons. */
+int mirp_predict_batch_reasons(mirp_ctx* ctx, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
+                               const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
+                               int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* params, MirpMirna** mirnas,
+                               int32_t** n_mirnas, int32_t** status, int32_t** reasons, int64_t* n_reasons, int32_t* reasons_stride);
+
 /* ------------------------------------------------------------------------------------------------
  * Device-resident pipeline: inputs are uploaded once, every stage leaves its results in HBM for the
  * next one, and only what a caller asks for is copied back.

@@ -168,6 +168,9 @@ def load_library():
     lib.mirp_predict_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp,
                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mirp_predict_batch.restype = C.c_int
+    lib.mirp_predict_batch_reasons.argtypes = [vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int32, vp, vp,
+                                               C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.mirp_predict_batch_reasons.restype = C.c_int
     i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
     lib.mirp_load_genome.argtypes = [vp, C.c_int32, vp, vp]
     lib.mirp_load_alignments.argtypes = [vp, vp, C.c_int64]
@@ -350,6 +353,29 @@ class Context:
         self._check(rc, "mirp_predict_batch")
         a_o = _copy_out(self.lib, o, records.MIRNA_DTYPE, n * records.MAX_MIRNA_PER_WINDOW).reshape(n, records.MAX_MIRNA_PER_WINDOW)
         return a_o, _copy_out(self.lib, no, np.int32, n), _copy_out(self.lib, st, np.int32, n)
+
+    def predict_batch_reasons(self, windows, matures, alns, fold_raw, params):
+        """predict_batch plus the -d records (mirp_predict_batch_reasons): -> (mirnas, n_mirnas, status, reasons[n_records, stride]); the layout
+        of a record is documented at mirp_predict_reasons in include/mirprefer.h."""
+        from . import records
+        windows = np.ascontiguousarray(windows, dtype=records.WINDOW_DTYPE)
+        matures = np.ascontiguousarray(matures, dtype=records.MATURE_DTYPE)
+        alns = np.ascontiguousarray(alns)
+        lines = np.ascontiguousarray(fold_raw["lines"])
+        ss = np.ascontiguousarray(fold_raw["ss"])
+        nl = np.ascontiguousarray(fold_raw["n_lines"], dtype=np.int32)
+        n = len(windows)
+        pp = (C.c_int32 * 6)(*[int(x) for x in params])
+        vp = C.c_void_p
+        o, no, st, rr = vp(), vp(), vp(), vp()
+        nr, rs = C.c_int64(), C.c_int32()
+        rc = self.lib.mirp_predict_batch_reasons(self.h, windows.ctypes.data, n, matures.ctypes.data, len(matures), alns.ctypes.data if len(alns) else None, len(alns),
+                                                 lines.ctypes.data, ss.ctypes.data, int(fold_raw["stride"]), int(fold_raw["max_lines"]),
+                                                 nl.ctypes.data, pp, C.byref(o), C.byref(no), C.byref(st), C.byref(rr), C.byref(nr), C.byref(rs))
+        self._check(rc, "mirp_predict_batch_reasons")
+        a_o = _copy_out(self.lib, o, records.MIRNA_DTYPE, n * records.MAX_MIRNA_PER_WINDOW).reshape(n, records.MAX_MIRNA_PER_WINDOW)
+        rec = _copy_out(self.lib, rr, np.int32, nr.value * rs.value).reshape(nr.value, max(rs.value, 1)) if rr.value else np.zeros((0, max(rs.value, 1)), np.int32)
+        return a_o, _copy_out(self.lib, no, np.int32, n), _copy_out(self.lib, st, np.int32, n), rec
 
     # ---- device-resident pipeline -------------------------------------------------------------
     def load_genome(self, contigs):

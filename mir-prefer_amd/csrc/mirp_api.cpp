@@ -188,10 +188,10 @@ extern "C" int mirp_fold_batch_summary(mirp_ctx* c, const char* seqs, const int6
 template <class T>
 static T* host_alloc(size_t n) { return (T*)std::calloc(std::max<size_t>(n, 1), sizeof(T)); }
 
-extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
-                                  const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
-                                  int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* pp, MirpMirna** mirnas,
-                                  int32_t** n_mirnas, int32_t** status) {
+static int predict_batch_impl(mirp_ctx* c, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
+                              const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
+                              int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* pp, MirpMirna** mirnas,
+                              int32_t** n_mirnas, int32_t** status, int32_t** reasons, int64_t* n_reasons, int32_t* reasons_stride) {
     if (!c) return -1;
     if (!windows || !matures || !alns || !lines || !ss || !n_lines || !pp || !mirnas || !n_mirnas || !status || n_windows < 0)
         return fail(c, -1, "mirp_predict_batch: null argument");
@@ -225,10 +225,26 @@ extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_
             hipMemcpyAsync(d_n, n_lines, 4 * (size_t)n_windows, hipMemcpyHostToDevice, c->stream) != hipSuccess)
             return bail(-2, "H2D copy failed");
         int grid = std::min(n_windows, c->n_cu * 16);
+        // reasons mode (-d): one int32 record per window and per evaluated (mature, structure) pair, layout as mirp_predict_reasons
+        const int rstride = 21 + pp->n_samples;
+        unsigned int rcap = reasons ? (unsigned int)std::min<unsigned long long>((unsigned long long)n_windows * 96ull + 1024ull, 0x7fffffffull / (unsigned)rstride) : 0u;
+        unsigned int* d_cnt = reasons ? (unsigned int*)T.get(16) : nullptr;
+        int* d_pool = reasons ? (int*)T.get((size_t)rcap * rstride * 4) : nullptr;
+        if (reasons && (!d_cnt || !d_pool)) return bail(-6, "device allocation failed (reasons pool)");
+        if (reasons && hipMemsetAsync(d_cnt, 0, 16, c->stream) != hipSuccess) return bail(-2, "memset failed");
         if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)d_w, n_windows, (const MirpMature*)d_m, (const MirpAln*)d_a, n_alns,
                                  (const MirpFoldLine*)d_l, (const char*)d_s, ss_stride, max_lines, (const int*)d_n, *pp, (MirpMirna*)d_o,
-                                 (int*)d_no, (int*)d_st) != hipSuccess)
+                                 (int*)d_no, (int*)d_st, d_cnt, d_pool, rcap, rstride) != hipSuccess)
             return bail(-2, "predict kernel launch failed");
+        if (reasons) {
+            unsigned int n = 0;
+            if (hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+                return bail(-2, "predict kernel execution failed");
+            if (n > rcap) return bail(-6, "mirp_predict_batch_reasons: record pool overflow");
+            int32_t* h = host_alloc<int32_t>((size_t)n * rstride);
+            if (!h || (n && hipMemcpy(h, d_pool, (size_t)n * rstride * 4, hipMemcpyDeviceToHost) != hipSuccess)) { std::free(h); return bail(-2, "D2H copy failed"); }
+            *reasons = h; *n_reasons = n; *reasons_stride = rstride;
+        }
         if (hipMemcpyAsync(h_o, d_o, sizeof(MirpMirna) * (size_t)n_windows * MIRP_MAX_MIRNA_PER_WINDOW, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(h_no, d_no, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(h_st, d_st, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -237,6 +253,24 @@ extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_
     }
     *mirnas = h_o; *n_mirnas = h_no; *status = h_st;
     return 0;
+}
+
+extern "C" int mirp_predict_batch(mirp_ctx* c, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
+                                  const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
+                                  int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* pp, MirpMirna** mirnas,
+                                  int32_t** n_mirnas, int32_t** status) {
+    return predict_batch_impl(c, windows, n_windows, matures, n_matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, mirnas, n_mirnas, status,
+                              nullptr, nullptr, nullptr);
+}
+
+extern "C" int mirp_predict_batch_reasons(mirp_ctx* c, const MirpWindow* windows, int32_t n_windows, const MirpMature* matures, int64_t n_matures,
+                                          const MirpAln* alns, int64_t n_alns, const MirpFoldLine* lines, const char* ss, int32_t ss_stride,
+                                          int32_t max_lines, const int32_t* n_lines, const MirpPredictParams* pp, MirpMirna** mirnas,
+                                          int32_t** n_mirnas, int32_t** status, int32_t** reasons, int64_t* n_reasons, int32_t* reasons_stride) {
+    if (!reasons || !n_reasons || !reasons_stride) return fail(c, -1, "mirp_predict_batch_reasons: null argument");
+    *reasons = nullptr; *n_reasons = 0; *reasons_stride = 0;
+    return predict_batch_impl(c, windows, n_windows, matures, n_matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, mirnas, n_mirnas, status,
+                              reasons, n_reasons, reasons_stride);
 }
 
 int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,

@@ -63,6 +63,7 @@ enum {
     MS_FAIL_MAX_BULGE_GT_2, MS_FAIL_TOTAL_LOOP_GT_5, MS_FAIL_NUM_BULGE_GT_2, MS_REFERENCE_EXCEPTION
 };
 typedef struct { int32_t code; int32_t star_s, star_e, fold_s, fold_e; int32_t prime5, total_dots, total_bps; int32_t star_l0, star_l1, mat_l0, mat_l1; } OracleMatureStar;
+int oracle_duplex_code(const char *mature, int ml, const char *star, int sl);   /* stat_duplex + pass_stat_duplex alone: MS_* code */
 int oracle_maturestar(const char *ss, int len, int m0, int m1, int foldstart, int regionstart, int regionend, int strand, OracleMatureStar *out);
 
 #define ORACLE_MAX_SAMPLES 16

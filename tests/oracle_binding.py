@@ -156,6 +156,10 @@ class Oracle:
         n = self.lib.oracle_structures(arr, len(lines), minlen, out, MAX_STRUCTS)
         return [(out[k].norm_energy, out[k].fold_start, out[k].ss.decode(), out[k].sstype) for k in range(n)]
 
+    def duplex_code(self, mature, star):
+        self.lib.oracle_duplex_code.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        return int(self.lib.oracle_duplex_code(mature.encode(), len(mature), star.encode(), len(star)))
+
     def maturestar(self, ss, m0, m1, foldstart, regionstart, regionend, strand):
         o = MatureStar()
         self.lib.oracle_maturestar(ss.encode(), len(ss), m0, m1, foldstart, regionstart, regionend, strand, C.byref(o))

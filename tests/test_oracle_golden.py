@@ -265,3 +265,61 @@ def test_gapped_alignments_depth_matches_samtools(oracle, tmp_path):
         assert names == [c[0] for c in g["contigs"]] and len(segs) > 50
         depth, _ = oracle.coverage_peaks(_coverage_records(alns, segs), lens, g["cutoff"])
         assert records.depth_text(depth, names) == g["depth_cut"]
+
+
+MS_CODE = {"FAIL_STRUCTURE_MATCHED_BASES": 1, "FAIL_STRUCTURE_MATURE_NOT_IN_FOLD_REGION": 2, "FAIL_STRUCTURE_MATURE_NOT_IN_ONE_ARM": 3,
+           "FAIL_STRUCTURE_MATURE_MATCH_SMALL_THAN_14": 4, "FAIL_STRUCTURE_MATURE_STAR_OVERLAP": 5, "FAIL_STRUCTURE_STAR_OUT_OF_FOLD_REGION": 6,
+           "FAIL_STRUCTURE_STAR_NOT_IN_ONE_ARM": 7, "FAIL_STRUCTURE_TOO_MANY_BULGE_OR_LOOP": 8, "FAIL_STRUCTURE_MAX_BULGE_LARGE_THAN_2": 9,
+           "FAIL_STRUCTURE_TOTAL_LOOP_SIZE_LARGER_THAN_5": 10, "FAIL_STRUCTURE_NUM_BULGE_MORE_THAN_2": 11}
+
+
+def test_structure_rules_match_direct_reference_calls(oracle):
+    """the oracle's a8 (oracle_structures) and a9 (oracle_maturestar) against DIRECT calls of the reference's
+    get_structures_next_extendregion / is_stem_loop / filter_ss / has_one_good_bifurcation and get_maturestar_info / stat_duplex /
+    pass_stat_duplex on seeded dot-brackets (tests/golden/tools/gen_struct_golden.py): every failure code of MP:1848-1999 at least 20 times,
+    FAIL_STRUCTURE_TOO_MANY_BULGE_OR_LOOP and FAIL_STRUCTURE_MATCHED_BASES included, which no pipeline fixture reaches."""
+    g = gu.load_json("struct_rules.json.gz")
+    assert len(g["structures"]) + len(g["maturestar"]) + len(g["duplex"]) >= 10000
+    counts = g["maturestar_code_counts"]
+    assert all(counts.get(k, 0) >= 20 for k in MS_CODE), counts
+    # a8: the structure list of one RNALfold line
+    n_multi = 0
+    for c in g["structures"]:
+        got = oracle.structures_from_lines([(c["ss"], int(round(c["energy"] * 100)), c["start"])], 55)
+        want = [(e, s, x, t) for e, s, x, t in c["extend"]]
+        assert [(s, x, t) for _, s, x, t in got] == [(s, x, t) for _, s, x, t in want], c["ss"]
+        for (ge, _, _, _), (we, _, _, _) in zip(got, want):
+            assert ge == we          # float(E) / len(ss): the same double
+        n_multi += len(want) > 1
+        if len(c["ss"]) >= 55:
+            # a line that is a stem-loop is exactly one type-0 entry holding the whole line
+            assert c["is_stem_loop"] == (len(want) == 1 and want[0][3] == 0 and want[0][2] == c["ss"]) or not c["is_stem_loop"]
+    assert n_multi > 100
+    # a9: get_maturestar_info
+    seen = {}
+    for c in g["maturestar"]:
+        r = c["result"]
+        o = oracle.maturestar(c["ss"], c["mature"][0], c["mature"][1], c["foldstart"], c["regionstart"], c["regionend"], 1 if c["strand"] == "-" else 0)
+        if "raises" in r:
+            assert o.code == 12, c
+            continue
+        if isinstance(r["ok"], str):
+            assert o.code == MS_CODE[r["ok"]], (c, o.code)
+            seen[r["ok"]] = seen.get(r["ok"], 0) + 1
+        else:
+            ss_, se_, fs_, fe_, star_ss, prime5, mature_ss, dots, bps = r["ok"]
+            assert o.code == 0, (c, o.code)
+            assert (o.star_s, o.star_e, o.fold_s, o.fold_e, bool(o.prime5), o.total_dots, o.total_bps) == (ss_, se_, fs_, fe_, prime5, dots, bps), c
+            assert c["ss"][o.star_l0:o.star_l1] == star_ss and c["ss"][o.mat_l0:o.mat_l1] == mature_ss
+    assert all(seen.get(k, 0) >= 20 for k in MS_CODE)
+    # stat_duplex + pass_stat_duplex on duplex halves alone
+    fails = 0
+    for c in g["duplex"]:
+        code = oracle.duplex_code(c["mature"], c["star"])
+        if "raises" in c["stat"]:
+            assert code == 12
+            continue
+        want = c["pass"]["ok"][0]
+        assert code == (MS_CODE[want] if want else 0), c
+        fails += want is not None
+    assert fails > 200

@@ -3,7 +3,7 @@ against the reference's own decisions and result list (tests/golden/*/expected.j
 import numpy as np
 import pytest
 
-from mir_prefer_amd import records
+from mir_prefer_amd import records, synth
 from tests import golden_util as gu
 
 pytestmark = pytest.mark.gpu
@@ -56,3 +56,85 @@ def test_fold_then_predict_matches_reference(name, gpu_ctx, oracle):
             result.append(rec(w, mir[w, 0]))
     exp_res = [e[:10] for e in gu.unjson(c["exp"]["result_raw"])]
     assert result == exp_res and len(result) > 5
+
+
+def _batch(cases, max_len=352):
+    """One window per case: a single RNALfold line (the case's dot-bracket) and a single candidate mature."""
+    n = len(cases)
+    W = np.zeros(n, dtype=records.WINDOW_DTYPE)
+    M = np.zeros(n, dtype=records.MATURE_DTYPE)
+    lines = np.zeros((n, 1), dtype=[("start", "<i4"), ("len", "<i4"), ("energy", "<i4"), ("printed", "<i4")])
+    ss = np.zeros((n, 1, max_len), dtype=np.uint8)
+    for k, c in enumerate(cases):
+        st = 1 if c["strand"] == "-" else 0
+        W[k] = (0, c["regionstart"], c["regionend"], st, c["regionstart"], c["regionend"], 0, 0, 0, 1, 0, k, 0, c["regionend"] - c["regionstart"], 0)
+        M[k] = (c["mature"][0], c["mature"][1], st, 100)
+        b = c["ss"].encode()
+        lines[k, 0] = (c["foldstart"], len(b), c.get("energy_dcal", -1000), 1)
+        ss[k, 0, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+    raw = {"lines": lines, "ss": ss, "n_lines": np.ones(n, dtype=np.int32), "stride": max_len, "max_lines": 1}
+    return W, M, raw
+
+
+def _is_stem_loop(ss):          # MP:1602-1608 with minloopsize 3
+    return ss.find(")") - ss.rfind("(") - 1 >= 3
+
+
+def test_duplex_rules_on_device_match_direct_reference_calls(gpu_ctx):
+    """predict_kernel's a8 / a9 against DIRECT calls of the reference's functions (tests/golden/struct_rules.json.gz), through
+    the -d records of mirp_predict_batch_reasons: the get_maturestar_info code of every (mature, structure) pair -- each failure code of
+    MP:1848-1999 at least 20 times, FAIL_STRUCTURE_TOO_MANY_BULGE_OR_LOOP and FAIL_STRUCTURE_MATCHED_BASES included -- the star / fold coordinates of
+    the passing ones, and the structure list (pieces of filter_ss, MP:1685-1724) of 4,000 seeded lines."""
+    from tests.test_oracle_golden import MS_CODE
+    g = gu.load_json("struct_rules.json.gz")
+    alns = np.zeros(1, dtype=synth.ALN_DTYPE)
+    alns["tid"] = 0; alns["pos"] = 1; alns["len"] = 20; alns["depth"] = 1
+    # ---- a9: cases whose string the predict stage hands to get_maturestar_info as it is: a line that is ONE structure by itself (`whole`: a
+    # stem-loop, type 0, or a good bifurcation that filter_ss leaves in one piece, type 1)
+    cases = [c for c in g["maturestar"] if c["whole"] is not None and "raises" not in c["result"]]
+    assert sum(c["whole"] == 1 for c in cases) > 100 and all(_is_stem_loop(c["ss"]) == (c["whole"] == 0) for c in cases)
+    W, M, raw = _batch(cases)
+    params = (1, 1, 100, 0, 1, 55)          # every mature length counts
+    mir, nm, st, rec = gpu_ctx.predict_batch_reasons(W, M, alns, raw, params)
+    assert (st == 0).all()
+    pair = {int(r[0]): r for r in rec if r[1] >= 0}
+    perw = {int(r[0]): r for r in rec if r[1] < 0}
+    assert len(perw) == len(cases)
+    seen = {}
+    for k, c in enumerate(cases):
+        want = c["result"]["ok"]
+        assert perw[k][2] == 1 and k in pair, (k, c["ss"])
+        r = pair[k]
+        assert (int(r[4]), int(r[5])) == (0, len(c["ss"]))
+        if isinstance(want, str):
+            assert int(r[6]) == MS_CODE[want], (c, int(r[6]))
+            seen[want] = seen.get(want, 0) + 1
+        else:
+            assert int(r[6]) == 0, (c, int(r[6]))
+            assert [int(r[10]), int(r[11]), int(r[8]), int(r[9])] == want[:4], c
+            seen["OK"] = seen.get("OK", 0) + 1
+    assert all(seen.get(code, 0) >= 20 for code in MS_CODE), seen
+    assert seen["OK"] > 500
+    # ---- a8: structure list of a line (stem-loop -> the line itself; else the pieces filter_ss keeps, stem-loops and good bifurcations)
+    cases = []
+    for c in g["structures"]:
+        n = len(c["ss"])
+        cases.append({"ss": c["ss"], "strand": "+", "foldstart": c["start"], "regionstart": 1000, "regionend": 1000 + c["start"] + n + 5,
+                      "mature": [1000 + c["start"] - 1 + 3, 1000 + c["start"] - 1 + 24], "energy_dcal": int(round(c["energy"] * 100)), "extend": c["extend"]})
+    W, M, raw = _batch(cases)
+    mir, nm, st, rec = gpu_ctx.predict_batch_reasons(W, M, alns, raw, (1, 1, 100, 0, 1, 55))
+    assert (st == 0).all()
+    pairs, perw = {}, {}
+    for r in rec:
+        if r[1] < 0:
+            perw[int(r[0])] = r
+        else:
+            pairs.setdefault(int(r[0]), []).append(r)
+    n_split = 0
+    for k, c in enumerate(cases):
+        want = [(s, x) for _, s, x, _ in c["extend"]]
+        assert int(perw[k][2]) == len(want), (c["ss"], int(perw[k][2]), want)
+        got = sorted((int(r[2]), c["foldstart"] + int(r[4]), c["ss"][int(r[4]):int(r[4]) + int(r[5])]) for r in pairs.get(k, []))
+        assert [(s, x) for _, s, x in got] == want, (c["ss"], got, want)
+        n_split += len(want) > 1
+    assert n_split > 100
