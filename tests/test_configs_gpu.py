@@ -71,7 +71,7 @@ def _check_candidate(ctx, alns, contig_lens, cut, L, rng, n_depth=400):
     return win
 
 
-def _check_fold_and_predict(ctx, win, alns, names, sample_names, L, rng, oracle, n_fold=24, n_filter=160):
+def _check_fold_and_predict(ctx, win, alns, names, sample_names, L, rng, oracle, n_fold=24, n_filter=160, model="vienna-2.1.2"):
     from tests.test_edge_and_scale_gpu import _window_lines
     W = win["windows"]
     nwin = len(W)
@@ -86,7 +86,7 @@ def _check_fold_and_predict(ctx, win, alns, names, sample_names, L, rng, oracle,
     structs = {}
     for j, k in enumerate(pick):
         b = W[k]
-        ref = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+        ref = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L, model=model)
         if j < n_fold:
             assert _window_lines(raw, k) == ref["lines"] and raw["mfe"][k] == ref["mfe"], k
         else:
@@ -116,8 +116,12 @@ def _check_fold_and_predict(ctx, win, alns, names, sample_names, L, rng, oracle,
     return nwin, len(res), n_pass
 
 
-def test_config2_tair10_full_genome_three_samples(gpu_ctx, oracle):
+@pytest.mark.parametrize("model", ["vienna-2.1.2", "vienna-1.8.5"])
+def test_config2_tair10_full_genome_three_samples(model, gpu_ctx, oracle):
+    """model vienna-1.8.5: the same full-size run through fold_lds_kernel<1> + fold185_lds_epilogue_kernel (Turner-1999, dangles 1, multi-component
+    structure lines), fold lines and filter decisions against that model's oracle."""
     rng = np.random.RandomState(2)
+    gpu_ctx.set_fold_model(model)
     ds = synth.make_dataset(TAIR10, 48000, n_samples=3, seed=3, contig_names=["Chr%d" % (i + 1) for i in range(5)])
     alns = ds.sorted_alns()
     assert len(ds.sample_names) == 3 and sum(TAIR10) == 119146348
@@ -128,9 +132,13 @@ def test_config2_tair10_full_genome_three_samples(gpu_ctx, oracle):
     assert 60000 < nwin < 100000
     win = _check_candidate(gpu_ctx, alns, ds.contig_lens, 10, 300, rng)
     assert len(np.unique(win["windows"]["tid"])) == 5
-    n, nres, n_pass = _check_fold_and_predict(gpu_ctx, win, alns, ds.contig_names, ds.sample_names, 300, rng, oracle)
+    try:
+        n, nres, n_pass = _check_fold_and_predict(gpu_ctx, win, alns, ds.contig_names, ds.sample_names, 300, rng, oracle, model=model,
+                                                  n_filter=160 if model == "vienna-2.1.2" else 80)
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
     assert nres > 4000 and n_pass > 5
-    print("config[2]: %d windows, %d loci, device memory in use %.1f GB" % (n, nres, _mem_used_gb()))
+    print("config[2] (%s): %d windows, %d loci, device memory in use %.1f GB" % (model, n, nres, _mem_used_gb()))
 
 
 def _genome_with_reads_on(lens, names, with_reads, loci_per_mb, n_samples, seed):

@@ -52,21 +52,47 @@ def test_fold_maximal_asymmetric_interior_loop_tie(gpu_ctx, oracle):
     _compare(gpu_ctx, oracle, [s], 300)
 
 
-def test_fold_lane_fill_is_transparent(gpu_ctx, oracle, monkeypatch):
-    """The interior-loop phase tops its blocks of paired cells up with cells of the next diagonal (whose stacked pair follows one interval
-    later).  With that switched off (diagnostic flag 256 of MIRP_FOLD_DEBUG, re-read on every call) the fill kernel must archive the same
-    tables: same lines from both modes, and both equal to the oracle.  GU-rich windows put hundreds of paired cells on a diagonal."""
+_FILL2_WORKER = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+from mir_prefer_amd import capi
+seqs = json.load(open(sys.argv[2]))
+ctx = capi.Context(0)
+out = ctx.fold_batch(seqs, 300)
+json.dump([[g["status"], g["mfe"], g["lines"]] for g in out], open(sys.argv[3], "w"))
+"""
+
+
+def test_two_diagonal_fill_schedule_equals_the_product_kernel(gpu_ctx, oracle, tmp_path):
+    """fold_lds2_kernel.hip (two anti-diagonals per barrier interval: stacked pairs / 1-bulges finished in phase B, multiloop closings pushed two
+    diagonals ahead, fML handed over by DPP) is a second, independently scheduled implementation of the fill.  Its build
+    (libmirprefer_vfill2.so, make VARIANT=fill2 VFLAGS=-DMIRP_FILL2, built by __graft_entry__.build) runs in a child process through MIRP_LIB and must
+    produce the product kernel's lines and the oracle's: GU-rich windows put hundreds of paired cells on a diagonal, short windows end on an odd
+    number of diagonals, n = 350 fills the LDS layout."""
+    import json
+    import os
     import random
+    import subprocess
+    import sys
+    from mir_prefer_amd import capi
+    lib = os.path.join(os.path.dirname(capi.LIB_PATH), "libmirprefer_vfill2.so")
+    if not os.path.exists(lib):
+        pytest.fail("libmirprefer_vfill2.so is not built: run __graft_entry__.build()")
     r = random.Random(5)
     seqs = seqgen.windows(14, 24, 280, 350) + ["".join(r.choice("GU") for _ in range(330)), "".join(r.choice("GGGUUC") for _ in range(300))]
-    with_fill = gpu_ctx.fold_batch(seqs, 300)
-    monkeypatch.setenv("MIRP_FOLD_DEBUG", "256")
-    without = gpu_ctx.fold_batch(seqs, 300)
-    monkeypatch.delenv("MIRP_FOLD_DEBUG")
-    for s, g, h in zip(seqs, with_fill, without):
+    seqs += seqgen.windows(15, 30, 5, 120) + ["".join(r.choice("ACGU") for _ in range(n)) for n in (348, 349, 350, 301, 300, 299)]
+    product = gpu_ctx.fold_batch(seqs, 300)
+    (tmp_path / "w.py").write_text(_FILL2_WORKER)
+    (tmp_path / "in.json").write_text(json.dumps(seqs))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, str(tmp_path / "w.py"), root, str(tmp_path / "in.json"), str(tmp_path / "out.json")], env=dict(os.environ, MIRP_LIB=lib),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    other = json.load(open(tmp_path / "out.json"))
+    for s, g, h in zip(seqs, product, other):
         want = oracle.lfold(s, 300)
-        assert g["status"] == 0 and h["status"] == 0
-        assert g["lines"] == want["lines"] and h["lines"] == want["lines"] and g["mfe"] == h["mfe"] == want["mfe"], s
+        assert g["status"] == 0 and h[0] == 0
+        assert g["lines"] == want["lines"] and [tuple(x) for x in h[2]] == want["lines"] and g["mfe"] == h[1] == want["mfe"], s
 
 
 def test_fold_edge_cases(gpu_ctx, oracle):
