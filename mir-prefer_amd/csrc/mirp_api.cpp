@@ -232,10 +232,14 @@ static int predict_batch_impl(mirp_ctx* c, const MirpWindow* windows, int32_t n_
         int* d_pool = reasons ? (int*)T.get((size_t)rcap * rstride * 4) : nullptr;
         if (reasons && (!d_cnt || !d_pool)) return bail(-6, "device allocation failed (reasons pool)");
         if (reasons && hipMemsetAsync(d_cnt, 0, 16, c->stream) != hipSuccess) return bail(-2, "memset failed");
-        if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)d_w, n_windows, (const MirpMature*)d_m, (const MirpAln*)d_a, n_alns,
-                                 (const MirpFoldLine*)d_l, (const char*)d_s, ss_stride, max_lines, (const int*)d_n, *pp, (MirpMirna*)d_o,
-                                 (int*)d_no, (int*)d_st, d_cnt, d_pool, rcap, rstride) != hipSuccess)
-            return bail(-2, "predict kernel launch failed");
+        (void)grid;
+        {
+            std::string err;
+            if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)d_w, n_windows, (const MirpMature*)d_m, (const MirpAln*)d_a, n_alns,
+                                                  (const MirpFoldLine*)d_l, (const char*)d_s, ss_stride, max_lines, (const int*)d_n, *pp, (MirpMirna*)d_o,
+                                                  (int*)d_no, (int*)d_st, d_cnt, d_pool, rcap, rstride, nullptr, 0, nullptr, &err))
+                return bail(rc, "mirp_predict_batch: " + err);
+        }
         if (reasons) {
             unsigned int n = 0;
             if (hipMemcpyAsync(&n, d_cnt, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
@@ -243,7 +247,10 @@ static int predict_batch_impl(mirp_ctx* c, const MirpWindow* windows, int32_t n_
             if (n > rcap) return bail(-6, "mirp_predict_batch_reasons: record pool overflow");
             int32_t* h = host_alloc<int32_t>((size_t)n * rstride);
             if (!h || (n && hipMemcpy(h, d_pool, (size_t)n * rstride * 4, hipMemcpyDeviceToHost) != hipSuccess)) { std::free(h); return bail(-2, "D2H copy failed"); }
-            *reasons = h; *n_reasons = n; *reasons_stride = rstride;
+            size_t k2 = 0;          // records of a first pass whose window was run again at larger capacities carry window -1
+            for (size_t k = 0; k < n; k++)
+                if (h[k * rstride] >= 0) { if (k2 != k) std::memcpy(h + k2 * rstride, h + k * rstride, 4 * (size_t)rstride); k2++; }
+            *reasons = h; *n_reasons = (int64_t)k2; *reasons_stride = rstride;
         }
         if (hipMemcpyAsync(h_o, d_o, sizeof(MirpMirna) * (size_t)n_windows * MIRP_MAX_MIRNA_PER_WINDOW, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(h_no, d_no, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

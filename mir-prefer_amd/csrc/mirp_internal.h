@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string>
 #include "../../include/mirprefer.h"
 #include "fold_params.h"
 
@@ -22,12 +23,19 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
                           int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss,
                           int* out_nlines, int* out_mfe, int* out_status);
 
+struct PredictCaps { int p_cap, s_cap, m_cap; };          // pieces per line, structures per window, candidate matures per window (predict_kernel.hip)
+PredictCaps predict_default_caps(int max_lines, int ss_stride);
 size_t predict_lds_bytes(int max_lines, int ss_stride);
+size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps);
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount = nullptr,
                           int* rpool = nullptr, unsigned int rcap = 0, int rstride = 0, const int* wsel = nullptr, int n_sel = 0,
-                          const int* skip = nullptr);
+                          const int* skip = nullptr, const int* wslot = nullptr, const PredictCaps* caps = nullptr, int* need = nullptr);
+// launch + re-run of the windows that exceeded a capacity, with capacities sized for them (predict_kernel.hip)
+int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, int n_windows, const MirpMature* matures, const MirpAln* alns, long long n_alns,
+                       const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines, const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out,
+                       int* status, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, std::string* err);
 
 // fold_lds_kernel.hip
 size_t fold_lds_bytes(int max_lines);

@@ -488,20 +488,22 @@ extern "C" int mirp_get_fold_overflow(mirp_ctx* c, int32_t** windows, int64_t* n
 // again at full capacity, a second launch over those with the side buffers
 static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride) {
     const long long nw = c->n_windows;
-    const int grid = (int)std::min<long long>(nw, (long long)c->n_cu * 16);
     const int* skip = c->n_side > 0 ? (const int*)c->side_idx.p : nullptr;
-    if (mirp::launch_predict(c->stream, grid, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
-                             (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, pp,
-                             (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip) != hipSuccess)
-        return fail(c, -2, "predict kernel launch failed");
+    std::string err;
+    // every launch re-runs the windows that exceeded a capacity of the kernel (structures, pieces per line, candidate matures) at capacities
+    // sized for them (run_predict_launch): the reference has no such limits
+    if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+                                          (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, pp,
+                                          (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip, &err))
+        return fail(c, rc, "mirp_predict: " + err);
     if (c->n_side > 0) {
         if (mirp::predict_lds_bytes(c->side_max_lines, c->fold_stride) > 160 * 1024)
             return fail(c, -5, "mirp_predict: a window with more structure lines than the default capacity exceeds the LDS budget of the predict kernel at this PRECURSOR_LEN");
-        if (mirp::launch_predict(c->stream, (int)std::min<long long>(c->n_side, (long long)c->n_cu * 4), (const MirpWindow*)c->windows.p, (int)nw,
-                                 (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns, (const MirpFoldLine*)c->lines2.p, (const char*)c->ss2.p,
-                                 c->fold_stride, c->side_max_lines, (const int*)c->nlines2.p, pp, (MirpMirna*)c->p_out.p, (int*)c->p_nout.p,
-                                 (int*)c->p_status.p, rcount, rpool, rcap, rstride, (const int*)c->side_list.p, (int)c->n_side, nullptr) != hipSuccess)
-            return fail(c, -2, "predict kernel launch failed (windows over the default line capacity)");
+        if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+                                              (const MirpFoldLine*)c->lines2.p, (const char*)c->ss2.p, c->fold_stride, c->side_max_lines, (const int*)c->nlines2.p, pp,
+                                              (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, (const int*)c->side_list.p,
+                                              (int)c->n_side, nullptr, &err))
+            return fail(c, rc, "mirp_predict (windows over the default line capacity): " + err);
     }
     return 0;
 }
@@ -588,7 +590,10 @@ extern "C" int mirp_predict_reasons(mirp_ctx* c, const MirpPredictParams* pp, in
         if (n <= cap) {
             int32_t* h = host_copy<int32_t>(c, d_pool, (size_t)n * rstride);
             if (!h) return fail(c, -2, "D2H failed");
-            *records = h; *n_records = n;
+            size_t k2 = 0;          // records of a first pass whose window was run again at larger capacities carry window -1
+            for (size_t k = 0; k < n; k++)
+                if (h[k * rstride] >= 0) { if (k2 != k) std::memcpy(h + k2 * rstride, h + k * rstride, 4 * (size_t)rstride); k2++; }
+            *records = h; *n_records = (int64_t)k2;
             return 0;
         }
         if ((unsigned long long)n * rstride > 0x7fffffffull) return fail(c, -6, "mirp_predict_reasons: record pool too large");

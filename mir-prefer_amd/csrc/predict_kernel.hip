@@ -8,13 +8,18 @@
 // Phase 2 (lane per structure, loop over matures): get_maturestar_info + check_expression_new.
 // Phase 3 (lane 0): the sequential "lowest normalised energy that passes" rule (MP:2246-2343).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <string>
+#include <vector>
 #include "mirp_internal.h"
 
 namespace mirp {
 
-#define PW_MIN_STRUCTS 192   // structures per window (lines * pieces): capacity = max(PW_MIN_STRUCTS, 2 * max_lines)
-#define PW_MAX_PIECES 6
-#define PW_MAX_MATURES 40
+// Capacities of one launch (PredictCaps, mirp_internal.h): p_cap pieces per structure line (filter_ss keeps pieces longer than 55 characters: at most
+// len / 56 of them), s_cap structures per window (lines x pieces), m_cap candidate matures per window.  A window that needs more is flagged
+// (status 2 / 3) with what it needs, and run_predict_launch re-runs just those windows with capacities sized for them: the reference has no
+// such limits (MP:1541-1599, 2241), so neither does the result.
+#define PW_MIN_STRUCTS 192
 
 // One structure piece of a window: line index, offset and length inside the line, kind (0 stem-loop, 1 good bifurcation).
 // start and normalised energy are recomputed from the line record.
@@ -263,28 +268,31 @@ __global__ void __launch_bounds__(64) predict_kernel(
     int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
     MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status,
     unsigned int* __restrict__ rcount, int* __restrict__ rpool, unsigned int rcap, int rstride,
-    const int* __restrict__ wsel, int n_sel, const int* __restrict__ skip) {
+    const int* __restrict__ wsel, int n_sel, const int* __restrict__ skip, const int* __restrict__ wslot, PredictCaps caps, int* __restrict__ need) {
     // wsel == nullptr: every window w in [0, n_windows) with its fold output at slot w, except those with skip[w] >= 0 (folded again at full
-    // line capacity: a second launch handles them); wsel != nullptr: the windows wsel[k], k in [0, n_sel), with their fold output at slot k.
+    // line capacity: a second launch handles them); wsel != nullptr: the windows wsel[k], k in [0, n_sel), with their fold output at slot
+    // wslot[k] (wslot == nullptr: slot k).  need (optional): need[2 w] = structures, need[2 w + 1] = pieces of one line the window has.
     extern __shared__ __align__(16) unsigned char smem[];
     const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
     unsigned* textw = (unsigned*)smem;                                   // max_lines * wpl
-    const int max_structs = 2 * max_lines > PW_MIN_STRUCTS ? 2 * max_lines : PW_MIN_STRUCTS;
+    const int max_structs = caps.s_cap, PW_MAX_PIECES = caps.p_cap, PW_MAX_MATURES = caps.m_cap;
     PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * wpl * 4 + 15) & ~(size_t)15)); // max_structs
-    PStruct* slot = sts + max_structs;                                // 64 * PW_MAX_PIECES
+    PStruct* slot = sts + max_structs;                                // 64 * p_cap
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
+    int* morder = cnts + 64;                                             // m_cap: mature indices in stable depth-descending order (MP:2241)
     const int lane = threadIdx.x;
     const int n_iter = wsel ? n_sel : n_windows;
     for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
         const int w = wsel ? wsel[it] : it;
         if (!wsel && skip && skip[it] >= 0) continue;      // block-uniform
+        const int sl = wslot ? wslot[it] : it;             // slot of the window's fold output
         const MirpWindow W = windows[w];
-        const int nl = n_lines[it] < max_lines ? n_lines[it] : max_lines;
-        const MirpFoldLine* wl = lines + (size_t)it * max_lines;
-        int st_flag = 0;
+        const int nl = n_lines[sl] < max_lines ? n_lines[sl] : max_lines;
+        const MirpFoldLine* wl = lines + (size_t)sl * max_lines;
+        int st_flag = 0, need_pieces = 0;
         // stage the window's structure text, 2 bits per character (lane = one packed word = 16 characters)
         {
-            const char* src = ss + (size_t)it * max_lines * ss_stride;
+            const char* src = ss + (size_t)sl * max_lines * ss_stride;
             for (int x = lane; x < nl * wpl; x += 64) {
                 const int ln = x / wpl, wi = x - ln * wpl;
                 const char* p = src + (size_t)ln * ss_stride + wi * 16;
@@ -335,6 +343,7 @@ __global__ void __launch_bounds__(64) predict_kernel(
                                             PStruct p; p.line = (unsigned short)k; p.off = (unsigned short)ps; p.len = (unsigned short)pl; p.type = (unsigned short)type;
                                             slot[lane * PW_MAX_PIECES + cnt++] = p;
                                         } else st_flag = 2;
+                                        need_pieces++;
                                     }
                                 }
                                 pregap0 = prelast + 1;
@@ -355,22 +364,28 @@ __global__ void __launch_bounds__(64) predict_kernel(
             nst += tot;
             __syncthreads();
         }
+        if (need) {          // what this window needs, for the re-run of flagged windows: structures in all, pieces of its richest line
+            int np = need_pieces;
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(np, o); np = t > np ? t : np; }
+            if (lane == 0) { need[2 * (size_t)w] = nst; need[2 * (size_t)w + 1] = np; }
+        }
         if (nst > max_structs) nst = max_structs;
         // ---- phases 2+3 per mature, depth-descending stable order (MP:2241)
         int nm = W.n_matures < PW_MAX_MATURES ? W.n_matures : PW_MAX_MATURES;
         if (W.n_matures > PW_MAX_MATURES) st_flag = 3;
+        for (int k = lane; k < nm; k += 64) {          // rank of mature k among the first nm: lane-parallel, then the order is a table
+            const int dk = matures[W.mature_off + k].depth;
+            int r = 0;
+            for (int j = 0; j < nm; j++) { const int dj = matures[W.mature_off + j].depth; if (dj > dk || (dj == dk && j < k)) r++; }
+            morder[r] = k;
+        }
+        __syncthreads();
         int nout = 0;
         bool any_in_range = false;
         for (int k = 0; k < nm; k++) { MirpMature m = matures[W.mature_off + k]; int l = m.end - m.start; if (!(l < pp.min_mature_len || l > pp.max_mature_len)) any_in_range = true; }
         if (nst > 0 && any_in_range) {
             for (int rank = 0; rank < nm; rank++) {
-                // rank-th mature in stable depth-descending order
-                int mi = -1;
-                for (int k = 0; k < nm; k++) {
-                    int dk = matures[W.mature_off + k].depth, r = 0;
-                    for (int j = 0; j < nm; j++) { int dj = matures[W.mature_off + j].depth; if (dj > dk || (dj == dk && j < k)) r++; }
-                    if (r == rank) { mi = k; break; }
-                }
+                const int mi = morder[rank];          // rank-th mature in stable depth-descending order
                 MirpMature m = matures[W.mature_off + mi];
                 int ml = m.end - m.start;
                 if (ml < pp.min_mature_len || ml > pp.max_mature_len) continue;
@@ -487,18 +502,28 @@ __global__ void __launch_bounds__(64) predict_kernel(
     }
 }
 
-size_t predict_lds_bytes(int max_lines, int ss_stride) {
+PredictCaps predict_default_caps(int max_lines, int ss_stride) {
+    PredictCaps c;
+    c.p_cap = std::max(6, ss_stride / 56 + 1);
+    c.s_cap = 2 * max_lines > PW_MIN_STRUCTS ? 2 * max_lines : PW_MIN_STRUCTS;
+    c.m_cap = 64;
+    return c;
+}
+
+size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps) {
     size_t b = (((size_t)max_lines * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15);
-    b += sizeof(PStruct) * ((size_t)(2 * max_lines > PW_MIN_STRUCTS ? 2 * max_lines : PW_MIN_STRUCTS) + 64 * PW_MAX_PIECES);
-    b += sizeof(int) * 64;
+    b += sizeof(PStruct) * ((size_t)caps.s_cap + 64 * (size_t)caps.p_cap);
+    b += sizeof(int) * (64 + (size_t)caps.m_cap);
     return (b + 15) & ~(size_t)15;
 }
+size_t predict_lds_bytes(int max_lines, int ss_stride) { return predict_lds_bytes(max_lines, ss_stride, predict_default_caps(max_lines, ss_stride)); }
 
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount, int* rpool,
-                          unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip) {
-    size_t lds = predict_lds_bytes(max_lines, ss_stride);
+                          unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, const int* wslot, const PredictCaps* caps_in, int* need) {
+    const PredictCaps caps = caps_in ? *caps_in : predict_default_caps(max_lines, ss_stride);
+    size_t lds = predict_lds_bytes(max_lines, ss_stride, caps);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(rpool ? (const void*)predict_kernel<true> : (const void*)predict_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -506,11 +531,83 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
     }
     if (rpool)
         hipLaunchKernelGGL(predict_kernel<true>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                           max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride, wsel, n_sel, skip);
+                           max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride, wsel, n_sel, skip, wslot, caps, need);
     else
         hipLaunchKernelGGL(predict_kernel<false>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                           max_lines, n_lines, pp, out, n_out, status, nullptr, nullptr, 0u, 0, wsel, n_sel, skip);
+                           max_lines, n_lines, pp, out, n_out, status, nullptr, nullptr, 0u, 0, wsel, n_sel, skip, wslot, caps, need);
     return hipGetLastError();
+}
+
+// records of the first pass that belong to windows which are run again: r[0] = -1 (the host drops them)
+__global__ void reasons_invalidate_kernel(int* __restrict__ rpool, unsigned int n, int rstride, const unsigned char* __restrict__ flagged) {
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        int* r = rpool + (size_t)k * rstride;
+        if (r[0] >= 0 && flagged[r[0]]) r[0] = -1;
+    }
+}
+
+// One launch of the filter plus, when windows exceeded a capacity, a second launch over just those windows with capacities sized from what they
+// reported (need[]) and their number of candidate matures.  scope: the launch covers the windows wsel[0..n_sel) (slots wslot or k) or, with
+// wsel == nullptr, every window except skip[w] >= 0.  Returns 0, or a negative code with *err set (LDS budget exceeded: -5).
+int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, int n_windows, const MirpMature* matures, const MirpAln* alns, long long n_alns,
+                       const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines, const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out,
+                       int* status, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, std::string* err) {
+    const int n_iter = wsel ? n_sel : n_windows;
+    if (n_iter <= 0) return 0;
+    int* need = nullptr;
+    if (hipMalloc((void**)&need, 8 * (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
+    struct Free { int* p; int* a = nullptr; int* b = nullptr; unsigned char* f = nullptr; ~Free() { (void)hipFree(p); if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (f) (void)hipFree(f); } } guard{need};
+    if (hipMemsetAsync(need, 0, 8 * (size_t)n_windows, stream) != hipSuccess) { *err = "memset failed"; return -2; }
+    const int grid = std::min(n_iter, n_cu * 16);
+    if (launch_predict(stream, grid, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride,
+                       wsel, n_sel, skip, nullptr, nullptr, need) != hipSuccess) { *err = "predict kernel launch failed"; return -2; }
+    std::vector<int> h_status((size_t)n_windows), h_sel, h_skip;
+    unsigned int n1 = 0;
+    if (hipMemcpyAsync(h_status.data(), status, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        (rcount && hipMemcpyAsync(&n1, rcount, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) || hipStreamSynchronize(stream) != hipSuccess) {
+        *err = "predict kernel execution failed"; return -2;
+    }
+    if (wsel) { h_sel.resize((size_t)n_sel); if (hipMemcpy(h_sel.data(), wsel, 4 * (size_t)n_sel, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; } }
+    else if (skip) { h_skip.resize((size_t)n_windows); if (hipMemcpy(h_skip.data(), skip, 4 * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; } }
+    std::vector<int> rw, rs;          // windows to run again, their slots
+    for (int it = 0; it < n_iter; it++) {
+        const int w = wsel ? h_sel[(size_t)it] : it;
+        if (!wsel && skip && h_skip[(size_t)it] >= 0) continue;
+        if (h_status[(size_t)w] == 2 || h_status[(size_t)w] == 3) { rw.push_back(w); rs.push_back(it); }
+    }
+    if (rw.empty()) return 0;
+    std::vector<int> h_need(2 * (size_t)n_windows);
+    std::vector<MirpWindow> h_w((size_t)n_windows);
+    if (hipMemcpy(h_need.data(), need, 8 * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(h_w.data(), windows, sizeof(MirpWindow) * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; }
+    PredictCaps caps = predict_default_caps(max_lines, ss_stride);
+    for (int w : rw) {
+        caps.s_cap = std::max(caps.s_cap, h_need[2 * (size_t)w]);
+        caps.p_cap = std::max(caps.p_cap, h_need[2 * (size_t)w + 1]);
+        caps.m_cap = std::max(caps.m_cap, h_w[(size_t)w].n_matures);
+    }
+    if (predict_lds_bytes(max_lines, ss_stride, caps) > 160 * 1024) {
+        *err = "a window has more structures / candidate matures than the filter kernel can hold in LDS (" + std::to_string(caps.s_cap) + " structures, " +
+               std::to_string(caps.m_cap) + " matures)";
+        return -5;
+    }
+    if (hipMalloc((void**)&guard.a, 4 * rw.size()) != hipSuccess || hipMalloc((void**)&guard.b, 4 * rw.size()) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
+    if (hipMemcpy(guard.a, rw.data(), 4 * rw.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(guard.b, rs.data(), 4 * rs.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "H2D failed"; return -2;
+    }
+    if (rpool && n1 > 0) {          // the first pass already wrote (truncated) records for these windows
+        std::vector<unsigned char> fl((size_t)n_windows, 0);
+        for (int w : rw) fl[(size_t)w] = 1;
+        if (hipMalloc((void**)&guard.f, (size_t)n_windows) != hipSuccess || hipMemcpy(guard.f, fl.data(), (size_t)n_windows, hipMemcpyHostToDevice) != hipSuccess) {
+            *err = "device allocation failed (predict)"; return -6;
+        }
+        const unsigned int nn = std::min(n1, rcap);
+        hipLaunchKernelGGL(reasons_invalidate_kernel, dim3((nn + 255) / 256 > 4096 ? 4096 : (nn + 255) / 256), dim3(256), 0, stream, rpool, nn, rstride, (const unsigned char*)guard.f);
+    }
+    if (launch_predict(stream, std::min((int)rw.size(), n_cu * 4), windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
+                       rcount, rpool, rcap, rstride, guard.a, (int)rw.size(), nullptr, guard.b, &caps, nullptr) != hipSuccess) { *err = "predict kernel launch failed (re-run)"; return -2; }
+    if (hipStreamSynchronize(stream) != hipSuccess) { *err = "predict kernel execution failed (re-run)"; return -2; }
+    return 0;
 }
 
 }  // namespace mirp

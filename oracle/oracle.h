@@ -7,7 +7,7 @@ extern "C" {
 #endif
 
 #define ORACLE_MAX_LINES 384
-#define ORACLE_MAX_SS 512
+#define ORACLE_MAX_SS 1152   /* lines of PRECURSOR_LEN up to 1000 (+50 +dangles) */
 
 typedef struct {
     char ss[ORACLE_MAX_SS]; /* dot-bracket text exactly as RNALfold prints it (incl. dangle dots) */

@@ -9,7 +9,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 MAX_LINES = 384
-MAX_SS = 512
+MAX_SS = 1152
 
 
 class FoldLine(C.Structure):

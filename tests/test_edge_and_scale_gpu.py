@@ -258,28 +258,54 @@ def test_planted_repeat_windows_are_refolded_alone(gpu_ctx, oracle):
     assert (out["status"] == 0).all() and len(out["result"]) > 1000
 
 
-def test_filter_capacity_overflow_is_reported_not_truncated(gpu_ctx):
-    """PRECURSOR_LEN well above 350: a dense region with more candidate matures than the filter kernel's table holds (40) must come back
-    with a non-zero per-window status (mirp_predict returns it; the stage driver turns it into exit status -1), never as a silently
-    shortened candidate list."""
+def test_dense_region_at_large_precursor_len_matches_oracle(gpu_ctx, oracle):
+    """PRECURSOR_LEN = 1000 (the reference accepts 60-3000, MP:167-184): one 1,040-nt region of 40 peaks with 80+ candidate matures -- more than the
+    filter kernel's default table holds -- and structure lines of up to ~1,050 characters with many pieces.  The window is flagged by the first
+    launch and run again at capacities sized for it (run_predict_launch); the answer is the oracle's check_loci, not an error."""
     L = 1000
     ds = synth.make_dataset([40000], 0, n_samples=1, seed=9, contig_names=["c1"])
+    rng = np.random.RandomState(5)
+    # plant a long imperfect hairpin under part of the region so that some structures carry a real duplex
+    arm = synth._BASES[rng.randint(0, 4, size=60)]
+    hp = np.concatenate([arm, synth._BASES[rng.randint(0, 4, size=12)], synth._revcomp(arm)])
+    ds.contigs[0][1][5200:5200 + len(hp)] = hp
     recs = []
-    # 26 peaks 35 nt apart (each >= 19 nt above the threshold, separated by uncovered bases): one 900-nt region, two matures per peak
-    for k in range(26):
-        p = 5000 + 35 * k
-        recs += [(0, p, 60, 21, 0, 0), (0, p + 1, 40, 21, 0, 0), (0, p + 2, 30, 20, 0, 0)]
+    for k in range(40):          # 40 peaks 26 nt apart (each >= 19 nt above the threshold): one region of 1,040 nt, two or three matures per peak
+        p = 5000 + 26 * k
+        recs += [(0, p, 60 + k, 21, 0, 0), (0, p + 1, 40, 21, 0, 0), (0, p + 2, 30, 20, 0, 0)]
+    recs += [(0, 5203, 900, 22, 0, 0), (0, 5203 + 74, 35, 22, 0, 0)]
     alns = np.array(recs, dtype=synth.ALN_DTYPE)
+    alns = alns[np.argsort(alns["pos"], kind="stable")]
     gpu_ctx.load_genome(ds.contigs)
     gpu_ctx.load_alignments(alns)
-    npk, nloci, nwin = gpu_ctx.candidate(10, 100, L, np.zeros(1, np.int32))
-    assert npk == 26 and nloci == 1 and nwin == 1
-    W = gpu_ctx.get_windows()["windows"]
-    assert W[0]["n_matures"] > 40
+    order = np.zeros(1, np.int32)
+    npk, nloci, nwin = gpu_ctx.candidate(10, 100, L, order)
+    assert nloci == 1 and nwin == 1
+    win = gpu_ctx.get_windows()
+    W = win["windows"]
+    assert W[0]["n_matures"] > 64
     gpu_ctx.fold(L)
     assert (gpu_ctx.fold_status() == 0).all()
     out = gpu_ctx.predict(1, 18, 23, False, True)
-    assert out["status"][0] == 3
+    assert out["status"][0] == 0
+    b = W[0]
+    ref = oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)
+    raw = gpu_ctx.get_fold()
+    assert _window_lines(raw, 0) == ref["lines"]
+    structs = oracle.structures_from_lines(ref["lines"], 55)
+    mats = win["matures"][b["mature_off"]:b["mature_off"] + b["n_matures"]]
+    r = oracle.check_loci(structs, mats, b, alns, (1, 18, 23, 0, 1, 55))
+    assert out["n_passed"][0] == len(r)
+    if r:
+        m, ss, o = out["result"][0], out["ss"][0], r[0]
+        assert [m["fold_s"], m["fold_e"], m["mat_s"], m["mat_e"], m["star_s"], m["star_e"], ss, m["strand"], bool(m["has_star"])] == \
+               [o.fold_s, o.fold_e, o.mat_s, o.mat_e, o.star_s, o.star_e, o.ss.decode(), o.strand, bool(o.has_star)]
+    # the -d records of the re-run window replace the truncated ones of the first pass: one record per (mature in range, structure) pair
+    rec = gpu_ctx.predict_reasons(1, 18, 23, False, True)
+    perw = [x for x in rec if x[1] < 0]
+    assert len(perw) == 1 and perw[0][2] == len(structs)
+    n_in = sum(1 for m_ in mats if 18 <= m_["end"] - m_["start"] <= 23)
+    assert len([x for x in rec if x[1] >= 0]) == n_in * len(structs)
 
 
 def test_difference_arrays_are_clean_between_passes(gpu_ctx, oracle):
