@@ -57,7 +57,7 @@ __device__ unsigned long long g_l2_clk[16 * 4 + 8];
 #define L2_NBW 6            // phase-B waves: 6 x 63 = 378 >= 346 columns
 
 struct Lds2Layout {
-    unsigned fml, ring, acc, S, pax, qbr, lent, loi, tabs, misc, total;
+    unsigned fml, ring, acc, S, pax, qbr, lent, loi, tabs, misc, hc, total;
 };
 __host__ __device__ constexpr Lds2Layout lds2_layout() {
     Lds2Layout L{};
@@ -72,6 +72,7 @@ __host__ __device__ constexpr Lds2Layout lds2_layout() {
     L.loi = o; o += lds_al(2 * L2_LISTCAP);                                // outer-pair table index of the entry
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
     L.misc = o; o += lds_al((16 + ARCH_RB) * 4);
+    L.hc = o; o += 32;                                                     // code of the mismatch bonus of an outer pair by its two neighbour bases (MIRP_E1)
     L.total = o;
     return L;
 }
@@ -129,6 +130,8 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
     typedef __attribute__((address_space(3))) int* lds_i32p;
 
     // ---- one-time: hot parameter tables into LDS
+    if (tid == 0) misc[2] = 0;          // set when the compiled-in parameter structure does not hold (MIRP_E1)
+    __syncthreads();
     for (int x = tid; x < 64; x += LNT) T.stack[x] = (short)min(P->stack[x >> 3][x & 7], (int)I16_INF);
     for (int x = tid; x < 31; x += LNT) { T.bulge[x] = (short)min(P->bulge[x], (int)I16_INF); T.internal_loop[x] = (short)min(P->internal_loop[x], (int)I16_INF); }
     for (int x = tid; x < 200; x += LNT) {
@@ -153,6 +156,25 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
     __syncthreads();
 
+#ifdef MIRP_E1
+    // Outer-pair terms without a table read: in the Turner-2004 set mismatchI[t][a][b] = F(t) + H(a, b) with F = 0 for CG / GC and 70 for the AU / GU
+    // classes, H one of {0, -80, -100, -60} (A.G, G.A / G.G, U.U mismatches), and mismatch1nI[t][a][b] = F(t).  The constants are compiled in
+    // (no registers held across the kernel) and CHECKED against the parameters in use when the workgroup starts: a set that differs sends
+    // every window to the generic kernel.  A list entry carries the 2-bit code of H for its cell, so phase A1 needs no second LDS round trip
+    // in front of its ring reads.
+    constexpr int E1_F = 70, E1_TAU = 50, E1_H1 = -80, E1_H2 = -100, E1_H3 = -60;
+    unsigned char* hcd = smem + LY.hc;
+    if (tid < 25) {
+        const int a = tid / 5, b = tid % 5;
+        const int code = (a == 1 && b == 3) ? 1 : ((a == 3 && b == 1) || (a == 3 && b == 3)) ? 2 : (a == 4 && b == 4) ? 3 : 0;
+        const int hv = code == 1 ? E1_H1 : code == 2 ? E1_H2 : code == 3 ? E1_H3 : 0;
+        hcd[tid] = (unsigned char)code;
+        int ok = P->TerminalAU == E1_TAU;
+        for (int t = 1; t <= 6; t++) ok = ok && P->mismatchI[t][a][b] == (t > 2 ? E1_F : 0) + hv && P->mismatch1nI[t][a][b] == (t > 2 ? E1_F : 0);
+        if (!ok) misc[2] = 1;          // (misc[2] starts at 0: see below)
+    }
+    __syncthreads();
+#endif
     // phase-B column of this thread: waves 0..5 own 63 columns each, lane 63 shadows the first column of the next wave
     const bool bwave = wave < L2_NBW;
     const int bx = wave * L2_BW + lane;                  // column index, i = bx + 1
@@ -169,7 +191,12 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
         short* carch = slabs + (size_t)win * 3 * slab_shorts;      // per-window slab: c, fML and trace-back triangles (read by fold_lds_epilogue_kernel)
         short* fml_out = carch + slab_shorts;
         unsigned short* tb_out = reinterpret_cast<unsigned short*>(carch + 2 * slab_shorts);
-        if (n < 1 || n > LCAP - 2) {   // wave-uniform: empty window, or too long for this kernel (-> generic kernel)
+#ifdef MIRP_E1
+        const bool unsupported = misc[2] != 0;
+#else
+        const bool unsupported = false;
+#endif
+        if (n < 1 || n > LCAP - 2 || unsupported) {   // wave-uniform: empty window, too long for this kernel, or parameters it cannot use (-> generic kernel)
             if (tid == 0) {
                 out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0;
                 if (n >= 1) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; }
@@ -225,8 +252,14 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
             }
             base = __builtin_amdgcn_readfirstlane(base);
             const int lb = ((e >> 1) & 1) * L2_LISTCAP + base;
+#ifdef MIRP_E1
+            // oi = type * 25 + S[i+1] * 5 + S[j-1]: the entry keeps the H code of the two neighbour bases instead
+            if (lt0) { const int k = lb + (int)__popcll(b0 & lane_lt); lent[k] = (unsigned short)((bx + 1) | (lt0 << 9) | ((int)hcd[oi0 - lt0 * 25] << 13)); }
+            if (lt1) { const int k = lb + (int)__popcll(b0) + (int)__popcll(b1 & lane_lt); lent[k] = (unsigned short)((bx + 1) | (lt1 << 9) | (1 << 12) | ((int)hcd[oi1 - lt1 * 25] << 13)); }
+#else
             if (lt0) { const int k = lb + (int)__popcll(b0 & lane_lt); lent[k] = (unsigned short)((bx + 1) | (lt0 << 9)); loi[k] = (unsigned char)oi0; }
             if (lt1) { const int k = lb + (int)__popcll(b0) + (int)__popcll(b1 & lane_lt); lent[k] = (unsigned short)((bx + 1) | (lt1 << 9) | (1 << 12)); loi[k] = (unsigned char)oi1; }
+#endif
         };
         // list of the first pair with interior loops, (6, 7)
         if (bwave && D >= 6) {
@@ -362,7 +395,9 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
                     const int k = blk * 64 + lane;
                     const bool inl = k < ncp;
                     const unsigned ent = inl ? (unsigned)clist[k] : (1u | (1u << 9));      // idle lanes: harmless dummy cell
+#ifndef MIRP_E1
                     const int oi = inl ? (int)coi[k] : 25;
+#endif
                     const bool second = (ent >> 12) & 1;
                     const bool act = inl && (steady || (int)second == pass);
                     const bool shift = steady && second;             // ring rows and j of the second diagonal relative to dd
@@ -371,12 +406,22 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
                     unsigned* ck = second ? ckey1 : ckey0;
                     unsigned res = KEY_NONE;
                     int au1 = 0, mmo = 0, mm1 = 0;
+#ifdef MIRP_E1
+                    {
+                        const int hcode = (ent >> 13) & 3;
+                        const int hval = hcode == 0 ? 0 : hcode == 1 ? E1_H1 : hcode == 2 ? E1_H2 : E1_H3;
+                        const int f = type > 2 ? E1_F : 0;
+                        au1 = type > 2 ? E1_TAU : 0;
+                        mmo = f + hval; mm1 = f;
+                    }
+#else
                     if (role < 14) {
                         au1 = type > 2 ? (int)T.TerminalAU : 0;
                         mmo = T.mismatchI[oi]; mm1 = T.mismatch1nI[oi];
                     }
 #ifdef MIRP_ROWS14
                     else mmo = T.mismatchI[oi];
+#endif
 #endif
                     if (role < 8) {
 #define MIRP_GEN(CK)                                                                      \
