@@ -66,7 +66,7 @@ json.dump([[g["status"], g["mfe"], g["lines"]] for g in out], open(sys.argv[3], 
 def test_two_diagonal_fill_schedule_equals_the_product_kernel(gpu_ctx, oracle, tmp_path):
     """fold_lds2_kernel.hip (two anti-diagonals per barrier interval: stacked pairs / 1-bulges finished in phase B, multiloop closings pushed two
     diagonals ahead, fML handed over by DPP) is a second, independently scheduled implementation of the fill.  Its build
-    (libmirprefer_vfill2.so, make VARIANT=fill2 VFLAGS=-DMIRP_FILL2, built by __graft_entry__.build) runs in a child process through MIRP_LIB and must
+    (libmirprefer_vfill2.so, make VARIANT=fill2 VFLAGS="-DMIRP_FILL2 -DMIRP_E1", built by __graft_entry__.build) runs in a child process through MIRP_LIB and must
     produce the product kernel's lines and the oracle's: GU-rich windows put hundreds of paired cells on a diagonal, short windows end on an odd
     number of diagonals, n = 350 fills the LDS layout."""
     import json
