@@ -31,5 +31,8 @@ for sub in ("sq", "sq2"):
             out.setdefault(k.split("::")[1] + "_sq_per_launch", {}).update({c: v / len(nl[k]) for c, v in acc[k].items()})
 json.dump(out, open("profiles/%s_hbm_traffic_and_sq_pmc.json" % tag, "w"), indent=1, sort_keys=True)
 shutil.copy(glob.glob("gpurun_out/%s_stats/*/*kernel_stats.csv" % tag)[0], "profiles/%s_kernel_stats.csv" % tag)
+f185 = glob.glob("gpurun_out/%s_stats185/*/*kernel_stats.csv" % tag)
+if f185:
+    shutil.copy(f185[0], "profiles/%s_vienna185_kernel_stats.csv" % tag)
 print(json.dumps({k: v for k, v in out.items() if k.endswith("per_launch")}, indent=1))
 print({k: v for k, v in out["kernels"].items() if "fold" in k})
