@@ -400,16 +400,28 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
     const double t0 = now_s();
     Parsed P;
     std::string err;
-    if (parse_all(paths, n_paths, n_threads, &P, &err, me, W)) return fail(c, -1, err);
+    int bad = parse_all(paths, n_paths, n_threads, &P, &err, me, W) ? 1 : 0;
     const int nc = (int)P.names.size();
-    if (W > 1)
-        for (int t = 0; t < nc; t++)
-            if (owner_of_tid[t] < 0 || owner_of_tid[t] >= W) return fail(c, -1, std::string(who) + ": owner_of_tid out of range");
+    if (!bad && W > 1)
+        for (int t = 0; t < nc && !bad; t++)
+            if (owner_of_tid[t] < 0 || owner_of_tid[t] >= W) { bad = 1; err = std::string(who) + ": owner_of_tid out of range"; }
     // a record past the end of its contig would overflow the position bits of the sort key (and the reference's samtools rejects it)
-    for (auto& f : P.per_file)
-        for (auto& ch : f)
-            for (const MirpAln& r : ch.recs)
-                if ((int64_t)r.pos > P.lens[r.tid] + 1) return fail(c, -1, "alignment position " + std::to_string(r.pos) + " is beyond the end of sequence " + P.names[r.tid] + " (LN:" + std::to_string(P.lens[r.tid]) + ")");
+    if (!bad)
+        for (auto& f : P.per_file)
+            for (auto& ch : f)
+                for (const MirpAln& r : ch.recs)
+                    if (!bad && (int64_t)r.pos > P.lens[r.tid] + 1) {
+                        bad = 1;
+                        err = "alignment position " + std::to_string(r.pos) + " is beyond the end of sequence " + P.names[r.tid] + " (LN:" + std::to_string(P.lens[r.tid]) + ")";
+                    }
+    if (W > 1) {          // a rank that found a bad line in ITS byte range must not leave the others inside the exchange: agree first
+        long long mine = bad;
+        std::vector<long long> all;
+        if (int rc = mirp::dist_allgather_ll(c, &mine, 1, all)) return rc;
+        for (int r = 0; r < W; r++)
+            if (all[(size_t)r] && !bad) { bad = 1; err = std::string(who) + ": rank " + std::to_string(r) + " failed to parse its part of the SAM files"; }
+    }
+    if (bad) return fail(c, -1, err);
     const double t1 = now_s();
     MirpAln* all = nullptr;
     MirpAln* segs = nullptr;

@@ -66,7 +66,12 @@ owner = np.zeros(len(names), dtype=np.int32)
 for r, part in enumerate(dist.partition_contigs(lens, world)):
     owner[part] = r
 regions = json.load(open(os.path.join(out, "regions.json")))
-cn, cl, sn, alns, segs, sec = ctx.ingest_sams_shard(sams, owner, regions=regions or None)
+try:
+    cn, cl, sn, alns, segs, sec = ctx.ingest_sams_shard(sams, owner, regions=regions or None)
+except ValueError as e:
+    open(os.path.join(out, "failed_%d.txt" % rank), "w").write(str(e))
+    ctx.close()
+    sys.exit(3)
 np.savez(os.path.join(out, "shard_%d.npz" % rank), alns=alns, segs=segs, owner=owner)
 tot = ctx.dist_allreduce_sum([len(alns), rank])
 g = ctx.gather_records(np.full((rank + 2, 3), rank, dtype=np.int32), dst=world - 1)
@@ -132,3 +137,25 @@ def test_sharded_ingest_equals_single_rank_ingest(world, with_regions, tmp_path)
     assert seen == len(alns)
     g = np.load(tmp_path / "gathered.npy")
     assert g.tolist() == [[r] * 3 for r in range(world) for _ in range(r + 2)]
+
+
+def test_sharded_ingest_fails_on_every_rank_together(tmp_path):
+    """A malformed line in ONE rank's byte range: every rank returns the error (agreed before the exchange) instead of the others waiting in it."""
+    ds, sams = _dataset(tmp_path, seed=21)
+    lines = open(sams[0]).read().splitlines()
+    k = len(lines) * 3 // 4          # well inside the second rank's half
+    f = lines[k].split("\t")
+    f[3] = "notanumber"
+    lines[k] = "\t".join(f)
+    open(sams[0], "w").write("\n".join(lines) + "\n")
+    import json
+    (tmp_path / "regions.json").write_text(json.dumps([]))
+    xdir = tmp_path / "x"
+    xdir.mkdir()
+    wk = tmp_path / "worker.py"
+    wk.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(wk), ROOT, str(r), "2", str(xdir), str(tmp_path)] + sams, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], logs
+    msgs = [open(tmp_path / ("failed_%d.txt" % r)).read() for r in range(2)]
+    assert "SAM position is not a number" in msgs[1] and "rank 1 failed" in msgs[0]
