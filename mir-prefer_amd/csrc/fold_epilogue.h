@@ -185,6 +185,7 @@ __device__ inline long long* epi_acc() { __shared__ long long acc[32]; return ac
 #endif
 #define BT_STACK 96
 #define MIRP_EPI_DMAX 300   // largest pair distance a tiled archive holds (fold_lds_kernel.hip: LDMAX)
+#define TB_GENERIC 64   // trace-back code of a cell whose interior loop is one with n1 >= 2 that the fill kernel did not name (1 + (1 << 5 | 31): no real shape)
 #define BT_LINE 16      // cells of a helix line fetched per round trip (each is its own cache line of the trace-back triangle)
 
 // Wave-cooperative backtrack of one locally optimal structure (all 64 lanes call it with
@@ -373,6 +374,44 @@ __device__ int backtrack_wave(const WinCtx& X, const Tab& T, int start, int jend
     return L;
 }
 
+// Interior loop of a pair (i, j) whose trace-back code is TB_GENERIC: some loop with n1 >= 2 realises c(i,j) = cij and no loop with n1 <= 1 does
+// (fill kernel: the packed generic rows carry no shape code).  The reference's search from p = i + 3 on -- p ascending, q descending, first match;
+// lane = (p parity, n2), NB rounds of candidates fetched together.  Returns p << 16 | q, or -1.  Kept out of line: inlined into the backtrack
+// its energy function's table pointers pushed the whole kernel over its register budget (35 -> 93 spilled VGPRs), for a path few pairs take.
+template <class Tab>
+__device__ __forceinline__ int bt_search_unnamed(const WinCtx& X, const Tab& T, int i, int j, int cij) {
+    const int lane = threadIdx.x & 63;
+    const int type = ptype_at(X, i, j);
+    const int hp = lane >> 5, n2 = lane & 31, q = j - 1 - n2;
+    constexpr int NR = (MAXLOOP - 2) / 2 + 1;         // pairs of n1 = 2 .. MAXLOOP (+ 1)
+    constexpr int NB = 3;
+    int res = -1;
+#pragma unroll 1
+    for (int kb = 0; kb < NR && res < 0; kb += NB) {
+        int cc[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int n1 = 2 + 2 * (kb + k) + hp, p = i + 1 + n1;
+            cc[k] = INF;
+            if (n1 + n2 <= MAXLOOP && q - p >= TURN + 1) cc[k] = T.C(q - p, p);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            if (res < 0) {
+                const int n1 = 2 + 2 * (kb + k) + hp, p = i + 1 + n1;
+                bool hit = false;
+                if (cc[k] < INF) {
+                    const int t2 = rtype_of(pair_type(X.S[p], X.S[q]));
+                    hit = (cij == cc[k] + intloop_x(X, n1, n2, type, t2, X.S[i + 1], X.S[j - 1], X.S[p - 1], X.S[q + 1]));
+                }
+                const int fl = first_lane(__ballot(hit));
+                if (fl >= 0) res = (i + 3 + 2 * (kb + k) + (fl >> 5)) << 16 | (j - 1 - (fl & 31));
+            }
+        }
+    }
+    return res;
+}
+
 // Backtrack over a TILED archive with trace-back codes (Tab::kTiled).  Same search orders and results as backtrack_wave; what changes is how often
 // it goes to memory: the walk is a chain of dependent round trips (~1 us each under load), so every fetch brings an 8 x 8 PATCH of the archive
 // anchored at the current pair or segment (i, j) -- lane (a, b) holds cell (i + a, j - b): trace-back code, c and (for a multiloop segment) fML,
@@ -405,7 +444,15 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
         if (sp + 3 >= BT_STACK) return -20;
         int tbv = 0, cv = INF;          // the current patch: trace-back codes and c of the cells (i + pa, j - pb) at fetch time
         int r = 0, c = 0;               // the walk's position inside it
-        if (ml == 0) {
+        bool defer = false;
+        if (ml == 2) {
+            // a traced pair whose loop the fill kernel did not name (TB_GENERIC, pushed by the walk below)
+            const int hit = bt_search_unnamed(X, T, i, j, T.C(j - i, i));
+            if (hit < 0) return -25;
+            i = hit >> 16; j = hit & 0xffff;
+            if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
+            r = 8; c = 8;
+        } else if (ml == 0) {
             // unpaired 5' bases: the reference pops (i + 1, j) while f3[i] == f3[i + 1]; here 64 positions per step
             for (;;) {
                 const int x = i + lane;
@@ -525,12 +572,19 @@ __device__ int backtrack_wave_tiled(const WinCtx& X, const Tab& T, int start, in
             for (;;) {
                 const int code = __builtin_amdgcn_readlane(tbv, r * 8 + c);
                 if (code <= 0) break;                               // hairpin or multiloop closes here
+                if (code == TB_GENERIC) {       // unnamed loop: searched at the top of the sector loop, where the patch and the walk's position are dead
+                    if (lane == 0) { stk[3 * sp] = i; stk[3 * sp + 1] = j; stk[3 * sp + 2] = 2; }
+                    sp++;
+                    defer = true;
+                    break;
+                }
                 const int n1 = (code - 1) >> 5, n2 = (code - 1) & 31;
                 i += 1 + n1; j -= 1 + n2;
                 if (lane == 0) { buf[i - start] = '('; buf[j - start] = ')'; }
                 r += 1 + n1; c += 1 + n2;
                 if (r > 7 || c > 7) break;
             }
+            if (defer) break;
             if (r > 7 || c > 7) continue;
             const int cij = __builtin_amdgcn_readlane(cv, r * 8 + c);
             const int type = ptype_at(X, i, j);

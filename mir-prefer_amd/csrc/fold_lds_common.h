@@ -182,6 +182,38 @@ __device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb
         }
     }
 }
+__device__ __forceinline__ unsigned a1_key(unsigned b, int adj);
+// The same rows with two candidates per lane and instruction: the run of a lane is read as aligned 32-bit words, the size / asymmetry
+// term is added to both halves with one saturating packed add (65535 stays 65535), one packed min keeps both running minima.  The
+// candidates lose their shape code that way: the job's key says "some generic loop" (code 63) and the epilogue finds the shape.
+// CLS = parity class of the lane's cell (wave-uniform): 0 = the run starts on a word boundary, 1 = one short after it.
+template <bool CHECK, int CLS, int U>
+__device__ __forceinline__ void a1_gen_row_pk(const A1& a, const unsigned* rbw, us2& bg) {
+    if (!CHECK || U <= a.um) {
+        constexpr int NW = CLS ? (U - 1) / 2 : (U - 2) / 2;
+        const unsigned* rp = rbw + ((a.r0 - U) & 31) * (CSTR / 2);
+        unsigned v[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) v[k] = rp[k];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            us2 x, c;
+            const unsigned cc = a.P->gen_pk[CLS][U - 6][k];
+            __builtin_memcpy(&x, &v[k], 4); __builtin_memcpy(&c, &cc, 4);
+            bg = __builtin_elementwise_min(bg, __builtin_elementwise_add_sat(x, c));
+        }
+    }
+}
+template <bool CHECK, int CLS, int... Us>
+__device__ __forceinline__ unsigned a1_generic_pk(const A1& a, int i, int j, int mm_outer) {
+    us2 bg = {65535, 65535};
+    // first word of the lane's runs: column i + 3 (n1 = 2) in class 0, i + 2 in class 1 -- both even
+    const unsigned* rbw = reinterpret_cast<const unsigned*>(a.cring + ((i + 3) & ~1));
+    (a1_gen_row_pk<CHECK, CLS, Us>(a, rbw, bg), ...);
+    const unsigned m = bg[0] < bg[1] ? bg[0] : bg[1];
+    return a1_key(m << 10 | 63u, -32768 + mm_outer);
+}
+
 // job-local key (term << 10 | code) -> cell key ((energy + KEY_BIAS) << 10 | code); `adj` turns the job's term into the loop energy
 __device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
     return b >= KEY_INF ? KEY_NONE : ((unsigned)((int)(b >> 10) + adj + KEY_BIAS) << 10) | (b & 1023u);
