@@ -182,41 +182,35 @@ __device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb
         }
     }
 }
-__device__ __forceinline__ unsigned a1_key(unsigned b, int adj);
-// The same rows with two candidates per lane and instruction: the run of a lane is read as aligned 32-bit words, the size / asymmetry
-// term is added to both halves with one saturating packed add (65535 stays 65535), one packed min keeps both running minima.  The
-// candidates lose their shape code that way: the job's key says "some generic loop" (code 63) and the epilogue finds the shape.
-// CLS = parity class of the lane's cell (wave-uniform): 0 = the run starts on a word boundary, 1 = one short after it.
-template <bool CHECK, int CLS, int U>
-__device__ __forceinline__ void a1_gen_row_pk(const A1& a, const unsigned* rbw, us2& bg) {
-    if (!CHECK || U <= a.um) {
-        constexpr int NW = CLS ? (U - 1) / 2 : (U - 2) / 2;
-        const unsigned* rp = rbw + ((a.r0 - U) & 31) * (CSTR / 2);
-        unsigned v[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) v[k] = rp[k];
-#pragma unroll
-        for (int k = 0; k < NW; k++) {
-            us2 x, c;
-            const unsigned cc = a.P->gen_pk[CLS][U - 6][k];
-            __builtin_memcpy(&x, &v[k], 4); __builtin_memcpy(&c, &cc, 4);
-            bg = __builtin_elementwise_min(bg, __builtin_elementwise_add_sat(x, c));
-        }
-    }
-}
-template <bool CHECK, int CLS, int... Us>
-__device__ __forceinline__ unsigned a1_generic_pk(const A1& a, int i, int j, int mm_outer) {
-    us2 bg = {65535, 65535};
-    // first word of the lane's runs: column i + 3 (n1 = 2) in class 0, i + 2 in class 1 -- both even
-    const unsigned* rbw = reinterpret_cast<const unsigned*>(a.cring + ((i + 3) & ~1));
-    (a1_gen_row_pk<CHECK, CLS, Us>(a, rbw, bg), ...);
-    const unsigned m = bg[0] < bg[1] ? bg[0] : bg[1];
-    return a1_key(m << 10 | 63u, -32768 + mm_outer);
-}
-
 // job-local key (term << 10 | code) -> cell key ((energy + KEY_BIAS) << 10 | code); `adj` turns the job's term into the loop energy
 __device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
     return b >= KEY_INF ? KEY_NONE : ((unsigned)((int)(b >> 10) + adj + KEY_BIAS) << 10) | (b & 1023u);
+}
+// The same row when the asymmetry term saturates at |n1 - n2| >= WD (FoldParams::gen_wing_d; WD = 5 with Turner-2004): the candidates
+// beyond that -- the two wings of the row -- share one term, so their ring entries are minimised as they are (two per v_min3_u32) and the term
+// is added once; only the 2 WD - 1 or fewer candidates around n1 = n2 pay an add of their own.  The wing minimum names no shape: its key
+// carries code 63, and a cell that ends up with that code has its loop found by the epilogue (TB_GENERIC, bt_search_unnamed) -- rarely,
+// MFE structures seldom hold loops that lopsided.  A row of U has U - 3 candidates: 54 VALU instructions before, 20 now at U = 30.
+template <bool CHECK, int WD, int U>
+__device__ __forceinline__ void a1_gen_row_w(const A1& a, const unsigned short* rb, unsigned& bg) {
+    if (!CHECK || U <= a.um) {
+        lds_vu16 rp = (lds_vu16)(rb + ((a.r0 - U) & 31) * CSTR);
+        unsigned v[U - 3];      // all reads of the run in flight before the first use
+#pragma unroll
+        for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = rp[n1];
+        unsigned w = 65535u;    // wing minimum, ring units
+        unsigned e[2 * WD];     // keys of the centre candidates
+        int ne = 0;
+#pragma unroll
+        for (int n1 = 2; n1 <= U - 2; n1++) {
+            const int dd = 2 * n1 - U;      // n1 - n2
+            if (dd <= -WD || dd >= WD) w = v[n1 - 2] < w ? v[n1 - 2] : w;
+            else e[ne++] = (v[n1 - 2] << 10) + a.P->gen_key[U - 6][n1];
+        }
+        if (U - 4 >= WD) { const unsigned k = (w << 10) + a.P->gen_wing_key[U - 6]; bg = k < bg ? k : bg; }      // the row has wings
+#pragma unroll
+        for (int k = 0; k < ne; k++) bg = e[k] < bg ? e[k] : bg;
+    }
 }
 template <bool CHECK, int... Us>
 __device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int mm_outer) {
@@ -224,6 +218,13 @@ __device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int mm
     const unsigned short* rb = a.cring + i + 1;
     (a1_gen_row<CHECK, Us>(a, rb, bg), ...);
     return a1_key(bg, -32768 + mm_outer);      // mm_outer = mismatchI of the outer pair (i, j), fetched by the caller ahead of the rows
+}
+template <bool CHECK, int WD, int... Us>
+__device__ __forceinline__ unsigned a1_generic_w(const A1& a, int i, int j, int mm_outer) {
+    unsigned bg = KEY_INF;
+    const unsigned short* rb = a.cring + i + 1;
+    (a1_gen_row_w<CHECK, WD, Us>(a, rb, bg), ...);
+    return a1_key(bg, -32768 + mm_outer);
 }
 
 // bulges, n1 = 0, n2 = U in [LO, HI]: p = i+1, q = j-1-U

@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     (void)dbg_flags_arg; (void)dbg_cycles_arg;
 #endif
     constexpr int DMLR = MODEL ? 5 : 3;      // depth of the DML ring
+    constexpr int GEN_WD = 5;                // default model: |n1 - n2| from which the asymmetry term of a generic loop is saturated (checked on the host: FoldParams::gen_wing_d)
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     long long wB = 0, wA1 = 0, wA2 = 0, wW = 0, wt = 0; // per-wave: phase B, interior loops, multiloop splits, barrier wait (lane 0 of each wave)
     unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
@@ -352,18 +353,31 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (!(dbg_flags & 4)) {
 #define MIRP_GEN(CK)                                                                      \
     switch (role) {                                                                       \
-    case 0: res = a1_generic<CK, 30, 23>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 28, 29>(a, i, j, xi); else a1_i1f<28, 29>(a, i, j, xi); break;      \
-    case 1: res = a1_generic<CK, 29, 24>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 25, 27>(a, i, j, xi); else a1_i1f<25, 27>(a, i, j, xi); break;      \
-    case 2: res = a1_generic<CK, 28, 25>(a, i, j, mmo); if (CK || slow) a1_i0<CK, 26, 29>(a, i, j, xi); else a1_i0f<26, 29>(a, i, j, xi); break;      \
-    case 3: res = a1_generic<CK, 27, 26>(a, i, j, mmo); if (CK || slow) a1_b1<CK, 26, 30>(a, i, j, xb); else a1_b1f<26, 30>(a, i, j, xb); break;      \
-    case 4: res = a1_generic<CK, 22, 17, 12, 7>(a, i, j, mmo); break;                    \
-    case 5: res = a1_generic<CK, 21, 18, 11, 8>(a, i, j, mmo); break;                    \
-    case 6: res = a1_generic<CK, 20, 16, 13, 9>(a, i, j, mmo); break;                    \
-    default: res = a1_generic<CK, 19, 15, 14, 10, 6>(a, i, j, mmo); break;               \
+    case 0: res = MIRP_A1G<CK MIRP_A1WD, 30, 23>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 28, 29>(a, i, j, xi); else a1_i1f<28, 29>(a, i, j, xi); break;      \
+    case 1: res = MIRP_A1G<CK MIRP_A1WD, 29, 24>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 25, 27>(a, i, j, xi); else a1_i1f<25, 27>(a, i, j, xi); break;      \
+    case 2: res = MIRP_A1G<CK MIRP_A1WD, 28, 25>(a, i, j, mmo); if (CK || slow) a1_i0<CK, 26, 29>(a, i, j, xi); else a1_i0f<26, 29>(a, i, j, xi); break;      \
+    case 3: res = MIRP_A1G<CK MIRP_A1WD, 27, 26>(a, i, j, mmo); if (CK || slow) a1_b1<CK, 26, 30>(a, i, j, xb); else a1_b1f<26, 30>(a, i, j, xb); break;      \
+    case 4: res = MIRP_A1G<CK MIRP_A1WD, 22, 17, 12, 7>(a, i, j, mmo); break;                    \
+    case 5: res = MIRP_A1G<CK MIRP_A1WD, 21, 18, 11, 8>(a, i, j, mmo); break;                    \
+    case 6: res = MIRP_A1G<CK MIRP_A1WD, 20, 16, 13, 9>(a, i, j, mmo); break;                    \
+    default: res = MIRP_A1G<CK MIRP_A1WD, 19, 15, 14, 10, 6>(a, i, j, mmo); break;               \
     }
                             // the 2-row generic groups run on the phase-B waves, which have slack left: they also take a few bulge / 1xn shapes
                             unsigned xb = KEY_INF, xi = KEY_INF;
-                            if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
+                            // default model: the saturated-asymmetry candidates of a row go through one minimum (a1_gen_row_w)
+                            if constexpr (MODEL == 0) {
+#define MIRP_A1G a1_generic_w
+#define MIRP_A1WD , GEN_WD
+                                if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
+#undef MIRP_A1G
+#undef MIRP_A1WD
+                            } else {
+#define MIRP_A1G a1_generic
+#define MIRP_A1WD
+                                if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
+#undef MIRP_A1G
+#undef MIRP_A1WD
+                            }
                             if (role < 4) {
                                 const unsigned rb = a1_key(xb, -32768 - OTH_BIAS + au1);
                                 const unsigned ri = a1_key(xi, -32768 - OTH_BIAS + mm1);
@@ -893,6 +907,7 @@ size_t fold_lds_epilogue_bytes(int max_lines) {
 
 size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout<1>().total; }
 int fold_lds_max_n() { return LCAP - 2; }
+int fold_lds_gen_wing_d() { return 5; }      // GEN_WD of fold_lds_kernel<0>
 int fold_lds_max_span() { return LSPAN; }
 
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,

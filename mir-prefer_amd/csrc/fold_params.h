@@ -18,9 +18,11 @@ struct FoldParams {
     unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
     unsigned k1n0_key[31];        // 1 x k loop (n1 = 1, n2 = k): (internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048) << 10 | 1 << 5 | k
     unsigned k1n1_key[31];        // k x 1 loop (n1 = k, n2 = 1): ... | k << 5 | 1
-    // generic loops, two candidates per 32-bit word of a ring row (packed 16-bit add / min): [class][u-6][word], class 0: the lane's run starts
-    // word-aligned at n1 = 2 (word k = n1 2+2k | 3+2k), class 1: it starts one short earlier (word k = n1 1+2k | 2+2k); 65535 = no candidate
-    unsigned gen_pk[2][25][16];
+    // generic loops whose asymmetry term is saturated (|n1 - n2| >= gen_wing_d: ninio |n1 - n2| >= MAX_NINIO): all of a row's share one
+    // size / asymmetry term, so the fill kernel takes the minimum over their ring entries first and adds the term once.  That minimum names
+    // no shape: code 63 = "some loop with n1 >= 2", which sorts after every shape with n1 <= 1 and before every other one (TB_GENERIC, fold_epilogue.h)
+    unsigned gen_wing_key[25];    // [u-6]: (internal_loop[u] + MAX_NINIO) << 10 | 63
+    int gen_wing_d;               // smallest |n1 - n2| with a saturated term: 5 with Turner-2004 (ninio 60, MAX_NINIO 300)
     // (the key tables come first so that the fill kernel's scalar loads reach them with immediate offsets from the one base pointer)
     int stack[8][8];
     int bulge[31];

@@ -33,6 +33,10 @@ extern "C" int mirp_create(int device, mirp_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -2; }
     FoldParams* hp = new FoldParams();
     mirp_fill_fold_params(hp);
+    if (hp->gen_wing_d != mirp::fold_lds_gen_wing_d()) {      // the fill kernel compiles this property of the table in (a1_gen_row_w)
+        std::fprintf(stderr, "mirp_create: energy model and fill kernel disagree on the saturation of the asymmetry term (%d vs %d)\n", hp->gen_wing_d, mirp::fold_lds_gen_wing_d());
+        delete hp; delete c; return -5;
+    }
     if (hipMalloc((void**)&c->d_params, sizeof(FoldParams)) != hipSuccess ||
         hipMemcpy(c->d_params, hp, sizeof(FoldParams), hipMemcpyHostToDevice) != hipSuccess) {
         delete hp; delete c; return -2;

@@ -45,6 +45,7 @@ size_t fold_lds_slab_shorts(int n_cap);
 void fold_lds_epi_clocks_print();
 #endif
 int fold_lds_max_n();
+int fold_lds_gen_wing_d();
 int fold_lds_max_span();
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,

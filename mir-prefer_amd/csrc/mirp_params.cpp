@@ -16,24 +16,10 @@ static void fill_derived(FoldParams* p) {
                 int y = std::abs(2 * n1 - u) * p->ninio;
                 v = ((unsigned)(p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO)) << 10) | (unsigned)(n1 << 5 | (u - n1));
             }
-            if (std::getenv("MIRP_TEST_GENERIC63") && v != (65535u << 10)) v = (v & ~1023u) | 63u;     // TEMP: step-1 test of the epilogue's shape search
             p->gen_key[u - 6][n1] = v;
         }
-    for (int cls = 0; cls < 2; cls++)
-        for (int u = 6; u <= MIRP_MAXLOOP; u++)
-            for (int k = 0; k < 16; k++) {
-                unsigned h[2];
-                for (int x = 0; x < 2; x++) {
-                    const int n1 = 2 - cls + 2 * k + x;
-                    h[x] = 65535u;
-                    if (n1 >= 2 && n1 <= u - 2) {
-                        const int y = std::abs(2 * n1 - u) * p->ninio;
-                        const int e = p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO);
-                        h[x] = (e < 0 || e > 30000) ? 65535u : (unsigned)e;      // (never with the shipped tables; a1_gen_row_pk needs 0 <= e)
-                    }
-                }
-                p->gen_pk[cls][u - 6][k] = h[0] | h[1] << 16;
-            }
+    p->gen_wing_d = p->ninio > 0 ? (p->MAX_NINIO + p->ninio - 1) / p->ninio : 1 << 20;
+    for (int u = 6; u <= MIRP_MAXLOOP; u++) p->gen_wing_key[u - 6] = ((unsigned)(p->internal_loop[u] + p->MAX_NINIO) << 10) | 63u;
     for (int u = 0; u <= MIRP_MAXLOOP; u++) {
         const unsigned kb = (unsigned)(p->bulge[u] + 2048) << 10;
         p->kb0_key[u] = kb | (unsigned)u;
