@@ -288,18 +288,27 @@ def e2e_cli(ds, fold_model):
             opt["OUTPUT_DETAILS_FOR_DEBUG"] = False
             p = pipeline.Pipeline(opt, 0, fold_model=fold_model)
             stages = {}
-            for st in ("prepare", "candidate", "fold", "predict"):
+            # the stage sequence of the `pipeline` verb (Pipeline.run_pipeline): the candidate stage's host artefacts and the fold text are
+            # written behind the next stage's device work
+            gpu = {}
+            for st, kw in (("prepare", {}), ("candidate", {"defer": True}), ("fold", {"defer": True}), ("predict", {})):
                 t = time.time()
-                res = getattr(p, "run_" + st)()
+                res = getattr(p, "run_" + st)(**kw)
                 stages[st] = time.time() - t
+                tm = p.ctx.last_timings()
+                if st == "candidate":
+                    gpu[st] = (tm["coverage_ms"] + tm["candidate_rest_ms"]) / 1e3
+                elif st in ("fold", "predict"):
+                    gpu[st] = tm[st + "_ms"] / 1e3
             wall = time.time() - t0
             p.ctx.close()
         finally:
             sys.stdout.close()
             sys.stdout = so
         out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs)
-        return {"wall_s": wall, "stage_s": stages, "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": len(res or []),
-                "note": "in-process CLI stage drivers (config parse -> prepare -> candidate -> fold -> predict incl. every stage artefact and report file); "
+        return {"wall_s": wall, "stage_s": stages, "stage_gpu_s": gpu, "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": len(res or []),
+                "note": "in-process CLI stage drivers in the `pipeline` verb's sequence (config parse -> prepare -> candidate -> fold -> predict incl. every stage "
+                        "artefact and report file; stage_gpu_s = the device time inside each stage, the rest is host); "
                         "interpreter start-up not included"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -6,6 +6,7 @@
 own stages exchange text (depth file, FASTA, RNALfold output, gff3); binary artefacts are .npz instead of pickles/BAMs."""
 import os
 import pickle
+import threading
 import sys
 import time
 
@@ -294,7 +295,10 @@ class Pipeline:
         self.state = "candidate"
 
     # ---- candidate (MP:3361-3438)
-    def run_candidate(self):
+    def run_candidate(self, defer=False):
+        """defer (the `pipeline` verb on one rank): the Python-side artefacts of the stage -- the pickled dict_loci, ExRegionA.gff3, the window
+        dump and the checkpoint record -- are written by a host thread behind the fold kernels (the device call releases the interpreter
+        lock); run_fold joins it once the fold is done.  Ranks > 1 exchange objects in that code, which must stay on the main thread."""
         if not previous_stage_saved(self.recovername, "prepare"):
             self._fail_stage()
         self._say("Starting identifying candidate regions")
@@ -326,6 +330,27 @@ class Pipeline:
                                     fi.seek(sp[t][0])
                                     fo.write(fi.read(sp[t][1] - sp[t][0]))
         loci, psorted = self.ctx.get_loci()
+        w = self.ctx.get_windows()
+        fastaname = self._p(prefix + ".rnalfold.in_%d.fa" % r)       # one piece per rank, like the reference's pieces per process
+        self.ctx.write_window_fasta(fastaname, names)                # headers (MP:1124-1140) + sequences, formatted by the library's worker threads
+        self._cand_fasta = fastaname
+        counts = (int(self.counts[1]), int(self.counts[2]))
+        if defer and self.world == 1:
+            self._cand_thread = threading.Thread(target=self._candidate_artifacts, args=(loci, psorted, w, depthname, fastaname, counts))
+            self._cand_thread.start()
+        else:
+            self._candidate_artifacts(loci, psorted, w, depthname, fastaname, counts)
+        self._say("Done (candidate stage)\n")
+        self._barrier()
+
+    def _join_candidate(self):
+        t = getattr(self, "_cand_thread", None)
+        if t is not None:
+            t.join()
+            self._cand_thread = None
+
+    def _candidate_artifacts(self, loci, psorted, w, depthname, fastaname, counts):
+        names, prefix, r = self.data["names"], self.opt["NAME_PREFIX"], self.rank
         lociname = self._p(prefix + "_loci_dump.dump")
         dict_loci = {}
         for d_ in self._all_gather(records.loci_to_dict(loci, psorted, names, self.opt["PRECURSOR_LEN"])):
@@ -338,12 +363,9 @@ class Pipeline:
         if r == 0:
             with open(exname, "w") as f:
                 f.write(records.exregion_gff_text(dict_loci))
-        w = self.ctx.get_windows()
-        fastaname = self._p(prefix + ".rnalfold.in_%d.fa" % r)       # one piece per rank, like the reference's pieces per process
-        self.ctx.write_window_fasta(fastaname, names)                # headers (MP:1124-1140) + sequences, formatted by the library's worker threads
         dumpname = self._p(prefix + ".alndump_%d.npz" % r)
         np.savez(dumpname, windows=w["windows"], wpeaks=w["wpeaks"], matures=w["matures"])
-        parts = self._all_gather((fastaname, dumpname, int(self.counts[1]), int(self.counts[2])))
+        parts = self._all_gather((fastaname, dumpname, counts[0], counts[1]))
         nloci, nfasta = sum(x[2] for x in parts), sum(x[3] for x in parts)
         if r == 0:
             d = load_recover_file(self.recovername)
@@ -353,8 +375,6 @@ class Pipeline:
             d["files"]["candidate"] = [x[0] for x in parts] + [x[1] for x in parts]
             _save_recover(self.recovername, d)
             sys.stdout.write("%d candidate loci generated, %d regions to fold.\n" % (nloci, nfasta))
-        self._say("Done (candidate stage)\n")
-        self._barrier()
 
     def _fold_device(self):
         """Fold every window on the device; returns the per-window status array.  A window can produce more structure lines than the
@@ -365,13 +385,14 @@ class Pipeline:
 
     # ---- fold (MP:3441-3495)
     def run_fold(self, write_text=True, defer=False):
-        """defer (the `pipeline` verb): the RNALfold-format text is formatted and written behind the predict stage's device work; the fold
-        stage is recorded in the checkpoint file once that file is complete (run_predict joins the writer first)."""
-        if not previous_stage_saved(self.recovername, "candidate"):
+        """defer (the `pipeline` verb): the RNALfold-format text is formatted and written behind the predict stage's device and report work;
+        the fold stage is recorded in the checkpoint file once that file is complete (run_predict joins the writer before it records itself)."""
+        if getattr(self, "_cand_thread", None) is None and not previous_stage_saved(self.recovername, "candidate"):
             self._fail_stage()
         self._say("Starting folding candidate sequences.")
         self._ensure_candidate()
         status = self._fold_device()
+        self._join_candidate()          # the candidate stage's host artefacts were being written behind the fold kernels (`pipeline` verb)
         self.state = "fold"
         prefix = self.opt["NAME_PREFIX"]
         foldname = self._p(prefix + "_rnalfoldoutput_%d" % self.rank)
@@ -415,11 +436,12 @@ class Pipeline:
         if len(bad):      # a capacity of the filter kernel was exceeded (structure pieces / candidate matures of one window): never truncate silently
             sys.stderr.write("Error occurred when predicting miRNAs: window %d exceeds the capacity of the filter kernel (status %d).\n" % (bad[0], out["status"][bad[0]]))
         self._agree_ok(len(bad) == 0, "predict")
-        if pending is not None:          # the fold stage's text file was being written behind the filter kernel: complete it, then record the stage
-            self.ctx.wait_text()
-            self._barrier()
-            self._record_fold(pending)
-            self._pending_fold = None
+        def finish_fold():          # the fold stage's text file is being written behind this stage: complete it, then record the stage
+            if getattr(self, "_pending_fold", None) is not None:
+                self.ctx.wait_text()
+                self._barrier()
+                self._record_fold(self._pending_fold)
+                self._pending_fold = None
         prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
         if self.opt.get("OUTPUT_DETAILS_FOR_DEBUG"):          # -d: why the other regions are not miRNAs (MP:3532-3543)
             rec = self.ctx.predict_reasons(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"],
@@ -458,9 +480,11 @@ class Pipeline:
             result = [m for part in parts for m in part[0]]     # rank order, as pieces in the reference
             payloads = [x for part in parts for x in part[1]]
         if self.rank != 0:
+            finish_fold()
             self._barrier()
             return []
         if not result:
+            finish_fold()
             _msg("0 miRNA identified. No result files generated.")
             self._barrier()
             return result
@@ -481,6 +505,7 @@ class Pipeline:
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         rm_thread.join()
+        finish_fold()
         d = load_recover_file(self.recovername)
         d["last_stage"] = "predict"
         d["finished_stages"]["predict"] = {"gffname": gffname, "maturename": maturename, "stemloopname": stemloopname}
@@ -494,7 +519,7 @@ class Pipeline:
 
     def run_pipeline(self):
         self.run_prepare()
-        self.run_candidate()
+        self.run_candidate(defer=True)
         self.run_fold(defer=True)
         return self.run_predict()
 

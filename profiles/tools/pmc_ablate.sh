@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for F in $1; do
   export MIRP_FOLD_DEBUG=$F
   rm -rf gpurun_out/pa_$F
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d gpurun_out/pa_$F -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc ${PMC_CTRS:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY} --output-format csv -d gpurun_out/pa_$F -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
   python3 - "$F" <<'PY'
 import csv, glob, collections, sys
 f = glob.glob("gpurun_out/pa_%s/*/*counter_collection.csv" % sys.argv[1])[0]
