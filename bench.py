@@ -110,6 +110,7 @@ def parse_args():
     ap.add_argument("--micro-windows", type=int, default=1 << 16, help="windows per family of the fold micro-benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-cov-shard", action="store_true", help="skip the coverage-stage measurement at a config[4] rank shard's size (configs.coverage_config4_shard)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of wall-clock per CPU-baseline leg")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--ingest-records", type=int, default=8000000,
@@ -497,6 +498,7 @@ def main():
         fill_s = float(np.mean(fill_ms)) / 1e3
         epi_s = float(np.mean(epi_ms)) / 1e3
         cov_s = float(np.mean(cov_ms)) / 1e3
+        cov_fused = ctx.last_coverage_fused()
         wins = ctx.get_windows()
         W = wins["windows"]
         lens = W["seq_len"].astype(np.int64)
@@ -550,7 +552,7 @@ def main():
             "roofline_hbm": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": fold_s * 1e3,
                              "note": "HBM view of the fold (algorithmic bytes / time / 8 TB/s); << 1 is expected: the tables are LDS-resident"},
-            "roofline_coverage": {"kernel": "cov_scatter_kernel + cov_scan_kernel + cov_unscatter_kernel", "bound": "hbm", "achieved": b_cov / cov_s / 1e9,
+            "roofline_coverage": {"kernel": "cov_tile_first_kernel + cov_scan_kernel<fused>" if cov_fused else "cov_scatter_kernel + cov_scan_kernel + cov_unscatter_kernel", "bound": "hbm", "achieved": b_cov / cov_s / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_cov / cov_s / 1e9 / HBM_PEAK_GBS, "avg_ms": cov_s * 1e3,
                                   "bytes_algorithmic": b_cov, "bytes_moved_model": b_cov_moved, "achieved_moved": b_cov_moved / cov_s / 1e9,
                                   "frac_moved": b_cov_moved / cov_s / 1e9 / HBM_PEAK_GBS,
@@ -596,6 +598,29 @@ def main():
                                    "stage_ms": {"coverage": float(np.mean([x[3]["coverage_ms"] for x in k2])), "candidate_rest": float(np.mean([x[3]["candidate_rest_ms"] for x in k2])),
                                                 "fold_fill_kernel": float(np.mean([x[4][0] for x in k2])), "fold_epilogue_kernel": float(np.mean([x[4][1] for x in k2])),
                                                 "predict": float(np.mean([x[3]["predict_ms"] for x in k2]))}}
+                if not a.no_cov_shard:
+                    # the coverage stage at the size of one rank's share of config[4] (8 x 31.25 Mb, 2.5e7 packed records: 0.1 records per base), where
+                    # the scatter's global atomics used to bound it: the candidate stage alone, no fold
+                    rng4 = np.random.RandomState(4)
+                    c4 = [("ctg%02d" % t, synth._BASES[rng4.randint(0, 4, size=31250000, dtype=np.uint8)]) for t in range(8)]
+                    a4 = synth.packed_records_shard(8, 31250000, 150000, 167, seed=44)
+                    ctx.load_genome(c4)
+                    ctx.load_alignments(a4)
+                    o4 = np.arange(8, dtype=np.int32)
+                    ms4, nw4 = [], 0
+                    for _ in range(6):
+                        _, _, nw4 = ctx.candidate(CUT, GAP, L, o4)
+                        ms4.append(ctx.last_timings()["coverage_ms"])
+                    g4 = float(sum(len(x) + 1 for _, x in c4))
+                    alg4, mov4 = 16.0 * len(a4) + 16.0 * g4, 48.0 * len(a4) + 8.0 * g4
+                    t4 = float(np.mean(ms4[1:])) / 1e3
+                    cfgs["coverage_config4_shard"] = {
+                        "avg_ms": t4 * 1e3, "min_ms": float(min(ms4)), "path": "fused scan (tiles built from the sorted records in LDS)" if ctx.last_coverage_fused() else "atomic scatter + scan",
+                        "records": int(len(a4)), "positions": int(g4), "windows": int(nw4), "bytes_algorithmic": alg4, "bytes_moved_model": mov4,
+                        "achieved": alg4 / t4 / 1e9, "frac": alg4 / t4 / 1e9 / HBM_PEAK_GBS, "achieved_moved": mov4 / t4 / 1e9, "frac_moved": mov4 / t4 / 1e9 / HBM_PEAK_GBS,
+                        "unit": "GB/s", "note": "bytes_moved_model = 48 A + 8 G: the records are read three times (tile index, own tile, next tile), every tile "
+                                                 "with a covered base is written to the dense arrays once (upper bound: all of them)"}
+                    del c4, a4
                 cfgs["note"] = ("config3 / config4 are multi-GPU workloads: `python bench.py --gpus 8 --workload config3|config4` (a rank's shard of either is covered at "
                                 "full size by tests/test_configs_gpu.py); the headline above stays config1")
                 line["configs"] = cfgs

@@ -216,6 +216,10 @@ int mirp_last_timings(mirp_ctx* ctx, double ms[4]);
 int64_t mirp_last_fold_fallbacks(mirp_ctx* ctx);
 /* Number of windows of the last mirp_fold that needed more than max_lines structure lines and were folded again at full capacity. */
 int64_t mirp_last_fold_overflow(mirp_ctx* ctx);
+/* Which way the last coverage pass (mirp_candidate / mirp_get_depth) took: 1 = the scan built every tile's difference values from the sorted
+ * records in LDS (dense inputs without coverage segments), 0 = atomic scatter into the dense difference arrays; informational, the results are
+ * identical (the `samtools depth` replacement, /root/reference/miR_PREFeR.py:877-949). */
+int mirp_last_coverage_fused(mirp_ctx* ctx);
 
 /* Device time of the kernels of the last mirp_fold, HIP events on the context's stream: ms[0] = fill kernel(s) (fold_lds_kernel: the
  * dynamic program), ms[1] = epilogue kernel(s) (exterior sweep, enumeration, backtracks), summed over the sub-batches of the main pass. */

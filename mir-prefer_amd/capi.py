@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIRP_LIB") or os.path.join(_HERE, "libmirprefer.so")   # MIRP_LIB: dev tools load the diagnostics build (make DIAG=1)
-ABI_VERSION = 5      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
+ABI_VERSION = 6      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
 
 
 class MirpError(RuntimeError):
@@ -201,6 +201,8 @@ def load_library():
     lib.mirp_microbench.restype = C.c_int
     lib.mirp_last_fold_overflow.argtypes = [vp]
     lib.mirp_last_fold_overflow.restype = C.c_int64
+    lib.mirp_last_coverage_fused.argtypes = [vp]
+    lib.mirp_last_coverage_fused.restype = C.c_int
     lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mirp_write_fold_text.restype = C.c_int
     lib.mirp_write_fold_text_async.argtypes = [vp, C.c_char_p, C.c_char_p]
@@ -546,6 +548,10 @@ class Context:
 
     def last_fold_overflow(self):
         return int(self.lib.mirp_last_fold_overflow(self.h))
+
+    def last_coverage_fused(self):
+        """True when the last coverage pass built its tiles from the sorted records in LDS (dense inputs), False for the atomic scatter path."""
+        return bool(self.lib.mirp_last_coverage_fused(self.h))
 
     def fold_summary(self):
         vp = C.c_void_p

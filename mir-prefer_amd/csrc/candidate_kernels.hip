@@ -131,7 +131,39 @@ struct RunStart { long long gx; int dp, dm; };
 // one fully coalesced kilobyte (a thread-contiguous layout makes each instruction touch 64 cache lines for 16 bytes apiece and thrashes the
 // vector L1).  A thread therefore holds SCAN_NV groups of four consecutive positions, 256 positions apart.
 #define SCAN_NV (SCAN_IPT / 4)
-__global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict__ diff_p, const int* __restrict__ diff_m, long long gtot,
+// first[t] = index of the first record (sorted by (tid, pos)) whose start slot lies in tile t or later; first[n_tiles] = n.  One thread per
+// record boundary: where the tile index steps from tp to t, the tiles tp + 1 .. t begin at record k.
+__device__ __forceinline__ long long cov_start_slot(const MirpAln& r, const long long* __restrict__ goff, const long long* __restrict__ clen) {
+    const long long L = clen[r.tid];
+    long long s = r.pos;
+    if (s < 1) s = 1;
+    if (s > L + 1) s = L + 1;          // (a record past the contig end contributes nothing; clamped so that the slots stay sorted across contigs)
+    return goff[r.tid] + s - 1;
+}
+__global__ void __launch_bounds__(256) cov_tile_first_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
+                                                             const long long* __restrict__ clen, long long n_tiles, long long* __restrict__ first) {
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k <= n; k += (long long)gridDim.x * blockDim.x) {
+        const long long t = k < n ? cov_start_slot(alns[k], goff, clen) / SCAN_TILE : n_tiles;
+        const long long tp = k > 0 ? cov_start_slot(alns[k - 1], goff, clen) / SCAN_TILE : -1;
+        for (long long x = tp + 1; x <= t && x <= n_tiles; x++) first[x] = k;
+    }
+}
+__global__ void __launch_bounds__(256) cov_maxlen_kernel(const MirpAln* __restrict__ alns, long long n, int* __restrict__ out) {
+    int m = 0;
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) { const int l = alns[k].len; m = l > m ? l : m; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+// FUSED: the tile's difference values do not come from the dense arrays (one global atomic pair per record before, 8 bytes read per base here) but
+// are built in LDS from the sorted records themselves: the records that start in this tile or the one before it (first[]; no record is longer
+// than a tile -- checked on the host) add their +w / -w with LDS atomics.  A tile that holds a covered base, or continues a run, then writes its
+// values to the dense arrays once, with plain coalesced stores: that is all the run walk ever reads.  No clearing pass, no global atomics.
+template <bool FUSED>
+__global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ diff_p, int* __restrict__ diff_m, long long gtot,
+                                                           const MirpAln* __restrict__ alns, const long long* __restrict__ goff, const long long* __restrict__ clen,
+                                                           const long long* __restrict__ first,
                                                            int cutoff, unsigned long long* __restrict__ stat_d,
                                                            unsigned long long* __restrict__ stat_c, unsigned int* __restrict__ ticket,
                                                            RunStart* __restrict__ starts, long long starts_cap,
@@ -148,6 +180,44 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict
     const long long base = (long long)tile * SCAN_TILE;
     const long long wbase = base + (long long)wave * (64 * SCAN_IPT);
     int vp[SCAN_IPT], vm[SCAN_IPT];
+    if constexpr (FUSED) {
+        extern __shared__ __align__(16) int ld[];          // [2][SCAN_TILE]: + strand, - strand
+        const long long k0 = first[tile > 0 ? tile - 1 : 0], k1 = first[tile + 1];
+        if (k0 == k1) {          // no record starts in this tile or the one before it: nothing can change here (most tiles of a sparse sample)
+#pragma unroll
+            for (int v = 0; v < SCAN_IPT; v++) { vp[v] = 0; vm[v] = 0; }
+        } else {
+            for (int x = tid * 4; x < 2 * SCAN_TILE; x += SCAN_NT * 4) *reinterpret_cast<int4*>(ld + x) = make_int4(0, 0, 0, 0);
+            __syncthreads();
+            constexpr int RU = 4;          // records in flight per thread: the loop is a chain of dependent loads (record, then its contig's offsets) otherwise
+            for (long long kb = k0 + tid; kb < k1; kb += (long long)SCAN_NT * RU) {
+                MirpAln r[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) { const long long k = kb + (long long)u * SCAN_NT; if (k < k1) r[u] = alns[k]; }
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    if (kb + (long long)u * SCAN_NT >= k1) continue;
+                    int w = (int)(r[u].depth > (unsigned)cutoff ? (unsigned)cutoff : r[u].depth);
+                    const CovSlots c = cov_slots(r[u], goff, clen, nullptr, nullptr);
+                    if (!c.ok || w == 0) continue;
+                    if (r[u].strand & 2) w = -w;
+                    int* d = ld + ((r[u].strand & 1) ? SCAN_TILE : 0);
+                    const long long a = c.i0 - base, b = c.i1 - base;
+                    if (a >= 0 && a < SCAN_TILE) atomicAdd(&d[a], w);
+                    if (b >= 0 && b < SCAN_TILE) atomicAdd(&d[b], -w);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < SCAN_NV; v++) {
+                const int o = wave * (64 * SCAN_IPT) + v * 256 + lane * 4;
+                const int4 a = *reinterpret_cast<const int4*>(ld + o);
+                const int4 b = *reinterpret_cast<const int4*>(ld + SCAN_TILE + o);
+                vp[v * 4] = a.x; vp[v * 4 + 1] = a.y; vp[v * 4 + 2] = a.z; vp[v * 4 + 3] = a.w;
+                vm[v * 4] = b.x; vm[v * 4 + 1] = b.y; vm[v * 4 + 2] = b.z; vm[v * 4 + 3] = b.w;
+            }
+        }
+    } else
 #pragma unroll
     for (int v = 0; v < SCAN_NV; v++) {
         const long long x = wbase + v * 256 + lane * 4;
@@ -219,6 +289,25 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(const int* __restrict
     }
     int es[SCAN_NV], ea[SCAN_NV], ts, ta;
     tile_excl_scan2<SCAN_NV>(ns, na, es, ea, ts, ta, sh);
+    if constexpr (FUSED) {
+        // ta = covered bases of the tile; a run can also reach in from the tile before (depth carried in above the threshold) and its walk then reads
+        // this tile's first values
+        const bool carried = (int)(((unsigned)s_carry[0] + (unsigned)s_carry[1]) & 0x7fffffffu) > cutoff;
+        if (ta > 0 || carried) {
+#pragma unroll
+            for (int v = 0; v < SCAN_NV; v++) {
+                const long long x = wbase + v * 256 + lane * 4;
+                if (x + 3 < gtot) {
+                    *reinterpret_cast<int4*>(diff_p + x) = make_int4(vp[v * 4], vp[v * 4 + 1], vp[v * 4 + 2], vp[v * 4 + 3]);
+                    *reinterpret_cast<int4*>(diff_m + x) = make_int4(vm[v * 4], vm[v * 4 + 1], vm[v * 4 + 2], vm[v * 4 + 3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x + j < gtot) { diff_p[x + j] = vp[v * 4 + j]; diff_m[x + j] = vm[v * 4 + j]; }
+                }
+            }
+        }
+    }
     // ---- look-back #2: ordered output offsets
     if (tid == 0) st_status(&stat_c[tile], pack2(tile == 0 ? 2u : 1u, (unsigned)ts, (unsigned)ta));
     if (tid < 64) {
@@ -578,8 +667,25 @@ void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long 
                      unsigned long long* stat_c, unsigned int* ticket, void* starts, long long starts_cap, MirpDepthPos* depth_out,
                      long long depth_cap, long long* depth_gx, unsigned long long* totals) {
     long long tiles = cov_scan_tiles(gtot);
-    hipLaunchKernelGGL(cov_scan_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, st, diff_p, diff_m, gtot, cutoff, stat_d, stat_c, ticket,
+    hipLaunchKernelGGL(cov_scan_kernel<false>, dim3((unsigned)tiles), dim3(SCAN_NT), 0, st, const_cast<int*>(diff_p), const_cast<int*>(diff_m), gtot, nullptr, nullptr,
+                       nullptr, nullptr, cutoff, stat_d, stat_c, ticket, (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
+}
+int cov_scan_tile_positions() { return SCAN_TILE; }
+void launch_cov_maxlen(hipStream_t st, const MirpAln* alns, long long n, int* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cov_maxlen_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, alns, n, out);
+}
+hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, long long* first, int* diff_p,
+                                 int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d, unsigned long long* stat_c, unsigned int* ticket, void* starts,
+                                 long long starts_cap, MirpDepthPos* depth_out, long long depth_cap, long long* depth_gx, unsigned long long* totals) {
+    const long long tiles = cov_scan_tiles(gtot);
+    const size_t lds = 2 * (size_t)SCAN_TILE * sizeof(int);
+    hipError_t e = hipFuncSetAttribute((const void*)cov_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cov_tile_first_kernel, dim3(grid_for(n + 1, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, tiles, first);
+    hipLaunchKernelGGL(cov_scan_kernel<true>, dim3((unsigned)tiles), dim3(SCAN_NT), lds, st, diff_p, diff_m, gtot, alns, goff, clen, first, cutoff, stat_d, stat_c, ticket,
                        (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
+    return hipGetLastError();
 }
 size_t run_start_bytes() { return sizeof(RunStart); }
 void launch_run_walk(hipStream_t st, const void* starts, long long n_runs, const int* diff_p, const int* diff_m, long long gtot, int cutoff,

@@ -52,6 +52,9 @@ struct mirp_ctx {
     std::vector<long long> h_clen, h_goff, h_gboff;
     DevBuf genome, clen, goff, gboff, alns, order, segs, sort_tmp, sort_counts;
     long long n_segs = 0;
+    DevBuf tile_first;               // fused coverage scan: first record of every tile (candidate_kernels.hip)
+    int max_aln_len = -1;             // longest resident record (reference span), -1 = not known: the fused scan needs it <= one tile
+    bool cov_fused = false;           // the last run_coverage took the fused path (nothing to clear afterwards)
     void* diff_clean_ptr = nullptr;   // the difference arrays at this address are all zero (run_coverage / clean_coverage)
     size_t diff_clean_bytes = 0;
     bool ingest_resident = false;     // the alignments came from mirp_ingest_sams_gpu (already validated and sorted on the device)

@@ -577,7 +577,7 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
     const double t4 = now_s();
     if (fill_meta(P, out)) return bail(-6, "out of memory");
     out->alns = all; out->n_alns = n; out->segs = segs; out->n_segs = ns;
-    c->n_alns = n; c->n_segs = ns;
+    c->n_alns = n; c->n_segs = ns; c->max_aln_len = -1;
     c->have_candidate = c->have_fold = c->have_result = false;
     c->ingest_resident = true; c->ingest_n_contigs = (int)P.names.size();
     if (seconds) { seconds[0] = t1 - t0; seconds[1] = t2 - t1; seconds[2] = t3 - t2; seconds[3] = t4 - t3; }

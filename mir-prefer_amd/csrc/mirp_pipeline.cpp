@@ -2,6 +2,7 @@
 // Host orchestration only; every stage leaves its results in HBM for the next one.
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "mirp_ctx.h"
 
 namespace mirp {
@@ -114,7 +115,7 @@ extern "C" int mirp_load_alignments(mirp_ctx* c, const MirpAln* alns, int64_t n)
     }
     if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<int64_t>(n, 1))) return fail(c, -6, "device allocation failed (alignments)");
     if (n) HIPCHK(c, hipMemcpy(c->alns.p, alns, sizeof(MirpAln) * (size_t)n, hipMemcpyHostToDevice));
-    c->n_alns = n; c->n_segs = 0; c->ingest_resident = false;
+    c->n_alns = n; c->n_segs = 0; c->ingest_resident = false; c->max_aln_len = -1;
     c->have_candidate = c->have_fold = c->have_result = false;
     return 0;
 }
@@ -145,6 +146,35 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     unsigned long long* stat_d = (unsigned long long*)c->stat.p;
     unsigned long long* stat_c = stat_d + tiles;
     unsigned int* ticket = (unsigned int*)(stat_c + tiles);
+    HIPCHK(c, hipMemsetAsync(c->stat.p, 0, 16 * (size_t)tiles + 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->totals.p, 0, 64, c->stream));
+    // Fused path (no coverage segments, no record longer than a scan tile): the scan builds every tile's difference values from the sorted records
+    // in LDS and writes the dense arrays only where a run walk will read them -- no global atomics, no clearing pass.
+    // Measured (profiles/tools/cov_time.py): cfg[4] shard, 0.1 records per base: 1.27 ms fused against 2.11 ms + the clearing pass; config[1],
+    // 0.002 records per base: 0.137 against 0.123 ms (two more launches, nothing to gain from 138 k atomics) -- so the density picks the path.
+    // MIRP_COV_FUSED=1 / 0 forces it (tests run both on the same input).
+    c->cov_fused = false;
+    const char* force = std::getenv("MIRP_COV_FUSED");
+    const bool want = force ? force[0] == '1' : c->n_alns >= c->gtot / 32;
+    if (c->n_segs == 0 && c->n_alns > 0 && want) {
+        if (c->max_aln_len < 0) {
+            int* d_max = (int*)((char*)c->totals.p + 32);          // (cleared above)
+            mirp::launch_cov_maxlen(c->stream, (const MirpAln*)c->alns.p, c->n_alns, d_max);
+            int m = 0;
+            HIPCHK(c, hipMemcpyAsync(&m, d_max, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->max_aln_len = m;
+        }
+        c->cov_fused = c->max_aln_len <= mirp::cov_scan_tile_positions();
+    }
+    if (c->cov_fused) {
+        if (c->tile_first.ensure(8 * (size_t)(tiles + 2))) return fail(c, -6, "device allocation failed (coverage)");
+        c->diff_clean_ptr = nullptr;          // the dense arrays hold the written tiles' values from now on: the atomic path clears them before it runs again
+        HIPCHK(c, mirp::launch_cov_scan_fused(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p,
+                                              (long long*)c->tile_first.p, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p,
+                                              std::max<long long>(c->n_alns + c->n_segs, 1), depth_out, depth_cap, depth_gx, (unsigned long long*)c->totals.p));
+        return 0;
+    }
     // the difference arrays are all zero between passes (clean_coverage clears what a pass wrote); a full clear only for a new buffer or after
     // a pass that did not get to clean up
     if (c->diff_clean_ptr != c->diff.p || c->diff_clean_bytes < 8 * (size_t)(gtot + 8)) {
@@ -152,8 +182,6 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
         c->diff_clean_bytes = c->diff.cap;
     }
     c->diff_clean_ptr = nullptr;          // dirty from here until clean_coverage
-    HIPCHK(c, hipMemsetAsync(c->stat.p, 0, 16 * (size_t)tiles + 64, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->totals.p, 0, 64, c->stream));
     mirp::launch_cov_scatter(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p, c->cand.cutoff,
                              diff_p, diff_m);
     if (c->n_segs > 0)       // gapped alignments: their own [pos, pos + len(SEQ)) taken back out, their M / = / X blocks added
@@ -167,6 +195,7 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
 
 // clears the positions the last run_coverage wrote (two per record / segment): the arrays are all zero again
 static int clean_coverage(mirp_ctx* c) {
+    if (c->cov_fused) return 0;          // the fused scan wrote whole tiles with plain stores and relies on no invariant of the arrays
     int* diff_p = (int*)c->diff.p;
     int* diff_m = diff_p + ((c->gtot + 3) / 4) * 4;
     mirp::launch_cov_unscatter(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p, diff_p, diff_m);
@@ -616,3 +645,4 @@ extern "C" int mirp_last_fold_kernel_ms(mirp_ctx* c, double ms[2]) {
 
 extern "C" int64_t mirp_last_fold_fallbacks(mirp_ctx* c) { return c ? (int64_t)c->last_fallback : -1; }
 extern "C" int64_t mirp_last_fold_overflow(mirp_ctx* c) { return c ? (int64_t)c->n_side : -1; }
+extern "C" int mirp_last_coverage_fused(mirp_ctx* c) { return c ? (c->cov_fused ? 1 : 0) : -1; }

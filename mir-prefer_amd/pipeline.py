@@ -336,7 +336,14 @@ class Pipeline:
         self._cand_fasta = fastaname
         counts = (int(self.counts[1]), int(self.counts[2]))
         if defer and self.world == 1:
-            self._cand_thread = threading.Thread(target=self._candidate_artifacts, args=(loci, psorted, w, depthname, fastaname, counts))
+            self._cand_error = None
+
+            def job():
+                try:
+                    self._candidate_artifacts(loci, psorted, w, depthname, fastaname, counts)
+                except BaseException as e:          # surfaces in _join_candidate, on the main thread
+                    self._cand_error = e
+            self._cand_thread = threading.Thread(target=job)
             self._cand_thread.start()
         else:
             self._candidate_artifacts(loci, psorted, w, depthname, fastaname, counts)
@@ -348,6 +355,8 @@ class Pipeline:
         if t is not None:
             t.join()
             self._cand_thread = None
+            if self._cand_error is not None:
+                raise self._cand_error
 
     def _candidate_artifacts(self, loci, psorted, w, depthname, fastaname, counts):
         names, prefix, r = self.data["names"], self.opt["NAME_PREFIX"], self.rank

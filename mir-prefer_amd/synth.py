@@ -240,3 +240,25 @@ def write_sam_fast(path, sample_name, recs, contig_names, contig_lens, cigars=No
                 f.write(m.tobytes())
                 total += m.size
     return total
+
+
+def packed_records_shard(n_contigs, contig_len, n_loci, reads_per_locus, seed):
+    """config[4]: alignment records generated directly as packed 16-byte records: clusters of distinct isomiR-like reads."""
+    rng = np.random.RandomState(seed)
+    per = n_loci // n_contigs
+    tid = np.repeat(np.arange(n_contigs, dtype=np.int32), per)
+    slot = contig_len // per
+    start = (np.tile(np.arange(per, dtype=np.int64), n_contigs) * slot + rng.randint(100, slot - 500, size=n_contigs * per)).astype(np.int64)
+    strand = rng.randint(0, 2, size=len(start)).astype(np.uint8)
+    width = rng.randint(8, 90, size=len(start))
+    nl = len(start)
+    a = np.zeros(nl * reads_per_locus, dtype=ALN_DTYPE)
+    a["tid"] = np.repeat(tid, reads_per_locus)
+    a["pos"] = (np.repeat(start, reads_per_locus) + (rng.randint(0, 1 << 30, size=len(a)) % np.repeat(width, reads_per_locus))).astype(np.int32) + 1
+    a["len"] = rng.randint(18, 26, size=len(a)).astype(np.uint16)
+    a["depth"] = rng.randint(1, 40, size=len(a)).astype(np.uint32)
+    flip = rng.rand(len(a)) < 0.04
+    a["strand"] = np.repeat(strand, reads_per_locus) ^ flip.astype(np.uint8)
+    a["sample"] = 0
+    key = a["tid"].astype(np.int64) << 32 | a["pos"].astype(np.int64)
+    return a[np.argsort(key, kind="stable")]

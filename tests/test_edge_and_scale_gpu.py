@@ -355,3 +355,57 @@ def test_difference_arrays_are_clean_between_passes(gpu_ctx, oracle):
                 cov[int(r["tid"])][int(r["strand"]) & 1, s:e] += w
         want = [(t, p, int(cov[t][0, p]), int(cov[t][1, p])) for t in range(2) for p in range(1, lens[t] + 1) if cov[t][0, p] + cov[t][1, p] > 10]
         assert [(int(d["tid"]), int(d["pos"]), int(d["dp"]), int(d["dm"])) for d in got] == want, seed
+
+
+def test_fused_coverage_scan_equals_atomic_path_and_brute_force(gpu_ctx, monkeypatch):
+    """Two ways to the same depth: the scan that builds each tile's difference values from the sorted records in LDS (cov_scan_kernel<true>, picked for
+    dense inputs) and the atomic scatter into the dense arrays (sparse inputs, coverage segments).  MIRP_COV_FUSED forces either; both run on one
+    context in turn (each leaves the dense arrays in the state the other expects), on inputs that sit on the scan's tile edges (8192 positions):
+    contig boundaries next to a tile boundary, records that start in one tile and end in the next, records that reach over a contig end, an
+    empty contig, a record longer than a tile (which sends the pass down the atomic path by itself).  Depth list and peaks against brute force."""
+    T = 8192
+    lens = [T - 1, 2 * T + 3, 5, 3 * T - 2, 40000]
+    rng = np.random.RandomState(11)
+    genome = [("c%d" % k, synth._BASES[rng.randint(0, 4, size=l)]) for k, l in enumerate(lens)]
+    order = np.arange(len(lens), dtype=np.int32)
+    gpu_ctx.load_genome(genome)
+
+    def alns_of(n, seed, long_one):
+        r = np.random.RandomState(seed)
+        a = np.zeros(n, dtype=synth.ALN_DTYPE)
+        a["tid"] = r.choice([0, 1, 3, 4], size=n)
+        L = np.array(lens)[a["tid"]]
+        # clusters around the tile edges of the guarded coordinate space and uniform background
+        near = (r.randint(1, 6, size=n) * T - r.randint(-40, 40, size=n)) % np.maximum(L, 1) + 1
+        a["pos"] = np.where(r.rand(n) < 0.6, near, r.randint(1, 1 << 30, size=n) % L + 1)
+        a["pos"][:40] = L[:40] - r.randint(0, 12, size=40)          # reach over the contig end
+        a["len"] = r.randint(18, 60, size=n)
+        a["depth"] = r.randint(1, 40, size=n)
+        a["strand"] = r.randint(0, 2, size=n)
+        if long_one:
+            a["len"][n // 2] = T + 100
+        key = a["tid"].astype(np.int64) << 32 | a["pos"].astype(np.int64)
+        return a[np.argsort(key, kind="stable")]
+
+    def brute(a):
+        cov = [np.zeros((2, l + 2), dtype=np.int64) for l in lens]
+        for r_ in a:
+            t = int(r_["tid"])
+            s, e = int(r_["pos"]), min(int(r_["pos"]) + int(r_["len"]), lens[t] + 1)
+            cov[t][int(r_["strand"]) & 1, s:e] += min(int(r_["depth"]), 10)
+        return [(t, p, int(cov[t][0, p]), int(cov[t][1, p])) for t in range(len(lens)) for p in range(1, lens[t] + 1) if cov[t][0, p] + cov[t][1, p] > 10]
+
+    for n, seed, long_one in ((30000, 1, False), (200, 2, False), (12000, 3, True), (30000, 4, False)):
+        a = alns_of(n, seed, long_one)
+        gpu_ctx.load_alignments(a)
+        want = brute(a)
+        got = {}
+        for mode in ("1", "0", "1"):
+            monkeypatch.setenv("MIRP_COV_FUSED", mode)
+            gpu_ctx.candidate(10, 100, 300, order)
+            d = gpu_ctx.get_depth()
+            pk = gpu_ctx.get_peaks()
+            got[mode] = ([(int(x["tid"]), int(x["pos"]), int(x["dp"]), int(x["dm"])) for x in d], [tuple(int(v) for v in x) for x in pk])
+            assert got[mode][0] == want, (seed, mode)
+        assert got["1"][1] == got["0"][1], seed
+    monkeypatch.delenv("MIRP_COV_FUSED")
