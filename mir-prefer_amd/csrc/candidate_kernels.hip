@@ -140,10 +140,27 @@ __device__ __forceinline__ long long cov_start_slot(const MirpAln& r, const long
     if (s > L + 1) s = L + 1;          // (a record past the contig end contributes nothing; clamped so that the slots stay sorted across contigs)
     return goff[r.tid] + s - 1;
 }
+// The same pass leaves every tile's TOTAL of difference values in agg[strand][tile]: a record adds +w and -w, which cancel inside one tile, so only
+// the few records whose two slots lie in different tiles (reads are tens of bases, a tile is 8192) touch it.  The exclusive prefix of those totals
+// is the depth carried into a tile -- the fused scan reads it instead of looking back for it.
 __global__ void __launch_bounds__(256) cov_tile_first_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
-                                                             const long long* __restrict__ clen, long long n_tiles, long long* __restrict__ first) {
+                                                             const long long* __restrict__ clen, long long n_tiles, int cutoff, long long* __restrict__ first,
+                                                             int* __restrict__ agg /* [2][n_tiles], zero */) {
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k <= n; k += (long long)gridDim.x * blockDim.x) {
-        const long long t = k < n ? cov_start_slot(alns[k], goff, clen) / SCAN_TILE : n_tiles;
+        long long t = n_tiles;
+        if (k < n) {
+            const MirpAln r = alns[k];
+            t = cov_start_slot(r, goff, clen) / SCAN_TILE;
+            int w = (int)(r.depth > (unsigned)cutoff ? (unsigned)cutoff : r.depth);
+            const CovSlots c = cov_slots(r, goff, clen, nullptr, nullptr);
+            const long long ta = c.i0 / SCAN_TILE, tb = c.i1 / SCAN_TILE;
+            if (c.ok && w != 0 && ta != tb) {
+                if (r.strand & 2) w = -w;
+                int* a = agg + ((r.strand & 1) ? n_tiles : 0);
+                atomicAdd(&a[ta], w);
+                atomicAdd(&a[tb], -w);
+            }
+        }
         const long long tp = k > 0 ? cov_start_slot(alns[k - 1], goff, clen) / SCAN_TILE : -1;
         for (long long x = tp + 1; x <= t && x <= n_tiles; x++) first[x] = k;
     }
@@ -163,7 +180,8 @@ __global__ void __launch_bounds__(256) cov_maxlen_kernel(const MirpAln* __restri
 template <bool FUSED>
 __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ diff_p, int* __restrict__ diff_m, long long gtot,
                                                            const MirpAln* __restrict__ alns, const long long* __restrict__ goff, const long long* __restrict__ clen,
-                                                           const long long* __restrict__ first,
+                                                           const long long* __restrict__ first, const long long* __restrict__ carry_p,
+                                                           const long long* __restrict__ carry_m,
                                                            int cutoff, unsigned long long* __restrict__ stat_d,
                                                            unsigned long long* __restrict__ stat_c, unsigned int* __restrict__ ticket,
                                                            RunStart* __restrict__ starts, long long starts_cap,
@@ -239,7 +257,10 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ dif
     for (int v = 0; v < SCAN_NV; v++) { gp[v] = vp[v * 4] + vp[v * 4 + 1] + vp[v * 4 + 2] + vp[v * 4 + 3]; gm[v] = vm[v * 4] + vm[v * 4 + 1] + vm[v * 4 + 2] + vm[v * 4 + 3]; }
     int tp, tm;
     tile_excl_scan2<SCAN_NV>(gp, gm, ep, em, tp, tm, sh);
-    // ---- look-back #1: depth carried into this tile
+    // ---- look-back #1: depth carried into this tile (fused: known beforehand, see cov_tile_first_kernel)
+    if constexpr (FUSED) {
+        if (tid == 0) { s_carry[0] = (int)((unsigned long long)carry_p[tile] & 0x7fffffffull); s_carry[1] = (int)((unsigned long long)carry_m[tile] & 0x7fffffffull); }
+    } else {
     if (tid == 0) st_status(&stat_d[tile], pack2(tile == 0 ? 2u : 1u, (unsigned)tp, (unsigned)tm));
     if (tid < 64) {
         unsigned cp = 0, cm = 0;
@@ -263,6 +284,7 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ dif
             if (lane == 0) st_status(&stat_d[tile], pack2(2u, cp + (unsigned)tp, cm + (unsigned)tm));
         }
         if (lane == 0) { s_carry[0] = (int)(cp & 0x7fffffffu); s_carry[1] = (int)(cm & 0x7fffffffu); }
+    }
     }
     __syncthreads();
     // depths are >= 0 everywhere, but tile aggregates of a *difference* array can be negative: they are
@@ -668,22 +690,32 @@ void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long 
                      long long depth_cap, long long* depth_gx, unsigned long long* totals) {
     long long tiles = cov_scan_tiles(gtot);
     hipLaunchKernelGGL(cov_scan_kernel<false>, dim3((unsigned)tiles), dim3(SCAN_NT), 0, st, const_cast<int*>(diff_p), const_cast<int*>(diff_m), gtot, nullptr, nullptr,
-                       nullptr, nullptr, cutoff, stat_d, stat_c, ticket, (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
+                       nullptr, nullptr, nullptr, nullptr, cutoff, stat_d, stat_c, ticket, (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
 }
 int cov_scan_tile_positions() { return SCAN_TILE; }
 void launch_cov_maxlen(hipStream_t st, const MirpAln* alns, long long n, int* out) {
     if (n <= 0) return;
     hipLaunchKernelGGL(cov_maxlen_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, alns, n, out);
 }
-hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, long long* first, int* diff_p,
+size_t cov_fused_aux_bytes(long long gtot) { const size_t t = (size_t)cov_scan_tiles(gtot); return 8 * (t + 2) + 4 * 2 * t + 16 + 8 * 2 * (t + 2); }
+hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, void* aux, int* diff_p,
                                  int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d, unsigned long long* stat_c, unsigned int* ticket, void* starts,
                                  long long starts_cap, MirpDepthPos* depth_out, long long depth_cap, long long* depth_gx, unsigned long long* totals) {
     const long long tiles = cov_scan_tiles(gtot);
     const size_t lds = 2 * (size_t)SCAN_TILE * sizeof(int);
     hipError_t e = hipFuncSetAttribute((const void*)cov_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cov_tile_first_kernel, dim3(grid_for(n + 1, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, tiles, first);
-    hipLaunchKernelGGL(cov_scan_kernel<true>, dim3((unsigned)tiles), dim3(SCAN_NT), lds, st, diff_p, diff_m, gtot, alns, goff, clen, first, cutoff, stat_d, stat_c, ticket,
+    // aux: first[tiles + 2] | agg[2][tiles] (+ pad) | carry_p[tiles + 2] | carry_m[tiles + 2]
+    long long* first = (long long*)aux;
+    int* agg = (int*)(first + tiles + 2);
+    long long* carry_p = (long long*)(((uintptr_t)(agg + 2 * tiles) + 15) & ~(uintptr_t)15);
+    long long* carry_m = carry_p + tiles + 2;
+    e = hipMemsetAsync(agg, 0, 4 * 2 * (size_t)tiles, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cov_tile_first_kernel, dim3(grid_for(n + 1, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, tiles, cutoff, first, agg);
+    launch_excl_scan(st, agg, carry_p, tiles);
+    launch_excl_scan(st, agg + tiles, carry_m, tiles);
+    hipLaunchKernelGGL(cov_scan_kernel<true>, dim3((unsigned)tiles), dim3(SCAN_NT), lds, st, diff_p, diff_m, gtot, alns, goff, clen, first, carry_p, carry_m, cutoff, stat_d, stat_c, ticket,
                        (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
     return hipGetLastError();
 }

@@ -68,7 +68,8 @@ long long cov_scan_tiles(long long gtot);
 size_t run_start_bytes();
 int cov_scan_tile_positions();
 void launch_cov_maxlen(hipStream_t st, const MirpAln* alns, long long n, int* out);
-hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, long long* first, int* diff_p,
+size_t cov_fused_aux_bytes(long long gtot);
+hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, void* aux, int* diff_p,
                                  int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d, unsigned long long* stat_c, unsigned int* ticket, void* starts,
                                  long long starts_cap, MirpDepthPos* depth_out, long long depth_cap, long long* depth_gx, unsigned long long* totals);
 void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d,

@@ -168,10 +168,10 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
         c->cov_fused = c->max_aln_len <= mirp::cov_scan_tile_positions();
     }
     if (c->cov_fused) {
-        if (c->tile_first.ensure(8 * (size_t)(tiles + 2))) return fail(c, -6, "device allocation failed (coverage)");
+        if (c->tile_first.ensure(mirp::cov_fused_aux_bytes(gtot))) return fail(c, -6, "device allocation failed (coverage)");
         c->diff_clean_ptr = nullptr;          // the dense arrays hold the written tiles' values from now on: the atomic path clears them before it runs again
         HIPCHK(c, mirp::launch_cov_scan_fused(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p,
-                                              (long long*)c->tile_first.p, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p,
+                                              c->tile_first.p, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p,
                                               std::max<long long>(c->n_alns + c->n_segs, 1), depth_out, depth_cap, depth_gx, (unsigned long long*)c->totals.p));
         return 0;
     }
