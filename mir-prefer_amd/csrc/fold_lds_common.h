@@ -196,8 +196,19 @@ __device__ __forceinline__ void a1_gen_row_w(const A1& a, const unsigned short* 
     if (!CHECK || U <= a.um) {
         lds_vu16 rp = (lds_vu16)(rb + ((a.r0 - U) & 31) * CSTR);
         unsigned v[U - 3];      // all reads of the run in flight before the first use
+#ifdef MIRP_X_NOGENLDS          // timing experiment: the row's values without touching LDS
+#pragma unroll
+        for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = 50000u + (((unsigned)(size_t)rp + (unsigned)n1) & 1023u);
+#else
 #pragma unroll
         for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = rp[n1];
+#endif
+#ifdef MIRP_X_NOGENVALU         // timing experiment: the reads, folded with the fewest instructions that keep them alive
+        { unsigned x = 0;
+#pragma unroll
+          for (int n1 = 2; n1 <= U - 2; n1++) x |= v[n1 - 2];
+          bg = (x << 10) < bg ? (x << 10) : bg; return; }
+#endif
         unsigned w = 65535u;    // wing minimum, ring units
         unsigned e[2 * WD];     // keys of the centre candidates
         int ne = 0;
@@ -352,10 +363,15 @@ __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best
         int x[N];
 #pragma unroll
         for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR];
+#ifdef MIRP_X_RINGONLY          // timing experiment: what a ring of c + bulge / 1xn term would leave of these jobs (no code read, no table gather)
+#pragma unroll
+        for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxp; }
+#else
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = ql[LO + k];
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb0_key[LO + k]; best = e < best ? e : best; }
     }
@@ -373,10 +389,15 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
         int x[N];
 #pragma unroll
         for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR + (LO + k)];
+#ifdef MIRP_X_RINGONLY
+#pragma unroll
+        for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxq; }
+#else
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = pl[LO + k];
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb1_key[LO + k]; best = e < best ? e : best; }
     }
@@ -394,10 +415,15 @@ __device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best
         int x[N];
 #pragma unroll
         for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR];
+#ifdef MIRP_X_RINGONLY          // timing experiment: what a ring of c + bulge / 1xn term would leave of these jobs (no code read, no table gather)
+#pragma unroll
+        for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxp; }
+#else
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = ql[LO + k];
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n0_key[LO + k]; best = e < best ? e : best; }
     }
@@ -415,10 +441,15 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
         int x[N];
 #pragma unroll
         for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR + (LO + k)];
+#ifdef MIRP_X_RINGONLY
+#pragma unroll
+        for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxq; }
+#else
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = pl[LO + k];
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n1_key[LO + k]; best = e < best ? e : best; }
     }

@@ -644,8 +644,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     m = e < m ? e : m;
                 }
                 m = md < m ? md : m;
+#ifndef MIRP_TIMING_ONLY          // (timing experiments compute garbage on purpose: no hand-over to the generic kernel)
                 if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
                     (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
+#endif
                 const short c16 = cv >= INF ? (short)I16_INF : (short)cv;
                 const unsigned short m16 = m >= INF ? (unsigned short)65535 : (unsigned short)(m + FML_BIAS);
                 const unsigned short g16 = cv < INF ? (unsigned short)(cv + mmI + 32768) : (unsigned short)65535;

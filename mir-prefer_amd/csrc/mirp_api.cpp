@@ -331,6 +331,9 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         const char* clk_env = std::getenv("MIRP_FOLD_CLOCKS");
         long long* dbg_cycles = clk_env ? (long long*)(ctl + 8) : nullptr;
         if (clk_env && std::atoi(clk_env) == 2) dbg_flags |= 1 << 20;      // light mode: per wave only busy (reported as splits) and barrier wait
+#elif defined(MIRP_ABLATE) || defined(MIRP_TIMING_ONLY)
+        const int dbg_flags = 16;          // timing experiments whose fill results are wrong by construction: no epilogue (it could walk garbage forever)
+        long long* dbg_cycles = nullptr;
 #else
         const int dbg_flags = 0;
         long long* dbg_cycles = nullptr;
