@@ -23,11 +23,13 @@ The JSON line carries, beside the contract's keys:
                  out of LDS: `peak` is the measured conflict-free ds_read_b32 rate of this GPU (mirp_microbench), `peak_guide` the figure of
                  MI355X_MICROARCH.md (75 TB/s of ds_read_b32 = 9.4e12 relaxations/s at 8 B per relaxation), fractions against both;
   roofline_hbm   the HBM view north_star asks for (algorithmic bytes / measured time / 8 TB/s), expected << 1 for an LDS-resident DP;
-  roofline_coverage  the one HBM-bound stage (scatter + scan + clearing of the written positions);
+  roofline_coverage  the one HBM-bound stage on the headline workload (sparse input: atomic scatter + scan + clearing of the written positions);
+                 configs.coverage_config4_shard = the same stage at a config[4] rank shard's size, where the fused scan runs (tiles built from the
+                 sorted records in LDS; --no-cov-shard skips it);
   configs        (N = 1, default workload) config2 on the same GPU, the vienna-1.8.5 model, and the fold micro-benchmark of SURVEY.md 8d
                  (2^16 windows, n = L = 300: uniform / 50 % planted hairpins / GC = 0.65) with generic-fallback counts per family;
   cpu_baseline   the CPU oracle (the build's own restatement of the reference, "port") timed on this box AFTER the GPU timing;
-  e2e            the CLI `pipeline` verb on files of the same workload (SAM + FASTA in -> gff3 and reports out), wall-clock by stage.
+  e2e            the CLI `pipeline` verb on files of the same workload (SAM + FASTA in -> gff3 and reports out), wall-clock and device time by stage.
 """
 import argparse
 import json
