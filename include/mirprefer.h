@@ -220,6 +220,9 @@ int64_t mirp_last_fold_overflow(mirp_ctx* ctx);
  * records in LDS (dense inputs without coverage segments), 0 = atomic scatter into the dense difference arrays; informational, the results are
  * identical (the `samtools depth` replacement, /root/reference/miR_PREFeR.py:877-949). */
 int mirp_last_coverage_fused(mirp_ctx* ctx);
+/* Pins the coverage path of the following mirp_candidate / mirp_get_depth calls: -1 = picked by record density (default), 0 = atomic scatter,
+ * 1 = fused scan whenever the input allows it (no coverage segments, no record longer than a scan tile).  For tests and measurements. */
+int mirp_set_coverage_path(mirp_ctx* ctx, int32_t mode);
 
 /* Device time of the kernels of the last mirp_fold, HIP events on the context's stream: ms[0] = fill kernel(s) (fold_lds_kernel: the
  * dynamic program), ms[1] = epilogue kernel(s) (exterior sweep, enumeration, backtracks), summed over the sub-batches of the main pass. */

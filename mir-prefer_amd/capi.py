@@ -203,6 +203,8 @@ def load_library():
     lib.mirp_last_fold_overflow.restype = C.c_int64
     lib.mirp_last_coverage_fused.argtypes = [vp]
     lib.mirp_last_coverage_fused.restype = C.c_int
+    lib.mirp_set_coverage_path.argtypes = [vp, C.c_int32]
+    lib.mirp_set_coverage_path.restype = C.c_int
     lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mirp_write_fold_text.restype = C.c_int
     lib.mirp_write_fold_text_async.argtypes = [vp, C.c_char_p, C.c_char_p]
@@ -548,6 +550,10 @@ class Context:
 
     def last_fold_overflow(self):
         return int(self.lib.mirp_last_fold_overflow(self.h))
+
+    def set_coverage_path(self, mode):
+        """-1: by record density (default), 0: atomic scatter, 1: fused scan where the input allows it."""
+        self._check(self.lib.mirp_set_coverage_path(self.h, int(mode)), "mirp_set_coverage_path")
 
     def last_coverage_fused(self):
         """True when the last coverage pass built its tiles from the sorted records in LDS (dense inputs), False for the atomic scatter path."""

@@ -54,6 +54,7 @@ struct mirp_ctx {
     long long n_segs = 0;
     DevBuf tile_first;               // fused coverage scan: first record of every tile (candidate_kernels.hip)
     int max_aln_len = -1;             // longest resident record (reference span), -1 = not known: the fused scan needs it <= one tile
+    int cov_mode = -1;                // mirp_set_coverage_path: -1 = by record density, 0 = atomic scatter, 1 = fused scan (where the input allows it)
     bool cov_fused = false;           // the last run_coverage took the fused path (nothing to clear afterwards)
     void* diff_clean_ptr = nullptr;   // the difference arrays at this address are all zero (run_coverage / clean_coverage)
     size_t diff_clean_bytes = 0;

@@ -152,10 +152,9 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     // in LDS and writes the dense arrays only where a run walk will read them -- no global atomics, no clearing pass.
     // Measured (profiles/tools/cov_time.py): cfg[4] shard, 0.1 records per base: 1.27 ms fused against 2.11 ms + the clearing pass; config[1],
     // 0.002 records per base: 0.137 against 0.123 ms (two more launches, nothing to gain from 138 k atomics) -- so the density picks the path.
-    // MIRP_COV_FUSED=1 / 0 forces it (tests run both on the same input).
+    // mirp_set_coverage_path forces it (tests run both on the same input).
     c->cov_fused = false;
-    const char* force = std::getenv("MIRP_COV_FUSED");
-    const bool want = force ? force[0] == '1' : c->n_alns >= c->gtot / 32;
+    const bool want = c->cov_mode >= 0 ? c->cov_mode == 1 : c->n_alns >= c->gtot / 32;
     if (c->n_segs == 0 && c->n_alns > 0 && want) {
         if (c->max_aln_len < 0) {
             int* d_max = (int*)((char*)c->totals.p + 32);          // (cleared above)
@@ -646,3 +645,9 @@ extern "C" int mirp_last_fold_kernel_ms(mirp_ctx* c, double ms[2]) {
 extern "C" int64_t mirp_last_fold_fallbacks(mirp_ctx* c) { return c ? (int64_t)c->last_fallback : -1; }
 extern "C" int64_t mirp_last_fold_overflow(mirp_ctx* c) { return c ? (int64_t)c->n_side : -1; }
 extern "C" int mirp_last_coverage_fused(mirp_ctx* c) { return c ? (c->cov_fused ? 1 : 0) : -1; }
+extern "C" int mirp_set_coverage_path(mirp_ctx* c, int32_t mode) {
+    if (!c) return -1;
+    if (mode < -1 || mode > 1) return fail(c, -1, "mirp_set_coverage_path: mode is -1 (by record density), 0 (atomic scatter) or 1 (fused scan)");
+    c->cov_mode = mode;
+    return 0;
+}

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from mir_prefer_amd import synth, capi
 ctx = capi.Context(0)
+if os.environ.get("MIRP_COV_FUSED") in ("0", "1"):          # tools only: pin the coverage path
+    ctx.set_coverage_path(int(os.environ["MIRP_COV_FUSED"]))
 def run(tag, contigs, alns, order):
     ctx.load_genome(contigs); ctx.load_alignments(alns)
     ms = []

@@ -357,9 +357,9 @@ def test_difference_arrays_are_clean_between_passes(gpu_ctx, oracle):
         assert [(int(d["tid"]), int(d["pos"]), int(d["dp"]), int(d["dm"])) for d in got] == want, seed
 
 
-def test_fused_coverage_scan_equals_atomic_path_and_brute_force(gpu_ctx, monkeypatch):
+def test_fused_coverage_scan_equals_atomic_path_and_brute_force(gpu_ctx):
     """Two ways to the same depth: the scan that builds each tile's difference values from the sorted records in LDS (cov_scan_kernel<true>, picked for
-    dense inputs) and the atomic scatter into the dense arrays (sparse inputs, coverage segments).  MIRP_COV_FUSED forces either; both run on one
+    dense inputs) and the atomic scatter into the dense arrays (sparse inputs, coverage segments).  mirp_set_coverage_path forces either; both run on one
     context in turn (each leaves the dense arrays in the state the other expects), on inputs that sit on the scan's tile edges (8192 positions):
     contig boundaries next to a tile boundary, records that start in one tile and end in the next, records that reach over a contig end, an
     empty contig, a record longer than a tile (which sends the pass down the atomic path by itself).  Depth list and peaks against brute force."""
@@ -400,12 +400,13 @@ def test_fused_coverage_scan_equals_atomic_path_and_brute_force(gpu_ctx, monkeyp
         gpu_ctx.load_alignments(a)
         want = brute(a)
         got = {}
-        for mode in ("1", "0", "1"):
-            monkeypatch.setenv("MIRP_COV_FUSED", mode)
+        for mode in (1, 0, 1):
+            gpu_ctx.set_coverage_path(mode)
             gpu_ctx.candidate(10, 100, 300, order)
+            assert gpu_ctx.last_coverage_fused() == (mode == 1 and not long_one)
             d = gpu_ctx.get_depth()
             pk = gpu_ctx.get_peaks()
             got[mode] = ([(int(x["tid"]), int(x["pos"]), int(x["dp"]), int(x["dm"])) for x in d], [tuple(int(v) for v in x) for x in pk])
             assert got[mode][0] == want, (seed, mode)
-        assert got["1"][1] == got["0"][1], seed
-    monkeypatch.delenv("MIRP_COV_FUSED")
+        assert got[1][1] == got[0][1], seed
+    gpu_ctx.set_coverage_path(-1)
