@@ -429,12 +429,29 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         tdist = mdist.init_host_group()          # CPU-side gloo group only: host objects and the timing barrier (torch never touches the GPU here)
         world = tdist.get_world_size()
+    rccl_error = None
     share_dir = os.environ.get("MIRP_BENCH_SHARE_GPU")      # dev: all ranks on GPU 0, the library's exchanges over its local transport (a directory)
     ctx = capi.Context(0 if share_dir else local_rank)
-    if world > 1 and share_dir:
+    if world > 1 and share_dir and os.environ.get("MIRP_BENCH_FORCE_GLOO"):      # dev: exercises the host-object exchange below on one GPU
+        rccl_error = "forced (MIRP_BENCH_FORCE_GLOO)"
+    elif world > 1 and share_dir:
         ctx.dist_init_local(share_dir, rank, world)
     elif world > 1:
-        mdist.init_context(ctx, rank, world)        # the library's RCCL communicator, one rank per GPU
+        # the library's RCCL communicator, one rank per GPU.  Should it not come up on some node (every rank must agree, so the outcome is shared over
+        # the host group), the loci lists are gathered as host objects over gloo instead -- the line then says so; the measured step is the same.
+        why = None
+        try:
+            mdist.init_context(ctx, rank, world)
+        except Exception as e:          # capi.MirpError: dlopen / ncclCommInitRank failed
+            why = "%s" % (e,)
+        box = [None] * world
+        tdist.all_gather_object(box, why)
+        bad = [w for w in box if w]
+        if bad:
+            rccl_error = bad[0]
+            if why is None:
+                ctx.dist_finalize()
+            sys.stderr.write("[bench] RCCL communicator not available (%s): loci lists go over the gloo host group\n" % rccl_error)
     ctx.set_fold_model(a.fold_model)
 
     # ---- synthetic workload: every rank generates and holds only the contigs it owns
@@ -456,9 +473,13 @@ def main():
         ctx.fold(L)
         fb[0], fb[1] = ctx.last_fold_fallbacks(), ctx.last_fold_overflow()
         out = ctx.predict(n_samples, 18, 23, False, True)
-        if world > 1:          # the exchange step of the path: loci lists of all ranks on rank 0, over RCCL from the device-resident result
+        if world > 1 and rccl_error is None:          # the exchange step of the path: loci lists of all ranks on rank 0, over RCCL from the device-resident result
             g = ctx.gather_loci(0)
             total = len(g["result"])
+        elif world > 1:
+            parts = [None] * world if rank == 0 else None
+            tdist.gather_object(np.ascontiguousarray(out["result"]), parts, dst=0)
+            total = sum(len(x) for x in parts) if rank == 0 else 0
         else:
             total = len(out["result"])
         return nwin, total, ctx.last_timings(), ctx.last_fold_kernel_ms()
@@ -467,7 +488,8 @@ def main():
         # every C-ABI call above returns after its stream has drained; across ranks: a RCCL reduction on the library's communicator and the
         # CPU-side barrier
         if world > 1:
-            ctx.dist_barrier()
+            if rccl_error is None:
+                ctx.dist_barrier()
             tdist.barrier()
 
     for _ in range(a.warmup):
@@ -541,6 +563,7 @@ def main():
                        "fold_flavour": "vienna-2.1.2 (Turner-2004, d2)" if a.fold_model == "vienna-2.1.2" else "vienna-1.8.5 (Turner-1999, d1)",
                        "fold_generic_fallback_windows": int(fb[0]), "fold_line_overflow_windows": int(fb[1]),
                        "exchange": ("none (1 GPU)" if world == 1 else "mirp_gather_loci over the local transport (ranks share GPU 0: dev run)" if share_dir
+                                    else "loci lists as host objects over gloo (RCCL communicator not available: %s)" % rccl_error if rccl_error
                                     else "mirp_gather_loci over RCCL (library-owned communicator), host objects over gloo")},
             "roofline": {"kernel": "fold_lds_kernel<%d>" % (0 if a.fold_model == "vienna-2.1.2" else 1),
                          "bound": "lds" if lds_roof <= valu_roof else "valu", "achieved": achieved / 1e12, "peak": roof / 1e12, "unit": "T relaxations/s",
@@ -642,7 +665,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         tdist.barrier()
-        ctx.dist_finalize()
+        if rccl_error is None:
+            ctx.dist_finalize()
     ctx.close()
     if world > 1:
         tdist.destroy_process_group()
