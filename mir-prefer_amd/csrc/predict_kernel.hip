@@ -524,6 +524,9 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
                           unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, const int* wslot, const PredictCaps* caps_in, int* need) {
     const PredictCaps caps = caps_in ? *caps_in : predict_default_caps(max_lines, ss_stride);
     size_t lds = predict_lds_bytes(max_lines, ss_stride, caps);
+#ifdef MIRP_PRED_LDS_PAD
+    lds += MIRP_PRED_LDS_PAD;      // timing experiment: fewer resident windows per CU
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(rpool ? (const void*)predict_kernel<true> : (const void*)predict_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -558,7 +561,10 @@ int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, 
     if (hipMalloc((void**)&need, 8 * (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
     struct Free { int* p; int* a = nullptr; int* b = nullptr; unsigned char* f = nullptr; ~Free() { (void)hipFree(p); if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (f) (void)hipFree(f); } } guard{need};
     if (hipMemsetAsync(need, 0, 8 * (size_t)n_windows, stream) != hipSuccess) { *err = "memset failed"; return -2; }
-    const int grid = std::min(n_iter, n_cu * 16);
+#ifndef MIRP_PRED_GRID
+#define MIRP_PRED_GRID 64
+#endif
+    const int grid = std::min(n_iter, n_cu * MIRP_PRED_GRID);
     if (launch_predict(stream, grid, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride,
                        wsel, n_sel, skip, nullptr, nullptr, need) != hipSuccess) { *err = "predict kernel launch failed"; return -2; }
     std::vector<int> h_status((size_t)n_windows), h_sel, h_skip;
