@@ -23,7 +23,7 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
                           int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss,
                           int* out_nlines, int* out_mfe, int* out_status);
 
-struct PredictCaps { int p_cap, s_cap, m_cap; };          // pieces per line, structures per window, candidate matures per window (predict_kernel.hip)
+struct PredictCaps { int p_cap, s_cap, m_cap, l_cap; };   // pieces per line, structures per window, candidate matures per window, staged lines per window (predict_kernel.hip)
 PredictCaps predict_default_caps(int max_lines, int ss_stride);
 size_t predict_lds_bytes(int max_lines, int ss_stride);
 size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps);

@@ -262,7 +262,10 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
 // REASONS: the -d mode of the reference (check_loci's dict_why_not_miRNA_reasons, MP:2206-2347): every evaluated (mature, structure) pair is
 // appended to a record pool (rstride ints per record, layout in mirp_pipeline.cpp) together with one record per window; nothing else changes.
 template <bool REASONS>
-__global__ void __launch_bounds__(64) predict_kernel(
+#ifndef MIRP_PRED_WPS
+#define MIRP_PRED_WPS 4
+#endif
+__global__ void __launch_bounds__(64, MIRP_PRED_WPS) predict_kernel(
     const MirpWindow* __restrict__ windows, int n_windows, const MirpMature* __restrict__ matures,
     const MirpAln* __restrict__ alns, long long n_alns, const MirpFoldLine* __restrict__ lines, const char* __restrict__ ss,
     int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
@@ -271,15 +274,17 @@ __global__ void __launch_bounds__(64) predict_kernel(
     const int* __restrict__ wsel, int n_sel, const int* __restrict__ skip, const int* __restrict__ wslot, PredictCaps caps, int* __restrict__ need) {
     // wsel == nullptr: every window w in [0, n_windows) with its fold output at slot w, except those with skip[w] >= 0 (folded again at full
     // line capacity: a second launch handles them); wsel != nullptr: the windows wsel[k], k in [0, n_sel), with their fold output at slot
-    // wslot[k] (wslot == nullptr: slot k).  need (optional): need[2 w] = structures, need[2 w + 1] = pieces of one line the window has.
+    // wslot[k] (wslot == nullptr: slot k).  need (optional): need[3 w] = structures, need[3 w + 1] = pieces of one line, need[3 w + 2] = staged lines the window has.
     extern __shared__ __align__(16) unsigned char smem[];
     const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
-    unsigned* textw = (unsigned*)smem;                                   // max_lines * wpl
-    const int max_structs = caps.s_cap, PW_MAX_PIECES = caps.p_cap, PW_MAX_MATURES = caps.m_cap;
-    PStruct* sts = (PStruct*)(smem + (((size_t)max_lines * wpl * 4 + 15) & ~(size_t)15)); // max_structs
+    unsigned* textw = (unsigned*)smem;                                   // l_cap * wpl: only the lines phase 1 looks at (printed, >= minlen) are staged
+    const int max_structs = caps.s_cap, PW_MAX_PIECES = caps.p_cap, PW_MAX_MATURES = caps.m_cap, L_CAP = caps.l_cap;
+    PStruct* sts = (PStruct*)(smem + (((size_t)L_CAP * wpl * 4 + 15) & ~(size_t)15)); // max_structs
     PStruct* slot = sts + max_structs;                                // 64 * p_cap
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
     int* morder = cnts + 64;                                             // m_cap: mature indices in stable depth-descending order (MP:2241)
+    unsigned short* lslot = (unsigned short*)(morder + PW_MAX_MATURES);  // max_lines: staged slot of a line, 0xffff = not staged
+    unsigned short* lline = lslot + max_lines;                           // l_cap: line of a staged slot
     const int lane = threadIdx.x;
     const int n_iter = wsel ? n_sel : n_windows;
     for (int it = blockIdx.x; it < n_iter; it += gridDim.x) {
@@ -290,11 +295,27 @@ __global__ void __launch_bounds__(64) predict_kernel(
         const int nl = n_lines[sl] < max_lines ? n_lines[sl] : max_lines;
         const MirpFoldLine* wl = lines + (size_t)sl * max_lines;
         int st_flag = 0, need_pieces = 0;
-        // stage the window's structure text, 2 bits per character (lane = one packed word = 16 characters)
+        // which lines are staged: the printed ones of at least minlen characters (MP:1568-1570), in line order; about half of a window's lines
+        // (23 of 42 on the benchmark input), which is what lets 16 instead of 11 windows be resident per CU
+        int n_used = 0;
+        for (int lb = 0; lb < nl; lb += 64) {
+            const int k = lb + lane;
+            bool used = false;
+            if (k < nl) { const MirpFoldLine ln = wl[k]; used = ln.printed && ln.len >= pp.minlen; }
+            const unsigned long long bal = __ballot(used);
+            const int u = n_used + (int)__popcll(bal & ((1ull << lane) - 1ull));
+            if (k < nl) lslot[k] = (used && u < L_CAP) ? (unsigned short)u : (unsigned short)0xffff;
+            if (used && u < L_CAP) lline[u] = (unsigned short)k;
+            if (used && u >= L_CAP) st_flag = 2;          // more lines than this launch stages: the window is run again with room for all of them
+            n_used += (int)__popcll(bal);
+        }
+        __syncthreads();
+        // stage their text, 2 bits per character (lane = one packed word = 16 characters)
         {
             const char* src = ss + (size_t)sl * max_lines * ss_stride;
-            for (int x = lane; x < nl * wpl; x += 64) {
-                const int ln = x / wpl, wi = x - ln * wpl;
+            const int nu = n_used < L_CAP ? n_used : L_CAP;
+            for (int x = lane; x < nu * wpl; x += 64) {
+                const int us = x / wpl, wi = x - us * wpl, ln = lline[us];
                 const char* p = src + (size_t)ln * ss_stride + wi * 16;
                 const int lim = ss_stride - wi * 16;       // bytes of this line left
                 unsigned v = 0;
@@ -318,8 +339,9 @@ __global__ void __launch_bounds__(64) predict_kernel(
             int k = lb + lane, cnt = 0;
             if (k < nl) {
                 MirpFoldLine ln = wl[k];
-                SS s; s.w = textw + (size_t)k * wpl; s.o = 0;
-                if (ln.printed && ln.len >= pp.minlen) {
+                const int us = lslot[k];
+                SS s; s.w = textw + (size_t)(us == 0xffff ? 0 : us) * wpl; s.o = 0;
+                if (ln.printed && ln.len >= pp.minlen && us != 0xffff) {
                     if (d_is_stem_loop(s, ln.len)) {
                         PStruct p; p.line = (unsigned short)k; p.off = 0; p.len = (unsigned short)ln.len; p.type = 0;
                         slot[lane * PW_MAX_PIECES + cnt++] = p;
@@ -367,7 +389,7 @@ __global__ void __launch_bounds__(64) predict_kernel(
         if (need) {          // what this window needs, for the re-run of flagged windows: structures in all, pieces of its richest line
             int np = need_pieces;
             for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(np, o); np = t > np ? t : np; }
-            if (lane == 0) { need[2 * (size_t)w] = nst; need[2 * (size_t)w + 1] = np; }
+            if (lane == 0) { need[3 * (size_t)w] = nst; need[3 * (size_t)w + 1] = np; need[3 * (size_t)w + 2] = n_used; }
         }
         if (nst > max_structs) nst = max_structs;
         // ---- phases 2+3 per mature, depth-descending stable order (MP:2241)
@@ -400,7 +422,7 @@ __global__ void __launch_bounds__(64) predict_kernel(
                         const PStruct p = sts[s];
                         const MirpFoldLine ln = wl[p.line];
                         const double ne = ((double)ln.energy / 100.0) / (double)ln.len;
-                        SS str; str.w = textw + (size_t)p.line * wpl; str.o = p.off;
+                        SS str; str.w = textw + (size_t)lslot[p.line] * wpl; str.o = p.off;
                         MStar ms;
                         d_maturestar(str, p.len, m.start, m.end, ln.start + p.off, W.ws, W.we, m.strand, ms);
                         int pass = 0, has_star = 0, star_s = ms.star_s, star_e = ms.star_e, impf = 0;
@@ -502,18 +524,29 @@ __global__ void __launch_bounds__(64) predict_kernel(
     }
 }
 
+#ifndef MIRP_PRED_LCAP
+#define MIRP_PRED_LCAP 48
+#endif
 PredictCaps predict_default_caps(int max_lines, int ss_stride) {
     PredictCaps c;
     c.p_cap = std::max(6, ss_stride / 56 + 1);
+#ifdef MIRP_PRED_SCAP_BY_LCAP          // (experiment: structures sized from the staged lines)
+    { const int lc = max_lines <= 96 ? std::min(max_lines, MIRP_PRED_LCAP) : max_lines; c.s_cap = 2 * lc > 96 ? 2 * lc : 96; }
+#else
     c.s_cap = 2 * max_lines > PW_MIN_STRUCTS ? 2 * max_lines : PW_MIN_STRUCTS;
+#endif
     c.m_cap = 64;
+    // lines staged per window: the main launch (max_lines = 96) takes 40 -- 99.98 % of the benchmark's windows have fewer printed lines of >= 55
+    // characters (profiles/tools/nl_hist.py), the rest is run again; launches over the full-capacity side buffers stage everything
+    c.l_cap = max_lines <= 96 ? std::min(max_lines, MIRP_PRED_LCAP) : max_lines;
     return c;
 }
 
 size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps) {
-    size_t b = (((size_t)max_lines * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15);
+    size_t b = (((size_t)caps.l_cap * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15);
     b += sizeof(PStruct) * ((size_t)caps.s_cap + 64 * (size_t)caps.p_cap);
     b += sizeof(int) * (64 + (size_t)caps.m_cap);
+    b += sizeof(unsigned short) * ((size_t)max_lines + (size_t)caps.l_cap);
     return (b + 15) & ~(size_t)15;
 }
 size_t predict_lds_bytes(int max_lines, int ss_stride) { return predict_lds_bytes(max_lines, ss_stride, predict_default_caps(max_lines, ss_stride)); }
@@ -558,9 +591,9 @@ int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, 
     const int n_iter = wsel ? n_sel : n_windows;
     if (n_iter <= 0) return 0;
     int* need = nullptr;
-    if (hipMalloc((void**)&need, 8 * (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
+    if (hipMalloc((void**)&need, 12 * (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
     struct Free { int* p; int* a = nullptr; int* b = nullptr; unsigned char* f = nullptr; ~Free() { (void)hipFree(p); if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (f) (void)hipFree(f); } } guard{need};
-    if (hipMemsetAsync(need, 0, 8 * (size_t)n_windows, stream) != hipSuccess) { *err = "memset failed"; return -2; }
+    if (hipMemsetAsync(need, 0, 12 * (size_t)n_windows, stream) != hipSuccess) { *err = "memset failed"; return -2; }
 #ifndef MIRP_PRED_GRID
 #define MIRP_PRED_GRID 64
 #endif
@@ -582,37 +615,54 @@ int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, 
         if (h_status[(size_t)w] == 2 || h_status[(size_t)w] == 3) { rw.push_back(w); rs.push_back(it); }
     }
     if (rw.empty()) return 0;
-    std::vector<int> h_need(2 * (size_t)n_windows);
     std::vector<MirpWindow> h_w((size_t)n_windows);
-    if (hipMemcpy(h_need.data(), need, 8 * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(h_w.data(), windows, sizeof(MirpWindow) * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; }
-    PredictCaps caps = predict_default_caps(max_lines, ss_stride);
-    for (int w : rw) {
-        caps.s_cap = std::max(caps.s_cap, h_need[2 * (size_t)w]);
-        caps.p_cap = std::max(caps.p_cap, h_need[2 * (size_t)w + 1]);
-        caps.m_cap = std::max(caps.m_cap, h_w[(size_t)w].n_matures);
-    }
-    if (predict_lds_bytes(max_lines, ss_stride, caps) > 160 * 1024) {
-        *err = "a window has more structures / candidate matures than the filter kernel can hold in LDS (" + std::to_string(caps.s_cap) + " structures, " +
-               std::to_string(caps.m_cap) + " matures)";
-        return -5;
-    }
+    if (hipMemcpy(h_w.data(), windows, sizeof(MirpWindow) * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; }
     if (hipMalloc((void**)&guard.a, 4 * rw.size()) != hipSuccess || hipMalloc((void**)&guard.b, 4 * rw.size()) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
-    if (hipMemcpy(guard.a, rw.data(), 4 * rw.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(guard.b, rs.data(), 4 * rs.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        *err = "H2D failed"; return -2;
-    }
     if (rpool && n1 > 0) {          // the first pass already wrote (truncated) records for these windows
         std::vector<unsigned char> fl((size_t)n_windows, 0);
         for (int w : rw) fl[(size_t)w] = 1;
         if (hipMalloc((void**)&guard.f, (size_t)n_windows) != hipSuccess || hipMemcpy(guard.f, fl.data(), (size_t)n_windows, hipMemcpyHostToDevice) != hipSuccess) {
             *err = "device allocation failed (predict)"; return -6;
         }
-        const unsigned int nn = std::min(n1, rcap);
-        hipLaunchKernelGGL(reasons_invalidate_kernel, dim3((nn + 255) / 256 > 4096 ? 4096 : (nn + 255) / 256), dim3(256), 0, stream, rpool, nn, rstride, (const unsigned char*)guard.f);
     }
-    if (launch_predict(stream, std::min((int)rw.size(), n_cu * 4), windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
-                       rcount, rpool, rcap, rstride, guard.a, (int)rw.size(), nullptr, guard.b, &caps, nullptr) != hipSuccess) { *err = "predict kernel launch failed (re-run)"; return -2; }
-    if (hipStreamSynchronize(stream) != hipSuccess) { *err = "predict kernel execution failed (re-run)"; return -2; }
+    PredictCaps caps = predict_default_caps(max_lines, ss_stride);
+    std::vector<int> h_need(3 * (size_t)n_windows);
+    // A flagged window says what it needs (need[]), but what it says can be short of the truth: a line that was not staged contributed neither its
+    // structures nor its pieces.  So the windows that are still flagged after a re-run go round again with what they report then; every round
+    // stages at least the lines the one before asked for, so the third has seen everything.
+    for (int round = 0; round < 3 && !rw.empty(); round++) {
+        if (hipMemcpy(h_need.data(), need, 12 * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; }
+        for (int w : rw) {
+            caps.s_cap = std::max(caps.s_cap, h_need[3 * (size_t)w]);
+            caps.p_cap = std::max(caps.p_cap, h_need[3 * (size_t)w + 1]);
+            caps.l_cap = std::max(caps.l_cap, std::min(h_need[3 * (size_t)w + 2], max_lines));
+            caps.m_cap = std::max(caps.m_cap, h_w[(size_t)w].n_matures);
+        }
+        if (predict_lds_bytes(max_lines, ss_stride, caps) > 160 * 1024) {
+            *err = "a window has more structures / candidate matures than the filter kernel can hold in LDS (" + std::to_string(caps.s_cap) + " structures, " +
+                   std::to_string(caps.m_cap) + " matures)";
+            return -5;
+        }
+        if (hipMemcpy(guard.a, rw.data(), 4 * rw.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(guard.b, rs.data(), 4 * rs.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            *err = "H2D failed"; return -2;
+        }
+        if (rpool && n1 > 0) {          // records of these windows written so far are void
+            unsigned int n2 = 0;
+            if (hipMemcpy(&n2, rcount, 4, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; }
+            const unsigned int nn = std::min(n2, rcap);
+            if (nn > 0)
+                hipLaunchKernelGGL(reasons_invalidate_kernel, dim3((nn + 255) / 256 > 4096 ? 4096 : (nn + 255) / 256), dim3(256), 0, stream, rpool, nn, rstride, (const unsigned char*)guard.f);
+        }
+        if (launch_predict(stream, std::min((int)rw.size(), n_cu * 4), windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
+                           rcount, rpool, rcap, rstride, guard.a, (int)rw.size(), nullptr, guard.b, &caps, need) != hipSuccess) { *err = "predict kernel launch failed (re-run)"; return -2; }
+        if (hipMemcpyAsync(h_status.data(), status, 4 * (size_t)n_windows, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            *err = "predict kernel execution failed (re-run)"; return -2;
+        }
+        std::vector<int> rw2, rs2;
+        for (size_t k = 0; k < rw.size(); k++)
+            if (h_status[(size_t)rw[k]] == 2 || h_status[(size_t)rw[k]] == 3) { rw2.push_back(rw[k]); rs2.push_back(rs[k]); }
+        rw.swap(rw2); rs.swap(rs2);
+    }
     return 0;
 }
 

@@ -138,3 +138,60 @@ def test_duplex_rules_on_device_match_direct_reference_calls(gpu_ctx):
         assert [(s, x) for _, s, x in got] == want, (c["ss"], got, want)
         n_split += len(want) > 1
     assert n_split > 100
+
+
+def test_window_with_more_long_lines_than_the_filter_kernel_stages(gpu_ctx):
+    """The filter kernel stages the text of 48 printed lines of >= 55 characters per window (99.98 % of the benchmark's windows have fewer) and runs
+    a window with more again with room for all of them.  One window of 90 lines -- 70 of them long and printed, short and unprinted ones in
+    between -- must give, line by line, the records that the same lines give as 70 one-line windows (those are pinned against the reference's
+    own functions in the test above)."""
+    g = gu.load_json("struct_rules.json.gz")
+    alns = np.zeros(1, dtype=synth.ALN_DTYPE)
+    alns["tid"] = 0; alns["pos"] = 1; alns["len"] = 20; alns["depth"] = 1
+    longs = [c for c in g["structures"] if len(c["ss"]) >= 55][:70]
+    shorts = [c for c in g["structures"] if len(c["ss"]) < 55][:10]
+    assert len(longs) == 70 and len(shorts) == 10
+    rs, re_ = 1000, 1000 + 400
+    mature = [rs + 10, rs + 31]
+    singles = [{"ss": c["ss"], "strand": "+", "foldstart": c["start"], "regionstart": rs, "regionend": re_, "mature": mature,
+                "energy_dcal": int(round(c["energy"] * 100))} for c in longs]
+    W1, M1, raw1 = _batch(singles)
+    params = (1, 1, 100, 0, 1, 55)
+    _, _, st1, rec1 = gpu_ctx.predict_batch_reasons(W1, M1, alns, raw1, params)
+    assert (st1 == 0).all()
+    want = {}
+    for r in rec1:
+        if r[1] >= 0:
+            want.setdefault(int(r[0]), []).append(tuple(int(x) for x in (r[4], r[5], r[6], r[8], r[9], r[10], r[11])))
+    # the combined window: long line j sits at line index pos[j]; a short line after every 7th, an unprinted copy of a long one after every 10th
+    order = []
+    for j, c in enumerate(longs):
+        order.append(("long", j, c))
+        if j % 7 == 6:
+            order.append(("short", None, shorts[j // 7]))
+        if j % 10 == 9:
+            order.append(("unprinted", None, c))
+    assert 85 <= len(order) <= 96
+    ml, stride = 96, 352
+    lines = np.zeros((1, ml), dtype=raw1["lines"].dtype)
+    ss = np.zeros((1, ml, stride), dtype=np.uint8)
+    pos = {}
+    for k, (kind, j, c) in enumerate(order):
+        b = c["ss"].encode()
+        lines[0, k] = (c["start"], len(b), int(round(c["energy"] * 100)), 0 if kind == "unprinted" else 1)
+        ss[0, k, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        if kind == "long":
+            pos[k] = j
+    W = W1[:1].copy(); M = M1[:1].copy()
+    raw = {"lines": lines, "ss": ss, "n_lines": np.array([len(order)], dtype=np.int32), "stride": stride, "max_lines": ml}
+    _, _, st, rec = gpu_ctx.predict_batch_reasons(W, M, alns, raw, params)
+    assert (st == 0).all()
+    got = {}
+    for r in rec:
+        if r[1] >= 0:
+            got.setdefault(int(r[3]), []).append(tuple(int(x) for x in (r[4], r[5], r[6], r[8], r[9], r[10], r[11])))
+    assert sorted(got) == sorted(k for k in pos if pos[k] in want)
+    for k, j in pos.items():
+        assert sorted(got.get(k, [])) == sorted(want.get(j, [])), (k, j)
+    perw = [r for r in rec if r[1] < 0]
+    assert len(perw) == 1 and int(perw[0][2]) == sum(len(v) for v in want.values())
