@@ -611,11 +611,15 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int type = pair_type(s_i, s_j);
                 const int rt = rtype_of(type);
                 const int tau = T.TerminalAU, mli = T.ML_intern, mlc = T.ML_closing;
+#ifdef MIRP_X_NOPBTAB          // timing experiment: phase B without its second round of LDS reads (what precomputing the sequence-only terms would remove)
+                const int mmH = -(type * 7 + s_ip1), mmMc = -(rt * 3 + s_jm1), mmMs = -(type + s_im1 * 5), dg5 = -s_im1, dg3 = -s_jp1, mmI = rt * 10 - s_jp1;
+#else
                 const int mmH = T.mismatchH[type * 25 + s_ip1 * 5 + s_jm1];
                 const int mmMc = T.mismatchM[rt * 25 + s_jm1 * 5 + s_ip1];
                 const int mmMs = T.mismatchM[type * 25 + s_im1 * 5 + s_jp1];
                 const int dg5 = T.dangle5[type * 5 + s_im1], dg3 = T.dangle3[type * 5 + s_jp1];
                 const int mmI = T.mismatchI[rt * 25 + s_jp1 * 5 + s_im1];
+#endif
                 // ---- arithmetic
                 const int au = type > 2 ? tau : 0;
                 int cv = INF, tb = 0;
