@@ -53,6 +53,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     (void)dbg_flags_arg; (void)dbg_cycles_arg;
 #endif
     constexpr int DMLR = MODEL ? 5 : 3;      // depth of the DML ring
+    // outer-pair terms of a list entry (default model): two 10-bit signed fields above the 12 bits of i and type; the host checks that the tables fit
+#define ENT_OUTER(mmo, mm1) ((unsigned)(((mmo) & 1023) | (((mm1) & 1023) << 10)))
+    const int tau_s = __builtin_amdgcn_readfirstlane(P->TerminalAU);
     constexpr int GEN_WD = 5;                // default model: |n1 - n2| from which the asymmetry term of a generic loop is saturated (checked on the host: FoldParams::gen_wing_d)
     long long tA = 0, tB = 0, tS = 0, tE = 0, t0 = 0;   // diagnostic phase clocks (thread 0 only, dbg_cycles != nullptr)
     long long wB = 0, wA1 = 0, wA2 = 0, wW = 0, wt = 0; // per-wave: phase B, interior loops, multiloop splits, barrier wait (lane 0 of each wave)
@@ -67,7 +70,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     // special-hairpin energies by start position (tri-, tetra-, hexaloops): only read on diagonals 4, 5 and 7, so they borrow the ring rows
     // of diagonals 29-31, which are first written on diagonal 29
     short* spec = (short*)(cring + 29 * CSTR);
-    // [3][LSEG]: i | type << 9 | oi << 16, paired cells of diagonal d in buffer d % 3 (compact, unordered).  oi = type * 25 + S[i+1] * 5 + S[j-1]
+    // [3][LSEG]: paired cells of diagonal d in buffer d % 3 (compact, unordered).  Default model: i | type << 9 | mmo << 12 | mm1 << 22, mmo / mm1 = the cell's
+    // outer-pair terms mismatchI / mismatch1nI [type][S[i+1]][S[j-1]] as 10-bit signed values (ENT_OUTER below): phase B, which has the time, looks them up
+    // when it builds the entry, and a block's prologue in phase A1 goes from the entry straight to arithmetic -- no dependent table read in front
+    // of every block of every wave (timing build -DMIRP_X_NOOUTER: worth 2 ms).  vienna-1.8.5: 16-bit entries i | type << 9.  (Before: oi = type * 25 + S[i+1] * 5 + S[j-1]
     // indexes the outer pair's mismatch tables: it rides in the entry so that phase A1 goes from the entry straight to the tables (reading the two
     // bases first was one more LDS round trip in front of every block of every wave)
     using list_t = std::conditional_t<MODEL == 0, unsigned, unsigned short>;     // vienna-1.8.5: 16-bit entries, phase A1 reads the two bases itself
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             int base = 0;
             if (lane == 0) base = atomicAdd(&lcnt[dd % 6], (int)__popcll(bal));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (t) list[(dd % 3) * LSEG + base + __popcll(bal & ((1ull << lane) - 1ull))] = (list_t)(i | (t << 9) | (oi << 16));
+            if (t) list[(dd % 3) * LSEG + base + __popcll(bal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)i | ((unsigned)t << 9) | ((unsigned)oi << 12));
         }
     };
 
@@ -178,7 +184,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // paired-cell lists of the first three diagonals (list of diagonal d lives in buffer d % 3, its length in lcnt[d % 6])
         for (int dd = 4; dd <= 6 && dd <= D; dd++) {
             int t = 0, oi = 0;
-            if (tid < n - dd) { t = pair_type(S[tid + 1], S[tid + 1 + dd]); oi = t * 25 + S[tid + 2] * 5 + S[tid + dd]; }
+            if (tid < n - dd) {
+                t = pair_type(S[tid + 1], S[tid + 1 + dd]);
+                const int x = t * 25 + S[tid + 2] * 5 + S[tid + dd];
+                oi = MODEL == 0 ? ENT_OUTER((int)T.mismatchI[x], (int)T.mismatch1nI[x]) : 0;
+            }
             list_append(dd, tid + 1, t, oi);
         }
         __syncthreads();
@@ -244,8 +254,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const unsigned fb0 = (unsigned)(size_t)(lds_cu32)reinterpret_cast<const unsigned*>(fml + i);
                     unsigned va = fb0 + (unsigned)so1, vb = fb0 + (unsigned)so2;
 #define MIRP_SSTEP() do { va += (unsigned)si1; vb += (unsigned)si2; asm volatile("s_sub_i32 %0, %0, %2\n\ts_sub_i32 %1, %1, %2" : "+s"(si1), "+s"(si2) : "s"(sss) : "scc"); } while (0)
+#ifdef MIRP_X_NOSPLITLDS          // timing experiment: the split loop's address arithmetic and packed min-plus without its LDS reads
+#define MIRP_LDA() (va | 0x40004000u)
+#define MIRP_LDB(o) ((vb + (o)) | 0x40004000u)
+#else
 #define MIRP_LDA() (*(lds_cu32)(va))
 #define MIRP_LDB(o) (*(lds_cu32)(vb + (o)))
+#endif
                     // K splits with all their reads in flight before the first use.  The tail of a wave's split range (up to 7 splits) goes through
                     // the 4-, 2- and 1-deep groups: at most three LDS round trips instead of one per split.
                     auto group = [&](auto ODD, auto KK) {
@@ -344,10 +359,15 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     // their two round trips (bases, then tables) overlap the job's own reads instead of following them
                     int au1 = 0, mmo = 0, mm1 = 0;
                     if (role < 14) {
-                        int oi = ent >> 16;
-                        if constexpr (MODEL != 0) { lds_vu8 Sv = (lds_vu8)S; oi = type * 25 + (int)Sv[i + 1] * 5 + (int)Sv[j - 1]; }
-                        au1 = type > 2 ? (int)T.TerminalAU : 0;
-                        mmo = T.mismatchI[oi]; mm1 = T.mismatch1nI[oi];
+                        if constexpr (MODEL == 0) {
+                            au1 = type > 2 ? tau_s : 0;
+                            mmo = ((int)(ent << 10)) >> 22; mm1 = ((int)ent) >> 22;          // the 10-bit signed fields of the entry
+                        } else {
+                            lds_vu8 Sv = (lds_vu8)S;
+                            const int oi = type * 25 + (int)Sv[i + 1] * 5 + (int)Sv[j - 1];
+                            au1 = type > 2 ? (int)T.TerminalAU : 0;
+                            mmo = T.mismatchI[oi]; mm1 = T.mismatch1nI[oi];
+                        }
                     }
                     if (role < 8) {
                         if (!(dbg_flags & 4)) {
@@ -578,7 +598,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             const int od = tri_off(d, n), od1 = tri_off(d - 1, n);
             const int x = tid;
-            int lt = 0, lbase = 0, loi = 0;
+            int lt = 0, lbase = 0, loi = 0, ent_terms = 0;
             unsigned long long lbal = 0;
             const bool do_list = d + 3 <= D && !(dbg_flags & 32768);
             if (tid == 0) lcnt[(d + 4) % 6] = 0;
@@ -599,7 +619,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 // the list range is claimed here, between the two rounds: the atomic's return is first looked at after the cell's stores, so its
                 // round trip is not in front of anything (issued ahead of round 1 it put two LDS round trips in front of the whole chain)
                 if (do_list) {
-                    if (j + 3 <= n) { lt = pair_type(s_i, s_j3); loi = lt * 25 + s_ip1 * 5 + s_j2; }
+                    if (j + 3 <= n) { lt = pair_type(s_i, s_j3); loi = lt * 25 + s_ip1 * 5 + s_j2; }          // index of the entry's outer-pair terms: read in round 2
                     lbal = __ballot(lt != 0);
                     // hand-issued: the compiler's atomic optimizer wraps atomicAdd in a wave reduction whose readfirstlane waits right here
                     if (lbal && lane == 0) {
@@ -620,6 +640,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int dg5 = T.dangle5[type * 5 + s_im1], dg3 = T.dangle3[type * 5 + s_jp1];
                 const int mmI = T.mismatchI[rt * 25 + s_jp1 * 5 + s_im1];
 #endif
+                ent_terms = ENT_OUTER((int)T.mismatchI[loi], (int)T.mismatch1nI[loi]);          // (a type-0 row is valid memory, the value is not used)
                 // ---- arithmetic
                 const int au = type > 2 ? tau : 0;
                 int cv = INF, tb = 0;
@@ -657,14 +678,16 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const unsigned short g16 = cv < INF ? (unsigned short)(cv + mmI + 32768) : (unsigned short)65535;
                 cring[(d & 31) * CSTR + i] = g16;
                 if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
+#ifndef MIRP_X_NOHBM           // (timing experiment: no archive stores)
                 if (!(dbg_flags & 65536)) { carch[abase + 8 * d] = c16; tb_out[abase + 8 * d] = (unsigned short)tb; }
+#endif
                 fml[od + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
                 ckey[i] = KEY_NONE; mdec[i] = INF;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lbase) : : "memory");   // the atomic's return is first needed here
             const int lb = __builtin_amdgcn_readfirstlane(lbase);
-            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((x + 1) | (lt << 9) | (loi << 16));
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)(x + 1) | ((unsigned)lt << 9) | ((unsigned)ent_terms << 12));
         };
         if (Dm >= 4) phaseA(4);
         __syncthreads();

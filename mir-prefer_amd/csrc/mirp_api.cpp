@@ -37,6 +37,13 @@ extern "C" int mirp_create(int device, mirp_ctx** out) {
         std::fprintf(stderr, "mirp_create: energy model and fill kernel disagree on the saturation of the asymmetry term (%d vs %d)\n", hp->gen_wing_d, mirp::fold_lds_gen_wing_d());
         delete hp; delete c; return -5;
     }
+    for (int t = 1; t <= 6; t++)          // the fill kernel's list entries carry these two terms of a cell as 10-bit signed fields (fold_lds_kernel.hip, ENT_OUTER)
+        for (int a = 0; a < 5; a++)
+            for (int b = 0; b < 5; b++)
+                if (hp->mismatchI[t][a][b] < -512 || hp->mismatchI[t][a][b] > 511 || hp->mismatch1nI[t][a][b] < -512 || hp->mismatch1nI[t][a][b] > 511) {
+                    std::fprintf(stderr, "mirp_create: interior-loop mismatch energies outside the fill kernel's list-entry range\n");
+                    delete hp; delete c; return -5;
+                }
     if (hipMalloc((void**)&c->d_params, sizeof(FoldParams)) != hipSuccess ||
         hipMemcpy(c->d_params, hp, sizeof(FoldParams), hipMemcpyHostToDevice) != hipSuccess) {
         delete hp; delete c; return -2;
