@@ -140,17 +140,7 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
         T.mismatchM[x] = (short)P->mismatchM[t][a][b]; T.mismatch1nI[x] = (short)min(P->mismatch1nI[t][a][b], (int)I16_INF);
         T.mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], (int)I16_INF);
     }
-    for (int x = tid; x < 625; x += LNT) {
-        const int pa = x / 25, qb = x % 25, sp = pa / 5, sp1 = pa % 5, sq = qb / 5, sq1 = qb % 5;
-        const int t2 = rtype_of(pair_type(sp, sq));
-        int xb = 0, x1 = 0;
-        if (t2) {
-            const int mi = P->mismatchI[t2][sq1][sp1];
-            xb = (t2 > 2 ? P->TerminalAU : 0) - mi;
-            x1 = P->mismatch1nI[t2][sq1][sp1] - mi;
-        }
-        T.XB[x] = (short)xb; T.X1[x] = (short)x1;
-    }
+    xt_fill(T, P, tid, LNT);
     if (tid < 40) { T.dangle5[tid] = (short)P->dangle5[tid / 5][tid % 5]; T.dangle3[tid] = (short)P->dangle3[tid / 5][tid % 5]; }
     if (tid < 25) T.rt2[tid] = (unsigned char)rtype_of(pair_type(tid / 5, tid % 5));
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
@@ -234,8 +224,8 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
             // combined pair codes (only interior positions are ever read: p - 1 >= 1, q + 1 <= n)
             if (x >= 1) {
-                pax[x] = (unsigned short)((S[x] * 5 + (x > 1 ? S[x - 1] : 0)) * 50);
-                qbr[n + 1 - x] = (unsigned char)((S[x] * 5 + (x < n ? S[x + 1] : 0)) * 2);
+                pax[x] = (unsigned short)xt_pcode(S[x], x > 1 ? (int)S[x - 1] : 0);
+                qbr[n + 1 - x] = (unsigned char)xt_qcode(S[x], x < n ? (int)S[x + 1] : 0);
             }
         }
         __syncthreads();      // the character copy is dead: its bytes become the key / split-minimum arrays

@@ -30,13 +30,39 @@ struct LdsTables {          // int16 copies of the hot parameter tables
     short bulge[32];
     short internal_loop[32];
     short mismatchI[200], mismatchH[200], mismatchM[200], mismatch1nI[200], mismatch23I[200];
-    // inner-pair terms by combined pair code idx = PA(p)*25 + QB(q), PA = S[p]*5 + S[p-1], QB = S[q]*5 + S[q+1]; relative to G0:
-    short XB[628];          // TerminalAU(inner) - mismatchI(inner)           (bulges of size >= 2)
-    short X1[628];          // mismatch1nI(inner) - mismatchI(inner)          (1 x n loops, n >= 3)
+    // inner-pair terms relative to G0, as bytes (term + FoldParams::xb_bias / x1_bias), at index xt_pcode(p) + xt_qcode(q) (below): 175 bytes = 44
+    // dwords per table, fewer than the LDS has banks -- a wave's gather never has two lanes on different dwords of one bank.  (Before: 625
+    // shorts at PA(p) * 25 + QB(q); the 3- to 4-way conflicts of those gathers cost 3.3 ms of the kernel: timing build -DMIRP_X_XBBCAST.)
+    unsigned char XB[176];  // TerminalAU(inner) - mismatchI(inner)           (bulges of size >= 2)
+    unsigned char X1[176];  // mismatch1nI(inner) - mismatchI(inner)          (1 x n loops, n >= 3)
     short dangle5[40], dangle3[40];   // [type*5 + base], clamped <= 0 (vienna-1.8.5 model)
     unsigned char rt2[28];  // rtype(pair_type(a, b)) at [a*5+b]
     short ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO, pad[3];
 };
+// Index of an inner pair (p, q) in XB / X1: slot(S[p], S[q]) * 25 + S[q+1] * 5 + S[p-1], where the slot is a SUM of a p part and a q part that
+// is distinct for the six pair types (A-U 1, C-G 2, G-C 3, G-U 4, U-A 5, U-G 6; what other base combinations land on does not matter, their ring
+// entry is INF) -- so the index is pcode(p) + qcode(q) of two per-position codes, as before, but the table has 7 x 25 entries instead of 625.
+__host__ __device__ constexpr int xt_pslot(int s) { return s == 3 ? 3 : s == 4 ? 4 : 0; }                      // A 0, C 0, G 3, U 4
+__host__ __device__ constexpr int xt_qslot(int s) { return s == 1 ? 1 : s == 3 ? 2 : s == 4 ? 1 : 0; }        // A 1, C 0, G 2, U 1
+__host__ __device__ constexpr int xt_pcode(int sp, int sp_m1) { return xt_pslot(sp) * 25 + sp_m1; }
+__host__ __device__ constexpr int xt_qcode(int sq, int sq_p1) { return xt_qslot(sq) * 25 + sq_p1 * 5; }
+static_assert(xt_pslot(1) + xt_qslot(4) == 1 && xt_pslot(2) + xt_qslot(3) == 2 && xt_pslot(3) + xt_qslot(2) == 3 && xt_pslot(3) + xt_qslot(4) == 4 &&
+              xt_pslot(4) + xt_qslot(1) == 5 && xt_pslot(4) + xt_qslot(3) == 6, "inner-pair table slots");
+template <class TAB>
+__device__ inline void xt_fill(TAB& T, const FoldParams* __restrict__ P, int tid, int nt) {
+    for (int x = tid; x < 175; x += nt) {
+        const int slot = x / 25, a = (x % 25) / 5, b = x % 5;          // a = S[q+1], b = S[p-1]
+        const int sp = slot == 1 ? 1 : slot == 2 ? 2 : (slot == 3 || slot == 4) ? 3 : 4, sq = slot == 1 ? 4 : slot == 2 ? 3 : slot == 3 ? 2 : slot == 4 ? 4 : slot == 5 ? 1 : 3;
+        const int t2 = slot ? rtype_of(pair_type(sp, sq)) : 0;
+        int xb = 0, x1 = 0;
+        if (t2) {
+            const int mi = P->mismatchI[t2][a][b];
+            xb = (t2 > 2 ? P->TerminalAU : 0) - mi;
+            x1 = P->mismatch1nI[t2][a][b] - mi;
+        }
+        T.XB[x] = (unsigned char)(xb + P->xb_bias); T.X1[x] = (unsigned char)(x1 + P->x1_bias);
+    }
+}
 #define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
 #define MIRP_CK(d) ((d) % 3)
 #define CRING_ROWS 33       // diagonal dd lives in row dd & 31; row 32 mirrors row 0, so "the row after row r" is always r + 1 (phase A1 mixes lanes of two diagonals)
@@ -160,8 +186,8 @@ struct A1 {
     const LdsTables* T;
     const unsigned char* S;
     const unsigned short* cring;
-    const unsigned short* pax;     // PA(x) * 50: byte offset of row PA in XB / X1
-    const unsigned char* qbr;      // QB(n + 1 - y) * 2 at y: the q side is walked downwards, so it is stored reversed (ascending immediates)
+    const unsigned short* pax;     // xt_pcode(S[x], S[x-1])
+    const unsigned char* qbr;      // xt_qcode(S[x], S[x+1]) at n + 1 - x: the q side is walked downwards, so it is stored reversed (ascending immediates)
     int r0, um, n;
 };
 
@@ -244,12 +270,12 @@ __device__ __forceinline__ void a1_b0(const A1& a, int i, int j, unsigned& best)
     const unsigned idxp = a.pax[i + 1];
     lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
     const unsigned short* rb = a.cring + i + 1;
-    const char* xb = reinterpret_cast<const char*>(a.T->XB);
+    const unsigned char* xb = a.T->XB;
 #pragma unroll
     for (int U = LO; U <= HI; U++) {
         if (!CHECK || U <= a.um) {
             const unsigned idx2 = idxp + ql[U];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const int x = xb[idx2];
             const unsigned g = rb[((a.r0 - U) & 31) * CSTR];
             const unsigned e = ((g + (unsigned)x) << 10) + a.P->kb0_key[U];
             best = e < best ? e : best;
@@ -262,12 +288,12 @@ __device__ __forceinline__ void a1_b1(const A1& a, int i, int j, unsigned& best)
     const unsigned idxq = a.qbr[a.n + 2 - j];
     lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
     const unsigned short* rb = a.cring + i + 1;
-    const char* xb = reinterpret_cast<const char*>(a.T->XB);
+    const unsigned char* xb = a.T->XB;
 #pragma unroll
     for (int U = LO; U <= HI; U++) {
         if (!CHECK || U <= a.um) {
             const unsigned idx2 = idxq + pl[U];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const int x = xb[idx2];
             const unsigned g = rb[((a.r0 - U) & 31) * CSTR + U];
             const unsigned e = ((g + (unsigned)x) << 10) + a.P->kb1_key[U];
             best = e < best ? e : best;
@@ -280,12 +306,12 @@ __device__ __forceinline__ void a1_i0(const A1& a, int i, int j, unsigned& best)
     const unsigned idxp = a.pax[i + 2];
     lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
     const unsigned short* rb = a.cring + i + 2;
-    const char* xb = reinterpret_cast<const char*>(a.T->X1);
+    const unsigned char* xb = a.T->X1;
 #pragma unroll
     for (int K = LO; K <= HI; K++) {
         if (!CHECK || K + 1 <= a.um) {
             const unsigned idx2 = idxp + ql[K];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const int x = xb[idx2];
             const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR];
             const unsigned e = ((g + (unsigned)x) << 10) + a.P->k1n0_key[K];
             best = e < best ? e : best;
@@ -298,12 +324,12 @@ __device__ __forceinline__ void a1_i1(const A1& a, int i, int j, unsigned& best)
     const unsigned idxq = a.qbr[a.n + 3 - j];
     lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
     const unsigned short* rb = a.cring + i + 1;
-    const char* xb = reinterpret_cast<const char*>(a.T->X1);
+    const unsigned char* xb = a.T->X1;
 #pragma unroll
     for (int K = LO; K <= HI; K++) {
         if (!CHECK || K + 1 <= a.um) {
             const unsigned idx2 = idxq + pl[K];
-            const int x = *reinterpret_cast<const short*>(xb + idx2);
+            const int x = xb[idx2];
             const unsigned g = rb[((a.r0 - K - 1) & 31) * CSTR + K];
             const unsigned e = ((g + (unsigned)x) << 10) + a.P->k1n1_key[K];
             best = e < best ? e : best;
@@ -349,6 +375,11 @@ __device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, 
 // the table reads that depend on it as a second one, then the arithmetic.  The straightforward versions interleave a volatile read (kept
 // narrow on purpose, see a1_gen_row) with the reads that depend on it, and a volatile access is an ordering point for the scheduler: they
 // compile to one LDS round trip per candidate.
+#ifdef MIRP_X_XBBCAST          // timing experiment: every lane gathers the same table entry (no bank conflicts in the XB / X1 reads)
+#define MIRP_XIDX(e) (((e) & 0u))
+#else
+#define MIRP_XIDX(e) (e)
+#endif
 #define A1_CHUNK 10
 template <int LO, int HI>
 __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best) {
@@ -358,7 +389,7 @@ __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best
         const unsigned idxp = a.pax[i + 1];
         lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
         const unsigned short* rb = a.cring + i + 1;
-        const char* xb = reinterpret_cast<const char*>(a.T->XB);
+        const unsigned char* xb = a.T->XB;
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
@@ -370,7 +401,7 @@ __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = ql[LO + k];
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
+        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb0_key[LO + k]; best = e < best ? e : best; }
@@ -384,7 +415,7 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
         const unsigned idxq = a.qbr[a.n + 2 - j];
         lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
         const unsigned short* rb = a.cring + i + 1;
-        const char* xb = reinterpret_cast<const char*>(a.T->XB);
+        const unsigned char* xb = a.T->XB;
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
@@ -396,7 +427,7 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = pl[LO + k];
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
+        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb1_key[LO + k]; best = e < best ? e : best; }
@@ -410,7 +441,7 @@ __device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best
         const unsigned idxp = a.pax[i + 2];
         lds_vu8 ql = (lds_vu8)(a.qbr + (a.n + 2 - j));
         const unsigned short* rb = a.cring + i + 2;
-        const char* xb = reinterpret_cast<const char*>(a.T->X1);
+        const unsigned char* xb = a.T->X1;
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
@@ -422,7 +453,7 @@ __device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = ql[LO + k];
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxp + code[k]);
+        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n0_key[LO + k]; best = e < best ? e : best; }
@@ -436,7 +467,7 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
         const unsigned idxq = a.qbr[a.n + 3 - j];
         lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
         const unsigned short* rb = a.cring + i + 1;
-        const char* xb = reinterpret_cast<const char*>(a.T->X1);
+        const unsigned char* xb = a.T->X1;
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
@@ -448,7 +479,7 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
 #pragma unroll
         for (int k = 0; k < N; k++) code[k] = pl[LO + k];
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = *reinterpret_cast<const short*>(xb + idxq + code[k]);
+        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n1_key[LO + k]; best = e < best ? e : best; }

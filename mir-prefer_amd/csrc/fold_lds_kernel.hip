@@ -107,17 +107,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         T.mismatchM[x] = (short)P->mismatchM[t][a][b]; T.mismatch1nI[x] = (short)min(P->mismatch1nI[t][a][b], (int)I16_INF);
         T.mismatch23I[x] = (short)min(P->mismatch23I[t][a][b], (int)I16_INF);
     }
-    for (int x = tid; x < 625; x += LNT) {
-        const int pa = x / 25, qb = x % 25, sp = pa / 5, sp1 = pa % 5, sq = qb / 5, sq1 = qb % 5;
-        const int t2 = rtype_of(pair_type(sp, sq));
-        int xb = 0, x1 = 0;
-        if (t2) {
-            const int mi = P->mismatchI[t2][sq1][sp1];
-            xb = (t2 > 2 ? P->TerminalAU : 0) - mi;
-            x1 = P->mismatch1nI[t2][sq1][sp1] - mi;
-        }
-        T.XB[x] = (short)xb; T.X1[x] = (short)x1;
-    }
+    xt_fill(T, P, tid, LNT);
     if (tid < 40) { T.dangle5[tid] = (short)P->dangle5[tid / 5][tid % 5]; T.dangle3[tid] = (short)P->dangle3[tid / 5][tid % 5]; }
     if (tid < 25) T.rt2[tid] = (unsigned char)rtype_of(pair_type(tid / 5, tid % 5));
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
@@ -177,8 +167,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
             // combined pair codes (only interior positions are ever read: p - 1 >= 1, q + 1 <= n)
             if (x >= 1) {
-                pax[x] = (unsigned short)((S[x] * 5 + (x > 1 ? S[x - 1] : 0)) * 50);
-                qbr[n + 1 - x] = (unsigned char)((S[x] * 5 + (x < n ? S[x + 1] : 0)) * 2);
+                pax[x] = (unsigned short)xt_pcode(S[x], x > 1 ? (int)S[x - 1] : 0);
+                qbr[n + 1 - x] = (unsigned char)xt_qcode(S[x], x < n ? (int)S[x + 1] : 0);
             }
         }
         // paired-cell lists of the first three diagonals (list of diagonal d lives in buffer d % 3, its length in lcnt[d % 6])
@@ -299,8 +289,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 #undef MIRP_LDA
 #undef MIRP_LDB
                     const unsigned r0 = bu[0], r1 = bu[1];
+#ifdef MIRP_X_NOSPLITATOM      // timing experiment: plain stores instead of the split loop's two atomic minima
+                    if (i <= ncell && r0 < 65535u) mdec[i] = (int)r0 - 2 * FML_BIAS;
+                    if (i + 1 <= ncell && r1 < 65535u) mdec[i + 1] = (int)r1 - 2 * FML_BIAS;
+#else
                     if (i <= ncell && r0 < 65535u) atomicMin(&mdec[i], (int)r0 - 2 * FML_BIAS);
                     if (i + 1 <= ncell && r1 < 65535u) atomicMin(&mdec[i + 1], (int)r1 - 2 * FML_BIAS);
+#endif
                 }
             };
             // Half of the waves run the splits before the interior loops: the split loop loads the LDS pipe much more than the interior loops do,
@@ -350,7 +345,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int k = blk * 64 + lane;
                     const bool own = k < rem, ahead = !own && aent != 0;       // k >= rem only happens in the last block
                     const bool act = own || ahead;
+#ifdef MIRP_X_NOENT           // timing experiment: no list-entry read in front of a block
+                    const unsigned ent = own ? (unsigned)(((done + k) * 3 + 1) % 300 + 1) | (1u << 9) : ahead ? aent : (1u | (1u << 9));
+#else
                     const unsigned ent = own ? clist[done + k] : ahead ? aent : (1u | (1u << 9));   // idle lanes: harmless dummy cell
+#endif
                     const int i = ent & 511, type = (ent >> 9) & 7, j = i + d + (ahead ? 1 : 0);
                     a.cring = cring + (ahead ? CSTR : 0);
                     unsigned* ck = ahead ? ckey2 : ckey;
@@ -453,7 +452,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (ca < INF) { const unsigned k = ((unsigned)(ra + ca + KEY_BIAS) << 10) | ka; res = k < res ? k : res; }
                         if (cb2 < INF) { const unsigned k = ((unsigned)(rb2 + cb2 + KEY_BIAS) << 10) | kb2; res = k < res ? k : res; }
                     }
+#ifdef MIRP_X_NOATOM            // timing experiment: a plain store instead of the block's atomic minimum
+                    if (act && res != KEY_NONE) ck[i] = res;
+#else
                     if (act && res != KEY_NONE) atomicMin(&ck[i], res);
+#endif
                 }
                 if (role == 14 && done > 0 && !(dbg_flags & 32)) {   // stacked pairs of the cells that went ahead in the previous interval (done <= 63)
                     const bool act = lane < done;

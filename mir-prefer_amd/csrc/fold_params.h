@@ -23,6 +23,9 @@ struct FoldParams {
     // no shape: code 63 = "some loop with n1 >= 2", which sorts after every shape with n1 <= 1 and before every other one (TB_GENERIC, fold_epilogue.h)
     unsigned gen_wing_key[25];    // [u-6]: (internal_loop[u] + MAX_NINIO) << 10 | 63
     int gen_wing_d;               // smallest |n1 - n2| with a saturated term: 5 with Turner-2004 (ninio 60, MAX_NINIO 300)
+    // bias of the fill kernel's byte tables of inner-pair terms (LdsTables::XB / X1, fold_lds_common.h): table entry = term + bias in 0..255; the
+    // kb*_key / k1n*_key tables above carry the matching -bias
+    int xb_bias, x1_bias;
     // (the key tables come first so that the fill kernel's scalar loads reach them with immediate offsets from the one base pointer)
     int stack[8][8];
     int bulge[31];

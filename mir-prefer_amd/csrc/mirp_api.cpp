@@ -37,6 +37,7 @@ extern "C" int mirp_create(int device, mirp_ctx** out) {
         std::fprintf(stderr, "mirp_create: energy model and fill kernel disagree on the saturation of the asymmetry term (%d vs %d)\n", hp->gen_wing_d, mirp::fold_lds_gen_wing_d());
         delete hp; delete c; return -5;
     }
+    if (hp->xb_bias < 0) { std::fprintf(stderr, "mirp_create: inner-pair terms outside the fill kernel's byte-table range\n"); delete hp; delete c; return -5; }
     for (int t = 1; t <= 6; t++)          // the fill kernel's list entries carry these two terms of a cell as 10-bit signed fields (fold_lds_kernel.hip, ENT_OUTER)
         for (int a = 0; a < 5; a++)
             for (int b = 0; b < 5; b++)

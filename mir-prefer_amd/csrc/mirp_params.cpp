@@ -20,12 +20,32 @@ static void fill_derived(FoldParams* p) {
         }
     p->gen_wing_d = p->ninio > 0 ? (p->MAX_NINIO + p->ninio - 1) / p->ninio : 1 << 20;
     for (int u = 6; u <= MIRP_MAXLOOP; u++) p->gen_wing_key[u - 6] = ((unsigned)(p->internal_loop[u] + p->MAX_NINIO) << 10) | 63u;
+    // inner-pair terms of the bulge and 1 x n candidates relative to the ring entry (fold_lds_common.h: XB = TerminalAU - mismatchI, X1 = mismatch1nI -
+    // mismatchI of the inner pair seen from inside): stored as bytes, so their ranges become a bias that the candidates' size-term keys take back
+    {
+        static const int ptype[5][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, 1, 0}, {0, 0, 2, 0, 3}, {0, 6, 0, 4, 0}};      // [S[p]][S[q]], A C G U = 1 2 3 4
+        static const int rt[8] = {0, 2, 1, 4, 3, 6, 5, 7};
+        int lo_b = 0, hi_b = 0, lo_1 = 0, hi_1 = 0;
+        for (int sp = 1; sp <= 4; sp++)
+            for (int sq = 1; sq <= 4; sq++) {
+                const int t2 = rt[ptype[sp][sq]];
+                if (!t2) continue;
+                for (int a = 0; a < 5; a++)
+                    for (int b = 0; b < 5; b++) {
+                        const int mi = p->mismatchI[t2][a][b];
+                        const int xb = (t2 > 2 ? p->TerminalAU : 0) - mi, x1 = p->mismatch1nI[t2][a][b] - mi;
+                        lo_b = xb < lo_b ? xb : lo_b; hi_b = xb > hi_b ? xb : hi_b; lo_1 = x1 < lo_1 ? x1 : lo_1; hi_1 = x1 > hi_1 ? x1 : hi_1;
+                    }
+            }
+        p->xb_bias = -lo_b; p->x1_bias = -lo_1;
+        if (hi_b - lo_b > 255 || hi_1 - lo_1 > 255 || p->xb_bias > 2047 || p->x1_bias > 2047) p->xb_bias = p->x1_bias = -1;      // (mirp_create refuses the set)
+    }
     for (int u = 0; u <= MIRP_MAXLOOP; u++) {
-        const unsigned kb = (unsigned)(p->bulge[u] + 2048) << 10;
+        const unsigned kb = (unsigned)(p->bulge[u] + 2048 - (p->xb_bias > 0 ? p->xb_bias : 0)) << 10;
         p->kb0_key[u] = kb | (unsigned)u;
         p->kb1_key[u] = kb | (unsigned)(u << 5);
         int y = (u - 1) * p->ninio;
-        const unsigned k1 = (unsigned)((u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048) << 10;
+        const unsigned k1 = (unsigned)((u >= 1 && u + 1 <= MIRP_MAXLOOP ? p->internal_loop[u + 1] : 0) + (y < p->MAX_NINIO ? y : p->MAX_NINIO) + 2048 - (p->x1_bias > 0 ? p->x1_bias : 0)) << 10;
         p->k1n0_key[u] = k1 | (unsigned)(1 << 5 | u);
         p->k1n1_key[u] = k1 | (unsigned)(u << 5 | 1);
     }
