@@ -259,7 +259,11 @@ __device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int mm
 template <bool CHECK, int WD, int... Us>
 __device__ __forceinline__ unsigned a1_generic_w(const A1& a, int i, int j, int mm_outer) {
     unsigned bg = KEY_INF;
+#ifdef MIRP_X_GENBCAST          // timing experiment: every lane reads the same ring columns (no bank conflicts in the generic rows)
+    const unsigned short* rb = a.cring + 40 + (i & 1);
+#else
     const unsigned short* rb = a.cring + i + 1;
+#endif
     (a1_gen_row_w<CHECK, WD, Us>(a, rb, bg), ...);
     return a1_key(bg, -32768 + mm_outer);
 }
