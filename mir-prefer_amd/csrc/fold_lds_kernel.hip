@@ -433,7 +433,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             res = rb < ri ? rb : ri;
                         }
                     } else if (!(dbg_flags & 32) && a.um >= MAXLOOP && !slow) {
+#ifdef MIRP_X_NOSMALLGLOBAL     // timing experiment: the small-shape jobs without their global table loads
+                        res = role == 14 ? a1_small14f(a, i, j, type, ahead, true) : a1_small15f(a, i, j, type, true);
+#elif defined(MIRP_X_NOSMALL)        // timing experiment: no small-shape jobs at all
+                        res = KEY_NONE;
+#else
                         res = role == 14 ? a1_small14f(a, i, j, type, ahead, (dbg_flags & 16384) != 0) : a1_small15f(a, i, j, type, (dbg_flags & 16384) != 0);
+#endif
                     } else if (!(dbg_flags & 32)) {
                         const int si1 = S[i + 1], sj1 = S[j - 1];
                         int ra, ca, rb2, cb2;
