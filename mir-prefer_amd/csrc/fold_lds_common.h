@@ -168,7 +168,7 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.seq = o; o += lds_al(LCAP + 8);
     L.pax = o; o += lds_al((LCAP + 8) * 2);
     L.qb2 = o; o += lds_al(LCAP + 8);
-    L.list = o; o += lds_al(3 * LSEG * (MODEL ? 2 : 4));      // 32-bit entries in the default model (see `list` in the kernel); the vienna-1.8.5 layout has no room for them
+    L.list = o; o += lds_al(3 * LSEG * 4);      // 32-bit entries (see `list` in the kernel)
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
     L.misc = o; o += lds_al((48 + ARCH_RB) * 4);
     L.total = o;

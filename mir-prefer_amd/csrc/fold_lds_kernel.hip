@@ -73,10 +73,10 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     // [3][LSEG]: paired cells of diagonal d in buffer d % 3 (compact, unordered).  Default model: i | type << 9 | mmo << 12 | mm1 << 22, mmo / mm1 = the cell's
     // outer-pair terms mismatchI / mismatch1nI [type][S[i+1]][S[j-1]] as 10-bit signed values (ENT_OUTER below): phase B, which has the time, looks them up
     // when it builds the entry, and a block's prologue in phase A1 goes from the entry straight to arithmetic -- no dependent table read in front
-    // of every block of every wave (timing build -DMIRP_X_NOOUTER: worth 2 ms).  vienna-1.8.5: 16-bit entries i | type << 9.  (Before: oi = type * 25 + S[i+1] * 5 + S[j-1]
+    // of every block of every wave (timing build -DMIRP_X_NOOUTER: worth 2 ms).  (Before: oi = type * 25 + S[i+1] * 5 + S[j-1]
     // indexes the outer pair's mismatch tables: it rides in the entry so that phase A1 goes from the entry straight to the tables (reading the two
     // bases first was one more LDS round trip in front of every block of every wave)
-    using list_t = std::conditional_t<MODEL == 0, unsigned, unsigned short>;     // vienna-1.8.5: 16-bit entries, phase A1 reads the two bases itself
+    using list_t = unsigned;
     list_t* list = (list_t*)(smem + LY.list);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
     int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16..21: list lengths
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             if (tid < n - dd) {
                 t = pair_type(S[tid + 1], S[tid + 1 + dd]);
                 const int x = t * 25 + S[tid + 2] * 5 + S[tid + dd];
-                oi = MODEL == 0 ? ENT_OUTER((int)T.mismatchI[x], (int)T.mismatch1nI[x]) : 0;
+                oi = ENT_OUTER((int)T.mismatchI[x], (int)T.mismatch1nI[x]);
             }
             list_append(dd, tid + 1, t, oi);
         }
@@ -358,15 +358,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     // their two round trips (bases, then tables) overlap the job's own reads instead of following them
                     int au1 = 0, mmo = 0, mm1 = 0;
                     if (role < 14) {
-                        if constexpr (MODEL == 0) {
-                            au1 = type > 2 ? tau_s : 0;
-                            mmo = ((int)(ent << 10)) >> 22; mm1 = ((int)ent) >> 22;          // the 10-bit signed fields of the entry
-                        } else {
-                            lds_vu8 Sv = (lds_vu8)S;
-                            const int oi = type * 25 + (int)Sv[i + 1] * 5 + (int)Sv[j - 1];
-                            au1 = type > 2 ? (int)T.TerminalAU : 0;
-                            mmo = T.mismatchI[oi]; mm1 = T.mismatch1nI[oi];
-                        }
+                        au1 = type > 2 ? tau_s : 0;
+                        mmo = ((int)(ent << 10)) >> 22; mm1 = ((int)ent) >> 22;          // the 10-bit signed fields of the entry
                     }
                     if (role < 8) {
                         if (!(dbg_flags & 4)) {
@@ -594,7 +587,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 ckey[i] = KEY_NONE; mdec[i] = INF;
             }
             const int lb = __builtin_amdgcn_readfirstlane(lbase);      // lane 0 holds the claimed range
-            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((x + 1) | (lt << 9) | (loi << 16));
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)(x + 1) | ((unsigned)lt << 9) | (ENT_OUTER((int)T.mismatchI[loi], (int)T.mismatch1nI[loi]) << 12));
         };
         // Phase B of the default model, written as two rounds of loads and then arithmetic: every LDS read whose address depends on (i, j, d)
         // only is issued first (round 1), the parameter-table reads that need the pair type and the neighbouring bases follow together
