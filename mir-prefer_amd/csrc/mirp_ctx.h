@@ -62,7 +62,7 @@ struct mirp_ctx {
     int ingest_n_contigs = 0;
     DevBuf diff, stat, starts, totals, runs, keep, kscan, csq, cdest, peaks_sq, peaks_sorted;
     DevBuf head, hscan, rfirst, nent, isloc, nslots, escan, lscan, sscan, windows, roles, loci, wpeaks, matures, wseqs, woffs, wlens;
-    DevBuf p_out, p_nout, p_status, p_keep, p_kscan, p_res, p_text;
+    DevBuf p_out, p_nout, p_status, p_keep, p_kscan, p_res, p_text, p_need;
     // windows whose structure lines exceed the default capacity: re-folded alone at full capacity into these side buffers (mirp_fold)
     DevBuf side_cnt, side_idx, side_list, side_offs, side_lens, lines2, ss2, nlines2, mfe2, status2;
     long long n_side = 0;

@@ -35,7 +35,8 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
 // launch + re-run of the windows that exceeded a capacity, with capacities sized for them (predict_kernel.hip)
 int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, int n_windows, const MirpMature* matures, const MirpAln* alns, long long n_alns,
                        const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines, const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out,
-                       int* status, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, std::string* err);
+                       int* status, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, std::string* err,
+                       int* need_buf = nullptr);
 
 // fold_lds_kernel.hip
 size_t fold_lds_bytes(int max_lines);

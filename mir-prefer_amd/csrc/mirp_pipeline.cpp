@@ -518,11 +518,12 @@ static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, uns
     const long long nw = c->n_windows;
     const int* skip = c->n_side > 0 ? (const int*)c->side_idx.p : nullptr;
     std::string err;
+    if (c->p_need.ensure(12 * (size_t)std::max<long long>(nw, 1))) return fail(c, -6, "device allocation failed (predict)");
     // every launch re-runs the windows that exceeded a capacity of the kernel (structures, pieces per line, candidate matures) at capacities
     // sized for them (run_predict_launch): the reference has no such limits
     if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
                                           (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, pp,
-                                          (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip, &err))
+                                          (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip, &err, (int*)c->p_need.p))
         return fail(c, rc, "mirp_predict: " + err);
     if (c->n_side > 0) {
         if (mirp::predict_lds_bytes(c->side_max_lines, c->fold_stride) > 160 * 1024)
@@ -530,7 +531,7 @@ static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, uns
         if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
                                               (const MirpFoldLine*)c->lines2.p, (const char*)c->ss2.p, c->fold_stride, c->side_max_lines, (const int*)c->nlines2.p, pp,
                                               (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, (const int*)c->side_list.p,
-                                              (int)c->n_side, nullptr, &err))
+                                              (int)c->n_side, nullptr, &err, (int*)c->p_need.p))
             return fail(c, rc, "mirp_predict (windows over the default line capacity): " + err);
     }
     return 0;

@@ -587,12 +587,15 @@ __global__ void reasons_invalidate_kernel(int* __restrict__ rpool, unsigned int 
 // wsel == nullptr, every window except skip[w] >= 0.  Returns 0, or a negative code with *err set (LDS budget exceeded: -5).
 int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, int n_windows, const MirpMature* matures, const MirpAln* alns, long long n_alns,
                        const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines, const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out,
-                       int* status, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, std::string* err) {
+                       int* status, unsigned int* rcount, int* rpool, unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, std::string* err,
+                       int* need_buf) {
     const int n_iter = wsel ? n_sel : n_windows;
     if (n_iter <= 0) return 0;
-    int* need = nullptr;
-    if (hipMalloc((void**)&need, 12 * (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
-    struct Free { int* p; int* a = nullptr; int* b = nullptr; unsigned char* f = nullptr; ~Free() { (void)hipFree(p); if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (f) (void)hipFree(f); } } guard{need};
+    // need_buf: 12 * n_windows bytes of the caller's (the resident pipeline keeps one; an allocation and a release per call cost more than the
+    // filter's own device work on a small batch), else allocated here
+    int* need = need_buf;
+    if (!need && hipMalloc((void**)&need, 12 * (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
+    struct Free { int* p; int* a = nullptr; int* b = nullptr; unsigned char* f = nullptr; ~Free() { if (p) (void)hipFree(p); if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (f) (void)hipFree(f); } } guard{need_buf ? nullptr : need};
     if (hipMemsetAsync(need, 0, 12 * (size_t)n_windows, stream) != hipSuccess) { *err = "memset failed"; return -2; }
 #ifndef MIRP_PRED_GRID
 #define MIRP_PRED_GRID 64
