@@ -38,18 +38,29 @@ def peaks_to_dict(peaks, contig_names):
 
 
 def loci_to_dict(loci, peaks, contig_names, precursor_len=300):
-    """dict_loci of gen_candidate_region_typeA (miR_PREFeR.py:1302-1316)."""
+    """dict_loci of gen_candidate_region_typeA (miR_PREFeR.py:1302-1316).  The record arrays are turned into Python lists once (field access on a
+    numpy record costs about a microsecond, and there are a dozen per locus)."""
     d = {}
-    for lc in loci:
-        pk = [(int(p["start"]), int(p["end"]), STRAND[p["strand"]]) for p in peaks[lc["peak_first"]:lc["peak_first"] + lc["n_peaks"]]]
+    if len(loci) == 0:
+        return d
+    allpk = list(zip(peaks["start"].tolist(), peaks["end"].tolist(), [STRAND[x] for x in peaks["strand"].tolist()]))
+    tid, start, end = loci["tid"].tolist(), loci["start"].tolist(), loci["end"].tolist()
+    nwin, wins = loci["n_windows"].tolist(), loci["w"].tolist()
+    first, npk = loci["peak_first"].tolist(), loci["n_peaks"].tolist()
+    for k in range(len(tid)):
+        pk = allpk[first[k]:first[k] + npk[k]]
         # a single-peak region is the peak tuple itself, strand included (r_now = contiglist[0], miR_PREFeR.py:1259)
-        info = [pk[0] if len(pk) == 1 else (int(lc["start"]), int(lc["end"]))]
-        for k in range(lc["n_windows"]):
-            win = (int(lc["w"][k][0]), int(lc["w"][k][1]))
-            if lc["end"] - lc["start"] > precursor_len:
-                win = info[0]  # extend_region returns [region] itself (miR_PREFeR.py:1276-1277)
-            info.append((win, pk))
-        d.setdefault(contig_names[lc["tid"]], []).append(info)
+        region = pk[0] if len(pk) == 1 else (start[k], end[k])
+        info = [region]
+        long_region = end[k] - start[k] > precursor_len          # extend_region returns [region] itself (miR_PREFeR.py:1276-1277)
+        w = wins[k]
+        for x in range(nwin[k]):
+            info.append((region if long_region else (w[x][0], w[x][1]), pk))
+        name = contig_names[tid[k]]
+        if name in d:
+            d[name].append(info)
+        else:
+            d[name] = [info]
     return d
 
 
@@ -59,13 +70,14 @@ def exregion_gff_text(dict_loci):
     out = []
     for seqid in sorted(dict_loci):
         cnt = 0
+        head = seqid + "\tmiR-PREFeR\tExRegionA\t"
         for info in dict_loci[seqid]:
-            for win, peaks in info[1:]:
-                ws, we = win[0], win[1]       # a single-peak region longer than PRECURSOR_LEN is the peak tuple itself (start, end, strand)
-                other = "".join("%d:%d:%s|" % (p[0], p[1], p[2]) for p in peaks)
-                name = "ExRegionA_%d" % cnt
+            other = None
+            for win, peaks in info[1:]:          # a single-peak region longer than PRECURSOR_LEN is the peak tuple itself (start, end, strand)
+                if other is None:
+                    other = "".join(["%d:%d:%s|" % p for p in peaks])
+                out.append("%s%d\t%d\t.\t+\t.\tID=ExRegionA_%d;NAME=ExRegionA_%d;Other=%s" % (head, win[0], win[1], cnt, cnt, other))
                 cnt += 1
-                out.append("\t".join([seqid, "miR-PREFeR", "ExRegionA", str(ws), str(we), ".", "+", ".", "ID=%s;NAME=%s;Other=%s" % (name, name, other)]))
     return "\n".join(out) + "\n" if out else ""
 
 
