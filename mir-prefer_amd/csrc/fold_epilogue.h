@@ -783,8 +783,13 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
     for (int x = tid; x < n + 3; x += NT) f3[x] = 0;
     __syncthreads();
     EPI_T0();
+#ifdef MIRP_X_EPI_NOSWEEP          // timing experiment: no exterior sweep (f3 stays 0: no structures follow)
+    if constexpr (Tab::kTiled) {}
+    else {
+#else
     if constexpr (Tab::kTiled) f3_sweep_tiled<Tab, NT>(X, T, f3, btstk);
     else {
+#endif
     constexpr int NW = NT / 64;
     constexpr int RB = 32;   // rows per block: 32 consecutive i share their cache lines of every archived diagonal
     static_assert(RB == 32, "step 1 maps a half-wave onto the rows of a block");
@@ -899,7 +904,11 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
         int L = -10;
         EPI_T(2);
         if (pp >= 0) {
+#ifdef MIRP_X_EPI_NOBT             // timing experiment: sweep and enumeration only
+            if constexpr (Tab::kTiled) L = -10;
+#else
             if constexpr (Tab::kTiled) L = backtrack_wave_tiled(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
+#endif
             else L = backtrack_wave(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
         }
         EPI_T(3);
