@@ -381,6 +381,9 @@ __device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, 
 // compile to one LDS round trip per candidate.
 #ifdef MIRP_X_XBBCAST          // timing experiment: every lane gathers the same table entry (no bank conflicts in the XB / X1 reads)
 #define MIRP_XIDX(e) (((e) & 0u))
+#elif defined(MIRP_X_NOCODE)      // timing experiment: the table gather without the dependent code read in front of it
+#define MIRP_XIDX(e) ((e) & 127u)
+#define MIRP_NOCODE_READ 1
 #else
 #define MIRP_XIDX(e) (e)
 #endif
@@ -403,7 +406,11 @@ __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxp; }
 #else
 #pragma unroll
+#ifdef MIRP_NOCODE_READ
+        for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
+#else
         for (int k = 0; k < N; k++) code[k] = ql[LO + k];
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
 #endif
@@ -429,7 +436,11 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxq; }
 #else
 #pragma unroll
+#ifdef MIRP_NOCODE_READ
+        for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
+#else
         for (int k = 0; k < N; k++) code[k] = pl[LO + k];
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
 #endif
@@ -455,7 +466,11 @@ __device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxp; }
 #else
 #pragma unroll
+#ifdef MIRP_NOCODE_READ
+        for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
+#else
         for (int k = 0; k < N; k++) code[k] = ql[LO + k];
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
 #endif
@@ -481,7 +496,11 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxq; }
 #else
 #pragma unroll
+#ifdef MIRP_NOCODE_READ
+        for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
+#else
         for (int k = 0; k < N; k++) code[k] = pl[LO + k];
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
 #endif

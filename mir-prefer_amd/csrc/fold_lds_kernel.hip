@@ -284,7 +284,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (t + s1 <= d - 5) group(ODD, std::integral_constant<int, 2>{});
                         if (t <= d - 5) group(ODD, std::integral_constant<int, 1>{});
                     };
+#ifdef MIRP_X_SPLITODD          // timing experiment: every wave takes the aligned (odd t) path: no third read, no v_alignbit
+                    relax(std::true_type{});
+#else
                     if (odd) relax(std::true_type{}); else relax(std::false_type{});
+#endif
 #undef MIRP_SSTEP
 #undef MIRP_LDA
 #undef MIRP_LDB
