@@ -508,9 +508,10 @@ class Pipeline:
         stemloopname = os.path.join(outdir, prefix + "_miRNA.precursor.fa")
         ssname = os.path.join(outdir, prefix + "_miRNA.precursor.ss")
         write_fasta_ss(result, payloads, maturename, stemloopname, ssname)
+        texts = locus_texts(result, payloads)
         write_csv_and_stat(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
-                           os.path.join(outdir, "miRNA.stat.txt"))
-        write_html(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"))
+                           os.path.join(outdir, "miRNA.stat.txt"), texts=texts)
+        write_html(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"), texts=texts)
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         rm_thread.join()
@@ -715,25 +716,43 @@ def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder,
     return th
 
 
-def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
+def locus_texts(resultlist, contigs):
+    """Per locus: (precursor, mature, star) as the detail tables print them (reverse complement on the minus strand), plus the length and first base of
+    the forward-strand mature (gen_miRNA_stat, MP:2731-2741).  The csv and the html table print the same texts: run_predict builds them once and
+    hands them to both writers (`texts`)."""
+    out = []
+    for idx, m in enumerate(resultlist):
+        pre = _seq(contigs, idx, m, m[1], m[2] - 1)
+        mat = _seq(contigs, idx, m, m[3], m[4] - 1)
+        star = _seq(contigs, idx, m, m[5], m[6] - 1)
+        flen, ffirst = len(mat), mat[0]
+        if m[8] == "-":
+            pre, mat, star = _revcomp(pre), _revcomp(mat), _revcomp(star)
+        out.append((pre, mat, star, flen, ffirst))
+    return out
+
+
+def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname, texts=None):
     """gen_csv_table (MP:2744-2779) and the miRNA.stat.txt block of the predict stage (MP:3585-3593)."""
     dict_len, dict_first = {}, {}
+    if texts is None:
+        texts = locus_texts(resultlist, contigs)
+    cstr = [[[str(v) for v in per] for per in row] for row in np.asarray(counts).astype(np.int64).tolist()] if len(resultlist) else []
     with open(csvname, "w") as f:
         head = "miRNAID, Seqid(chromosome), start position, end position, strand, precursor sequence, secondary structure, mature sequence, star sequence, "
         f.write(head + "".join(s + "," + s + "," + s + "," + s + "," for s in samples) + "\n")
         f.write(head + "reads mapped to precursor, reads mapped to mature, reads mapped to star, reads mapped to antisense region," * len(samples) + "\n")
+        lines = []
         for idx, m in enumerate(resultlist):
-            pre = _seq(contigs, idx, m, m[1], m[2] - 1)
-            mat = _seq(contigs, idx, m, m[3], m[4] - 1)
-            star = _seq(contigs, idx, m, m[5], m[6] - 1)
-            dict_len[len(mat)] = dict_len.get(len(mat), 0) + 1                     # gen_miRNA_stat (MP:2731-2741) uses the forward-strand text
-            dict_first[mat[0]] = dict_first.get(mat[0], 0) + 1
-            if m[8] == "-":
-                pre, mat, star = _revcomp(pre), _revcomp(mat), _revcomp(star)
+            pre, mat, star, flen, ffirst = texts[idx]
+            dict_len[flen] = dict_len.get(flen, 0) + 1                     # gen_miRNA_stat (MP:2731-2741) uses the forward-strand text
+            dict_first[ffirst] = dict_first.get(ffirst, 0) + 1
             row = ["miRNA-precursor_%d" % idx, m[0], str(m[1]), str(m[2]), m[8], pre, m[7], mat, star]
             for s in range(len(samples)):
-                row += [str(int(v)) for v in counts[idx, s]]
-            f.write(", ".join(row) + "\n")
+                row += cstr[idx][s]
+            lines.append(", ".join(row))
+        if lines:
+            f.write("\n".join(lines) + "\n")
     with open(statname, "w") as f:
         f.write("Total number of predicted miRNAs: %d\n" % len(resultlist))
         f.write("Distribution of the length of the mature miRNAs:\n")
@@ -744,8 +763,21 @@ def write_csv_and_stat(resultlist, contigs, samples, counts, csvname, statname):
             f.write("%s: %d\n" % (k, dict_first[k]))
 
 
+_MIRBASE_PARTS = {}
+
+
 def _mirbase_form(seq, taxon):
-    """The miRBase BLAST search form the reference attaches to every mature sequence (gen_search_miRBase_str, MP:2773-2791)."""
+    """The miRBase BLAST search form the reference attaches to every mature sequence (gen_search_miRBase_str, MP:2773-2791); everything but the
+    sequence is the same for a taxon and is put together once."""
+    ps = _MIRBASE_PARTS.get(taxon)
+    if ps is None:
+        mark = "\x00SEQ\x00"
+        whole = _mirbase_form_text(mark, taxon)
+        ps = _MIRBASE_PARTS[taxon] = whole.split(mark)
+    return seq.join(ps)
+
+
+def _mirbase_form_text(seq, taxon):
     hidden = [("sequence", " " + seq), ("seqfile", ""), ("type", "mature"), ("search_method", "blastn"), ("evalue", "10"), ("maxalign", "100"),
               ("taxon", " " + taxon)]
     gap = " " * 5
@@ -755,24 +787,23 @@ def _mirbase_form(seq, taxon):
     return gap.join(parts)
 
 
-def write_html(resultlist, contigs, samples, counts, htmlname):
+def write_html(resultlist, contigs, samples, counts, htmlname, texts=None):
     """gen_html_table_file (MP:2793-2904): the two distribution tables of miRNA.stat.txt and the detail table of the csv as markup, with a miRBase
     search form per mature sequence and a link to the locus' read-mapping file."""
     dict_len, dict_first = {}, {}
     rows = []
+    if texts is None:
+        texts = locus_texts(resultlist, contigs)
+    cstr = [[[str(v) for v in per] for per in row] for row in np.asarray(counts).astype(np.int64).tolist()] if len(resultlist) else []
     for idx, m in enumerate(resultlist):
-        pre = _seq(contigs, idx, m, m[1], m[2] - 1)
-        mat = _seq(contigs, idx, m, m[3], m[4] - 1)
-        star = _seq(contigs, idx, m, m[5], m[6] - 1)
-        dict_len[len(mat)] = dict_len.get(len(mat), 0) + 1                         # forward-strand text, as in the stat file
-        dict_first[mat[0]] = dict_first.get(mat[0], 0) + 1
-        if m[8] == "-":
-            pre, mat, star = _revcomp(pre), _revcomp(mat), _revcomp(star)
+        pre, mat, star, flen, ffirst = texts[idx]
+        dict_len[flen] = dict_len.get(flen, 0) + 1                         # forward-strand text, as in the stat file
+        dict_first[ffirst] = dict_first.get(ffirst, 0) + 1
         name = "miRNA-precursor_%d" % idx
         cells = [name, m[0], str(m[1]), str(m[2]), m[8]]
         tail = [mat + _mirbase_form(mat, "Viridiplantae") + _mirbase_form(mat, "ALL"), star]
         for s in range(len(samples)):
-            tail += [str(int(v)) for v in counts[idx, s]]
+            tail += cstr[idx][s]
         td = "\t\t\t<td nowrap>%s</td>\n"
         rows.append("\t\t<tr>\n" + "".join(td % c for c in cells) + "\t\t\t<td nowrap> <code>" + pre + "<BR>" + m[7] + " </code></td>" +
                     "".join(td % c for c in tail) + '\t\t\t<td><a href="readmapping/' + name + '.map.txt" target="_blank">Click to see detailed mapping.</a></td>' +
