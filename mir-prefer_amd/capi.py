@@ -205,6 +205,10 @@ def load_library():
     lib.mirp_last_coverage_fused.restype = C.c_int
     lib.mirp_set_coverage_path.argtypes = [vp, C.c_int32]
     lib.mirp_set_coverage_path.restype = C.c_int
+    lib.mirp_set_fold_split_path.argtypes = [vp, C.c_int32]
+    lib.mirp_set_fold_split_path.restype = C.c_int
+    lib.mirp_last_fold_dense.argtypes = [vp]
+    lib.mirp_last_fold_dense.restype = C.c_int64
     lib.mirp_write_fold_text.argtypes = [vp, C.c_char_p, C.c_char_p]
     lib.mirp_write_fold_text.restype = C.c_int
     lib.mirp_write_fold_text_async.argtypes = [vp, C.c_char_p, C.c_char_p]
@@ -550,6 +554,13 @@ class Context:
 
     def last_fold_overflow(self):
         return int(self.lib.mirp_last_fold_overflow(self.h))
+
+    def set_fold_split_path(self, mode):
+        """0: multiloop splits over split candidates (default), 1: the dense split loop for every window (same tables either way)."""
+        self._check(self.lib.mirp_set_fold_split_path(self.h, int(mode)), "mirp_set_fold_split_path")
+
+    def last_fold_dense(self):
+        return int(self.lib.mirp_last_fold_dense(self.h))
 
     def set_coverage_path(self, mode):
         """-1: by record density (default), 0: atomic scatter, 1: fused scan where the input allows it."""

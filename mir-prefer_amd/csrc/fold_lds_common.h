@@ -155,15 +155,19 @@ __host__ __device__ inline int arch_rowblk_off(int b, int n, int dcap) {
 }
 
 struct LdsLayout {
-    unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total;
+    unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total, fml_bytes;
 };
 __host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
-template <int MODEL>
+// SPARSE: the multiloop splits run over a pool of split candidates (see "sparse splits" in fold_lds_kernel.hip): a third mdec buffer, and the pool
+// lives behind the window's fML triangle inside the fml region, which then takes everything the other arrays leave of the 160 KB.
+#define FML_REGION_BYTES (lds_al((tri_off(LDMAX + 1, LCAP) + 2) * 2))      // fML triangle, d = 4..LDMAX at n = LCAP
+#define POOL_MIN_CAP 1024    // a window whose length leaves room for fewer candidates goes to the dense kernel right away
+template <int MODEL, bool SPARSE = false>
 __host__ __device__ constexpr LdsLayout lds_layout() {
     LdsLayout L{};
     unsigned o = 0;
-    L.fml = o; o += lds_al((tri_off(LDMAX + 1, LCAP) + 2) * 2);                           // fML triangle, d = 4..LDMAX at n = LCAP
-    L.aux = o; o += lds_al(CRING_ROWS * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + 5 * LCAP * 4);   // c ring (32 diagonals + mirror row), DML ring (3; 5 in the vienna-1.8.5 model), 3 x ckey, 2 x mdec
+    if (!SPARSE) { L.fml = o; L.fml_bytes = FML_REGION_BYTES; o += L.fml_bytes; }
+    L.aux = o; o += lds_al(CRING_ROWS * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + (SPARSE ? 6 : 5) * LCAP * 4);   // c ring (32 diagonals + mirror row), DML ring (3; 5 in the vienna-1.8.5 model), 3 x ckey, 2 (sparse: 3) x mdec
     L.S = o; o += lds_al(LCAP + 8);
     L.seq = o; o += lds_al(LCAP + 8);
     L.pax = o; o += lds_al((LCAP + 8) * 2);
@@ -171,6 +175,7 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.list = o; o += lds_al(3 * LSEG * 4);      // 32-bit entries (see `list` in the kernel)
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
     L.misc = o; o += lds_al((48 + ARCH_RB) * 4);
+    if (SPARSE) { L.fml = o; L.fml_bytes = 160u * 1024u - o; o += L.fml_bytes; }
     L.total = o;
     return L;
 }

@@ -27,15 +27,27 @@ namespace mirp {
 
 // MODEL 0: vienna-2.1.2 (Turner-2004, dangles 2).  MODEL 1: vienna-1.8.5 (Turner-1999 values in the same parameter layout, dangles 1: four-way
 // dangle minima in the multiloop closing and the fML pair terms, fML also on the diagonal d = span; SURVEY.md Appendix B, d1 column).
-template <int MODEL>
+//
+// SPARSE (the product's first pass): the multiloop splits DML(i,j) = min_s fML(i,s-1) + fML(s,j) run over split CANDIDATES only.  With ML_BASE = 0
+//     DML(i,j) = min( DML(i,j-1),  min over s in Cand(j), i+TURN+2 <= s <= j-TURN-1, of fML(i,s-1) + fML(s,j) ),
+// Cand(j) = { s : fML(s,j) is realised STRICTLY by its pair term c(s,j) + MLstem } -- an entry that equals fML(s+1,j) is dominated by the split at
+// s+1 (fML(i,s) <= fML(i,s-1)), one that equals fML(s,j-1) is a split of (i,j-1), one that equals DML(s,j) = fML(s,u-1) + fML(u,j) is dominated by
+// the split at u.  The tables stay bit-identical (tests/tools/splitcand_gate.c checks the identity cell by cell on the CPU oracle's tables and
+// counts: 925 candidates per benchmark window, 2.5 % of the dense loop's relaxations).  Phase B appends the candidates it finds to a pool
+// {s-1, j, fML(s,j)} behind the window's fML triangle; phase A2 maps LANE = POOL ENTRY: the entry's column j holds exactly one cell of the
+// diagonal at hand, (j-d, j), which it relaxes with one gather + one LDS atomic minimum.  A row's thread carries DML(i,j-1) in a register.
+// A window whose pool overflows (tandem repeats) or whose length leaves no room for one is handed to the dense instantiation (second launch).
+template <int MODEL, bool SPARSE>
 __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int win_base, int span, short* __restrict__ slabs, size_t slab_shorts, int* __restrict__ win_state,
     unsigned int* __restrict__ work_counter, int* __restrict__ fallback_list,
     unsigned int* __restrict__ fallback_count, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
-    int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags_arg, long long* __restrict__ dbg_cycles_arg) {
+    int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status, int dbg_flags_arg, long long* __restrict__ dbg_cycles_arg,
+    const int* __restrict__ todo_list, const unsigned int* __restrict__ todo_count, int* __restrict__ dense_list, unsigned int* __restrict__ dense_count) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr LdsLayout LY = lds_layout<MODEL>();
+    constexpr LdsLayout LY = lds_layout<MODEL, SPARSE>();
+    static_assert(!(MODEL && SPARSE), "sparse splits: default model only");
     // phase ablation flags and phase clocks exist in the diagnostics build only (make DIAG=1); the product kernel carries none of that code
 #ifdef MIRP_DIAG
     const int dbg_flags = dbg_flags_arg;
@@ -62,7 +74,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     unsigned short* fml = (unsigned short*)(smem + LY.fml);   // biased uint16 (see FML_BIAS)
     unsigned short* cring = (unsigned short*)(smem + LY.aux);       // [32][CSTR] G0 + 32768 as uint16, 65535 = INF
     short* dmlring = (short*)(cring + CRING_ROWS * CSTR);           // [DMLR][LCAP] int16
-    int* acc = (int*)(dmlring + DMLR * LCAP);                          // ckey[3 (diagonal % 3)][LCAP], then mdec[2 (diagonal parity)][LCAP]
+    int* acc = (int*)(dmlring + DMLR * LCAP);                          // ckey[3 (diagonal % 3)][LCAP], then mdec[2 (diagonal parity)][LCAP] (SPARSE: [3 (diagonal % 3)])
+    constexpr int NACC = SPARSE ? 6 : 5;
+    auto mdec_of = [&](int d) -> int* { return acc + (3 + (SPARSE ? d % 3 : (d & 1))) * LCAP; };
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
     unsigned short* pax = (unsigned short*)(smem + LY.pax);
@@ -79,7 +93,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     using list_t = unsigned;
     list_t* list = (list_t*)(smem + LY.list);
     LdsTables& T = *(LdsTables*)(smem + LY.tabs);
-    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 16..21: list lengths
+    int* misc = (int*)(smem + LY.misc);                             // 0: next window, 1: overflow flag, 2: candidate pool overflow, 3: candidates in the pool, 16..21: list lengths
     int* lcnt = misc + 16;                                          // [6]: entries in the list of diagonal d at d % 6
     int* rbt = misc + 48;                                           // [ARCH_RB]: row-block offsets of the window's archive slabs (arch_rowblk_off)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,14 +127,22 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     if (tid == 0) { T.ML_closing = (short)P->ML_closing; T.ML_intern = (short)P->ML_intern; T.TerminalAU = (short)P->TerminalAU; T.ninio = (short)P->ninio; T.MAX_NINIO = (short)P->MAX_NINIO; }
     __syncthreads();
 
+    const int n_todo = todo_count ? (int)*todo_count : n_work;      // second pass: the windows the sparse pass handed over
+    if (todo_count && blockIdx.x == 0 && tid == 0 && n_todo) atomicAdd(const_cast<unsigned int*>(todo_count) + 2, (unsigned)n_todo);   // ctl[5]: running total for mirp_last_fold_dense
     for (;;) {
         if (tid == 0) misc[0] = (int)atomicAdd(work_counter, 1u);
         __syncthreads();
-        const int win = misc[0];
+        const int wk = misc[0];
         __syncthreads();
-        if (win >= n_work) break;
+        if (wk >= n_todo) break;
+        const int win = todo_list ? todo_list[wk] : wk;
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
+        // sparse splits: the candidate pool (u32 {s-1, j << 9} + u16 fML(s,j) per entry) takes what the window's triangle leaves of the fml region
+        const int pool_off = SPARSE ? (int)lds_al(2u * (unsigned)(tri_off(((span < n - 1) ? span : n - 1) + 1, n > 5 ? n : 5) + 2)) : 0;
+        const int pool_cap = SPARSE ? ((((int)LY.fml_bytes - pool_off) / 6) & ~63) : 0;
+        unsigned* poolA = (unsigned*)(smem + LY.fml + pool_off);
+        unsigned short* poolB = (unsigned short*)(poolA + (pool_cap > 0 ? pool_cap : 0));
         short* carch = slabs + (size_t)win * 3 * slab_shorts;      // per-window slab: c, fML and trace-back triangles (read by fold_lds_epilogue_kernel)
         short* fml_out = carch + slab_shorts;
         unsigned short* tb_out = reinterpret_cast<unsigned short*>(carch + 2 * slab_shorts);
@@ -130,6 +152,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0;
                 if (n >= 1) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; }
             }
+        } else if (SPARSE && pool_cap < POOL_MIN_CAP) {   // wave-uniform: no room for a candidate pool behind this window's triangle (-> dense instantiation)
+            if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0; dense_list[atomicAdd(dense_count, 1u)] = win; }
         } else {
         const int D = (span - 1 < n - 1) ? span - 1 : n - 1;      // largest pair distance
         const int Dm = MODEL ? ((span < n - 1) ? span : n - 1) : D;   // last diagonal of the fill (vienna-1.8.5: fML exists at distance span, c does not)
@@ -145,9 +169,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
         for (int x = tid; x < DMLR * LCAP; x += LNT) dmlring[x] = (short)I16_INF;
-        for (int x = tid; x < 5 * LCAP; x += LNT) acc[x] = x >= 3 * LCAP ? INF : (int)KEY_NONE;   // ckey x 3 | mdec x 2
+        for (int x = tid; x < NACC * LCAP; x += LNT) acc[x] = x >= 3 * LCAP ? INF : (int)KEY_NONE;   // ckey x 3 | mdec x 2 (3)
         if (tid == 0) {
-            misc[1] = 0;
+            misc[1] = 0; misc[2] = 0; misc[3] = 0;
             for (int x = 0; x < 6; x++) lcnt[x] = 0;
         }
         if (tid >= 64 && tid < 64 + ARCH_RB) rbt[tid - 64] = arch_rowblk_off(tid - 64, n, span);
@@ -188,19 +212,41 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // interval as phase A of diagonal d+1, which only needs c of diagonals <= d-1 and fML of diagonals <= d-3.
         // split loop state carried across diagonals (see splits below)
         int sp_ncpad = 0, sp_nsub = 0, sp_pair = 0, sp_sub = 0, sp_so1 = 0, sp_si1 = 0, sp_so2 = 0, sp_si2 = 0;
+        int sp_snap = 0;          // sparse splits: pool size as read one interval ago (wave-uniform)
+        int dml_carry = INF;      // sparse splits: DML(i, j-1) of this thread's row i = tid + 1 (phase B carries it from diagonal to diagonal)
         int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
         const int abase = tid < 8 * ARCH_RB ? rbt[tid >> 3] + (tid & 7) - 32 : 0;   // archive offset of (d, i = tid + 1) is abase + 8 d
         int a1_ncp = __builtin_amdgcn_readfirstlane(lcnt[0]);   // phase A1: length of the next diagonal's list (first: diagonal 6)
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);   // best interior-loop candidate key per cell
-            int* mdec = acc + (3 + (d & 1)) * LCAP;
+            int* mdec = mdec_of(d);
             // phase A2: multiloop splits DML(i,j) = min_t fML(i, i+t) + fML(i+t+1, j).
             // The split point t is wave-uniform (scalar address arithmetic); every lane owns TWO consecutive cells (i, i+1), i odd.  Operand a
             // (diagonal t, cells i, i+1) is one aligned 32-bit word; operand b (diagonal d-t-1, cells i+t+1, i+t+2) is one aligned word for odd t
             // and straddles two words for even t (one v_alignbit).  The step between the splits of a wave is even, so that parity is
             // wave-uniform.  One packed saturating add and one packed min then relax both cells.
-            auto splits = [&]() {
+            // Sparse splits: lane = pool entry.  Every candidate (s, j) found up to diagonal d-5 relaxes the one cell of diagonal d in its column,
+            // (i, j) with i = j - d: DML(i,j) <- fML(i, s-1) + fML(s, j).  An entry younger than that has its left operand on a diagonal t < 4
+            // and is skipped by the same test that skips dead columns (i < 1).  The pool size is the one read an interval ago: phase B of
+            // the current interval may have claimed entries it has not written yet.  The blocks of 64 entries go to the waves from the top
+            // (waves 0-5 own phase B).
+            auto splits_sparse = [&]() {
+                const int lim = sp_snap;
+                { const int pn = __builtin_amdgcn_readfirstlane(((volatile int*)misc)[3]); sp_snap = pn < pool_cap ? pn : pool_cap; }
+                if (dbg_flags & 2) return;
+                for (int k = (LNW - 1 - wave) * 64 + lane; k < lim; k += LNT) {
+                    const unsigned ea = poolA[k];
+                    const unsigned vb = poolB[k];
+                    const int s1 = (int)(ea & 511u), j = (int)(ea >> 9);
+                    const int i = j - d, t = s1 - i;
+                    const bool ok = i >= 1 && t >= TURN + 1;
+                    const int o = 7 - 4 * n + (__mul24(t, 2 * n + 1 - t) >> 1) + ((t - 4 + (n & 1)) >> 1) + i;     // tri_off(t, n) + i
+                    const unsigned sum = (unsigned)fml[ok ? o : 1] + vb;
+                    if (ok && sum < 65535u) atomicMin(&mdec[i], (int)sum - 2 * FML_BIAS);
+                }
+            };
+            auto splits_dense = [&]() {
                 const int npair = (ncell + 1) >> 1;
                 const int ncpad = (npair + 63) & ~63;
                 // The lane mapping (pair, sub) and the start offsets / first differences of the two operand walks depend on d only through the
@@ -305,6 +351,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             // Half of the waves run the splits before the interior loops: the split loop loads the LDS pipe much more than the interior loops do,
             // so the two halves even out the LDS load of the interval (the phases are independent: both only feed phase B of this diagonal).
             const bool swap_order = (wave & 1) && !(dbg_flags & 2048);
+            auto splits = [&]() { if constexpr (SPARSE) splits_sparse(); else splits_dense(); };
             if (swap_order) splits();
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
@@ -600,7 +647,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         auto phaseB0 = [&](const int d) {
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
-            int* mdec = acc + (3 + (d & 1)) * LCAP;
+            int* mdec = mdec_of(d);
+            int cbase = 0, cand = 0; unsigned cent = 0, cval = 0;      // sparse splits: this cell as a split candidate
+            unsigned long long cbal = 0;
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             const int od = tri_off(d, n), od1 = tri_off(d - 1, n);
             const int x = tid;
@@ -615,7 +664,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
                 const int s_j3 = Sv[j + 3 <= n ? j + 3 : n];          // far end of cell (i, j+3): the paired-cell list of diagonal d+3
                 const int s_j2 = Sv[j + 2 <= n ? j + 2 : n];          // its 5' neighbour, for the entry's outer-pair table index
-                const int md = mdec[i];
+                int md = mdec[i];
+                if constexpr (SPARSE) { md = dml_carry < md ? dml_carry : md; dml_carry = md; }      // DML(i,j) = min(DML(i,j-1), candidate splits)
                 const unsigned kk = ckey[i];
                 const int dmlv = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1];
                 int fa = 65535, fb = 65535;
@@ -672,9 +722,18 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     // lds_mlstem(type, i > 1 ? S[i-1] : -1, j < n ? S[j+1] : -1)
                     const int stem = mli + au + ((i > 1 && j < n) ? mmMs : (i > 1) ? dg5 : (j < n) ? dg3 : 0);
                     const int e = cv + stem;
+                    if constexpr (SPARSE) cand = cv < INF && e < m && e < md;      // fML(i,j) strictly realised by the pair term: a split candidate of column j
                     m = e < m ? e : m;
                 }
                 m = md < m ? md : m;
+                if constexpr (SPARSE) {
+                    cbal = __ballot(cand != 0);
+                    if (cbal && lane == 0) {      // claim the wave's pool range (hand-issued like the list claim above; its return is first needed after the stores)
+                        const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&misc[3];
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(cbase) : "v"(pa), "v"((int)__popcll(cbal)) : "memory");
+                    }
+                    cent = (unsigned)(i - 1) | ((unsigned)j << 9);
+                }
 #ifndef MIRP_TIMING_ONLY          // (timing experiments compute garbage on purpose: no hand-over to the generic kernel)
                 if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
                     (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
@@ -689,7 +748,19 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 #endif
                 fml[od + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
-                ckey[i] = KEY_NONE; mdec[i] = INF;
+                ckey[i] = KEY_NONE;
+                if constexpr (SPARSE) { mdec_of(d + 2)[i] = INF; cval = m16; }      // the buffer of diagonal d-1 is dead: it serves diagonal d+2 from the next interval on
+                else mdec[i] = INF;
+            }
+            if constexpr (SPARSE) {
+                if (cbal) {      // wave-uniform
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cbase) : : "memory");
+                    const int at = __builtin_amdgcn_readfirstlane(cbase) + (int)__popcll(cbal & ((1ull << lane) - 1ull));
+                    if (cand) {
+                        if (at < pool_cap) { poolA[at] = cent; poolB[at] = (unsigned short)cval; }
+                        else misc[2] = 1;
+                    }
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lbase) : : "memory");   // the atomic's return is first needed here
             const int lb = __builtin_amdgcn_readfirstlane(lbase);
@@ -700,7 +771,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
         for (int d = 4; d <= Dm; d++) {
             if (dbg_cycles && lane == 0) wt = clock64();
-            if constexpr (MODEL == 0) { if (dbg_flags & 4096) phaseB(d); else phaseB0(d); } else phaseB(d);
+            if constexpr (MODEL == 0) { if (!SPARSE && (dbg_flags & 4096)) phaseB(d); else phaseB0(d); } else phaseB(d);
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) { const long long t = clock64(); wB += t - wt; wt = t; }   // bit 20: light mode, busy / barrier only
             if (d + 1 <= Dm) phaseA(d + 1);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA2 += t - wt; wt = t; }
@@ -711,8 +782,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         const int overflow = misc[1];
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tE += t - t0; t0 = t; }
+        const int pool_over = SPARSE ? misc[2] : 0;
         if (overflow) {   // int16 range exceeded: hand the window to the generic kernel
             if (tid == 0) { unsigned int k = atomicAdd(fallback_count, 1u); fallback_list[k] = win_base + win; out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0; }
+        } else if (pool_over) {   // more split candidates than the pool holds: the dense instantiation folds this window
+            if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; win_state[win] = 0; dense_list[atomicAdd(dense_count, 1u)] = win; }
         } else {
             // hand the tables to the epilogue kernel: c and the trace-back codes were archived on the fly, fML is copied out now into the same tiled
             // layout.  A wave takes whole row blocks; lane = diagonal, so the 8 rows of a row block on one diagonal are one 16-byte store and a
@@ -940,28 +1014,47 @@ size_t fold_lds_epilogue_bytes(int max_lines) {
     return b + sizeof(EpiTables) + 16 + sizeof(short) * XTAB_N + nc + sizeof(short) * nc;
 }
 
-size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout<1>().total; }
+size_t fold_lds_bytes(int max_lines) { (void)max_lines; return lds_layout<0, true>().total; }
 int fold_lds_max_n() { return LCAP - 2; }
 int fold_lds_gen_wing_d() { return 5; }      // GEN_WD of fold_lds_kernel<0>
 int fold_lds_max_span() { return LSPAN; }
 
+// ctl (= work_counter): [0] work counter of the fill kernel, [1] of the epilogue, [2] work counter of the dense second pass, [3] windows handed to it
+// (dense_list: their indices), [4] windows handed to the generic kernel, [5] running total of [3] over the sub-batches
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
-                           int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between) {
+                           int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between, int* dense_list, int force_dense) {
     const size_t lds = model ? lds_layout<1>().total : lds_layout<0>().total;
-    const void* fn = model ? (const void*)fold_lds_kernel<1> : (const void*)fold_lds_kernel<0>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds_sp = lds_layout<0, true>().total;
+    hipError_t e = hipFuncSetAttribute((const void*)fold_lds_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout<1>().total);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fold_lds_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout<0>().total);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fold_lds_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
     if (e != hipSuccess) return e;
+    const int* no_list = nullptr; const unsigned int* no_count = nullptr;
     if (model)
-        hipLaunchKernelGGL(fold_lds_kernel<1>, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
-                           fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+        hipLaunchKernelGGL((fold_lds_kernel<1, false>), dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                           fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                           no_list, no_count, dense_list, work_counter + 3);
     else {
 #if !defined(MIRP_FILL2)
-        // product: the one-diagonal-per-interval fill kernel.  -DMIRP_FILL2 (dev builds, make VARIANT=...) selects the two-diagonal schedule of
+        // product: first pass with sparse multiloop splits (candidate pool), then the dense instantiation over the windows the first pass handed over
+        // (pool overflow, no room for a pool: zero on the benchmark inputs; the launch then finds an empty list).  force_dense (tests, A/B timing): the
+        // dense instantiation folds everything.  -DMIRP_FILL2 (dev builds, make VARIANT=...) selects the two-diagonal schedule of
         // fold_lds2_kernel.hip, which is parity-green but measured no faster
-        hipLaunchKernelGGL(fold_lds_kernel<0>, dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
-                           fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles);
+        if (!force_dense) {
+            hipLaunchKernelGGL((fold_lds_kernel<0, true>), dim3(grid), dim3(LNT), lds_sp, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                               fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                               no_list, no_count, dense_list, work_counter + 3);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fold_lds_kernel<0, false>), dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter + 2,
+                               fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                               (const int*)dense_list, (const unsigned int*)(work_counter + 3), dense_list, work_counter + 3);
+        } else
+            hipLaunchKernelGGL((fold_lds_kernel<0, false>), dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                               fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                               no_list, no_count, dense_list, work_counter + 3);
 #else
         e = launch_fold_lds2_fill(stream, grid, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter, fallback_list, fallback_count,
                                   out_nlines, out_mfe, out_status);

@@ -327,7 +327,8 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         // the two exchange the c / fML triangles of every window through per-window slabs in HBM
         const size_t slab = mirp::fold_lds_slab_shorts(std::min(n_cap, mirp::fold_lds_max_n() + 2));
         const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_work, ((size_t)8 << 30) / (slab * 6)));   // three 16-bit triangles per window: c, fML, trace-back codes
-        if (c->carch.ensure((size_t)sub * slab * 6) || c->fctl.ensure(1024) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub))
+        if (c->carch.ensure((size_t)sub * slab * 6) || c->fctl.ensure(1024) || c->flist.ensure(4 * (size_t)n_work) || c->wstate.ensure(4 * (size_t)sub) ||
+            c->dlist.ensure(4 * (size_t)sub))
             return fail(c, -6, "device allocation failed (fold LDS kernel)");
         HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 1024, c->stream));
         unsigned int* ctl = (unsigned int*)c->fctl.p;
@@ -349,7 +350,7 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         int n_sub = 0;
         for (int b0 = 0; b0 < n_work; b0 += sub) {
             const int nb = std::min(sub, n_work - b0);
-            if (b0 > 0) HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 8, c->stream));   // the two work counters; the fallback count keeps accumulating
+            if (b0 > 0) HIPCHK(c, hipMemsetAsync(c->fctl.p, 0, 16, c->stream));   // the work counters and the dense pass's list length; the fallback count (ctl[4]) and the number of windows handed to the dense pass (ctl[5]) keep accumulating
             const int grid = std::min(nb, c->n_cu);
             const int grid_epi = std::min(nb, c->n_cu * 8);
             while ((int)c->fold_ev.size() < 3 * (n_sub + 1)) { hipEvent_t ev; HIPCHK(c, hipEventCreate(&ev)); c->fold_ev.push_back(ev); }
@@ -358,15 +359,17 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             hipError_t e = mirp::launch_fold_lds(c->stream, m185 ? 1 : 0, grid, grid_epi, m185 ? c->d_params185l : c->d_params, d_seqs, d_offs + b0, d_lens ? d_lens + b0 : nullptr, nb, b0, span,
                                                  (short*)c->carch.p, slab, (int*)c->wstate.p, ctl, (int*)c->flist.p, ctl + 4, max_lines, stride,
                                                  d_lines + (size_t)b0 * max_lines, d_ss + (size_t)b0 * max_lines * stride, d_nlines + b0, d_mfe + b0,
-                                                 d_status + b0, dbg_flags, dbg_cycles, ev3[1]);
+                                                 d_status + b0, dbg_flags, dbg_cycles, ev3[1], (int*)c->dlist.p, c->fold_dense);
             if (e != hipSuccess) return fail(c, -2, std::string("fold LDS kernel launch failed: ") + hipGetErrorString(e));
             HIPCHK(c, hipEventRecord(ev3[2], c->stream));
             n_sub++;
         }
-        unsigned int nfb = 0;
-        HIPCHK(c, hipMemcpyAsync(&nfb, ctl + 4, 4, hipMemcpyDeviceToHost, c->stream));
+        unsigned int nfb2[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(nfb2, ctl + 4, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        const unsigned int nfb = nfb2[0];
         c->last_fallback = nfb;
+        c->last_dense = nfb2[1];
         c->fold_kernel_ms[0] = c->fold_kernel_ms[1] = 0;
         for (int k = 0; k < n_sub; k++) {
             float a = 0, b = 0;

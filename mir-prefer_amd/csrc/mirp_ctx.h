@@ -44,7 +44,7 @@ struct mirp_ctx {
     FoldParams185* d_params185 = nullptr;   // created on the first use of the vienna-1.8.5 model (generic kernel)
     FoldParams* d_params185l = nullptr;     // Turner-1999 values in the layout of the LDS-resident kernels
     int fold_model = MIRP_FOLD_MODEL_VIENNA_212;
-    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist, wstate;
+    DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist, wstate, dlist;
     long long last_fallback = 0;
     // ---- device-resident pipeline state (mirp_pipeline.cpp)
     int n_contigs = 0;
@@ -54,6 +54,8 @@ struct mirp_ctx {
     long long n_segs = 0;
     DevBuf tile_first;               // fused coverage scan: first record of every tile (candidate_kernels.hip)
     int max_aln_len = -1;             // longest resident record (reference span), -1 = not known: the fused scan needs it <= one tile
+    int fold_dense = 0;               // mirp_set_fold_split_path: 1 = dense multiloop splits for every window
+    unsigned int last_dense = 0;      // windows of the last fold the candidate-pool pass handed to the dense fill kernel
     int cov_mode = -1;                // mirp_set_coverage_path: -1 = by record density, 0 = atomic scatter, 1 = fused scan (where the input allows it)
     bool cov_fused = false;           // the last run_coverage took the fused path (nothing to clear afterwards)
     void* diff_clean_ptr = nullptr;   // the difference arrays at this address are all zero (run_coverage / clean_coverage)

@@ -51,7 +51,7 @@ int fold_lds_max_span();
 hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi, const FoldParams* P, const unsigned char* seqs, const long long* offs, const int* lens,
                            int n_work, int win_base, int span, short* slabs, size_t slab_shorts, int* win_state, unsigned int* work_counter, int* fallback_list,
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
-                           int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between = nullptr);
+                           int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between, int* dense_list, int force_dense);
 
 // fold_lds2_kernel.hip: fill kernel of the default model, two diagonals per barrier interval
 size_t fold_lds2_bytes();

@@ -646,6 +646,13 @@ extern "C" int mirp_last_fold_kernel_ms(mirp_ctx* c, double ms[2]) {
 extern "C" int64_t mirp_last_fold_fallbacks(mirp_ctx* c) { return c ? (int64_t)c->last_fallback : -1; }
 extern "C" int64_t mirp_last_fold_overflow(mirp_ctx* c) { return c ? (int64_t)c->n_side : -1; }
 extern "C" int mirp_last_coverage_fused(mirp_ctx* c) { return c ? (c->cov_fused ? 1 : 0) : -1; }
+extern "C" int mirp_set_fold_split_path(mirp_ctx* c, int32_t mode) {
+    if (!c) return -1;
+    if (mode < 0 || mode > 1) return fail(c, -1, "mirp_set_fold_split_path: mode is 0 (split candidates) or 1 (dense splits)");
+    c->fold_dense = mode;
+    return 0;
+}
+extern "C" int64_t mirp_last_fold_dense(mirp_ctx* c) { return c ? (int64_t)c->last_dense : -1; }
 extern "C" int mirp_set_coverage_path(mirp_ctx* c, int32_t mode) {
     if (!c) return -1;
     if (mode < -1 || mode > 1) return fail(c, -1, "mirp_set_coverage_path: mode is -1 (by record density), 0 (atomic scatter) or 1 (fused scan)");
