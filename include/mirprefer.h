@@ -223,7 +223,7 @@ int mirp_last_coverage_fused(mirp_ctx* ctx);
 /* Pins the coverage path of the following mirp_candidate / mirp_get_depth calls: -1 = picked by record density (default), 0 = atomic scatter,
  * 1 = fused scan whenever the input allows it (no coverage segments, no record longer than a scan tile).  For tests and measurements. */
 int mirp_set_coverage_path(mirp_ctx* ctx, int32_t mode);
-/* Pins how the fill kernel of the following folds (default model) relaxes the multiloop splits: 0 = over split candidates (default; a window whose
+/* Pins how the fill kernel of the following folds relaxes the multiloop splits: 0 = over split candidates (default; a window whose
  * candidate pool overflows is folded by the dense kernel), 1 = the dense loop for every window.  The tables, and therefore every output, are
  * identical either way (RNALfold's DML minimum, /root/reference/miR_PREFeR.py:3053); for tests and measurements. */
 int mirp_set_fold_split_path(mirp_ctx* ctx, int32_t mode);

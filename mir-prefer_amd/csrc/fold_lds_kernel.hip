@@ -47,7 +47,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     const int* __restrict__ todo_list, const unsigned int* __restrict__ todo_count, int* __restrict__ dense_list, unsigned int* __restrict__ dense_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr LdsLayout LY = lds_layout<MODEL, SPARSE>();
-    static_assert(!(MODEL && SPARSE), "sparse splits: default model only");
     // phase ablation flags and phase clocks exist in the diagnostics build only (make DIAG=1); the product kernel carries none of that code
 #ifdef MIRP_DIAG
     const int dbg_flags = dbg_flags_arg;
@@ -233,8 +232,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             // (waves 0-5 own phase B).
             auto splits_sparse = [&]() {
                 const int lim = sp_snap;
-                { const int pn = __builtin_amdgcn_readfirstlane(((volatile int*)misc)[3]); sp_snap = pn < pool_cap ? pn : pool_cap; }
-                if (dbg_flags & 2) return;
+                const int pnv = ((volatile int*)misc)[3];      // issued here, looked at behind the loop: no LDS round trip in front of it
+                if (!(dbg_flags & 2))
                 for (int k = (LNW - 1 - wave) * 64 + lane; k < lim; k += LNT) {
                     const unsigned ea = poolA[k];
                     const unsigned vb = poolB[k];
@@ -245,6 +244,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const unsigned sum = (unsigned)fml[ok ? o : 1] + vb;
                     if (ok && sum < 65535u) atomicMin(&mdec[i], (int)sum - 2 * FML_BIAS);
                 }
+                { const int pn = __builtin_amdgcn_readfirstlane(pnv); sp_snap = pn < pool_cap ? pn : pool_cap; }
             };
             auto splits_dense = [&]() {
                 const int npair = (ncell + 1) >> 1;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             };
             // Half of the waves run the splits before the interior loops: the split loop loads the LDS pipe much more than the interior loops do,
             // so the two halves even out the LDS load of the interval (the phases are independent: both only feed phase B of this diagonal).
-            const bool swap_order = (wave & 1) && !(dbg_flags & 2048);
+            const bool swap_order = !SPARSE && (wave & 1) && !(dbg_flags & 2048);      // (the sparse splits are too short to matter: measured 0.5 ms better behind the interior loops)
             auto splits = [&]() { if constexpr (SPARSE) splits_sparse(); else splits_dense(); };
             if (swap_order) splits();
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) wt = clock64();
@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         auto phaseB = [&](const int d) {
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
-            int* mdec = acc + (3 + (d & 1)) * LCAP;
+            int* mdec = mdec_of(d);
+            int cand = 0; unsigned cent = 0, cval = 0;      // sparse splits: this cell as a split candidate
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             const int od = tri_off(d, n), od1 = tri_off(d - 1, n);     // scalar arithmetic instead of a table read on the cell's dependency chain
             const int x = tid;
@@ -549,7 +550,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int i = x + 1, j = i + d;
                 const int type = (MODEL && d > D) ? 0 : pair_type(S[i], S[j]);
                 int cv = INF;
-                const int md = mdec[i];
+                int md = mdec[i];
+                if constexpr (SPARSE) { md = dml_carry < md ? dml_carry : md; dml_carry = md; }      // DML(i,j) = min(DML(i,j-1), candidate splits)
                 int tb = 0;          // trace-back code: 0 = hairpin / multiloop / unpaired, else 1 + (n1 << 5 | n2) of the interior loop the backtrack takes
                 if (type) {
                     const unsigned kk = ckey[i];
@@ -597,6 +599,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     a = a == 65535 ? INF : a - FML_BIAS; b = b == 65535 ? INF : b - FML_BIAS;
                     m = a < b ? a : b;
                 }
+                const int mab = m;
                 if (MODEL) {
                     // fML pair terms, dangles 1: (i,j) plain, (i+1,j) with a 5' dangle, (i,j-1) with a 3' dangle, (i+1,j-1) with both.  Plain c of the
                     // neighbouring cells comes out of the G0 ring (G0 = c + mismatchI of the pair seen as an inner pair).
@@ -620,6 +623,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 } else if (type) {
                     int e = cv + lds_mlstem(T, P, type, i > 1 ? (int)S[i - 1] : -1, j < n ? (int)S[j + 1] : -1); m = e < m ? e : m;
                 }
+                if constexpr (SPARSE) cand = m < mab && m < md;      // fML(i,j) strictly realised by a pair term: a split candidate of column j
                 m = md < m ? md : m;
                 if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
                     (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
@@ -635,7 +639,21 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 tb_out[abase + 8 * d] = (unsigned short)tb;
                 fml[od + i] = m16;
                 dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
-                ckey[i] = KEY_NONE; mdec[i] = INF;
+                ckey[i] = KEY_NONE;
+                if constexpr (SPARSE) { mdec_of(d + 2)[i] = INF; cval = m16; cent = (unsigned)(i - 1) | ((unsigned)j << 9); }
+                else mdec[i] = INF;
+            }
+            if constexpr (SPARSE) {
+                const unsigned long long cbal = __ballot(cand != 0);
+                if (cbal) {      // wave-uniform
+                    int cbase = 0;
+                    if (lane == (int)__builtin_ctzll(cbal)) cbase = atomicAdd(&misc[3], (int)__popcll(cbal));
+                    const int at = __builtin_amdgcn_readlane(cbase, (int)__builtin_ctzll(cbal)) + (int)__popcll(cbal & ((1ull << lane) - 1ull));
+                    if (cand) {
+                        if (at < pool_cap) { poolA[at] = cent; poolB[at] = (unsigned short)cval; }
+                        else misc[2] = 1;
+                    }
+                }
             }
             const int lb = __builtin_amdgcn_readfirstlane(lbase);      // lane 0 holds the claimed range
             if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)(x + 1) | ((unsigned)lt << 9) | (ENT_OUTER((int)T.mismatchI[loi], (int)T.mismatch1nI[loi]) << 12));
@@ -1026,17 +1044,36 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
                            unsigned int* fallback_count, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe,
                            int* out_status, int dbg_flags, long long* dbg_cycles, hipEvent_t ev_between, int* dense_list, int force_dense) {
     const size_t lds = model ? lds_layout<1>().total : lds_layout<0>().total;
-    const size_t lds_sp = lds_layout<0, true>().total;
+    const size_t lds_sp = lds_layout<0, true>().total, lds_sp1 = lds_layout<1, true>().total;
     hipError_t e = hipFuncSetAttribute((const void*)fold_lds_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout<1>().total);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fold_lds_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout<0>().total);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fold_lds_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fold_lds_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layout<1, true>().total);
     if (e != hipSuccess) return e;
     const int* no_list = nullptr; const unsigned int* no_count = nullptr;
-    if (model)
-        hipLaunchKernelGGL((fold_lds_kernel<1, false>), dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
-                           fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
-                           no_list, no_count, dense_list, work_counter + 3);
-    else {
+    if (model) {
+        // The vienna-1.8.5 model stays on the dense split loop: with dangles 1 every pair gives up to four strictly pair-realised fML cells ((i,j),
+        // (i-1,j), (i,j+1), (i-1,j+1)), i.e. about four times the candidates, and the pool behind a 325-nt window's triangle (2,560 entries) overflows
+        // for most windows (measured: 161 ms = both passes).  MIRP_SPARSE185 (dev builds) runs the candidate-pool pass anyway.
+#ifdef MIRP_SPARSE185
+        const bool sparse185 = !force_dense;
+#else
+        const bool sparse185 = false;
+#endif
+        if (sparse185) {      // as the default model below: candidate-pool pass, then the dense instantiation over what it handed over
+            hipLaunchKernelGGL((fold_lds_kernel<1, true>), dim3(grid), dim3(LNT), lds_sp1, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                               fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                               no_list, no_count, dense_list, work_counter + 3);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fold_lds_kernel<1, false>), dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter + 2,
+                               fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                               (const int*)dense_list, (const unsigned int*)(work_counter + 3), dense_list, work_counter + 3);
+        } else
+            hipLaunchKernelGGL((fold_lds_kernel<1, false>), dim3(grid), dim3(LNT), lds, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
+                               fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,
+                               no_list, no_count, dense_list, work_counter + 3);
+    } else {
 #if !defined(MIRP_FILL2)
         // product: first pass with sparse multiloop splits (candidate pool), then the dense instantiation over the windows the first pass handed over
         // (pool overflow, no room for a pool: zero on the benchmark inputs; the launch then finds an empty list).  force_dense (tests, A/B timing): the
