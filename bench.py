@@ -20,8 +20,9 @@ holds a single HIP runtime; every C-ABI call returns after its stream has draine
 
 The JSON line carries, beside the contract's keys:
   roofline       the dominant kernel (fold_lds_kernel, the dynamic program) against the roof that bounds it -- integer min-plus relaxations
-                 out of LDS: `peak` is the measured conflict-free ds_read_b32 rate of this GPU (mirp_microbench), `peak_guide` the figure of
-                 MI355X_MICROARCH.md (75 TB/s of ds_read_b32 = 9.4e12 relaxations/s at 8 B per relaxation), fractions against both;
+                 out of LDS: `peak` is the figure of MI355X_MICROARCH.md (75 TB/s of ds_read_b32 = 9.4e12 relaxations/s at 8 B per relaxation) and
+                 `frac` the fraction of it; `peak_measured` / `frac_measured` use the conflict-free ds_read_b32 / VALU rates micro-benchmarked on this
+                 GPU (mirp_microbench); `pipe_busy` = LDS / VALU / SALU busy fractions from the committed PMC passes;
   roofline_hbm   the HBM view north_star asks for (algorithmic bytes / measured time / 8 TB/s), expected << 1 for an LDS-resident DP;
   roofline_coverage  the one HBM-bound stage on the headline workload (sparse input: atomic scatter + scan + clearing of the written positions);
                  configs.coverage_config4_shard = the same stage at a config[4] rank shard's size, where the fused scan runs (tiles built from the
@@ -47,6 +48,10 @@ CUT, GAP, L = 10, 100, 300
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LDS_GUIDE_RELAX_PER_S = 75e12 / 8.0      # MI355X_MICROARCH.md (LDS): ~75 TB/s aggregate for ds_read_b32; one relaxation = two 4-byte reads
 LOCI_PER_BP = N_LOCI / float(CHR1_LEN)   # every workload plants loci at the density of the headline one
+# Result sizes of the seeded workloads, per (workload, fold model): the number of miRNA loci the whole path reports.  tests/test_whole_workload_gpu.py
+# pins the config1 / vienna-2.1.2 list record by record on the CPU oracle; the bench refuses to print a throughput whose result list has another size
+# (a silent filter or fold regression must not produce a headline number).
+EXPECTED_LOCI = {("config1", "vienna-2.1.2"): 4002, ("config1", "vienna-1.8.5"): 3973, ("config2", "vienna-2.1.2"): 16016}
 TAIR10 = [30427671, 19698289, 23459830, 18585056, 26975502]
 MSU7 = [43300000, 35900000, 36400000, 35500000, 30000000, 31200000, 29700000, 28400000, 23000000, 23200000, 29000000, 27500000]
 
@@ -117,6 +122,8 @@ def parse_args():
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--ingest-records", type=int, default=8000000,
                     help="records of the synthetic SAM of the ingest leg (a cfg[4] rank shard is 25,000,000; the default keeps the run short)")
+    ap.add_argument("--allow-gloo", action="store_true", help="--gpus N: if the RCCL communicator does not come up, gather the loci lists as host objects over "
+                    "gloo and still print a line (marked in config.exchange); without this flag the run exits non-zero instead")
     ap.add_argument("--fold-model", default="vienna-2.1.2", choices=["vienna-2.1.2", "vienna-1.8.5"],
                     help="RNALfold flavour to reproduce (the headline metric is quoted on the default, Turner-2004)")
     return ap.parse_args()
@@ -454,7 +461,12 @@ def main():
             rccl_error = bad[0]
             if why is None:
                 ctx.dist_finalize()
-            sys.stderr.write("[bench] RCCL communicator not available (%s): loci lists go over the gloo host group\n" % rccl_error)
+            if not a.allow_gloo:      # a line produced over gloo would not be an RCCL number: refuse unless asked for
+                sys.stderr.write("[bench] RCCL communicator not available (%s); re-run with --allow-gloo to gather over the gloo host group instead\n" % rccl_error)
+                tdist.barrier()
+                tdist.destroy_process_group()
+                sys.exit(3)
+            sys.stderr.write("[bench] RCCL communicator not available (%s): loci lists go over the gloo host group (--allow-gloo)\n" % rccl_error)
     ctx.set_fold_model(a.fold_model)
 
     # ---- synthetic workload: every rank generates and holds only the contigs it owns
@@ -469,12 +481,12 @@ def main():
     ctx.load_genome(contigs)
     ctx.load_alignments(alns)
 
-    fb = [0, 0]
+    fb = [0, 0, 0]
 
     def step():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)
         ctx.fold(L)
-        fb[0], fb[1] = ctx.last_fold_fallbacks(), ctx.last_fold_overflow()
+        fb[0], fb[1], fb[2] = ctx.last_fold_fallbacks(), ctx.last_fold_overflow(), ctx.last_fold_dense()
         out = ctx.predict(n_samples, 18, 23, False, True)
         if world > 1 and rccl_error is None:          # the exchange step of the path: loci lists of all ranks on rank 0, over RCCL from the device-resident result
             g = ctx.gather_loci(0)
@@ -551,6 +563,12 @@ def main():
         except Exception:
             pass
         headline = a.workload == "config1" and a.genome == CHR1_LEN and a.loci == N_LOCI
+        loci_expected = EXPECTED_LOCI.get((a.workload, a.fold_model)) if (world == 1 and (headline or a.workload != "config1")) else None
+        if loci_expected is not None and int(nres) != loci_expected:
+            sys.stderr.write("[bench] RESULT CHECK FAILED: %d miRNA loci, expected %d for (%s, %s) -- no line printed\n" % (nres, loci_expected, a.workload, a.fold_model))
+            ctx.close()
+            sys.exit(4)
+        pipe = prof.get("fold_fill_pipe_busy") if (a.workload == "config1" and a.fold_model == "vienna-2.1.2") else None
         same_workload = headline and a.fold_model == "vienna-2.1.2"
         traffic = prof.get("fold_fill_hbm_bytes_per_launch") if same_workload else None
         g_tot = float(sum(len(sq) + 1 for _, sq in contigs))
@@ -568,15 +586,18 @@ def main():
                        "exchange": ("none (1 GPU)" if world == 1 else "mirp_gather_loci over the local transport (ranks share GPU 0: dev run)" if share_dir
                                     else "loci lists as host objects over gloo (RCCL communicator not available: %s)" % rccl_error if rccl_error
                                     else "mirp_gather_loci over RCCL (library-owned communicator), host objects over gloo")},
-            "roofline": {"kernel": "fold_lds_kernel<%d>" % (0 if a.fold_model == "vienna-2.1.2" else 1),
-                         "bound": "lds" if lds_roof <= valu_roof else "valu", "achieved": achieved / 1e12, "peak": roof / 1e12, "unit": "T relaxations/s",
-                         "frac": achieved / roof if roof > 0 else None, "peak_guide": LDS_GUIDE_RELAX_PER_S / 1e12,
-                         "frac_guide": achieved / LDS_GUIDE_RELAX_PER_S, "avg_launch_ms": fill_s * 1e3,
+            "roofline": {"kernel": "fold_lds_kernel<0, true>" if a.fold_model == "vienna-2.1.2" else "fold_lds_kernel<1, false>",
+                         "bound": "lds", "achieved": achieved / 1e12, "peak": LDS_GUIDE_RELAX_PER_S / 1e12, "unit": "T relaxations/s",
+                         "frac": achieved / LDS_GUIDE_RELAX_PER_S, "peak_measured": roof / 1e12, "frac_measured": achieved / roof if roof > 0 else None,
+                         "bound_measured": "lds" if lds_roof <= valu_roof else "valu", "avg_launch_ms": fill_s * 1e3, "pipe_busy": pipe,
+                         "windows_via_dense_split_pass": int(fb[2]),
                          "relaxations_per_launch": R, "lds_roof_T": lds_roof / 1e12, "valu_roof_T": valu_roof / 1e12, "microbench_wave_insts_per_s": mb,
                          "traffic": traffic, "traffic_source": prof.get("source") if traffic is not None else None,
-                         "note": "integer min-plus dynamic program out of LDS: bounded by LDS reads (2 per relaxation) or VALU issue (3 lane-ops per relaxation), "
-                                 "SURVEY.md 8d; peak = roofs micro-benchmarked on this GPU in this run, peak_guide = 75 TB/s of ds_read_b32 (MI355X_MICROARCH.md) / 8 B; "
-                                 "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes"},
+                         "note": "integer min-plus dynamic program out of LDS, SURVEY.md 8d: achieved = ALGORITHMIC relaxations of the batch (the dense count "
+                                 "R_ml + R_int + R_f3 from its pair-type counts; since round 4 the kernel relaxes the multiloop splits over split candidates only "
+                                 "and executes ~2.5 % of R_ml) / the fill kernel's time; peak = 75 TB/s of ds_read_b32 (MI355X_MICROARCH.md) / 8 B per relaxation; "
+                                 "peak_measured = min(LDS, VALU) roofs micro-benchmarked on this GPU in this run; pipe_busy = busy fractions of the LDS array, the "
+                                 "vector and the scalar issue ports from the committed rocprofv3 PMC passes (profiles/CURRENT.json); traffic = HBM bytes per launch from the same"},
             "roofline_hbm": {"kernel": "fold_lds_kernel + fold_lds_epilogue_kernel", "bound": "hbm", "achieved": b_fold / fold_s / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": b_fold / fold_s / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": fold_s * 1e3,
                              "note": "HBM view of the fold (algorithmic bytes / time / 8 TB/s); << 1 is expected: the tables are LDS-resident"},

@@ -1,0 +1,184 @@
+"""Whole-workload parity on the headline configuration (BASELINE config[1], the workload bench.py's number is quoted on): EVERY window's printed
+structure lines and MFE, and the complete result list, against the CPU oracle -- the reference's analogue is simply its full run
+(/root/reference/miR_PREFeR.py:3728-3739).  The oracle folds in a process pool (one worker per CPU the box grants), 19,686 windows take
+well under a minute.  Also: a 5,000-window slice of the same workload under the vienna-1.8.5 model, 5,000 folds of the five stress families
+(mixed, tandem repeats, two-letter alphabets, near-perfect long hairpins, N-rich; profiles/tools/stress_fold.py) and the two split paths of the
+fill kernel (split candidates / dense loop) against each other."""
+import concurrent.futures as cf
+import os
+import random
+
+import numpy as np
+import pytest
+
+from mir_prefer_amd import records, synth
+from tests import seqgen
+from tests.test_oracle_golden import mirna_record, run_predict
+
+pytestmark = pytest.mark.gpu
+
+G, N_LOCI, SEED, CUT, GAP, L = 30427671, 12000, 2, 10, 100, 300
+# expected sizes of the seeded workload (bench.py asserts the same numbers, see EXPECTED_LOCI there)
+N_WINDOWS = 19686
+
+
+def _ncpu():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def _oracle_chunk(args):
+    seqs, span, model = args
+    from tests import oracle_binding
+    o = oracle_binding.load()
+    out = []
+    for s in seqs:
+        r = o.lfold(s, span, model=model)
+        out.append((r["lines"], r["mfe"]))
+    return out
+
+
+def oracle_fold_all(seqs, span, model="vienna-2.1.2"):
+    """[(lines, mfe)] of the CPU oracle for every sequence, folded in a spawned process pool (the parent holds a GPU context)."""
+    import multiprocessing as mp
+    n = len(seqs)
+    step = 64
+    tasks = [(seqs[k:k + step], span, model) for k in range(0, n, step)]
+    out = []
+    with cf.ProcessPoolExecutor(_ncpu(), mp_context=mp.get_context("spawn")) as ex:
+        for part in ex.map(_oracle_chunk, tasks):
+            out.extend(part)
+    return out
+
+
+def gpu_lines(raw, k):
+    from mir_prefer_amd import capi
+    wl, wss = capi.fold_window_lines(raw, k)
+    nl = int(raw["n_lines"][k])
+    sel = np.nonzero(wl["printed"][:nl])[0]
+    return [(wss[j, :wl[j]["len"]].tobytes().decode(), int(wl[j]["energy"]), int(wl[j]["start"])) for j in sel]
+
+
+@pytest.fixture(scope="module")
+def config1(oracle):
+    ds = synth.make_dataset([G], N_LOCI, n_samples=1, seed=SEED, contig_names=["Chr1"])
+    alns = ds.sorted_alns()
+    _, peaks = oracle.coverage_peaks(alns, ds.contig_lens, CUT)
+    win = oracle.make_windows(peaks, alns, ds.contigs, np.zeros(1, np.int32), GAP, L, CUT * 0.5)
+    seqs = [win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes() for b in win["windows"]]
+    return {"ds": ds, "alns": alns, "win": win, "seqs": seqs}
+
+
+def test_config1_every_window_and_the_result_list(gpu_ctx, oracle, config1):
+    ds, alns, win, seqs = config1["ds"], config1["alns"], config1["win"], config1["seqs"]
+    gpu_ctx.set_fold_model("vienna-2.1.2")
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(CUT, GAP, L, np.zeros(1, np.int32))
+    assert nwin == len(win["windows"]) == N_WINDOWS
+    gw = gpu_ctx.get_windows()
+    GW, OW = gw["windows"], win["windows"]
+    for f in ("tid", "ws", "we", "strand", "loc_s", "loc_e", "tag", "n_peaks", "n_matures", "seq_len"):      # (the offsets index each side's own arrays)
+        assert np.array_equal(GW[f], OW[f]), f
+    for k in range(nwin):
+        a, b = GW[k], OW[k]
+        assert np.array_equal(gw["matures"][a["mature_off"]:a["mature_off"] + a["n_matures"]], win["matures"][b["mature_off"]:b["mature_off"] + b["n_matures"]]), k
+        assert np.array_equal(gw["wpeaks"][a["peak_off"]:a["peak_off"] + a["n_peaks"]], win["wpeaks"][b["peak_off"]:b["peak_off"] + b["n_peaks"]]), k
+        assert gw["seq"][a["seq_off"]:a["seq_off"] + a["seq_len"]].tobytes() == seqs[k], k
+    gpu_ctx.fold(L)
+    assert gpu_ctx.last_fold_fallbacks() == 0 and gpu_ctx.last_fold_dense() == 0      # every window through the candidate-pool fill kernel
+    raw = gpu_ctx.get_fold()
+    assert (raw["status"] == 0).all()
+    want = oracle_fold_all(seqs, L)
+    bad = [k for k in range(nwin) if raw["mfe"][k] != want[k][1] or gpu_lines(raw, k) != want[k][0]]
+    assert not bad, "windows whose structure lines / MFE differ from the oracle: %s" % bad[:10]
+    # the complete result list (filter_next_loci + check_loci over every window, MP:2350-2502)
+    out = gpu_ctx.predict(1, 18, 23, False, True)
+    assert (out["status"] == 0).all()
+    structs = [oracle.structures_from_lines(w[0], 55) for w in want]
+    case = {"cfg": {"MIN_MATURE_LEN": 18, "MAX_MATURE_LEN": 23, "ALLOW_3NT_OVERHANG": "N", "ALLOW_NO_STAR_EXPRESSION": "Y"}, "win": win,
+            "sample_names": ds.sample_names, "alns": alns}
+    decisions, result = run_predict(case, oracle, structs)
+    names = ds.contig_names
+    got = [[names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
+            records.STRAND[m["strand"]], bool(m["has_star"])] for m, ss in zip(out["result"], out["ss"])]
+    exp = [mirna_record(m, names) for _, m in result]
+    assert len(got) == len(exp)
+    assert got == exp
+    assert [int(m["window"]) for m in out["result"]] == [k for k, _ in result]
+    import bench
+    assert len(got) == bench.EXPECTED_LOCI[("config1", "vienna-2.1.2")]
+
+
+def test_config1_slice_vienna185_and_dense_split_path(gpu_ctx, config1):
+    """5,000 windows of the headline workload under the vienna-1.8.5 model against its oracle; the same slice through the default model's dense
+    split loop must reproduce the candidate-pool pass bit for bit (the first test pins that one on the oracle)."""
+    seqs = config1["seqs"][3000:8000]
+    try:
+        gpu_ctx.set_fold_model("vienna-1.8.5")
+        raw = gpu_ctx.fold_batch_raw(seqs, L)
+        assert (raw["status"] == 0).all()
+        want = oracle_fold_all(seqs, L, "vienna-1.8.5")
+        bad = [k for k in range(len(seqs)) if raw["mfe"][k] != want[k][1] or gpu_lines(raw, k) != want[k][0]]
+        assert not bad, bad[:10]
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
+    a = gpu_ctx.fold_batch_raw(seqs, L)
+    assert gpu_ctx.last_fold_dense() == 0
+    try:
+        gpu_ctx.set_fold_split_path(1)
+        b = gpu_ctx.fold_batch_raw(seqs, L)
+    finally:
+        gpu_ctx.set_fold_split_path(0)
+    for key in ("n_lines", "mfe", "status", "lines", "ss"):
+        assert np.array_equal(a[key], b[key]), key
+
+
+def _family(r, k):
+    n = r.randint(40, 350)
+    if k == 0:
+        return seqgen.window(r, 60, 350)
+    if k == 1:      # short tandem repeats
+        unit = "".join(r.choice("ACGU") for _ in range(r.randint(1, 7)))
+        return (unit * (n // len(unit) + 1))[:n]
+    if k == 2:      # two-letter alphabets
+        ab = r.choice(["GC", "AU", "GU", "ACG", "AGU"])
+        return "".join(r.choice(ab) for _ in range(n))
+    if k == 3:      # perfect / near-perfect long hairpins
+        arm = r.randint(20, 160)
+        a = "".join(r.choice("ACGU") for _ in range(arm))
+        rc = {"A": "U", "C": "G", "G": "C", "U": "A"}
+        b = [rc[c] for c in reversed(a)]
+        for _ in range(r.randint(0, 6)):
+            b[r.randrange(arm)] = r.choice("ACGU")
+        return (a + "".join(r.choice("ACGU") for _ in range(r.randint(3, 12))) + "".join(b))[:350]
+    return "".join(r.choice("ACGUN") if r.random() < 0.3 else r.choice("ACGU") for _ in range(n))      # N-rich
+
+
+@pytest.mark.parametrize("model,count", [("vienna-2.1.2", 5000), ("vienna-1.8.5", 1500)])
+def test_stress_families(gpu_ctx, model, count):
+    """The five sequence families of the differential stress (energy ties, tandem repeats whose split-candidate pools overflow into the dense
+    kernel, long hairpins, N runs), every line and MFE against the oracle."""
+    r = random.Random(20261003)
+    seqs = [_family(r, i % 5) for i in range(count)]
+    try:
+        gpu_ctx.set_fold_model(model)
+        got = gpu_ctx.fold_batch(seqs, L)
+        n_dense = gpu_ctx.last_fold_dense()
+        capped = [k for k, g in enumerate(got) if g["status"] == 1]      # more than 96 lines: folded again at full capacity, as the host does
+        if capped:
+            for k, g in zip(capped, gpu_ctx.fold_batch([seqs[k] for k in capped], L, max_lines=352)):
+                got[k] = g
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
+    if model == "vienna-2.1.2":
+        assert n_dense > 0      # the tandem-repeat family reaches the overflow pass
+    want = oracle_fold_all(seqs, L, model)
+    bad = [k for k in range(count) if got[k]["status"] != 0 or got[k]["mfe"] != want[k][1] or got[k]["lines"] != want[k][0]]
+    assert not bad, [seqs[k] for k in bad[:3]]
