@@ -100,6 +100,19 @@ int local_exchange(mirp_ctx* c, const std::vector<std::pair<const void*, long lo
         if (r_ != ncclSuccess) return fail((c), -7, std::string(#call) + ": " + g_rccl.GetErrorString(r_));                  \
     } while (0)
 
+// Inside an ncclGroupStart / ncclGroupEnd section an error must not return before the group is closed: an open group would silently queue every
+// later collective of this thread.  GROUPOP records the first failure and skips the remaining operations; group_end() closes the group and reports.
+#define GROUPOP(call)                                                                                                         \
+    do {                                                                                                                      \
+        if (g_first == ncclSuccess) { g_first = (call); if (g_first != ncclSuccess) g_what = #call; }                         \
+    } while (0)
+static int group_end(mirp_ctx* c, ncclResult_t g_first, const char* g_what) {
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (g_first != ncclSuccess) return fail(c, -7, std::string(g_what) + ": " + g_rccl.GetErrorString(g_first));
+    if (e != ncclSuccess) return fail(c, -7, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(e));
+    return 0;
+}
+
 extern "C" int mirp_dist_unique_id(uint8_t* id) {
     if (!id) return -1;
     static_assert(MIRP_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
@@ -203,16 +216,17 @@ int dist_gatherv_bytes(mirp_ctx* c, const void* d_src, long long mine, int dst, 
     }
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(c, g_rccl.GroupStart());
+    ncclResult_t g_first = ncclSuccess; const char* g_what = "";
     if (c->dist_rank == dst) {
         long long off = 0;
         for (int r = 0; r < c->dist_world; r++) {
-            if (r != dst && counts[r]) NCCLCHK(c, g_rccl.Recv((char*)d_dst + off, (size_t)counts[r], ncclUint8, r, comm, c->stream));
+            if (r != dst && counts[r]) GROUPOP(g_rccl.Recv((char*)d_dst + off, (size_t)counts[r], ncclUint8, r, comm, c->stream));
             off += counts[r];
         }
     } else if (mine) {
-        NCCLCHK(c, g_rccl.Send(d_src, (size_t)mine, ncclUint8, dst, comm, c->stream));
+        GROUPOP(g_rccl.Send(d_src, (size_t)mine, ncclUint8, dst, comm, c->stream));
     }
-    NCCLCHK(c, g_rccl.GroupEnd());
+    if (int rc = group_end(c, g_first, g_what)) return rc;
     if (c->dist_rank == dst && mine) {
         long long off = 0;
         for (int r = 0; r < dst; r++) off += counts[r];
@@ -248,12 +262,13 @@ int dist_alltoallv_bytes(mirp_ctx* c, const void* d_send, const std::vector<long
     }
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(c, g_rccl.GroupStart());
+    ncclResult_t g_first = ncclSuccess; const char* g_what = "";
     for (int r = 0; r < W; r++) {
         if (r == me) continue;
-        if (send_cnt[r]) NCCLCHK(c, g_rccl.Send((const char*)d_send + send_off[r], (size_t)send_cnt[r], ncclUint8, r, comm, c->stream));
-        if (recv_cnt[r]) NCCLCHK(c, g_rccl.Recv((char*)d_recv + recv_off[r], (size_t)recv_cnt[r], ncclUint8, r, comm, c->stream));
+        if (send_cnt[r]) GROUPOP(g_rccl.Send((const char*)d_send + send_off[r], (size_t)send_cnt[r], ncclUint8, r, comm, c->stream));
+        if (recv_cnt[r]) GROUPOP(g_rccl.Recv((char*)d_recv + recv_off[r], (size_t)recv_cnt[r], ncclUint8, r, comm, c->stream));
     }
-    NCCLCHK(c, g_rccl.GroupEnd());
+    if (int rc = group_end(c, g_first, g_what)) return rc;
     if (send_cnt[me]) HIPCHK(c, hipMemcpyAsync((char*)d_recv + recv_off[me], (const char*)d_send + send_off[me], (size_t)send_cnt[me], hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
@@ -302,8 +317,9 @@ extern "C" int mirp_gather_records(mirp_ctx* c, const void* rec, int64_t n, int3
     if (c->dist_rank == dst) {
         void* h = std::malloc((size_t)std::max<long long>(total, 1));
         if (!h) return fail(c, -6, "host allocation failed (gather)");
-        if (total) HIPCHK(c, hipMemcpyAsync(h, d_dst, (size_t)total, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipError_t he = total ? hipMemcpyAsync(h, d_dst, (size_t)total, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { std::free(h); return fail(c, -2, std::string("mirp_gather_records: ") + hipGetErrorString(he)); }
         *out = h; *n_out = total / rec_bytes;
     } else {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -340,11 +356,13 @@ extern "C" int mirp_gather_loci(mirp_ctx* c, int32_t dst, MirpMirna** result, in
         MirpMirna* hr = (MirpMirna*)std::calloc((size_t)std::max<long long>(total, 1), sizeof(MirpMirna));
         char* ht = (char*)std::calloc((size_t)std::max<long long>(total, 1), (size_t)c->fold_stride);
         if (!hr || !ht) { std::free(hr); std::free(ht); return fail(c, -6, "host allocation failed (gather)"); }
+        hipError_t he = hipSuccess;
         if (total) {
-            HIPCHK(c, hipMemcpyAsync(hr, d_rec, (size_t)total * sizeof(MirpMirna), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(ht, d_txt, (size_t)total * c->fold_stride, hipMemcpyDeviceToHost, c->stream));
+            he = hipMemcpyAsync(hr, d_rec, (size_t)total * sizeof(MirpMirna), hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(ht, d_txt, (size_t)total * c->fold_stride, hipMemcpyDeviceToHost, c->stream);
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) { std::free(hr); std::free(ht); return fail(c, -2, std::string("mirp_gather_loci: ") + hipGetErrorString(he)); }
         *result = hr; *n_result = total; *ss_text = ht;
     } else {
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -405,7 +405,10 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
     if (!bad && W > 1)
         for (int t = 0; t < nc && !bad; t++)
             if (owner_of_tid[t] < 0 || owner_of_tid[t] >= W) { bad = 1; err = std::string(who) + ": owner_of_tid out of range"; }
-    // a record past the end of its contig would overflow the position bits of the sort key (and the reference's samtools rejects it)
+    // A record past the end of its contig would overflow the position bits of the sort key.  Refused on both ingest paths (here and in
+    // mir-prefer_amd/ingest.py) -- a documented deviation: probed in round 4, the bundled samtools 0.1.18 ACCEPTS such a record (view -bS, sort, index,
+    // depth all succeed and print positions beyond LN), so the reference runs on with peaks outside the contig; this build stops with a message
+    // instead of reproducing that (waived behaviours).
     if (!bad)
         for (auto& f : P.per_file)
             for (auto& ch : f)
@@ -477,7 +480,11 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         for (int q = 0; q < W; q++) { soff[q] = stot; scnt[q] = blob_bytes(me, q); stot += (scnt[q] + 15) & ~15LL; }
         for (int s2 = 0; s2 < W; s2++) { roff[s2] = rtot; rcnt[s2] = blob_bytes(s2, me); rtot += (rcnt[s2] + 15) & ~15LL; }
         for (int s2 = 0; s2 < W; s2++) for (int f = 0; f < F; f++) { n += nrec(s2, f, me); ns += nseg(s2, f, me); }
-        if (n > 0x7fffffffLL) return fail(c, -5, std::string(who) + ": more than 2^31 records on one rank");
+        // Everything that can fail on ONE rank between the count exchange above and the all-to-all below (record limit, allocations, the upload) is
+        // collected in prep_rc instead of returning: the ranks agree on the outcome first, so that no rank leaves while its peers sit in the grouped
+        // ncclSend / ncclRecv of the exchange (which has no timeout).
+        int prep_rc = 0;
+        if (n > 0x7fffffffLL) prep_rc = fail(c, -5, std::string(who) + ": more than 2^31 records on one rank");
         std::vector<char> sendbuf((size_t)std::max<long long>(stot, 16));
         for (int q = 0; q < W; q++) {
             char* w = sendbuf.data() + soff[q];
@@ -488,13 +495,27 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
         }
         brec.clear(); bseg.clear(); bown.clear(); bspan.clear();
         TmpDevice T;
-        char* d_send = (char*)T.get((size_t)stot + 16);
-        char* d_recv = (char*)T.get((size_t)rtot + 16);
-        if (!d_send || !d_recv) return fail(c, -6, "device allocation failed (ingest exchange)");
-        if (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
-            c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1)))
-            return fail(c, -6, "device allocation failed (ingest)");
-        if (stot) HIPCHK(c, hipMemcpyAsync(d_send, sendbuf.data(), (size_t)stot, hipMemcpyHostToDevice, c->stream));
+        char* d_send = nullptr; char* d_recv = nullptr;
+        if (!prep_rc) {
+            d_send = (char*)T.get((size_t)stot + 16);
+            d_recv = (char*)T.get((size_t)rtot + 16);
+            if (!d_send || !d_recv) prep_rc = fail(c, -6, "device allocation failed (ingest exchange)");
+        }
+        if (!prep_rc && (c->alns.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) || c->sort_tmp.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(n, 1)) ||
+                         c->segs.ensure(sizeof(MirpAln) * (size_t)std::max<long long>(ns, 1))))
+            prep_rc = fail(c, -6, "device allocation failed (ingest)");
+        if (!prep_rc && stot) {
+            hipError_t he = hipMemcpyAsync(d_send, sendbuf.data(), (size_t)stot, hipMemcpyHostToDevice, c->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+            if (he != hipSuccess) prep_rc = fail(c, -2, std::string(who) + ": upload of the exchange buffer failed: " + hipGetErrorString(he));
+        }
+        {   // the outcome is collective: one flag per rank, every rank returns an error if any rank has one
+            const long long flag = prep_rc ? 1 : 0;
+            std::vector<long long> flags;
+            if (int rc = mirp::dist_allgather_ll(c, &flag, 1, flags)) return prep_rc ? prep_rc : rc;
+            for (int r = 0; r < W; r++)
+                if (flags[(size_t)r]) return prep_rc ? prep_rc : fail(c, -7, std::string(who) + ": rank " + std::to_string(r) + " failed before the record exchange");
+        }
         if (int rc = mirp::dist_alltoallv_bytes(c, d_send, soff, scnt, d_recv, roff, rcnt)) return rc;
         // unpack into (file, source) order; segment owners are re-based to the record's index in this rank's array
         owner.resize(std::max<size_t>((size_t)ns, 1)); span.resize(std::max<size_t>((size_t)ns, 1));

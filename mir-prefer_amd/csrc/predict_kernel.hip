@@ -621,7 +621,8 @@ int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, 
     std::vector<MirpWindow> h_w((size_t)n_windows);
     if (hipMemcpy(h_w.data(), windows, sizeof(MirpWindow) * (size_t)n_windows, hipMemcpyDeviceToHost) != hipSuccess) { *err = "D2H failed"; return -2; }
     if (hipMalloc((void**)&guard.a, 4 * rw.size()) != hipSuccess || hipMalloc((void**)&guard.b, 4 * rw.size()) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
-    if (rpool && n1 > 0 && hipMalloc((void**)&guard.f, (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
+    // (not gated on the first pass's record count: a re-run round can write the first records of a window that the next round voids)
+    if (rpool && hipMalloc((void**)&guard.f, (size_t)n_windows) != hipSuccess) { *err = "device allocation failed (predict)"; return -6; }
     PredictCaps caps = predict_default_caps(max_lines, ss_stride);
     std::vector<int> h_need(3 * (size_t)n_windows);
     // A flagged window says what it needs (need[]), but what it says can be short of the truth: a line that was not staged contributed neither its
@@ -643,7 +644,7 @@ int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, 
         if (hipMemcpy(guard.a, rw.data(), 4 * rw.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(guard.b, rs.data(), 4 * rs.size(), hipMemcpyHostToDevice) != hipSuccess) {
             *err = "H2D failed"; return -2;
         }
-        if (rpool && n1 > 0) {          // records written so far for the windows of THIS round are void (truncated by a capacity)
+        if (rpool) {          // records written so far for the windows of THIS round are void (truncated by a capacity)
             std::vector<unsigned char> fl((size_t)n_windows, 0);
             for (int w : rw) fl[(size_t)w] = 1;
             if (hipMemcpy(guard.f, fl.data(), (size_t)n_windows, hipMemcpyHostToDevice) != hipSuccess) { *err = "H2D failed"; return -2; }

@@ -112,6 +112,8 @@ def read_sams(paths, native=True, regions=None, with_segments=False):
                 cigar = sp[5]
                 rl = len(sp[9])
                 rec = (tid_of[sp[2]], int(sp[3]), int(m.group(1)), rl, 1 if flag & 16 else 0, si)
+                if rec[1] > lens[rec[0]] + 1:      # same rule and message as the native tokenizer (mirp_ingest.cpp): refused on both ingest paths
+                    raise ValueError("alignment position %d is beyond the end of sequence %s (LN:%d)" % (rec[1], sp[2], lens[rec[0]]))
                 sp_ref = rl
                 if cigar != "%dM" % rl:
                     for sg in cigar_segments(rec, cigar):

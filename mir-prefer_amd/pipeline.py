@@ -344,10 +344,10 @@ class Pipeline:
                 except BaseException as e:          # surfaces in _join_candidate, on the main thread
                     self._cand_error = e
             self._cand_thread = threading.Thread(target=job)
-            self._cand_thread.start()
+            self._cand_thread.start()          # "Done (candidate stage)" is said by _join_candidate, once the artefacts and the checkpoint record exist
         else:
             self._candidate_artifacts(loci, psorted, w, depthname, fastaname, counts)
-        self._say("Done (candidate stage)\n")
+            self._say("Done (candidate stage)\n")
         self._barrier()
 
     def _join_candidate(self):
@@ -357,6 +357,7 @@ class Pipeline:
             self._cand_thread = None
             if self._cand_error is not None:
                 raise self._cand_error
+            self._say("Done (candidate stage)\n")
 
     def _candidate_artifacts(self, loci, psorted, w, depthname, fastaname, counts):
         names, prefix, r = self.data["names"], self.opt["NAME_PREFIX"], self.rank
@@ -431,6 +432,22 @@ class Pipeline:
 
     # ---- predict (MP:3498-3627): the loci list, gff3, fasta / ss / csv / html / stat / readmapping files
     def run_predict(self):
+        """Every way out of the stage -- normal return, sys.exit of an agreed failure, an exception -- first joins the native writer thread of the fold
+        text (mirp_write_fold_text_async) and the candidate stage's artefact thread: a detached writer racing the process exit would leave a
+        truncated <prefix>_rnalfoldoutput file."""
+        try:
+            return self._run_predict()
+        finally:
+            t = getattr(self, "_cand_thread", None)
+            if t is not None:
+                t.join()
+                self._cand_thread = None
+            try:
+                self.ctx.wait_text()
+            except Exception:
+                pass
+
+    def _run_predict(self):
         pending = getattr(self, "_pending_fold", None)
         if pending is None and not previous_stage_saved(self.recovername, "fold"):
             self._fail_stage()

@@ -12,6 +12,7 @@
  */
 #include "../../oracle/lfold.c"
 
+double g_colbp, g_rowbp, g_both; long g_maxcolbp;
 int main(int argc, char **argv) {
     int span = argc > 1 ? atoi(argv[1]) : 300;
     char line[4096];
@@ -40,16 +41,20 @@ int main(int argc, char **argv) {
         /* candidates */
         unsigned char *cand = (unsigned char *)calloc(cells, 1);
         int *dml = (int *)malloc(cells * sizeof(int));
-        long total = 0;
+        long total = 0; static double tot_colbp = 0, tot_rowbp = 0, tot_both = 0; static long maxcolbp = 0;
+        long colbp = 0, rowbp = 0, both = 0;
         for (int i = 1; i <= n; i++)
             for (int j = i + TURN + 1; j <= n && j <= i + span; j++) {
                 int v = mget(&F, i, j), d = DML(&F, i, j);
                 dml[IDX(&F, i, j)] = d;
                 int other = imin(imin(mget(&F, i + 1, j), mget(&F, i, j - 1)), d);
                 if (v < other && v < INF / 2) { cand[IDX(&F, i, j)] = 1; total++; }
+                { int up = mget(&F, i + 1, j), lf = mget(&F, i, j - 1); if (v < INF / 2) { if (v < up) colbp++; if (v < lf) rowbp++; if (v < up && v < lf) both++; } }
                 tot_cells++;
                 if (ptype(&F, i, j)) tot_paired++;
             }
+        tot_colbp += colbp; tot_rowbp += rowbp; tot_both += both; if (colbp > maxcolbp) maxcolbp = colbp;
+        if (feof(stdin) || 1) { extern double g_colbp, g_rowbp, g_both; extern long g_maxcolbp; g_colbp = tot_colbp; g_rowbp = tot_rowbp; g_both = tot_both; g_maxcolbp = maxcolbp; }
         tot_cand += total; if (total > maxtotal) maxtotal = total;
         long wmaxcol = 0;
         for (int j = 1; j <= n; j++) { long c = 0; for (int s = 1; s < j; s++) if (j - s <= span && j - s > TURN && cand[IDX(&F, s, j)]) c++; if (c > maxlist) maxlist = c; if (c > wmaxcol) wmaxcol = c; tot_cols++; }
@@ -80,6 +85,7 @@ int main(int argc, char **argv) {
     printf("windows %ld  mismatches %ld\n", nwin, mism);
     printf("cells/window %.0f  paired %.0f (%.3f)  candidates %.0f (%.4f of cells, %.3f of paired)  max per window %ld\n", tot_cells / nwin, tot_paired / nwin,
            tot_paired / tot_cells, tot_cand / nwin, tot_cand / tot_cells, tot_cand / tot_paired, maxtotal);
+    printf("column breakpoints (fML(i,j) < fML(i+1,j)) %.0f per window (max %ld), row breakpoints (< fML(i,j-1)) %.0f, both %.0f\n", g_colbp / nwin, g_maxcolbp, g_rowbp / nwin, g_both / nwin);
     printf("mean |Cand(j)| %.2f  max |Cand(j)| %ld\n", tot_cand / tot_cols, maxlist);
     printf("dense splits/window %.0f   sparse visits/window %.0f   ratio %.4f\n", tot_dense / nwin, tot_sparse / nwin, tot_sparse / tot_dense);
     printf("wave64 (max over lanes x 64): sparse %.0f  dense %.0f  ratio %.4f\n", tot_wave64 / nwin, tot_wave_dense / nwin, tot_wave64 / tot_wave_dense);
