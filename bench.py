@@ -483,21 +483,49 @@ def main():
 
     fb = [0, 0, 0]
 
+    from mir_prefer_amd import balance, records
+    moved = [0, 0]          # windows this rank shipped / received in the last step (window-level re-balancing, mir-prefer_amd/balance.py)
+
     def step():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)
+        imported = []
+        if world > 1:
+            # even out the window lists before the fold: whole contigs per rank leave the ranks uneven (config3: 1.23 x the mean on the fullest
+            # rank), windows are independent.  Every rank computes the same plan from the counts; the payloads go over the library's communicator.
+            counts = [None] * world
+            tdist.all_gather_object(counts, int(nwin))
+            if rccl_error is None:
+                xchg = ctx.exchange_bytes
+            else:
+                def xchg(blocks):
+                    box = [None] * world
+                    tdist.all_gather_object(box, blocks)
+                    return [b[rank] for b in box]
+            keep, imported, _ = balance.exchange(xchg, rank, world, ctx.get_windows, alns, counts)
+            moved[0], moved[1] = int(nwin) - keep, sum(len(p["windows"]) for p in imported)
+            if keep != nwin:
+                ctx.limit_windows(keep)
+            nwin = keep + moved[1]
         ctx.fold(L)
         fb[0], fb[1], fb[2] = ctx.last_fold_fallbacks(), ctx.last_fold_overflow(), ctx.last_fold_dense()
+        tm_own, km_own = ctx.last_timings(), ctx.last_fold_kernel_ms()
+        for p in imported:
+            balance.fold_imported(ctx, p, L)
         out = ctx.predict(n_samples, 18, 23, False, True)
+        imp = [balance.predict_imported(ctx, p, (n_samples, 18, 23, 0, 1, 55)) for p in imported]
         if world > 1 and rccl_error is None:          # the exchange step of the path: loci lists of all ranks on rank 0, over RCCL from the device-resident result
             g = ctx.gather_loci(0)
             total = len(g["result"])
+            extra = np.concatenate([x["result"] for x in imp]) if imp else np.zeros(0, dtype=records.MIRNA_DTYPE)      # loci of imported windows
+            ge = ctx.gather_records(extra.view(np.int32).reshape(len(extra), records.MIRNA_DTYPE.itemsize // 4))
+            total += 0 if ge is None else len(ge)
         elif world > 1:
             parts = [None] * world if rank == 0 else None
-            tdist.gather_object(np.ascontiguousarray(out["result"]), parts, dst=0)
+            tdist.gather_object(np.concatenate([out["result"]] + [x["result"] for x in imp]), parts, dst=0)
             total = sum(len(x) for x in parts) if rank == 0 else 0
         else:
             total = len(out["result"])
-        return nwin, total, ctx.last_timings(), ctx.last_fold_kernel_ms()
+        return nwin, total, tm_own if not imported else dict(tm_own, predict_ms=ctx.last_timings()["predict_ms"]), km_own
 
     def sync():
         # every C-ABI call above returns after its stream has drained; across ranks: a RCCL reduction on the library's communicator and the
@@ -523,11 +551,11 @@ def main():
     ranks = None
     if world > 1:
         box = [None] * world
-        tdist.all_gather_object(box, (elapsed, float(nwin), t_own, len(alns), len(owned)))
+        tdist.all_gather_object(box, (elapsed, float(nwin), t_own, len(alns), len(owned), moved[0], moved[1]))
         elapsed = max(x[0] for x in box)
         total_windows = sum(x[1] for x in box)
         ranks = {"own_ms_per_step": [1e3 * x[2] / a.steps for x in box], "windows": [int(x[1]) for x in box], "alignments": [int(x[3]) for x in box],
-                 "contigs": [int(x[4]) for x in box]}
+                 "contigs": [int(x[4]) for x in box], "windows_shipped": [int(x[5]) for x in box], "windows_received": [int(x[6]) for x in box]}
         ranks["max_over_mean_time"] = max(ranks["own_ms_per_step"]) / (sum(ranks["own_ms_per_step"]) / world)
     else:
         total_windows = float(nwin)

@@ -143,6 +143,12 @@ int mirp_load_coverage_segments(mirp_ctx* ctx, const MirpAln* segs, int64_t n_se
  * covered contig is preceded, in @SQ order, by a covered contig held by ANOTHER shard sets this to 1 so that its first run is double-counted
  * as in the single-file run; default 0 (the context holds the whole genome). */
 int mirp_set_contig_shard(mirp_ctx* ctx, int32_t preceded_by_coverage_elsewhere);
+/* Window-level re-balancing of a sharded run (the reference fans PIECES of the candidate list out to its worker processes, not contigs:
+ * /root/reference/miR_PREFeR.py:1329-1354, 2468-2480).  After mirp_candidate a rank that holds more windows than its share keeps the first
+ * n_keep of them -- mirp_fold, mirp_predict, mirp_get_windows, mirp_get_fold and the text writers then see only those -- and ships the rest
+ * to under-loaded ranks (host side: mir-prefer_amd/balance.py), which fold and filter them through mirp_fold_batch / mirp_predict_batch.
+ * n_keep must not cut an L/R window pair.  The next mirp_candidate restores the full list. */
+int mirp_limit_windows(mirp_ctx* ctx, int64_t n_keep);
 /* Replaces gen_contig_typeA + gen_candidate_region_typeA + dump_loci_seqs_and_alignment_multiprocess
  * (MP:877-962, 1246-1371, 1065-1244). contig_order = contig indices in the order sorted(dict_contigs) visits them (MP:1309). */
 int mirp_candidate(mirp_ctx* ctx, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks, int64_t* n_loci,
@@ -266,6 +272,10 @@ int mirp_dist_barrier(mirp_ctx* ctx);
 int mirp_gather_loci(mirp_ctx* ctx, int32_t dst, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride);
 /* The same gather for arbitrary fixed-size host records (per-rank counts may differ); out = NULL and n_out = 0 on ranks other than dst. */
 int mirp_gather_records(mirp_ctx* ctx, const void* rec, int64_t n, int32_t rec_bytes, int32_t dst, void** out, int64_t* n_out);
+/* All-to-all of host byte blocks on the context's communicator (RCCL grouped send / recv, staged through the device; the local transport for ranks
+ * that share a GPU): send holds the blocks for rank 0 .. world-1 back to back, send_cnt[world] their sizes; *recv (mirp_free) receives the blocks
+ * of rank 0 .. world-1 back to back, recv_cnt[world] their sizes.  Carries the window payloads of the re-balancing step (see mirp_limit_windows). */
+int mirp_exchange_bytes(mirp_ctx* ctx, const void* send, const int64_t* send_cnt, void** recv, int64_t* recv_cnt);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side native ingest (no device involved).

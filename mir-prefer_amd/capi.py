@@ -205,6 +205,10 @@ def load_library():
     lib.mirp_last_coverage_fused.restype = C.c_int
     lib.mirp_set_coverage_path.argtypes = [vp, C.c_int32]
     lib.mirp_set_coverage_path.restype = C.c_int
+    lib.mirp_limit_windows.argtypes = [vp, C.c_int64]
+    lib.mirp_limit_windows.restype = C.c_int
+    lib.mirp_exchange_bytes.argtypes = [vp, vp, vp, C.POINTER(vp), vp]
+    lib.mirp_exchange_bytes.restype = C.c_int
     lib.mirp_set_fold_split_path.argtypes = [vp, C.c_int32]
     lib.mirp_set_fold_split_path.restype = C.c_int
     lib.mirp_last_fold_dense.argtypes = [vp]
@@ -554,6 +558,26 @@ class Context:
 
     def last_fold_overflow(self):
         return int(self.lib.mirp_last_fold_overflow(self.h))
+
+    def limit_windows(self, n_keep):
+        """Keeps the first n_keep windows of the last candidate() for the following stages (mirp_limit_windows)."""
+        self._check(self.lib.mirp_limit_windows(self.h, int(n_keep)), "mirp_limit_windows")
+        self._n_windows = int(n_keep)
+
+    def exchange_bytes(self, blocks):
+        """All-to-all of byte strings on the context's communicator: blocks[q] goes to rank q; returns the list of blocks received, by source rank."""
+        W = len(blocks)
+        cnt = np.array([len(b) for b in blocks], dtype=np.int64)
+        blob = b"".join(blocks)
+        recv, rcnt = C.c_void_p(), np.zeros(W, dtype=np.int64)
+        self._check(self.lib.mirp_exchange_bytes(self.h, blob if blob else None, cnt.ctypes.data, C.byref(recv), rcnt.ctypes.data), "mirp_exchange_bytes")
+        tot = int(rcnt.sum())
+        raw = C.string_at(recv.value, tot) if tot else b""
+        self.lib.mirp_free(recv)
+        out, o = [], 0
+        for r in range(W):
+            out.append(raw[o:o + int(rcnt[r])]); o += int(rcnt[r])
+        return out
 
     def set_fold_split_path(self, mode):
         """0: multiloop splits over split candidates (default), 1: the dense split loop for every window (same tables either way)."""

@@ -94,7 +94,8 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     (void)mirp_dist_finalize(c);
     c->dist_tmp.release();
     c->seqs.release(); c->offs.release(); c->ws.release(); c->lines.release(); c->ss.release();
-    c->nlines.release(); c->mfe.release(); c->status.release(); c->carch.release(); c->fctl.release(); c->flist.release(); c->wstate.release();
+    c->nlines.release(); c->mfe.release(); c->status.release(); c->carch.release(); c->fctl.release(); c->flist.release(); c->wstate.release(); c->dlist.release();
+    c->blines.release(); c->bss.release(); c->bnlines.release(); c->bmfe.release(); c->bstatus.release();
     for (DevBuf* b : {&c->genome, &c->clen, &c->goff, &c->gboff, &c->alns, &c->order, &c->diff, &c->stat, &c->starts, &c->totals, &c->runs,
                       &c->keep, &c->kscan, &c->csq, &c->cdest, &c->peaks_sq, &c->peaks_sorted, &c->head, &c->hscan, &c->rfirst, &c->nent,
                       &c->isloc, &c->nslots, &c->escan, &c->lscan, &c->sscan, &c->windows, &c->roles, &c->loci, &c->wpeaks, &c->matures,
@@ -155,8 +156,10 @@ static int fold_batch_impl(mirp_ctx* c, const char* seqs, const int64_t* offsets
         // batches bound the structure-text buffer
         const size_t per_win = (size_t)max_lines * stride;
         int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_seqs, ((size_t)1 << 30) / per_win));
-        if (c->lines.ensure(sizeof(MirpFoldLine) * (size_t)batch * max_lines) || c->ss.ensure((size_t)batch * per_win) ||
-            c->nlines.ensure(4 * (size_t)n_seqs) || c->mfe.ensure(4 * (size_t)n_seqs) || c->status.ensure(4 * (size_t)n_seqs))
+        // the batch path has its own output buffers: a batch call between mirp_fold and mirp_predict (the imported windows of a re-balanced run,
+        // balance.py) must not touch the resident fold output
+        if (c->blines.ensure(sizeof(MirpFoldLine) * (size_t)batch * max_lines) || c->bss.ensure((size_t)batch * per_win) ||
+            c->bnlines.ensure(4 * (size_t)n_seqs) || c->bmfe.ensure(4 * (size_t)n_seqs) || c->bstatus.ensure(4 * (size_t)n_seqs))
             return bail(-6, "device allocation failed (outputs)");
         double kms[2] = {0, 0};
         long long fallbacks = 0;
@@ -164,20 +167,20 @@ static int fold_batch_impl(mirp_ctx* c, const char* seqs, const int64_t* offsets
             const int nb = std::min(batch, n_seqs - b0);
             // windows of this batch are addressed relative to b0: shift the pointers
             int rc = mirp_run_fold(c, (const unsigned char*)c->seqs.p, (const long long*)c->offs.p + b0, nullptr, nb, n_max, span, max_lines, stride,
-                                   (MirpFoldLine*)c->lines.p, (char*)c->ss.p, (int*)c->nlines.p + b0, (int*)c->mfe.p + b0, (int*)c->status.p + b0);
+                                   (MirpFoldLine*)c->blines.p, (char*)c->bss.p, (int*)c->bnlines.p + b0, (int*)c->bmfe.p + b0, (int*)c->bstatus.p + b0);
             if (rc) return bail(rc, c->err);
             kms[0] += c->fold_kernel_ms[0]; kms[1] += c->fold_kernel_ms[1]; fallbacks += c->last_fallback;
             if (want_text &&
-                (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->lines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
+                (hipMemcpyAsync(h_lines + (size_t)b0 * max_lines, c->blines.p, sizeof(MirpFoldLine) * (size_t)nb * max_lines,
                                 hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                 hipMemcpyAsync(h_ss + (size_t)b0 * per_win, c->ss.p, (size_t)nb * per_win, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
+                 hipMemcpyAsync(h_ss + (size_t)b0 * per_win, c->bss.p, (size_t)nb * per_win, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
                 return bail(-2, "D2H copy failed");
             if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(-2, "fold kernel execution failed");
         }
         c->fold_kernel_ms[0] = kms[0]; c->fold_kernel_ms[1] = kms[1]; c->last_fallback = fallbacks;      // over all batches of this call
-        if (hipMemcpy(h_nl, c->nlines.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(h_mfe, c->mfe.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(h_st, c->status.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipMemcpy(h_nl, c->bnlines.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_mfe, c->bmfe.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_st, c->bstatus.p, 4 * (size_t)n_seqs, hipMemcpyDeviceToHost) != hipSuccess)
             return bail(-2, "D2H copy failed");
     }
     if (want_text) { *lines = h_lines; *ss = h_ss; } else { std::free(h_lines); std::free(h_ss); }

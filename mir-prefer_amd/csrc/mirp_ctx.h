@@ -45,6 +45,7 @@ struct mirp_ctx {
     FoldParams* d_params185l = nullptr;     // Turner-1999 values in the layout of the LDS-resident kernels
     int fold_model = MIRP_FOLD_MODEL_VIENNA_212;
     DevBuf seqs, offs, ws, lines, ss, nlines, mfe, status, carch, fctl, flist, wstate, dlist;
+    DevBuf blines, bss, bnlines, bmfe, bstatus;      // outputs of mirp_fold_batch (kept apart from the resident fold output of mirp_fold)
     long long last_fallback = 0;
     // ---- device-resident pipeline state (mirp_pipeline.cpp)
     int n_contigs = 0;

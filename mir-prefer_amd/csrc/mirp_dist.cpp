@@ -327,6 +327,58 @@ extern "C" int mirp_gather_records(mirp_ctx* c, const void* rec, int64_t n, int3
     return 0;
 }
 
+extern "C" int mirp_exchange_bytes(mirp_ctx* c, const void* send, const int64_t* send_cnt, void** recv, int64_t* recv_cnt) {
+    if (!c) return -1;
+    if (!send_cnt || !recv || !recv_cnt) return fail(c, -1, "mirp_exchange_bytes: null argument");
+    const int W = c->dist_world;
+    HIPCHK(c, hipSetDevice(c->device));
+    *recv = nullptr;
+    std::vector<long long> scnt((size_t)W), soff((size_t)W), all;
+    long long stot = 0;
+    for (int r = 0; r < W; r++) {
+        if (send_cnt[r] < 0 || (send_cnt[r] > 0 && !send)) return fail(c, -1, "mirp_exchange_bytes: bad argument");
+        scnt[r] = send_cnt[r]; soff[r] = stot; stot += (send_cnt[r] + 15) & ~15LL;
+    }
+    if (int rc = mirp::dist_allgather_ll(c, scnt.data(), W, all)) return rc;      // all[s * W + q] = bytes rank s sends to rank q
+    std::vector<long long> rcnt((size_t)W), roff((size_t)W);
+    long long rtot = 0, rsum = 0;
+    for (int s2 = 0; s2 < W; s2++) { rcnt[s2] = all[(size_t)s2 * W + c->dist_rank]; roff[s2] = rtot; rtot += (rcnt[s2] + 15) & ~15LL; rsum += rcnt[s2]; }
+    // allocations and the upload can fail on one rank only: agree before the grouped send / recv (as the sharded ingest does)
+    TmpDevice T;
+    char* d_send = (char*)T.get((size_t)stot + 16);
+    char* d_recv = (char*)T.get((size_t)rtot + 16);
+    char* h = (char*)std::malloc((size_t)std::max<long long>(rsum, 1));
+    int prep_rc = 0;
+    if (!d_send || !d_recv || !h) prep_rc = fail(c, -6, "allocation failed (exchange)");
+    if (!prep_rc) {
+        hipError_t he = hipSuccess;
+        for (int r = 0; r < W && he == hipSuccess; r++) {
+            const long long src_off = [&] { long long o = 0; for (int x = 0; x < r; x++) o += send_cnt[x]; return o; }();
+            if (scnt[r]) he = hipMemcpyAsync(d_send + soff[r], (const char*)send + src_off, (size_t)scnt[r], hipMemcpyHostToDevice, c->stream);
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) prep_rc = fail(c, -2, std::string("mirp_exchange_bytes: upload failed: ") + hipGetErrorString(he));
+    }
+    {
+        const long long flag = prep_rc ? 1 : 0;
+        std::vector<long long> flags;
+        int rc = mirp::dist_allgather_ll(c, &flag, 1, flags);
+        if (!rc) for (int r = 0; r < W && !rc; r++) if (flags[(size_t)r]) rc = prep_rc ? prep_rc : fail(c, -7, "mirp_exchange_bytes: rank " + std::to_string(r) + " failed before the exchange");
+        if (rc) { std::free(h); return prep_rc ? prep_rc : rc; }
+    }
+    if (int rc = mirp::dist_alltoallv_bytes(c, d_send, soff, scnt, d_recv, roff, rcnt)) { std::free(h); return rc; }
+    hipError_t he = hipSuccess;
+    long long o = 0;
+    for (int s2 = 0; s2 < W && he == hipSuccess; s2++) {
+        if (rcnt[s2]) he = hipMemcpyAsync(h + o, d_recv + roff[s2], (size_t)rcnt[s2], hipMemcpyDeviceToHost, c->stream);
+        recv_cnt[s2] = rcnt[s2]; o += rcnt[s2];
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) { std::free(h); return fail(c, -2, std::string("mirp_exchange_bytes: download failed: ") + hipGetErrorString(he)); }
+    *recv = h;
+    return 0;
+}
+
 // The exchange step of the path: the loci list of the last mirp_predict of every rank, gathered to rank dst in rank order straight
 // out of the device-resident result arrays (64-byte MirpMirna records + structure text rows).  Ranks other than dst get n_result = 0.
 extern "C" int mirp_gather_loci(mirp_ctx* c, int32_t dst, MirpMirna** result, int64_t* n_result, char** ss_text, int32_t* ss_stride) {

@@ -212,6 +212,16 @@ extern "C" int mirp_set_contig_shard(mirp_ctx* c, int32_t preceded_by_coverage_e
     return 0;
 }
 
+extern "C" int mirp_limit_windows(mirp_ctx* c, int64_t n_keep) {
+    if (!c) return -1;
+    if (!c->have_candidate) return fail(c, -1, "mirp_limit_windows: run mirp_candidate first");
+    if (n_keep < 0 || n_keep > c->n_windows) return fail(c, -1, "mirp_limit_windows: n_keep out of range");
+    // every later stage reads the window arrays as prefixes of length n_windows (offsets into wpeaks / matures / sequences stay valid)
+    c->n_windows = n_keep;
+    c->have_fold = false; c->have_result = false;
+    return 0;
+}
+
 extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks_out,
                               int64_t* n_loci_out, int64_t* n_windows_out) {
     if (!c) return -1;

@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-from . import capi, dist, gffmask, ingest, records
+from . import balance, capi, dist, gffmask, ingest, records
 
 STAGES = ["prepare", "candidate", "fold", "predict"]
 
@@ -78,6 +78,7 @@ class Pipeline:
         # the context's own RCCL communicator (cli.py / bench.py: mirp_dist_init) carries the data-path exchanges of a sharded run: the record routing
         # of the ingest and the gather of the loci list.  Without one (ranks that share a GPU in tests) those go through the host's object channel.
         self.rccl = world > 1 and self.ctx.dist_world() == world
+        self._imported, self._moves = [], None          # window-level re-balancing (balance.py)
 
     def _p(self, name):
         return os.path.join(self.tmp, name)
@@ -293,6 +294,34 @@ class Pipeline:
                 self.ctx.set_contig_shard(True)
                 self.counts = self.ctx.candidate(self.opt["READS_DEPTH_CUTOFF"], self.opt["MAX_GAP"], self.opt["PRECURSOR_LEN"], order)
         self.state = "candidate"
+        self._imported, self._moves = [], None          # window-level re-balancing happens once per candidate state, in front of the fold
+
+    def _balance(self):
+        """Several ranks: even out the window lists before the fold (balance.py).  Collective; every rank computes the same plan from the counts.
+        With -d the run keeps whole contigs per rank (the reasons file and the failed read-mapping layouts are written from the owner's state)."""
+        if self.world == 1 or self._moves is not None:
+            return
+        self._moves = []
+        if self.opt.get("OUTPUT_DETAILS_FOR_DEBUG"):
+            return
+        counts = self._all_gather(int(self.counts[2]))
+        if self.ctx.dist_world() == self.world:          # the context's communicator: RCCL, or the local transport of ranks that share a GPU
+            xchg = self.ctx.exchange_bytes
+        else:                                              # no library communicator (MIRP_DIST_BACKEND=gloo): host objects
+            def xchg(blocks):
+                return [b[self.rank] for b in self._all_gather(blocks)]
+        ok, res = True, None
+        try:
+            res = balance.exchange(xchg, self.rank, self.world, self.ctx.get_windows, self.data["alns"], counts)
+        except capi.MirpError as e:
+            sys.stderr.write(str(e) + "\n")
+            ok = False
+        self._agree_ok(ok, "window re-balancing")
+        keep, self._imported, self._moves = res
+        if keep != int(self.counts[2]):
+            self.ctx.limit_windows(keep)
+        if self._moves and self.rank == 0:
+            _msg("Re-balancing the fold: %s windows per rank, %d transfer(s) of windows between ranks." % (counts, len(self._moves)))
 
     # ---- candidate (MP:3361-3438)
     def run_candidate(self, defer=False):
@@ -390,8 +419,16 @@ class Pipeline:
         """Fold every window on the device; returns the per-window status array.  A window can produce more structure lines than the
         default capacity of 96 (tandem repeats do: one line per start position is possible); RNALfold has no such limit (MP:3053), so
         mirp_fold folds just those windows again at the capacity no window can exceed, into side buffers the later stages read."""
+        self._balance()
         self.ctx.fold(self.opt["PRECURSOR_LEN"])
-        return self.ctx.fold_status()
+        status = self.ctx.fold_status()
+        for p in self._imported:          # windows received from over-loaded ranks (balance.py): folded through the batch entry point
+            try:
+                balance.fold_imported(self.ctx, p, self.opt["PRECURSOR_LEN"])
+            except (RuntimeError, capi.MirpError) as e:
+                sys.stderr.write(str(e) + "\n")
+                status = np.concatenate([status, np.array([-1], dtype=status.dtype)])
+        return status
 
     # ---- fold (MP:3441-3495)
     def run_fold(self, write_text=True, defer=False):
@@ -415,7 +452,13 @@ class Pipeline:
             self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][self.rank], foldname, wait=not defer)
         else:
             open(foldname, "w").close()
-        foldnames = self._all_gather(foldname)
+        mine = [foldname]
+        for p in self._imported:          # the helper's share of the fold artefact: the windows it folded for rank `src`
+            part = foldname + ".from%d" % int(p["meta"][0])
+            with open(part, "w") as f:
+                f.write(balance.fold_text(p, self.data["names"]) if write_text else "")
+            mine.append(part)
+        foldnames = [x for part in self._all_gather(mine) for x in part]
         self._pending_fold = foldnames if defer else None
         if not defer:
             self._record_fold(foldnames)
@@ -461,6 +504,15 @@ class Pipeline:
         bad = np.nonzero(out["status"] != 0)[0]
         if len(bad):      # a capacity of the filter kernel was exceeded (structure pieces / candidate matures of one window): never truncate silently
             sys.stderr.write("Error occurred when predicting miRNAs: window %d exceeds the capacity of the filter kernel (status %d).\n" % (bad[0], out["status"][bad[0]]))
+        imp = []
+        if len(bad) == 0:
+            try:
+                params = (ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], 1 if self.opt["ALLOW_3NT_OVERHANG"] else 0,
+                          1 if self.opt["ALLOW_NO_STAR_EXPRESSION"] else 0, 55)
+                imp = [balance.predict_imported(self.ctx, p, params) for p in self._imported]
+            except (RuntimeError, capi.MirpError) as e:
+                sys.stderr.write("Error occurred when predicting miRNAs (imported windows): %s\n" % e)
+                bad = [0]
         self._agree_ok(len(bad) == 0, "predict")
         def finish_fold():          # the fold stage's text file is being written behind this stage: complete it, then record the stage
             if getattr(self, "_pending_fold", None) is not None:
@@ -494,9 +546,27 @@ class Pipeline:
         # order -- over the context's RCCL communicator straight from the device-resident result, or as host objects when the ranks have none.
         # The rank that owns a locus' contig also prepares what the report files need from the genome and the reads (locus_payloads).
         local = result_records(out, self.data["names"])
+        for x in imp:
+            local += result_records(x, self.data["names"])
         adjust_mature_star(local)
-        pay = locus_payloads(local, dict(self.data["contigs"]), self.data["names"], self.data["alns"], self.data["samples"])
-        if self.rccl:
+        if self._moves:
+            # re-balanced run: a rank's list holds loci of contigs it does not own, so every rank sees the whole list and prepares the report
+            # payloads of the loci on ITS contigs (it has their genome and reads); rank 0 puts them back in list order
+            result = [m for part in self._all_gather(local) for m in part]
+            mine_names = set(n for n, sq in self.data["contigs"] if len(sq))
+            idx = [k for k, m in enumerate(result) if m[0] in mine_names]
+            pay = locus_payloads([result[k] for k in idx], dict(self.data["contigs"]), self.data["names"], self.data["alns"], self.data["samples"])
+            payloads = [None] * len(result)
+            for idx_r, pay_r in self._all_gather((idx, pay)):
+                for k, x in zip(idx_r, pay_r):
+                    payloads[k] = x
+            if self.rank != 0:
+                result = []
+        else:
+            pay = locus_payloads(local, dict(self.data["contigs"]), self.data["names"], self.data["alns"], self.data["samples"])
+        if self._moves:
+            pass          # (result / payloads were assembled above)
+        elif self.rccl:
             g = self.ctx.gather_loci(0)
             result = result_records(g, self.data["names"]) if self.rank == 0 else []
             adjust_mature_star(result)

@@ -3,6 +3,7 @@ import gzip
 import os
 import shutil
 
+import numpy as np
 import pytest
 
 from mir_prefer_amd import cli, pipeline
@@ -147,6 +148,84 @@ def test_pipeline_verb_sharded_over_ranks(world, backend, tmp_path):
             assert set(np.unique(a["tid"]).tolist()) <= set(parts[r])
             total += len(a)
         assert total == sum(len(gu.load_pipeline_case("mini")["alns"]) for _ in range(1))
+
+
+def _read_outputs(out, prefix):
+    files = {}
+    for fn in [prefix + "_miRNA.gff3", prefix + "_miRNA.mature.fa", prefix + "_miRNA.precursor.fa", prefix + "_miRNA.precursor.ss", prefix + "_miRNA.detail.csv",
+               prefix + "_miRNA.detail.html", "miRNA.stat.txt"]:
+        files[fn] = open(out / fn).read()
+    for fn in sorted(os.listdir(out / "readmapping")):
+        files["readmapping/" + fn] = open(out / "readmapping" / fn).read()
+    return files
+
+
+@pytest.mark.parametrize("world,backend", [(3, "local"), (2, "gloo")])
+def test_window_rebalancing_moves_windows_and_keeps_the_files(world, backend, tmp_path):
+    """Window-level re-balancing in front of the fold (balance.py): the fullest rank ships the tail of its window list, the helpers fold + filter
+    the imported windows through the batch entry points, and every result file equals the single-process run's.  MIRP_BALANCE_MIN_MOVE=1 makes the
+    miniature move windows at all; the payloads travel over the library's transport (local) or as host objects (gloo)."""
+    exp, cfg, out = _setup("mini", tmp_path)
+    os.environ["MIRP_BALANCE_MIN_MOVE"] = "1"
+    try:
+        codes, logs = _run_ranks(world, ["-k", "--device", "0", "pipeline", cfg], 29561 + world, backend)
+    finally:
+        del os.environ["MIRP_BALANCE_MIN_MOVE"]
+    assert all(c == 0 for c in codes), logs
+    assert "Re-balancing the fold" in logs[0], logs[0]
+    prefix = exp["config"]["NAME_PREFIX"]
+    assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"]
+    rep = exp["reports"]
+    got = _read_outputs(out, prefix)
+    assert got[prefix + "_miRNA.detail.csv"] == rep["detail_csv"] and got[prefix + "_miRNA.precursor.ss"] == rep["precursor_ss"]
+    assert got[prefix + "_miRNA.mature.fa"] == rep["mature_fa"] and got[prefix + "_miRNA.precursor.fa"] == rep["precursor_fa"]
+    assert got[prefix + "_miRNA.detail.html"] == rep["detail_html"] and got["miRNA.stat.txt"] == rep["stat_txt"]
+    for fn, text in exp["readmapping"].items():
+        assert got["readmapping/" + fn] == text, fn
+    # the fold artefact: every window's RNALfold text exactly once over the ranks' files and the helpers' ".from<src>" parts
+    tmp = out / (prefix + "_tmp")
+    rec = pipeline.load_recover_file(str(tmp / (prefix + "_recover")))
+    names = rec["finished_stages"]["fold"]["foldnames"]
+    assert any(".from" in n for n in names)
+    lines = []
+    for n in names:
+        lines += open(n).read().upper().splitlines()
+    ref = "".join(p["rnalfold_out"] for p in exp["pieces"]).upper().splitlines()
+    assert sorted(l for l in lines if not l.startswith(">")) == sorted(l for l in ref if not l.startswith(">"))
+    assert sorted(l for l in lines if l.startswith(">")) == sorted(l for l in ref if l.startswith(">"))
+
+
+def test_window_rebalancing_at_config3_shape_equals_single_rank(tmp_path):
+    """BASELINE config[3]-shaped contig lengths (12 MSU7-like contigs, scaled to 1/150) on 3 ranks over the local transport: whole-contig LPT leaves
+    the ranks uneven, windows move, and every output file equals the 1-rank run's byte for byte."""
+    from mir_prefer_amd import synth
+    msu7 = [43300000, 35900000, 36400000, 35500000, 30000000, 31200000, 29700000, 28400000, 23000000, 23200000, 29000000, 27500000]
+    lens = [l // 150 for l in msu7]
+    ds = synth.make_dataset(lens, 900, n_samples=2, seed=77, contig_names=["Chr%d" % (k + 1) for k in range(12)])
+    # a skewed read set: the generator spreads its loci evenly, so only the four largest contigs keep their reads -- LPT puts two of them on one rank
+    ds.alns = ds.alns[ds.alns["tid"] < 4]
+    src = tmp_path / "in"
+    src.mkdir()
+    sams = ds.write_sams(str(src))
+    fa = str(src / "genome.fa")
+    ds.write_fasta(fa)
+    outs = {}
+    for tag, world in (("w1", 1), ("w3", 3)):
+        cfg = tmp_path / ("config_" + tag)
+        out = tmp_path / ("out_" + tag)
+        cfg.write_text("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = c3\nPRECURSOR_LEN = 300\nREADS_DEPTH_CUTOFF = 10\nMAX_GAP = 100\n"
+                       % (fa, ", ".join(sams), out))
+        if world == 1:
+            assert cli.main(["-k", "pipeline", str(cfg)]) == 0
+        else:
+            codes, logs = _run_ranks(world, ["-k", "--device", "0", "pipeline", str(cfg)], 29577, "local")
+            assert all(c == 0 for c in codes), logs
+            assert "Re-balancing the fold" in logs[0], logs[0]
+        outs[tag] = _read_outputs(out, "c3")
+    assert len(outs["w1"]) > 20
+    assert outs["w1"].keys() == outs["w3"].keys()
+    for k in outs["w1"]:
+        assert outs["w1"][k] == outs["w3"][k], k
 
 
 def test_sharded_run_fails_on_every_rank_together(tmp_path):

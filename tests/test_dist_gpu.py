@@ -159,3 +159,43 @@ def test_sharded_ingest_fails_on_every_rank_together(tmp_path):
     assert [p.returncode for p in procs] == [3, 3], logs
     msgs = [open(tmp_path / ("failed_%d.txt" % r)).read() for r in range(2)]
     assert "SAM position is not a number" in msgs[1] and "rank 1 failed" in msgs[0]
+
+
+def test_exported_window_payload_through_the_batch_path_equals_the_resident_path(gpu_ctx):
+    """balance.py's unit of work on ONE rank: a range of windows packed into a payload, folded and filtered through mirp_fold_batch /
+    mirp_predict_batch, must give the records the resident path (mirp_fold / mirp_predict) reports for those windows; and the rest of the list,
+    after mirp_limit_windows, the records of the rest."""
+    from mir_prefer_amd import balance
+    from tests import golden_util as gu
+    case = gu.load_pipeline_case("mini")
+    names = case["contig_names"]
+    order = np.argsort(np.array(names, dtype=object), kind="stable").astype(np.int32)
+    gpu_ctx.load_genome(case["contigs"])
+    gpu_ctx.load_alignments(case["alns"])
+    cfg = case["exp"]["config"]
+    _, _, nwin = gpu_ctx.candidate(cfg["READS_DEPTH_CUTOFF"], cfg["MAX_GAP"], cfg["PRECURSOR_LEN"], order)
+    gpu_ctx.fold(cfg["PRECURSOR_LEN"])
+    ns = len(case["sample_names"])
+    a3, ans = cfg["ALLOW_3NT_OVERHANG"] == "Y", cfg["ALLOW_NO_STAR_EXPRESSION"] == "Y"
+    full = gpu_ctx.predict(ns, cfg["MIN_MATURE_LEN"], cfg["MAX_MATURE_LEN"], a3, ans)
+    win = gpu_ctx.get_windows()
+    keep, ranges = balance.export_ranges([(0, 1, nwin // 2)], 0, nwin, win["windows"]["tag"])
+    (dst, a, b), = ranges
+    assert a == keep and b == nwin and 0 < keep < nwin
+    p = balance.unpack(balance.pack(win, case["alns"], a, b, 0))
+    balance.fold_imported(gpu_ctx, p, cfg["PRECURSOR_LEN"])
+    params = (ns, cfg["MIN_MATURE_LEN"], cfg["MAX_MATURE_LEN"], 1 if a3 else 0, 1 if ans else 0, 55)
+    got = balance.predict_imported(gpu_ctx, p, params)
+    tail = full["result"]["window"] >= keep
+    cols = [f for f in full["result"].dtype.names if f not in ("window",)]
+    assert len(got["result"]) == tail.sum() > 3
+    for f in cols:
+        assert np.array_equal(got["result"][f], full["result"][tail][f]), f
+    assert got["ss"] == [s for s, t in zip(full["ss"], tail) if t]
+    # the head of the list after the cut; a batch fold between the resident fold and the resident filter (what a helper rank does) must leave
+    # the resident fold output alone
+    gpu_ctx.limit_windows(keep)
+    gpu_ctx.fold(cfg["PRECURSOR_LEN"])
+    balance.fold_imported(gpu_ctx, p, cfg["PRECURSOR_LEN"])
+    head = gpu_ctx.predict(ns, cfg["MIN_MATURE_LEN"], cfg["MAX_MATURE_LEN"], a3, ans)
+    assert head["result"].tobytes() == full["result"][~tail].tobytes() and head["ss"] == [s for s, t in zip(full["ss"], tail) if not t]
