@@ -232,7 +232,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             // (waves 0-5 own phase B).
             auto splits_sparse = [&]() {
                 const int lim = sp_snap;
-                const int pnv = ((volatile int*)misc)[3];      // issued here, looked at behind the loop: no LDS round trip in front of it
+                // pool size for the NEXT interval: an LDS read issued here and first looked at behind the loop.  (Through the LDS address space on
+                // purpose: a volatile read through the generic pointer compiles to flat_load + s_waitcnt vmcnt(0), a stall in front of the loop.)
+                int pnv;
+                {
+                    const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&misc[3];
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(pnv) : "v"(pa) : "memory");
+                }
                 if (!(dbg_flags & 2))
                 for (int k = (LNW - 1 - wave) * 64 + lane; k < lim; k += LNT) {
                     const unsigned ea = poolA[k];
@@ -244,6 +250,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const unsigned sum = (unsigned)fml[ok ? o : 1] + vb;
                     if (ok && sum < 65535u) atomicMin(&mdec[i], (int)sum - 2 * FML_BIAS);
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pnv) : : "memory");
                 { const int pn = __builtin_amdgcn_readfirstlane(pnv); sp_snap = pn < pool_cap ? pn : pool_cap; }
             };
             auto splits_dense = [&]() {
@@ -386,6 +393,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 A1 a;
                 a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
                 const bool slow = (dbg_flags & 8192) != 0;     // diagnostics build: the one-round-trip-per-candidate versions of the jobs
+                {
                 for (int blk = 0; blk < nblk; blk++) {
                     {   // re-materialise the wave-uniform loop parameters per block: keeps the admissibility tests and row offsets as plain
                         // scalar compares inside the block instead of dozens of hoisted masks (SGPR spills)
@@ -518,6 +526,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     unsigned res = KEY_NONE;
                     a1_small<0, 0>(a, i, j, type, S[i + 1], S[j - 1], res);
                     if (act && res != KEY_NONE) atomicMin(&ckey[i], res);
+                }
                 }
                 if (dbg_cycles && lane == 0 && wave == 9 && !(dbg_flags & (1 << 20))) {   // diagnostics: interior-loop time of one wave by number of blocks
                     const int b = nblk < 3 ? nblk : 3;
