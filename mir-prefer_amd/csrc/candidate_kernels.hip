@@ -432,23 +432,43 @@ __global__ void __launch_bounds__(256) depth_fix_kernel(MirpDepthPos* __restrict
 // ------------------------------------------------------------------------------------------
 // generic single-block exclusive scan of int32 (small arrays: runs, regions)
 // ------------------------------------------------------------------------------------------
+// A thread owns SCAN1_NT consecutive elements per round (serial scan in registers, one wave scan + one 16-entry combine per round): 16,384
+// elements per round of the block instead of 1,024 -- at the 3 x 10^5 runs / regions of a config[4] rank shard 19 rounds instead of 300 (the
+// stage calls this scan seven times; round 3: 0.2 ms per call, more than the coverage scan itself).
+#define SCAN1_NT 16
 __global__ void __launch_bounds__(1024) excl_scan_i32_kernel(const int* __restrict__ in, long long* __restrict__ out, long long n) {
     __shared__ long long sh[16];
     __shared__ long long s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (long long b = 0; b < n; b += 1024) {
-        long long k = b + tid;
-        long long v = (k < n) ? in[k] : 0, iv = v;
+    for (long long b = 0; b < n; b += 1024 * SCAN1_NT) {
+        const long long k0 = b + (long long)tid * SCAN1_NT;
+        int v[SCAN1_NT];
+        if (k0 + SCAN1_NT <= n && (((size_t)(in + k0)) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < SCAN1_NT / 4; q++) {
+                const int4 x = *reinterpret_cast<const int4*>(in + k0 + 4 * q);
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SCAN1_NT; q++) v[q] = (k0 + q < n) ? in[k0 + q] : 0;
+        }
+        long long mine = 0;
+#pragma unroll
+        for (int q = 0; q < SCAN1_NT; q++) mine += v[q];
+        long long iv = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { long long t = __shfl_up(iv, o); if (lane >= o) iv += t; }
         if (lane == 63) sh[wave] = iv;
         __syncthreads();
         long long wpre = 0, tot = 0;
         for (int w = 0; w < 16; w++) { if (w < wave) wpre += sh[w]; tot += sh[w]; }
-        long long carry = s_carry;
-        if (k < n) out[k] = carry + wpre + iv - v;
+        const long long carry = s_carry;
+        long long run = carry + wpre + iv - mine;
+#pragma unroll
+        for (int q = 0; q < SCAN1_NT; q++) { if (k0 + q < n) out[k0 + q] = run; run += v[q]; }
         __syncthreads();
         if (tid == 0) s_carry = carry + tot;
         __syncthreads();
@@ -598,8 +618,10 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
                                                             double min_mature_depth, int wmax,
                                                             char* __restrict__ seqs, MirpMature* __restrict__ matures, int* __restrict__ rt_out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    int* dmax = (int*)smem;                       // [wmax]  depth of the most abundant read of the window strand at pos, 0 = none
-    unsigned short* lmax = (unsigned short*)(dmax + wmax);   // [wmax]
+    unsigned long long* best = (unsigned long long*)smem;        // [wmax]  (depth << 32 | ~index) of the most abundant read of the window strand that starts at pos
+    int* dmax = (int*)(best + wmax);              // [wmax]  its depth, 0 = none
+    int* tot = dmax + wmax;                       // [wmax]  total depth of the reads that start at pos (inspection copy only)
+    unsigned short* lmax = (unsigned short*)(tot + wmax);   // [wmax]
     const int lane = threadIdx.x;
     for (long long w = blockIdx.x; w < n_windows; w += gridDim.x) {
         MirpWindow win = W[w];
@@ -612,23 +634,52 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
         char* dst = seqs + win.seq_off;
         if (strand == 0) for (int x = lane; x < len; x += 64) dst[x] = (char)g[s - 1 + x];
         else for (int x = lane; x < len; x += 64) dst[x] = rc_char((char)g[e - 1 - x]);
-        // ---- a5: per start position, most abundant read of the window's strand; first seen wins ties (MP:1457)
+        // ---- a5: per start position, most abundant read of the window's strand; first seen wins ties (MP:1457).  One 64-ary search of the
+        // (tid, pos)-sorted records for the window's first record, then the records of [ws, we] are walked 64 at a time; a record votes for its
+        // start position with the key (depth << 32 | ~index): the maximum is the deepest read and, among equals, the first in array order.
+        // (Round 3 ran one binary search over ALL records per start position: 326 x 25 dependent loads per window, 3.6 ms at a config[4] shard.)
         const int width = we - ws + 1;
-        for (int x = lane; x < width; x += 64) {
-            int pos = ws + x, best_d = 0, best_l = 0, total = 0;
-            long long lo = 0, hi = n_alns;
-            while (lo < hi) { long long mid = (lo + hi) >> 1; MirpAln r = alns[mid]; if (r.tid < tid || (r.tid == tid && r.pos < pos)) lo = mid + 1; else hi = mid; }
-            for (long long k = lo; k < n_alns; k++) {
-                MirpAln r = alns[k];
-                if (r.tid != tid || r.pos != pos) break;
-                if ((int)r.strand != strand) continue;
-                if ((int)r.depth > best_d) { best_d = (int)r.depth; best_l = r.len; }
-                total += (int)r.depth;
+        for (int x = lane; x < width; x += 64) { best[x] = 0ull; tot[x] = 0; }
+        long long lo = 0, hi = n_alns;
+        auto less = [&](long long k) { const MirpAln r = alns[k]; return r.tid < tid || (r.tid == tid && r.pos < ws); };
+        while (hi - lo > 64) {
+            const long long step = (hi - lo + 63) >> 6;
+            const long long k = lo + (long long)(lane + 1) * step - 1;
+            const bool lt = k < hi ? less(k) : false;
+            const int c = __popcll(__ballot(lt));          // probes are ascending: the first c are below the key
+            const long long nlo = lo + (long long)c * step;
+            hi = (nlo + step < hi) ? nlo + step : hi;      // probe c (if any) is not below the key: the bound lies in (probe c-1, probe c]
+            lo = nlo;
+        }
+        {
+            const bool lt = lo + lane < hi ? less(lo + lane) : false;
+            lo += __popcll(__ballot(lt));
+        }
+        __syncthreads();
+        for (long long k0 = lo;; k0 += 64) {
+            const long long k = k0 + lane;
+            bool in = false;
+            if (k < n_alns) {
+                const MirpAln r = alns[k];
+                in = r.tid == tid && r.pos <= we;
+                if (in && (int)r.strand == strand) {
+                    const int x = r.pos - ws;
+                    atomicMax(&best[x], ((unsigned long long)r.depth << 32) | (unsigned long long)(0xffffffffu - (unsigned)(k - lo)));
+                    if (rt_out) atomicAdd(&tot[x], (int)r.depth);
+                }
             }
+            if (!(__ballot(in) >> 63)) break;               // the last lane is past the window (or the array): done
+        }
+        __syncthreads();
+        for (int x = lane; x < width; x += 64) {
+            const unsigned long long v = best[x];
+            const int best_d = (int)(v >> 32);
+            int best_l = 0;
+            if (best_d > 0) best_l = alns[lo + (long long)(0xffffffffu - (unsigned)v)].len;
             dmax[x] = best_d; lmax[x] = (unsigned short)best_l;
             if (rt_out) {   // inspection copy of the a5 table (mirp_get_window_readtable): [len of max, depth of max, total depth] per start position
                 int* o = rt_out + ((size_t)w * wmax + x) * 3;
-                o[0] = best_l; o[1] = best_d; o[2] = total;
+                o[0] = best_l; o[1] = best_d; o[2] = tot[x];
             }
         }
         __syncthreads();
@@ -763,7 +814,7 @@ void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, c
                            const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
                            MirpMature* matures, int* rt_out) {
     if (n_windows <= 0) return;
-    size_t lds = (size_t)wmax * 6 + 16;
+    size_t lds = (size_t)wmax * 18 + 32;
     hipLaunchKernelGGL(window_payload_kernel, dim3(grid_for(n_windows, 1, 16384)), dim3(64), lds, st, W, n_windows, P, alns, n_alns, genome, gboff, clen,
                        min_mature_depth, wmax, seqs, matures, rt_out);
 }
