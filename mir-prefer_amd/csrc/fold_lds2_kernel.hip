@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(LNT) fold_lds2_kernel(
                         int r0 = dd - 2, um = dd - 2 - (TURN + 1) < MAXLOOP ? dd - 2 - (TURN + 1) : MAXLOOP;
                         asm volatile("" : "+s"(r0), "+s"(um));
                         a.r0 = r0; a.um = um;
+                        a.rowtab = P->ring_rowoff[r0 & 31];
                     }
                     const int k = blk * 64 + lane;
                     const bool inl = k < ncp;

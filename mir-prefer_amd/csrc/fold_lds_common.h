@@ -64,6 +64,7 @@ __device__ inline void xt_fill(TAB& T, const FoldParams* __restrict__ P, int tid
     }
 }
 #define CSTR 354            // c-ring row stride in shorts (177 dwords: odd, spreads LDS banks)
+static_assert(CSTR == MIRP_RING_CSTR, "FoldParams::ring_rowoff is built for this row stride");
 #define MIRP_CK(d) ((d) % 3)
 #define CRING_ROWS 33       // diagonal dd lives in row dd & 31; row 32 mirrors row 0, so "the row after row r" is always r + 1 (phase A1 mixes lanes of two diagonals)
 
@@ -194,6 +195,7 @@ struct A1 {
     const unsigned short* pax;     // xt_pcode(S[x], S[x-1])
     const unsigned char* qbr;      // xt_qcode(S[x], S[x+1]) at n + 1 - x: the q side is walked downwards, so it is stored reversed (ascending immediates)
     int r0, um, n;
+    const int* __restrict__ rowtab;    // FoldParams::ring_rowoff[r0 & 31]: ring-row offset (shorts) of loop size u, i.e. ((r0 - u) & 31) * CSTR
 };
 
 // generic loops (n1, n2 >= 2) of size U: one contiguous run of ring row r0 - U.  The reads stay 16-bit on purpose (volatile keeps the
@@ -405,7 +407,7 @@ __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR];
+        for (int k = 0; k < N; k++) g[k] = rb[a.rowtab[LO + k]];
 #ifdef MIRP_X_RINGONLY          // timing experiment: what a ring of c + bulge / 1xn term would leave of these jobs (no code read, no table gather)
 #pragma unroll
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxp; }
@@ -435,7 +437,7 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k)) & 31) * CSTR + (LO + k)];
+        for (int k = 0; k < N; k++) g[k] = rb[a.rowtab[LO + k] + (LO + k)];
 #ifdef MIRP_X_RINGONLY
 #pragma unroll
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxq; }
@@ -465,7 +467,7 @@ __device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR];
+        for (int k = 0; k < N; k++) g[k] = rb[a.rowtab[LO + k + 1]];
 #ifdef MIRP_X_RINGONLY          // timing experiment: what a ring of c + bulge / 1xn term would leave of these jobs (no code read, no table gather)
 #pragma unroll
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxp; }
@@ -495,7 +497,7 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
         unsigned code[N], g[N];
         int x[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) g[k] = rb[((a.r0 - (LO + k) - 1) & 31) * CSTR + (LO + k)];
+        for (int k = 0; k < N; k++) g[k] = rb[a.rowtab[LO + k + 1] + (LO + k)];
 #ifdef MIRP_X_RINGONLY
 #pragma unroll
         for (int k = 0; k < N; k++) { code[k] = 0; x[k] = (int)idxq; }

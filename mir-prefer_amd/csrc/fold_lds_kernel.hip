@@ -400,6 +400,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         int r0 = d - 2, um = d - 2 - (TURN + 1) < MAXLOOP ? d - 2 - (TURN + 1) : MAXLOOP;
                         asm volatile("" : "+s"(r0), "+s"(um));
                         a.r0 = r0; a.um = um;
+                        a.rowtab = P->ring_rowoff[r0 & 31];
                     }
                     const int k = blk * 64 + lane;
                     const bool own = k < rem, ahead = !own && aent != 0;       // k >= rem only happens in the last block

@@ -7,6 +7,7 @@
 #define MIRP_TURN 3
 #define MIRP_MAXLOOP 30
 #define MIRP_INF 10000000
+#define MIRP_RING_CSTR 354        // row stride (shorts) of the fill kernel's c ring: CSTR of fold_lds_common.h (static_assert there)
 #define MIRP_HP_MAX 3104          // hairpin size table (log-extrapolated above 30 on the host)
 
 struct FoldParams {
@@ -26,6 +27,10 @@ struct FoldParams {
     // bias of the fill kernel's byte tables of inner-pair terms (LdsTables::XB / X1, fold_lds_common.h): table entry = term + bias in 0..255; the
     // kb*_key / k1n*_key tables above carry the matching -bias
     int xb_bias, x1_bias;
+    // ring-row offsets of the fill kernel's c ring (fold_lds_common.h: diagonal dd lives in row dd & 31, CSTR shorts per row): [r0 & 31][u] = ((r0 - u) & 31) * CSTR.
+    // The bulge / 1 x n jobs read a different ring row per candidate; with the row of the interval's r0 in SGPRs (one s_load burst per block) the
+    // address is one vector add instead of s_add + s_and + s_mul + v_add per candidate.
+    int ring_rowoff[32][32];
     // (the key tables come first so that the fill kernel's scalar loads reach them with immediate offsets from the one base pointer)
     int stack[8][8];
     int bulge[31];

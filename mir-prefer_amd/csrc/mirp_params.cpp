@@ -49,6 +49,8 @@ static void fill_derived(FoldParams* p) {
         p->k1n0_key[u] = k1 | (unsigned)(1 << 5 | u);
         p->k1n1_key[u] = k1 | (unsigned)(u << 5 | 1);
     }
+    for (int rr = 0; rr < 32; rr++)
+        for (int u = 0; u < 32; u++) p->ring_rowoff[rr][u] = ((rr - u) & 31) * MIRP_RING_CSTR;
 }
 
 void mirp_fill_fold_params(FoldParams* p) {
