@@ -7,7 +7,7 @@ import csv, glob, collections
 for f in glob.glob("gpurun_out/ic1/**/*counter_collection.csv", recursive=True):
     agg = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "fold_lds_kernel" in r["Kernel_Name"] and "epilogue" not in r["Kernel_Name"]:
+        if "fold_lds_kernel" in r["Kernel_Name"] and "epilogue" not in r["Kernel_Name"] and ("true>" in r["Kernel_Name"] or "<1" in r["Kernel_Name"]):
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     for k in agg: print(k, agg[k] / max(1, n[k]), n[k])
 PY

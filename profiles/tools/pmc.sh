@@ -13,7 +13,7 @@ for f in glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % tag, recursi
     agg = collections.defaultdict(float); n = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if ("fold_lds_kernel" in name and "epilogue" not in name) if kern == "fill" else (kern in name):
+        if ("fold_lds_kernel" in name and "epilogue" not in name and ("true>" in name or "<1" in name)) if kern == "fill" else (kern in name):
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
     print(tag, {k: "%.4g" % (v / len(n[k])) for k, v in sorted(agg.items())})
 PY

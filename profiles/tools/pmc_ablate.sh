@@ -11,7 +11,7 @@ import csv, glob, collections, sys
 f = glob.glob("gpurun_out/pa_%s/*/*counter_collection.csv" % sys.argv[1])[0]
 agg = collections.defaultdict(float); n = collections.defaultdict(set)
 for r in csv.DictReader(open(f)):
-    if "fold_lds_kernel" in r["Kernel_Name"] and "epilogue" not in r["Kernel_Name"]:
+    if "fold_lds_kernel" in r["Kernel_Name"] and "epilogue" not in r["Kernel_Name"] and ("true>" in r["Kernel_Name"] or "<1" in r["Kernel_Name"]):
         agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
 print("flags", sys.argv[1], {k: "%.3g" % (v / len(n[k])) for k, v in sorted(agg.items())})
 PY
