@@ -204,7 +204,7 @@ struct A1 {
 template <bool CHECK, int U>
 __device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb, unsigned& bg) {
     if (!CHECK || U <= a.um) {
-        lds_vu16 rp = (lds_vu16)(rb + ((a.r0 - U) & 31) * CSTR);
+        lds_vu16 rp = (lds_vu16)(rb + a.rowtab[U]);
         unsigned v[U - 3];      // all reads of the run in flight before the first use
 #pragma unroll
         for (int n1 = 2; n1 <= U - 2; n1++) v[n1 - 2] = rp[n1];
@@ -227,7 +227,7 @@ __device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
 template <bool CHECK, int WD, int U>
 __device__ __forceinline__ void a1_gen_row_w(const A1& a, const unsigned short* rb, unsigned& bg) {
     if (!CHECK || U <= a.um) {
-        lds_vu16 rp = (lds_vu16)(rb + ((a.r0 - U) & 31) * CSTR);
+        lds_vu16 rp = (lds_vu16)(rb + a.rowtab[U]);
         unsigned v[U - 3];      // all reads of the run in flight before the first use
 #ifdef MIRP_X_NOGENLDS          // timing experiment: the row's values without touching LDS
 #pragma unroll
