@@ -42,7 +42,7 @@ def plan(counts, threshold=THRESHOLD):
     target = -(-T // W)
     deficit = [max(0, target - n) for n in counts]
     surplus = [max(0, n - target) for n in counts]
-    small = max(MIN_MOVE, target // 64)      # a transfer below this is not worth a payload: the donor keeps those windows
+    small = MIN_MOVE      # a transfer below this is not worth a payload: the donor keeps those windows
     moves = []
     for s in sorted(range(W), key=lambda r: (-surplus[r], r)):
         for d in sorted(range(W), key=lambda r: (-deficit[r], r)):
