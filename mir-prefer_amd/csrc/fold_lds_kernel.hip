@@ -863,7 +863,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 // (L2) table reads, so it runs as many small workgroups (256 threads, ~16 KB LDS) per CU instead of sharing the
 // fill kernel's one-workgroup-per-CU geometry.
 // ------------------------------------------------------------------------------------------
+#ifndef ENT
 #define ENT 256
+#endif
 #ifndef MIRP_EPI_WGS
 #define MIRP_EPI_WGS 8
 #endif

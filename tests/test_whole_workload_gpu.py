@@ -1,9 +1,9 @@
 """Whole-workload parity on the headline configuration (BASELINE config[1], the workload bench.py's number is quoted on): EVERY window's printed
-structure lines and MFE, and the complete result list, against the CPU oracle -- the reference's analogue is simply its full run
-(/root/reference/miR_PREFeR.py:3728-3739).  The oracle folds in a process pool (one worker per CPU the box grants), 19,686 windows take
-well under a minute.  Also: a 5,000-window slice of the same workload under the vienna-1.8.5 model, 5,000 folds of the five stress families
-(mixed, tandem repeats, two-letter alphabets, near-perfect long hairpins, N-rich; profiles/tools/stress_fold.py) and the two split paths of the
-fill kernel (split candidates / dense loop) against each other."""
+structure lines and MFE, and the complete result list, against the CPU oracle, under both fold models -- the reference's analogue is simply its
+full run (/root/reference/miR_PREFeR.py:3728-3739).  The oracle folds in a process pool (one worker per CPU the box grants): 19,686 windows take
+under a minute.  Also: config[2] -- the candidate stage over the whole genome and a 12,000-window slice line by line and record by record --,
+6,500 folds of the five stress families (mixed, tandem repeats, two-letter alphabets, near-perfect long hairpins, N-rich;
+profiles/tools/stress_fold.py) and the two split paths of the fill kernel (split candidates / dense loop) against each other."""
 import concurrent.futures as cf
 import os
 import random
@@ -75,9 +75,17 @@ def config1(oracle):
     return {"ds": ds, "alns": alns, "win": win, "seqs": seqs}
 
 
-def test_config1_every_window_and_the_result_list(gpu_ctx, oracle, config1):
+@pytest.mark.parametrize("model", ["vienna-2.1.2", "vienna-1.8.5"])
+def test_config1_every_window_and_the_result_list(model, gpu_ctx, oracle, config1):
+    try:
+        gpu_ctx.set_fold_model(model)
+        _config1_whole(model, gpu_ctx, oracle, config1)
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
+
+
+def _config1_whole(model, gpu_ctx, oracle, config1):
     ds, alns, win, seqs = config1["ds"], config1["alns"], config1["win"], config1["seqs"]
-    gpu_ctx.set_fold_model("vienna-2.1.2")
     gpu_ctx.load_genome(ds.contigs)
     gpu_ctx.load_alignments(alns)
     _, _, nwin = gpu_ctx.candidate(CUT, GAP, L, np.zeros(1, np.int32))
@@ -95,7 +103,7 @@ def test_config1_every_window_and_the_result_list(gpu_ctx, oracle, config1):
     assert gpu_ctx.last_fold_fallbacks() == 0 and gpu_ctx.last_fold_dense() == 0      # every window through the candidate-pool fill kernel
     raw = gpu_ctx.get_fold()
     assert (raw["status"] == 0).all()
-    want = oracle_fold_all(seqs, L)
+    want = oracle_fold_all(seqs, L, model)
     bad = [k for k in range(nwin) if raw["mfe"][k] != want[k][1] or gpu_lines(raw, k) != want[k][0]]
     assert not bad, "windows whose structure lines / MFE differ from the oracle: %s" % bad[:10]
     # the complete result list (filter_next_loci + check_loci over every window, MP:2350-2502)
@@ -113,22 +121,13 @@ def test_config1_every_window_and_the_result_list(gpu_ctx, oracle, config1):
     assert got == exp
     assert [int(m["window"]) for m in out["result"]] == [k for k, _ in result]
     import bench
-    assert len(got) == bench.EXPECTED_LOCI[("config1", "vienna-2.1.2")]
+    assert len(got) == bench.EXPECTED_LOCI[("config1", model)]
 
 
-def test_config1_slice_vienna185_and_dense_split_path(gpu_ctx, config1):
-    """5,000 windows of the headline workload under the vienna-1.8.5 model against its oracle; the same slice through the default model's dense
-    split loop must reproduce the candidate-pool pass bit for bit (the first test pins that one on the oracle)."""
+def test_config1_slice_dense_split_path_equals_candidate_pool_pass(gpu_ctx, config1):
+    """5,000 windows of the headline workload through the default model's dense split loop must reproduce the candidate-pool pass bit for bit (the
+    test above pins that one on the oracle)."""
     seqs = config1["seqs"][3000:8000]
-    try:
-        gpu_ctx.set_fold_model("vienna-1.8.5")
-        raw = gpu_ctx.fold_batch_raw(seqs, L)
-        assert (raw["status"] == 0).all()
-        want = oracle_fold_all(seqs, L, "vienna-1.8.5")
-        bad = [k for k in range(len(seqs)) if raw["mfe"][k] != want[k][1] or gpu_lines(raw, k) != want[k][0]]
-        assert not bad, bad[:10]
-    finally:
-        gpu_ctx.set_fold_model("vienna-2.1.2")
     a = gpu_ctx.fold_batch_raw(seqs, L)
     assert gpu_ctx.last_fold_dense() == 0
     try:
@@ -182,3 +181,58 @@ def test_stress_families(gpu_ctx, model, count):
     want = oracle_fold_all(seqs, L, model)
     bad = [k for k in range(count) if got[k]["status"] != 0 or got[k]["mfe"] != want[k][1] or got[k]["lines"] != want[k][0]]
     assert not bad, [seqs[k] for k in bad[:3]]
+
+
+def test_config2_slice_of_12000_windows_lines_and_records(gpu_ctx, oracle):
+    """BASELINE config[2] (TAIR10-sized, 5 contigs, 3 samples, 70,244 windows): the candidate stage against the oracle over the whole genome, and a
+    contiguous slice of 12,000 windows (it crosses a contig boundary) line by line and record by record -- fold text through the batch entry
+    point, filter records out of the resident run's result list."""
+    from mir_prefer_amd import balance
+    import bench
+    specs, n_samples, background, _, _ = bench.workload_specs("config2", 1)          # the workload bench.py's `configs.config2` line is measured on
+    contigs, alns, sample_names = bench.build_shard(specs, set(range(len(specs))), n_samples, background)
+    ds = synth.Dataset(contigs, sample_names, alns, [])
+    order = np.arange(5, dtype=np.int32)
+    gpu_ctx.set_fold_model("vienna-2.1.2")
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(CUT, GAP, L, order)
+    gw = gpu_ctx.get_windows()
+    _, peaks = oracle.coverage_peaks(alns, ds.contig_lens, CUT)
+    win = oracle.make_windows(peaks, alns, ds.contigs, order, GAP, L, CUT * 0.5)
+    assert nwin == len(win["windows"]) == 70244
+    for f in ("tid", "ws", "we", "strand", "loc_s", "loc_e", "tag", "n_peaks", "n_matures", "seq_len"):
+        assert np.array_equal(gw["windows"][f], win["windows"][f]), f
+    W = win["windows"]
+    units = balance.parse_units(W["tag"])
+    a = int(units[np.searchsorted(units, 14000)]); b = int(units[np.searchsorted(units, a + 12000)])
+    assert len(np.unique(W["tid"][a:b])) >= 2
+    seqs = [win["seq"][w["seq_off"]:w["seq_off"] + w["seq_len"]].tobytes() for w in W[a:b]]
+    assert seqs == [gw["seq"][w["seq_off"]:w["seq_off"] + w["seq_len"]].tobytes() for w in gw["windows"][a:b]]
+    raw = gpu_ctx.fold_batch_raw(seqs, L)
+    assert (raw["status"] == 0).all()
+    want = oracle_fold_all(seqs, L)
+    bad = [k for k in range(b - a) if raw["mfe"][k] != want[k][1] or gpu_lines(raw, k) != want[k][0]]
+    assert not bad, bad[:10]
+    gpu_ctx.fold(L)
+    out = gpu_ctx.predict(3, 18, 23, False, True)
+    assert (out["status"] == 0).all() and len(out["result"]) == bench_expected("config2")
+    params = (3, 18, 23, 0, 1, 55)
+    exp = []
+    for u in range(int(np.searchsorted(units, a)), int(np.searchsorted(units, b))):
+        for k in range(int(units[u]), int(units[u + 1])):
+            w = W[k]
+            r = oracle.check_loci(oracle.structures_from_lines(want[k - a][0], 55), win["matures"][w["mature_off"]:w["mature_off"] + w["n_matures"]], w, alns, params)
+            assert out["n_passed"][k] == len(r), k
+            if r:
+                exp.append((k, mirna_record(r[0], ds.contig_names)))
+                break
+    sel = (out["result"]["window"] >= a) & (out["result"]["window"] < b)
+    got = [(int(m["window"]), [ds.contig_names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
+                               records.STRAND[m["strand"]], bool(m["has_star"])]) for m, ss, t in zip(out["result"], out["ss"], sel) if t]
+    assert len(got) > 1500 and got == exp
+
+
+def bench_expected(workload, model="vienna-2.1.2"):
+    import bench
+    return bench.EXPECTED_LOCI[(workload, model)]
