@@ -175,7 +175,7 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.qb2 = o; o += lds_al(LCAP + 8);
     L.list = o; o += lds_al(3 * LSEG * 4);      // 32-bit entries (see `list` in the kernel)
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
-    L.misc = o; o += lds_al((48 + ARCH_RB) * 4);
+    L.misc = o; o += lds_al((48 + ARCH_RB + ((SPARSE && MODEL) ? 48 : 0)) * 4);      // (vienna-1.8.5 candidate pass: + the 4 x 11-word bitmap of pooled pairs)
     if (SPARSE) { L.fml = o; L.fml_bytes = 160u * 1024u - o; o += L.fml_bytes; }
     L.total = o;
     return L;

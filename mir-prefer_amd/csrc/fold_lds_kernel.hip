@@ -139,9 +139,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
         // sparse splits: the candidate pool (u32 {s-1, j << 9} + u16 fML(s,j) per entry) takes what the window's triangle leaves of the fml region
         const int pool_off = SPARSE ? (int)lds_al(2u * (unsigned)(tri_off(((span < n - 1) ? span : n - 1) + 1, n > 5 ? n : 5) + 2)) : 0;
-        const int pool_cap = SPARSE ? ((((int)LY.fml_bytes - pool_off) / 6) & ~63) : 0;
+        // (vienna-1.8.5: 8-byte entries, one per PAIR -- see "pair pool" at splits_sparse185)
+        const int pool_cap = SPARSE ? ((((int)LY.fml_bytes - pool_off) / (MODEL ? 8 : 6)) & ~63) : 0;
         unsigned* poolA = (unsigned*)(smem + LY.fml + pool_off);
         unsigned short* poolB = (unsigned short*)(poolA + (pool_cap > 0 ? pool_cap : 0));
+        unsigned* poolB32 = poolA + (pool_cap > 0 ? pool_cap : 0);
+        unsigned* pbits = (unsigned*)(misc + 48 + ARCH_RB);      // [4][11]: pair (p, q) of diagonal dd is in the pool: bit p of row dd & 3
         short* carch = slabs + (size_t)win * 3 * slab_shorts;      // per-window slab: c, fML and trace-back triangles (read by fold_lds_epilogue_kernel)
         short* fml_out = carch + slab_shorts;
         unsigned short* tb_out = reinterpret_cast<unsigned short*>(carch + 2 * slab_shorts);
@@ -171,6 +174,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         for (int x = tid; x < NACC * LCAP; x += LNT) acc[x] = x >= 3 * LCAP ? INF : (int)KEY_NONE;   // ckey x 3 | mdec x 2 (3)
         if (tid == 0) {
             misc[1] = 0; misc[2] = 0; misc[3] = 0;
+            if constexpr (SPARSE && MODEL != 0) for (int x = 0; x < 44; x++) pbits[x] = 0;
             for (int x = 0; x < 6; x++) lcnt[x] = 0;
         }
         if (tid >= 64 && tid < 64 + ARCH_RB) rbt[tid - 64] = arch_rowblk_off(tid - 64, n, span);
@@ -249,6 +253,41 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int o = 7 - 4 * n + (__mul24(t, 2 * n + 1 - t) >> 1) + ((t - 4 + (n & 1)) >> 1) + i;     // tri_off(t, n) + i
                     const unsigned sum = (unsigned)fml[ok ? o : 1] + vb;
                     if (ok && sum < 65535u) atomicMin(&mdec[i], (int)sum - 2 * FML_BIAS);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pnv) : : "memory");
+                { const int pn = __builtin_amdgcn_readfirstlane(pnv); sp_snap = pn < pool_cap ? pn : pool_cap; }
+            };
+            // vienna-1.8.5 (dangles 1): the pool holds PAIRS.  A pair (p, q) reaches the multiloop through four cells -- (p,q) plain, (p-1,q) with
+            // its 5' dangle, (p,q+1) with its 3' dangle, (p-1,q+1) with both -- so one entry {p, q, c(p,q) + MLintern, d5, d3} relaxes the two cells
+            // of the diagonal in columns q and q+1, each over s = p and s = p-1: a term built from the pair is never below the true split value
+            // (fML(s,j) is the minimum over its variants) and equals it for every strict candidate, whose realising pair phase B pooled
+            // (tests/tools: gate185b -- 1,283 pairs per benchmark window against 3,142 candidate cells, identity checked cell by cell).
+            auto splits_sparse185 = [&]() {
+                const int lim = sp_snap;
+                int pnv;
+                {
+                    const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&misc[3];
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(pnv) : "v"(pa) : "memory");
+                }
+                if (!(dbg_flags & 2))
+                for (int k = (LNW - 1 - wave) * 64 + lane; k < lim; k += LNT) {
+                    const unsigned lo = poolA[k], hi = poolB32[k];
+                    const int p = (int)(lo & 511u), q = (int)((lo >> 9) & 511u);
+                    const int valb = (int)(hi & 0xffffu), e5 = -(int)((hi >> 16) & 255u), e3 = -(int)(hi >> 24);
+                    const int i0 = q - d, t0 = p - 1 - i0;
+                    const int oA0 = 7 - 4 * n + (__mul24(t0, 2 * n + 1 - t0) >> 1) + ((t0 - 4 + (n & 1)) >> 1) + i0;      // tri_off(t0, n) + i0
+                    const int oA1 = oA0 - tri_len_any(t0 - 1, n);                                                     // tri_off(t0 - 1, n) + i0
+                    const int oB1 = oA1 - tri_len_any(t0 - 2, n) + 1;                                                 // tri_off(t0 - 2, n) + i0 + 1
+                    const bool c0 = i0 >= 1, c1 = i0 >= 0 && q + 1 <= n;
+                    const bool vA0 = c0 && t0 >= TURN + 1, vA1 = c0 && t0 - 1 >= TURN + 1, vB0 = c1 && t0 - 1 >= TURN + 1, vB1 = c1 && t0 - 2 >= TURN + 1;
+                    const int a0 = fml[vA0 ? oA0 : 1], a1 = fml[vA1 ? oA1 : 1], b0 = fml[vB0 ? oA1 + 1 : 1], b1 = fml[vB1 ? oB1 : 1];
+                    int best0 = INF, best1 = INF;
+                    if (vA0 && a0 != 65535) best0 = a0 + valb;
+                    if (vA1 && a1 != 65535) { const int v = a1 + valb + e5; best0 = v < best0 ? v : best0; }
+                    if (vB0 && b0 != 65535) best1 = b0 + valb + e3;
+                    if (vB1 && b1 != 65535) { const int v = b1 + valb + e5 + e3; best1 = v < best1 ? v : best1; }
+                    if (best0 < INF) atomicMin(&mdec[i0], best0 - 2 * FML_BIAS);
+                    if (best1 < INF) atomicMin(&mdec[i0 + 1], best1 - 2 * FML_BIAS);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pnv) : : "memory");
                 { const int pn = __builtin_amdgcn_readfirstlane(pnv); sp_snap = pn < pool_cap ? pn : pool_cap; }
@@ -358,7 +397,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             // Half of the waves run the splits before the interior loops: the split loop loads the LDS pipe much more than the interior loops do,
             // so the two halves even out the LDS load of the interval (the phases are independent: both only feed phase B of this diagonal).
             const bool swap_order = !SPARSE && (wave & 1) && !(dbg_flags & 2048);      // (the sparse splits are too short to matter: measured 0.5 ms better behind the interior loops)
-            auto splits = [&]() { if constexpr (SPARSE) splits_sparse(); else splits_dense(); };
+            auto splits = [&]() { if constexpr (SPARSE && MODEL != 0) splits_sparse185(); else if constexpr (SPARSE) splits_sparse(); else splits_dense(); };
             if (swap_order) splits();
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) wt = clock64();
             // phase A1: interior-loop candidates.  The c ring holds G0(p,q) = c(p,q) + mismatchI[rtype(pq)][S[q+1]][S[p-1]] (+ 32768).
@@ -543,6 +582,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
             int* mdec = mdec_of(d);
             int cand = 0; unsigned cent = 0, cval = 0;      // sparse splits: this cell as a split candidate
+            int rp = 0, rq = 0, rval = 0, rtp = 0;          // vienna-1.8.5 candidate pass: the pair whose term realises fML of this cell, its plain term and type
+            if constexpr (SPARSE && MODEL != 0) { if (tid < 11) pbits[((d + 1) & 3) * 11 + tid] = 0; }      // the row of diagonal d-3 serves diagonal d+1 from the next interval on
             const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
             const int od = tri_off(d, n), od1 = tri_off(d - 1, n);     // scalar arithmetic instead of a table read on the cell's dependency chain
             const int x = tid;
@@ -614,7 +655,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     // fML pair terms, dangles 1: (i,j) plain, (i+1,j) with a 5' dangle, (i,j-1) with a 3' dangle, (i+1,j-1) with both.  Plain c of the
                     // neighbouring cells comes out of the G0 ring (G0 = c + mismatchI of the pair seen as an inner pair).
                     const int mli = T.ML_intern, tau = T.TerminalAU;
-                    if (type) { const int e = cv + mli + (type > 2 ? tau : 0); m = e < m ? e : m; }
+                    if (type) { const int e = cv + mli + (type > 2 ? tau : 0); if (e < m) { m = e; rp = i; rq = j; rval = e; rtp = type; } }
                     auto plain = [&](int dd, int ii, int& tp) -> int {
                         tp = 0;
                         if (dd < 4) return INF;
@@ -625,11 +666,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     };
                     int tp;
                     int cc = plain(d - 1, i + 1, tp);
-                    if (cc < INF) { const int e = cc + T.dangle5[tp * 5 + S[i]] + mli + (tp > 2 ? tau : 0); m = e < m ? e : m; }
+                    if (cc < INF) { const int pl = cc + mli + (tp > 2 ? tau : 0), e = pl + T.dangle5[tp * 5 + S[i]]; if (e < m) { m = e; rp = i + 1; rq = j; rval = pl; rtp = tp; } }
                     cc = plain(d - 1, i, tp);
-                    if (cc < INF) { const int e = cc + T.dangle3[tp * 5 + S[j]] + mli + (tp > 2 ? tau : 0); m = e < m ? e : m; }
+                    if (cc < INF) { const int pl = cc + mli + (tp > 2 ? tau : 0), e = pl + T.dangle3[tp * 5 + S[j]]; if (e < m) { m = e; rp = i; rq = j - 1; rval = pl; rtp = tp; } }
                     cc = plain(d - 2, i + 1, tp);
-                    if (cc < INF) { const int e = cc + T.dangle5[tp * 5 + S[i]] + T.dangle3[tp * 5 + S[j]] + mli + (tp > 2 ? tau : 0); m = e < m ? e : m; }
+                    if (cc < INF) { const int pl = cc + mli + (tp > 2 ? tau : 0), e = pl + T.dangle5[tp * 5 + S[i]] + T.dangle3[tp * 5 + S[j]]; if (e < m) { m = e; rp = i + 1; rq = j - 1; rval = pl; rtp = tp; } }
                 } else if (type) {
                     int e = cv + lds_mlstem(T, P, type, i > 1 ? (int)S[i - 1] : -1, j < n ? (int)S[j + 1] : -1); m = e < m ? e : m;
                 }
@@ -652,6 +693,16 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 ckey[i] = KEY_NONE;
                 if constexpr (SPARSE) { mdec_of(d + 2)[i] = INF; cval = m16; cent = (unsigned)(i - 1) | ((unsigned)j << 9); }
                 else mdec[i] = INF;
+                if constexpr (SPARSE && MODEL != 0) {
+                    if (cand) {      // the realising pair goes to the pool once: the first of its (up to four) candidate cells claims its bit
+                        const unsigned bit = 1u << (rp & 31);
+                        const unsigned old = atomicOr(&pbits[((rq - rp) & 3) * 11 + (rp >> 5)], bit);
+                        cand = (old & bit) ? 0 : 1;
+                        cent = (unsigned)rp | ((unsigned)rq << 9);
+                        cval = (unsigned)(rval + FML_BIAS) | ((unsigned)(-(int)T.dangle5[rtp * 5 + S[rp - 1]]) << 16) | ((unsigned)(-(int)T.dangle3[rtp * 5 + S[rq + 1]]) << 24);
+                        if (rval + FML_BIAS < 0 || rval + FML_BIAS > 65534) misc[1] = 1;      // (cannot happen inside the fML range check above; kept as a guard)
+                    }
+                }
             }
             if constexpr (SPARSE) {
                 const unsigned long long cbal = __ballot(cand != 0);
@@ -660,7 +711,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     if (lane == (int)__builtin_ctzll(cbal)) cbase = atomicAdd(&misc[3], (int)__popcll(cbal));
                     const int at = __builtin_amdgcn_readlane(cbase, (int)__builtin_ctzll(cbal)) + (int)__popcll(cbal & ((1ull << lane) - 1ull));
                     if (cand) {
-                        if (at < pool_cap) { poolA[at] = cent; poolB[at] = (unsigned short)cval; }
+                        if (at < pool_cap) { poolA[at] = cent; if constexpr (MODEL != 0) poolB32[at] = cval; else poolB[at] = (unsigned short)cval; }
                         else misc[2] = 1;
                     }
                 }
@@ -794,10 +845,60 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int lb = __builtin_amdgcn_readfirstlane(lbase);
             if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)(x + 1) | ((unsigned)lt << 9) | ((unsigned)ent_terms << 12));
         };
+        // Candidate pool: an entry is dead once its column has left the diagonal (j <= d + 1; pairs: q <= d), and dead entries still cost the
+        // readers a lane each.  Every MIRP_CPERIOD diagonals the pool is compacted in place: every wave keeps its slice in registers across a barrier, the
+        // survivors move left behind the survivors of the lower waves.  (Between two barriers of its own: phase B of this interval appends after it.)
+        auto compact_pool = [&](const int d) {
+            constexpr int CR = 4;                  // rounds of 64 entries per wave: 16 x 4 x 64 = 4096 >= any pool capacity
+            int* cnts = misc + 22;                 // [16]
+            int total = misc[3];
+            total = total < pool_cap ? total : pool_cap;
+            const int per = ((total + LNW * 64 - 1) / (LNW * 64)) * 64;      // entries per wave (multiple of 64)
+            unsigned ea[CR], eb[CR];
+            int nal = 0;
+            unsigned long long al[CR];
+#pragma unroll
+            for (int r = 0; r < CR; r++) {
+                const int k = wave * per + r * 64 + lane;
+                bool alive = false;
+                ea[r] = 0; eb[r] = 0;
+                if (r * 64 < per && k < total) {
+                    ea[r] = poolA[k];
+                    if constexpr (MODEL != 0) eb[r] = poolB32[k]; else eb[r] = poolB[k];
+                    const int col = (int)((ea[r] >> 9) & 511u);
+                    alive = MODEL ? (col >= d + 1) : (col >= d + 2);
+                }
+                al[r] = __ballot(alive);
+                nal += (int)__popcll(al[r]);
+            }
+            if (lane == 0) cnts[wave] = nal;
+            __syncthreads();
+            int pre = 0, tot = 0;
+            for (int w = 0; w < LNW; w++) { const int c = cnts[w]; pre += w < wave ? c : 0; tot += c; }
+#pragma unroll
+            for (int r = 0; r < CR; r++) {
+                if ((al[r] >> lane) & 1ull) {
+                    const int at = pre + (int)__popcll(al[r] & ((1ull << lane) - 1ull));
+                    poolA[at] = ea[r];
+                    if constexpr (MODEL != 0) poolB32[at] = eb[r]; else poolB[at] = (unsigned short)eb[r];
+                }
+                pre += (int)__popcll(al[r]);
+            }
+            if (tid == 0) misc[3] = tot;
+            sp_snap = __builtin_amdgcn_readfirstlane(tot);
+            __syncthreads();
+        };
         if (Dm >= 4) phaseA(4);
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
         for (int d = 4; d <= Dm; d++) {
+#ifndef MIRP_CPERIOD0
+#define MIRP_CPERIOD0 0       // default model: never (925 entries: a compaction's two barriers cost more than the dead lanes; measured 60.9 / 61.7 / 62.1 / 62.9 ms at never / 128 / 64 / 32)
+#endif
+#ifndef MIRP_CPERIOD1
+#define MIRP_CPERIOD1 64      // vienna-1.8.5 (1,283 pair entries, 70 instructions per visit): 89.5 ms without, 87.3 / 85.9 / 85.6 / 85.0 at 8 / 16 / 32 / 64
+#endif
+            if constexpr (SPARSE) { constexpr int CP = MODEL ? MIRP_CPERIOD1 : MIRP_CPERIOD0; if (CP > 0 && (d & (CP - 1)) == 0 && d >= 32) compact_pool(d); }
             if (dbg_cycles && lane == 0) wt = clock64();
             if constexpr (MODEL == 0) { if (!SPARSE && (dbg_flags & 4096)) phaseB(d); else phaseB0(d); } else phaseB(d);
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) { const long long t = clock64(); wB += t - wt; wt = t; }   // bit 20: light mode, busy / barrier only
@@ -1064,14 +1165,10 @@ hipError_t launch_fold_lds(hipStream_t stream, int model, int grid, int grid_epi
     if (e != hipSuccess) return e;
     const int* no_list = nullptr; const unsigned int* no_count = nullptr;
     if (model) {
-        // The vienna-1.8.5 model stays on the dense split loop: with dangles 1 every pair gives up to four strictly pair-realised fML cells ((i,j),
-        // (i-1,j), (i,j+1), (i-1,j+1)), i.e. about four times the candidates, and the pool behind a 325-nt window's triangle (2,560 entries) overflows
-        // for most windows (measured: 161 ms = both passes).  MIRP_SPARSE185 (dev builds) runs the candidate-pool pass anyway.
-#ifdef MIRP_SPARSE185
+        // vienna-1.8.5: with dangles 1 every pair gives up to four strictly pair-realised fML cells ((i,j), (i-1,j), (i,j+1), (i-1,j+1)), i.e. about four
+        // times the candidate cells of the default model (3,142 per benchmark window: a cell pool overflowed for most windows, 161 ms = both passes);
+        // the pool of this instantiation holds PAIRS instead (1,283 per window, 8-byte entries: splits_sparse185).
         const bool sparse185 = !force_dense;
-#else
-        const bool sparse185 = false;
-#endif
         if (sparse185) {      // as the default model below: candidate-pool pass, then the dense instantiation over what it handed over
             hipLaunchKernelGGL((fold_lds_kernel<1, true>), dim3(grid), dim3(LNT), lds_sp1, stream, P, seqs, offs, lens, n_work, win_base, span, slabs, slab_shorts, win_state, work_counter,
                                fallback_list, fallback_count, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status, dbg_flags, dbg_cycles,

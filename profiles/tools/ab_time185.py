@@ -12,3 +12,4 @@ ms = []
 for _ in range(4):
     ctx.fold(300); ms.append(ctx.last_fold_kernel_ms())
 print("%-40s vienna-1.8.5: fill %.2f ms  epilogue %.2f ms" % (os.path.basename(capi.LIB_PATH), float(np.mean([m[0] for m in ms[1:]])), float(np.mean([m[1] for m in ms[1:]]))), flush=True)
+print("windows handed to the dense pass: %d, generic fallbacks: %d" % (ctx.last_fold_dense(), ctx.last_fold_fallbacks()), flush=True)
