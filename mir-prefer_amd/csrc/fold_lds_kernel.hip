@@ -845,6 +845,130 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             const int lb = __builtin_amdgcn_readfirstlane(lbase);
             if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)(x + 1) | ((unsigned)lt << 9) | ((unsigned)ent_terms << 12));
         };
+        // Phase B of the vienna-1.8.5 model in the same two-round form (round 4): the straightforward phaseB above reads inside branches and lambdas --
+        // a dozen read-wait pairs per cell -- and cost the model 22 ms against the default model's phase B.  Same arithmetic, same order of the
+        // minima (the first of equal terms wins wherever the order matters: the realising pair of the candidate pass).
+        auto phaseB1 = [&](const int d) {
+            const int ncell = n - d;
+            unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);
+            int* mdec = mdec_of(d);
+            int cand = 0; unsigned cent = 0, cval = 0;
+            if constexpr (SPARSE) { if (tid < 11) pbits[((d + 1) & 3) * 11 + tid] = 0; }
+            const int hp_u = P->hairpinE[d - 1 < MIRP_HP_MAX ? d - 1 : MIRP_HP_MAX - 1];
+            const int od = tri_off(d, n), od1 = tri_off(d - 1, n);
+            const int x = tid;
+            int lt = 0, lbase = 0, loi = 0, ent_terms = 0;
+            unsigned long long lbal = 0;
+            const bool do_list = d + 3 <= D;
+            const bool has1 = d - 1 >= 4, has2 = d - 2 >= 4;      // the ring rows of diagonals d-1 / d-2 hold cells of this window
+            if (tid == 0) lcnt[(d + 4) % 6] = 0;
+            if (x < ncell) {
+                const int i = x + 1, j = i + d, u = d - 1;
+                // ---- round 1: everything addressed by (i, j, d) alone
+                lds_vu8 Sv = (lds_vu8)S;
+                const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
+                const int s_j3 = Sv[j + 3 <= n ? j + 3 : n], s_j2 = Sv[j + 2 <= n ? j + 2 : n];
+                int md = mdec[i];
+                if constexpr (SPARSE) { md = dml_carry < md ? dml_carry : md; dml_carry = md; }
+                const unsigned kk = ckey[i];
+                const int q11 = dmlring[((d + DMLR - 2) % DMLR) * LCAP + i + 1], q21 = dmlring[((d + DMLR - 3) % DMLR) * LCAP + i + 2];
+                const int q12 = dmlring[((d + DMLR - 3) % DMLR) * LCAP + i + 1], q22 = dmlring[((d + DMLR - 4) % DMLR) * LCAP + i + 2];
+                int fa = 65535, fb = 65535;
+                if (d > 4) { fa = fml[od1 + i]; fb = fml[od1 + i + 1]; }
+                const int tetra = u == 4 ? (int)spec[nc + i] : 0;
+                const unsigned g1 = has1 ? (unsigned)cring[((d - 1) & 31) * CSTR + i + 1] : 65535u;      // G0 of (i+1, j)
+                const unsigned g2 = has1 ? (unsigned)cring[((d - 1) & 31) * CSTR + i] : 65535u;          // G0 of (i, j-1)
+                const unsigned g3 = has2 ? (unsigned)cring[((d - 2) & 31) * CSTR + i + 1] : 65535u;      // G0 of (i+1, j-1)
+                if (do_list) {
+                    if (j + 3 <= n) { lt = pair_type(s_i, s_j3); loi = lt * 25 + s_ip1 * 5 + s_j2; }
+                    lbal = __ballot(lt != 0);
+                    if (lbal && lane == 0) {
+                        const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&lcnt[(d + 3) % 6];
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(lbase) : "v"(la), "v"((int)__popcll(lbal)) : "memory");
+                    }
+                }
+                // ---- pair types (arithmetic) and round 2: parameter tables (a type-0 row is valid memory, its value is never used)
+                const int type = d > D ? 0 : pair_type(s_i, s_j);
+                const int rt = rtype_of(type);
+                const int tp1 = pair_type(s_ip1, s_j), tp2 = pair_type(s_i, s_jm1), tp3 = pair_type(s_ip1, s_jm1);
+                const int tau = T.TerminalAU, mli = T.ML_intern, mlc = T.ML_closing;
+                const int mmH = T.mismatchH[type * 25 + s_ip1 * 5 + s_jm1];
+                const int e3 = T.dangle3[rt * 5 + s_ip1], e5 = T.dangle5[rt * 5 + s_jm1];
+                const int mmI = T.mismatchI[rt * 25 + s_jp1 * 5 + s_im1];
+                const int mi1 = T.mismatchI[rtype_of(tp1) * 25 + s_jp1 * 5 + s_i];
+                const int mi2 = T.mismatchI[rtype_of(tp2) * 25 + s_j * 5 + s_im1];
+                const int mi3 = T.mismatchI[rtype_of(tp3) * 25 + s_j * 5 + s_i];
+                const int d5_1 = T.dangle5[tp1 * 5 + s_i], d3_2 = T.dangle3[tp2 * 5 + s_j], d5_3 = T.dangle5[tp3 * 5 + s_i], d3_3 = T.dangle3[tp3 * 5 + s_j];
+                ent_terms = ENT_OUTER((int)T.mismatchI[loi], (int)T.mismatch1nI[loi]);
+                // ---- arithmetic
+                const int au = type > 2 ? tau : 0;
+                int cv = INF, tb = 0;
+                if (type) {
+                    const int cint = kk == KEY_NONE ? INF : (int)(kk >> 10) - KEY_BIAS;
+                    const int h = hp_u + (u == 3 ? au : mmH) + tetra;
+                    cv = h < cint ? h : cint;
+                    // multiloop closed by (i,j), dangles 1: min over { DML(i+1,j-1), DML(i+2,j-1)+d3, DML(i+1,j-2)+d5, DML(i+2,j-2)+d3+d5 }
+                    int X = INF;
+                    if (q11 != I16_INF) X = q11;
+                    if (q21 != I16_INF && q21 + e3 < X) X = q21 + e3;
+                    if (q12 != I16_INF && q12 + e5 < X) X = q12 + e5;
+                    if (q22 != I16_INF && q22 + e3 + e5 < X) X = q22 + e3 + e5;
+                    if (X < INF) { const int e = X + mlc + mli + au; cv = e < cv ? e : cv; }
+                    if (cint < INF && cint == cv && h != cv) tb = (int)(kk & 1023u) + 1;
+                }
+                int m = INF;
+                {
+                    const int a = fa == 65535 ? INF : fa - FML_BIAS, b = fb == 65535 ? INF : fb - FML_BIAS;
+                    m = a < b ? a : b;
+                }
+                const int mab = m;
+                int rp = 0, rq = 0, rval = 0, rtp = 0;
+                if (type) { const int e = cv + mli + au; if (e < m) { m = e; rp = i; rq = j; rval = e; rtp = type; } }
+                if (g1 != 65535u) { const int pl = (int)g1 - 32768 - mi1 + mli + (tp1 > 2 ? tau : 0), e = pl + d5_1; if (e < m) { m = e; rp = i + 1; rq = j; rval = pl; rtp = tp1; } }
+                if (g2 != 65535u) { const int pl = (int)g2 - 32768 - mi2 + mli + (tp2 > 2 ? tau : 0), e = pl + d3_2; if (e < m) { m = e; rp = i; rq = j - 1; rval = pl; rtp = tp2; } }
+                if (g3 != 65535u) { const int pl = (int)g3 - 32768 - mi3 + mli + (tp3 > 2 ? tau : 0), e = pl + d5_3 + d3_3; if (e < m) { m = e; rp = i + 1; rq = j - 1; rval = pl; rtp = tp3; } }
+                if constexpr (SPARSE) cand = m < mab && m < md;
+                m = md < m ? md : m;
+                if ((cv < INF && (cv > FIN_LIMIT || cv < -FIN_LIMIT)) || (m < INF && (m > FML_MAX || m < -FML_BIAS)) ||
+                    (md < INF && (md > FIN_LIMIT || md < -FIN_LIMIT))) misc[1] = 1;
+                const short c16 = cv >= INF ? (short)I16_INF : (short)cv;
+                const unsigned short m16 = m >= INF ? (unsigned short)65535 : (unsigned short)(m + FML_BIAS);
+                const unsigned short g16 = cv < INF ? (unsigned short)(cv + mmI + 32768) : (unsigned short)65535;
+                cring[(d & 31) * CSTR + i] = g16;
+                if ((d & 31) == 0) cring[32 * CSTR + i] = g16;
+                carch[abase + 8 * d] = c16;
+                tb_out[abase + 8 * d] = (unsigned short)tb;
+                fml[od + i] = m16;
+                dmlring[(d % DMLR) * LCAP + i] = md >= INF ? (short)I16_INF : (short)md;
+                ckey[i] = KEY_NONE;
+                if constexpr (SPARSE) {
+                    mdec_of(d + 2)[i] = INF;
+                    if (cand) {      // the realising pair goes to the pool once: the first of its (up to four) candidate cells claims its bit
+                        const unsigned bit = 1u << (rp & 31);
+                        const unsigned old = atomicOr(&pbits[((rq - rp) & 3) * 11 + (rp >> 5)], bit);
+                        cand = (old & bit) ? 0 : 1;
+                        cent = (unsigned)rp | ((unsigned)rq << 9);
+                        cval = (unsigned)(rval + FML_BIAS) | ((unsigned)(-(int)T.dangle5[rtp * 5 + Sv[rp - 1]]) << 16) | ((unsigned)(-(int)T.dangle3[rtp * 5 + Sv[rq + 1]]) << 24);
+                        if (rval + FML_BIAS < 0 || rval + FML_BIAS > 65534) misc[1] = 1;
+                    }
+                } else mdec[i] = INF;
+            }
+            if constexpr (SPARSE) {
+                const unsigned long long cbal = __ballot(cand != 0);
+                if (cbal) {      // wave-uniform
+                    int cbase = 0;
+                    if (lane == (int)__builtin_ctzll(cbal)) cbase = atomicAdd(&misc[3], (int)__popcll(cbal));
+                    const int at = __builtin_amdgcn_readlane(cbase, (int)__builtin_ctzll(cbal)) + (int)__popcll(cbal & ((1ull << lane) - 1ull));
+                    if (cand) {
+                        if (at < pool_cap) { poolA[at] = cent; poolB32[at] = cval; }
+                        else misc[2] = 1;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lbase) : : "memory");
+            const int lb = __builtin_amdgcn_readfirstlane(lbase);
+            if (lt) list[(d % 3) * LSEG + lb + __popcll(lbal & ((1ull << lane) - 1ull))] = (list_t)((unsigned)(x + 1) | ((unsigned)lt << 9) | ((unsigned)ent_terms << 12));
+        };
         // Candidate pool: an entry is dead once its column has left the diagonal (j <= d + 1; pairs: q <= d), and dead entries still cost the
         // readers a lane each.  Every MIRP_CPERIOD diagonals the pool is compacted in place: every wave keeps its slice in registers across a barrier, the
         // survivors move left behind the survivors of the lower waves.  (Between two barriers of its own: phase B of this interval appends after it.)
@@ -900,7 +1024,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 #endif
             if constexpr (SPARSE) { constexpr int CP = MODEL ? MIRP_CPERIOD1 : MIRP_CPERIOD0; if (CP > 0 && (d & (CP - 1)) == 0 && d >= 32) compact_pool(d); }
             if (dbg_cycles && lane == 0) wt = clock64();
-            if constexpr (MODEL == 0) { if (!SPARSE && (dbg_flags & 4096)) phaseB(d); else phaseB0(d); } else phaseB(d);
+            if constexpr (MODEL == 0) { if (!SPARSE && (dbg_flags & 4096)) phaseB(d); else phaseB0(d); } else { if (dbg_flags & 4096) phaseB(d); else phaseB1(d); }
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) { const long long t = clock64(); wB += t - wt; wt = t; }   // bit 20: light mode, busy / barrier only
             if (d + 1 <= Dm) phaseA(d + 1);
             if (dbg_cycles && lane == 0) { const long long t = clock64(); wA2 += t - wt; wt = t; }
