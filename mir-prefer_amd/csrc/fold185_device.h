@@ -537,14 +537,15 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
                                 const int d = d0 + u * 2 * NW, j = i + d;
                                 if (!(i >= 1 && j <= jmax)) continue;
                                 int a = V_INF, b = V_INF;
-                                int t = ptype(X, i, j);
-                                if (t) {
+                                // c is finite only where the two bases pair: the pair type (two sequence reads) is looked up for those cells only
+                                if (ca[u] < V_INF) {
+                                    const int t = ptype(X, i, j);
                                     const int e = ca[u] + AU(X, t);
                                     a = e;
                                     if (j < n) b = e + D3(X, t, S[j + 1]);
                                 }
-                                t = ptype(X, i + 1, j);
-                                if (t) {
+                                if (cb[u] < V_INF) {
+                                    const int t = ptype(X, i + 1, j);
                                     const int e = cb[u] + D5(X, t, S[i]) + AU(X, t);
                                     a = e < a ? e : a;
                                     if (j < n) { const int v = e + D3(X, t, S[j + 1]); b = v < b ? v : b; }
