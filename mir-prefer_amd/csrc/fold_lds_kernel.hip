@@ -220,6 +220,8 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
         const int abase = tid < 8 * ARCH_RB ? rbt[tid >> 3] + (tid & 7) - 32 : 0;   // archive offset of (d, i = tid + 1) is abase + 8 d
         int a1_ncp = __builtin_amdgcn_readfirstlane(lcnt[0]);   // phase A1: length of the next diagonal's list (first: diagonal 6)
+        int lc_pre = 0;           // list length of diagonal d+1 for phaseA(d), read at the top of the interval (see the main loop)
+        bool lc_have = false;
         auto phaseA = [&](const int d) {
             const int ncell = n - d;
             unsigned* ckey = reinterpret_cast<unsigned*>(acc + MIRP_CK(d) * LCAP);   // best interior-loop candidate key per cell
@@ -414,7 +416,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 const int done = a1_done;                  // leading cells of this diagonal's list that were relaxed in the previous interval
                 const int rem = ncp - done;
                 const int nblk = (rem + 63) >> 6;
-                const int ncp2 = __builtin_amdgcn_readfirstlane(lcnt[(d + 1) % 6]);
+                int ncp2;
+                if (lc_have) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lc_pre) : : "memory"); ncp2 = __builtin_amdgcn_readfirstlane(lc_pre); }
+                else ncp2 = __builtin_amdgcn_readfirstlane(lcnt[(d + 1) % 6]);
                 a1_ncp = ncp2;
                 const int room = nblk * 64 - rem;          // < 64: idle lanes of the last block
                 const int take2 = mix ? (room < ncp2 ? room : ncp2) : 0;
@@ -1024,6 +1028,13 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
 #endif
             if constexpr (SPARSE) { constexpr int CP = MODEL ? MIRP_CPERIOD1 : MIRP_CPERIOD0; if (CP > 0 && (d & (CP - 1)) == 0 && d >= 32) compact_pool(d); }
             if (dbg_cycles && lane == 0) wt = clock64();
+            if constexpr (MODEL != 0) {   // the length of the list phase A1 of this interval looks ahead to (diagonal d+2, built in the previous interval): read
+                // now, first looked at in phaseA -- on the waves that own cells the phase-B chain covers the round trip.  (vienna-1.8.5: -0.9 ms; the
+                // default model measured +0.4 ms with it and keeps the read in phaseA.)
+                const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&lcnt[(d + 2) % 6];
+                asm volatile("ds_read_b32 %0, %1" : "=v"(lc_pre) : "v"(la) : "memory");
+                lc_have = true;
+            }
             if constexpr (MODEL == 0) { if (!SPARSE && (dbg_flags & 4096)) phaseB(d); else phaseB0(d); } else { if (dbg_flags & 4096) phaseB(d); else phaseB1(d); }
             if (dbg_cycles && lane == 0 && !(dbg_flags & (1 << 20))) { const long long t = clock64(); wB += t - wt; wt = t; }   // bit 20: light mode, busy / barrier only
             if (d + 1 <= Dm) phaseA(d + 1);
