@@ -62,6 +62,8 @@ class Pipeline:
     """One device context + the option dict; the stage methods can run in one process (pipeline verb) or one per process
     (stage verbs): a stage that finds no device-resident state re-creates it from the previous stages' artefacts."""
 
+    _imported, _moves = (), None          # window-level re-balancing (balance.py): payloads received, the plan (None: not decided yet)
+
     def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2", rank=0, world=1, ctx=None):
         """rank / world: contig sharding over one process per GPU (`torch.distributed` initialised by the caller, see cli.py).  Every rank
         runs the stages on its own contigs (dist.partition_contigs); rank 0 merges the artefacts and writes the result files."""
