@@ -292,7 +292,10 @@ def e2e_cli(ds, fold_model):
         in_bytes = sum(os.path.getsize(p) for p in sams) + os.path.getsize(fa)
         so = sys.stdout
         sys.stdout = open(os.devnull, "w")
+        first_wall = None
         try:
+          for rep in range(2):      # two in-process runs, the second is reported (the first one's wall-clock is kept beside it: it pays the device allocations
+            shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)      # of a new context, which vary with what the process did before)
             t0 = time.time()
             opt = config.parse_configfile(cfg)
             opt["OUTPUT_DETAILS_FOR_DEBUG"] = False
@@ -312,13 +315,16 @@ def e2e_cli(ds, fold_model):
                     gpu[st] = tm[st + "_ms"] / 1e3
             wall = time.time() - t0
             p.ctx.close()
+            if rep == 0:
+                first_wall = wall
         finally:
             sys.stdout.close()
             sys.stdout = so
         out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs)
-        return {"wall_s": wall, "stage_s": stages, "stage_gpu_s": gpu, "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": len(res or []),
+        return {"wall_s": wall, "wall_s_first_run": first_wall, "stage_s": stages, "stage_gpu_s": gpu, "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": len(res or []),
                 "note": "in-process CLI stage drivers in the `pipeline` verb's sequence (config parse -> prepare -> candidate -> fold -> predict incl. every stage "
-                        "artefact and report file; stage_gpu_s = the device time inside each stage, the rest is host); "
+                        "artefact and report file; stage_gpu_s = the device time inside each stage, the rest is host); the second of two runs, each with a "
+                        "context of its own (wall_s_first_run: the first, which also pays the first device allocations of the process' second context); "
                         "interpreter start-up not included"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
