@@ -329,6 +329,21 @@ int mirp_report_readmapping(const int32_t* loci, int64_t n_loci, const char* ss,
                             const int64_t* contig_len, int32_t n_contigs, const char* sample_names, int32_t n_samples, const int64_t* counts,
                             char** text, int64_t** offsets);
 
+
+/* Report files of the predict stage, formatted and written by native threads, byte for byte what the reference writes:
+ * <prefix>_miRNA.gff3 (gen_gff_from_result MP:2619-2641), _miRNA.mature.fa / _miRNA.precursor.fa / _miRNA.precursor.ss
+ * (gen_mirna_fasta_ss_from_result MP:2963-3019), _miRNA.detail.csv (gen_csv_table MP:2744-2779), _miRNA.detail.html (gen_html_table_file
+ * MP:2793-2904), miRNA.stat.txt (MP:3585-3593).  Host only (no device).  The loci are in their final order (resultlist.sort(), MP:2622):
+ * loci[n][10] = {contig index, fold_s, fold_e, mat_s, mat_e, star_s, star_e, strand (0 '+', 1 '-'), star expressed (0 / 1), overhang
+ * (0 "2:2", 1 "2:3", 2 "3:3")}; contig_names / ss / precursor / sample_names = NUL-terminated strings back to back (precursor = forward-strand
+ * text chrom:fold_s-(fold_e-1), upper case, T -> U); counts[n][n_samples][4] = reads on precursor / mature / star / antisense region;
+ * mirbase_form = four strings: what stands before and behind the mature sequence in the miRBase search form for taxon "Viridiplantae", then for
+ * "ALL" (gen_search_miRBase_str MP:2773-2791).  A NULL path skips that file.  0 = ok, < 0 with a message in errbuf. */
+int mirp_write_reports(int64_t n_loci, const int32_t* loci, const char* contig_names, int32_t n_contigs, const char* ss, const char* precursor,
+                       const char* sample_names, int32_t n_samples, const int64_t* counts, const char* mirbase_form, const char* gff_path,
+                       const char* mature_fa_path, const char* precursor_fa_path, const char* ss_path, const char* csv_path, const char* html_path,
+                       const char* stat_path, char* errbuf, size_t errbuf_len);
+
 #ifdef __cplusplus
 }
 #endif

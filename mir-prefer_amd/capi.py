@@ -59,6 +59,28 @@ def report_readmapping(loci, ss_list, alns, contig_arrays, sample_names, counts0
     return [blob[o[k]:o[k + 1]].decode() for k in range(n)]
 
 
+def write_reports(loci, contig_names, ss_list, pre_list, sample_names, counts, mirbase_form, paths):
+    """The report files of the predict stage (mirp_write_reports, host only, native threads): loci = int32 [n, 10] {contig index, fold_s, fold_e, mat_s,
+    mat_e, star_s, star_e, strand, star expressed, overhang code} in final order, ss_list / pre_list = n structure / forward-strand precursor strings,
+    counts = int64 [n, n_samples, 4], mirbase_form = the four fixed pieces of the two miRBase search forms, paths = {"gff", "mature", "precursor",
+    "ss", "csv", "html", "stat"} -> file name (missing = not written)."""
+    lib = load_library()
+    loci = np.ascontiguousarray(loci, dtype=np.int32).reshape(-1, 10)
+    n = len(loci)
+    cnt = np.ascontiguousarray(counts, dtype=np.int64).reshape(n, len(sample_names), 4)
+    blob = lambda xs: b"".join(x.encode() + b"\0" for x in xs)
+    p = lambda k: paths[k].encode() if paths.get(k) else None
+    err = C.create_string_buffer(512)
+    fn = lib.mirp_write_reports
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int64, C.c_void_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_char_p] + [C.c_char_p] * 7 + \
+                  [C.c_char_p, C.c_size_t]
+    rc = fn(n, loci.ctypes.data if n else None, blob(contig_names), len(contig_names), blob(ss_list), blob(pre_list), blob(sample_names), len(sample_names),
+            cnt.ctypes.data if cnt.size else None, blob(mirbase_form), p("gff"), p("mature"), p("precursor"), p("ss"), p("csv"), p("html"), p("stat"), err, 512)
+    if rc != 0:
+        raise MirpError("%s (%d)" % (err.value.decode(), rc))
+
+
 def read_fasta(path, want=None):
     """Native FASTA reader (mirp_read_fasta): -> list of (name, uint8 array) in file order; with `want` (names) only those sequences are
     materialised, the others come back as None."""

@@ -409,3 +409,225 @@ extern "C" int mirp_report_readmapping(const int32_t* loci, int64_t n_loci, cons
     *text = out; *offsets = off;
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// Report files of the predict stage: the reference formats them locus by locus in Python (MP:2619-2641, 2644-2779, 2793-2904,
+// 2963-3019, 3585-3593); here four threads format the seven files from flat arrays.  The texts are the reference's, byte for byte.
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+// Python's s[a:b] on a string of length n (negative indices count from the end, everything clamps)
+inline void py_slice(const char* s, long long n, long long a, long long b, const char** out, size_t* len) {
+    if (a < 0) a += n;
+    if (b < 0) b += n;
+    a = std::max<long long>(0, std::min(a, n));
+    b = std::max<long long>(0, std::min(b, n));
+    *out = s + a; *len = b > a ? (size_t)(b - a) : 0;
+}
+inline void append_revcomp(std::string& o, const char* s, size_t n) {      // get_reverse_complement (MP:232-239): upper-case ATGCU only
+    for (size_t k = n; k-- > 0;) {
+        char c = s[k];
+        switch (c) { case 'A': c = 'U'; break; case 'T': c = 'A'; break; case 'G': c = 'C'; break; case 'C': c = 'G'; break; case 'U': c = 'A'; break; default: break; }
+        o.push_back(c);
+    }
+}
+int write_whole(const char* path, const std::string& text, std::string* err) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { *err = std::string("cannot open ") + path; return -8; }
+    bool ok = text.empty() || std::fwrite(text.data(), 1, text.size(), f) == text.size();
+    if (std::fclose(f) != 0) ok = false;
+    if (!ok) { *err = std::string("I/O error on ") + path; return -8; }
+    return 0;
+}
+}  // namespace
+
+extern "C" int mirp_write_reports(int64_t n, const int32_t* loci, const char* contig_names, int32_t n_contigs, const char* ss_blob, const char* pre_blob,
+                                  const char* sample_names, int32_t n_samples, const int64_t* counts, const char* mirbase_form, const char* gff_path,
+                                  const char* mature_fa_path, const char* precursor_fa_path, const char* ss_path, const char* csv_path, const char* html_path,
+                                  const char* stat_path, char* errbuf, size_t errbuf_len) {
+    auto bail = [&](int code, const std::string& m) { if (errbuf && errbuf_len) { std::snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return code; };
+    if (n < 0 || (n > 0 && (!loci || !contig_names || !ss_blob || !pre_blob || !counts)) || n_samples < 0 || (n_samples > 0 && !sample_names) ||
+        (html_path && !mirbase_form))
+        return bail(-1, "mirp_write_reports: bad argument");
+    const std::vector<std::string> names = split_names(contig_names ? contig_names : "", n > 0 ? n_contigs : 0);
+    const std::vector<std::string> samples = split_names(sample_names ? sample_names : "", n_samples);
+    std::vector<const char*> ssp((size_t)n), prep((size_t)n);
+    std::vector<size_t> ssl((size_t)n), prel((size_t)n);
+    {
+        const char* p = ss_blob; const char* q = pre_blob;
+        for (int64_t k = 0; k < n; k++) {
+            ssp[k] = p; ssl[k] = std::strlen(p); p += ssl[k] + 1;
+            prep[k] = q; prel[k] = std::strlen(q); q += prel[k] + 1;
+            if (loci[10 * k] < 0 || loci[10 * k] >= n_contigs) return bail(-1, "mirp_write_reports: contig index out of range");
+        }
+    }
+    std::string form[4];
+    if (mirbase_form) { const char* p = mirbase_form; for (int k = 0; k < 4; k++) { form[k] = p; p += form[k].size() + 1; } }
+    // per locus: precursor / mature / star as the detail tables print them, length and first base of the forward-strand mature (locus_texts)
+    struct Txt { std::string pre, mat, star; long long flen; char ffirst; };
+    std::vector<Txt> T((size_t)n);
+    auto texts = [&](size_t a, size_t b) {
+        for (size_t k = a; k < b; k++) {
+            const int32_t* m = loci + 10 * k;
+            const char* s; size_t l;
+            Txt& t = T[k];
+            const char *ms, *ss2; size_t ml, sl;
+            py_slice(prep[k], (long long)prel[k], m[3] - m[1], m[4] - 1 - m[1] + 1, &ms, &ml);
+            py_slice(prep[k], (long long)prel[k], m[5] - m[1], m[6] - 1 - m[1] + 1, &ss2, &sl);
+            py_slice(prep[k], (long long)prel[k], 0, m[2] - 1 - m[1] + 1, &s, &l);
+            t.flen = (long long)ml; t.ffirst = ml ? ms[0] : '?';
+            if (m[7]) { append_revcomp(t.pre, s, l); append_revcomp(t.mat, ms, ml); append_revcomp(t.star, ss2, sl); }
+            else { t.pre.assign(s, l); t.mat.assign(ms, ml); t.star.assign(ss2, sl); }
+        }
+    };
+    {
+        const int nt = n_workers((size_t)n);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back([&, t] { texts((size_t)n * t / nt, (size_t)n * (t + 1) / nt); });
+        for (auto& t : th) t.join();
+    }
+    // the two distribution tables of the stat file and the html page: length (numeric order) and first base (character order) of the forward-strand matures
+    std::vector<std::pair<long long, long long>> dlen;
+    std::vector<std::pair<char, long long>> dfirst;
+    for (int64_t k = 0; k < n; k++) {
+        auto a = std::find_if(dlen.begin(), dlen.end(), [&](const std::pair<long long, long long>& x) { return x.first == T[k].flen; });
+        if (a == dlen.end()) dlen.push_back({T[k].flen, 1}); else a->second++;
+        auto b = std::find_if(dfirst.begin(), dfirst.end(), [&](const std::pair<char, long long>& x) { return x.first == T[k].ffirst; });
+        if (b == dfirst.end()) dfirst.push_back({T[k].ffirst, 1}); else b->second++;
+    }
+    std::sort(dlen.begin(), dlen.end());
+    std::sort(dfirst.begin(), dfirst.end());
+    auto name_of = [&](std::string& o, const char* what, int64_t k) { o += what; put_int(o, k); };
+    std::string errs[4];
+    int rcs[4] = {0, 0, 0, 0};
+    std::vector<std::thread> th;
+    // ---- gff3
+    th.emplace_back([&] {
+        if (!gff_path) return;
+        std::string o;
+        o.reserve((size_t)n * 260 + 16);
+        for (int64_t k = 0; k < n; k++) {
+            const int32_t* m = loci + 10 * k;
+            const std::string& chr = names[(size_t)m[0]];
+            const char strand = m[7] ? '-' : '+';
+            o += chr; o += "\tmiR-PREFeR\tmiRNA-precursor\t"; put_int(o, m[1]); o.push_back('\t'); put_int(o, m[2] - 1); o += "\t.\t"; o.push_back(strand); o += "\t.\tID=";
+            name_of(o, "miRNA-precursor_", k); o += ";NAME="; name_of(o, "miRNA-precursor_", k);
+            o += ";Other=mature_expressed=y;star_expressed="; o.push_back(m[8] ? 'y' : 'n'); o += ";overhangsize="; o += m[9] == 2 ? "3:3" : m[9] == 1 ? "2:3" : "2:2"; o.push_back('\n');
+            o += chr; o += "\tmiR-PREFeR\tmiRNA\t"; put_int(o, m[3]); o.push_back('\t'); put_int(o, m[4] - 1); o += "\t.\t"; o.push_back(strand); o += "\t.\tID=";
+            name_of(o, "miRNA_", k); o += ";NAME="; name_of(o, "miRNA_", k); o += ";Other=\n";
+        }
+        rcs[0] = write_whole(gff_path, o, &errs[0]);
+    });
+    // ---- mature / precursor FASTA and the structure file with its M / S annotation line
+    th.emplace_back([&] {
+        if (!mature_fa_path && !precursor_fa_path && !ss_path) return;
+        std::string fm, fp, fs;
+        fm.reserve((size_t)n * 80); fp.reserve((size_t)n * 200); fs.reserve((size_t)n * 520);
+        std::string dot, id;
+        for (int64_t k = 0; k < n; k++) {
+            const int32_t* m = loci + 10 * k;
+            const std::string& chr = names[(size_t)m[0]];
+            const char strand = m[7] ? '-' : '+';
+            const Txt& t = T[k];
+            id.clear(); id.push_back('>'); id += chr; id.push_back(':'); put_int(id, m[3]); id.push_back('-'); put_int(id, m[4] - 1); id.push_back(' '); id.push_back(strand);
+            id.push_back(' '); name_of(id, "miRNA-precursor_", k);
+            fm += id; fm.push_back('\n'); fm += t.mat; fm.push_back('\n');
+            id.clear(); id.push_back('>'); id += chr; id.push_back(':'); put_int(id, m[1]); id.push_back('-'); put_int(id, m[2] - 1); id.push_back(' '); id.push_back(strand);
+            id.push_back(' '); name_of(id, "miRNA-precursor_", k);
+            fp += id; fp.push_back('\n'); fp += t.pre; fp.push_back('\n');
+            // "." / "M" / "S" over the forward-strand precursor, reversed on the minus strand (MP:2994-3006); Python's str * negative = ""
+            const long long ms = m[3] - m[1], me = m[4] - m[1], s0 = m[5] - m[1], s1 = m[6] - m[1], len = (long long)t.pre.size();
+            dot.clear();
+            auto rep = [&](char c, long long cnt) { if (cnt > 0) dot.append((size_t)cnt, c); };
+            if (ms < s0) { rep('.', ms); rep('M', me - ms); rep('.', s0 - me); rep('S', s1 - s0); rep('.', len - s1); }
+            else { rep('.', s0); rep('S', s1 - s0); rep('.', ms - s1); rep('M', me - ms); rep('.', len - me); }
+            if (m[7]) std::reverse(dot.begin(), dot.end());
+            fs += id; fs.push_back('\n'); fs += t.pre; fs.push_back('\n'); fs.append(ssp[k], ssl[k]); fs.push_back('\n'); fs += dot; fs.push_back('\n');
+        }
+        if (mature_fa_path) rcs[1] = write_whole(mature_fa_path, fm, &errs[1]);
+        if (!rcs[1] && precursor_fa_path) rcs[1] = write_whole(precursor_fa_path, fp, &errs[1]);
+        if (!rcs[1] && ss_path) rcs[1] = write_whole(ss_path, fs, &errs[1]);
+    });
+    // ---- detail csv and miRNA.stat.txt
+    th.emplace_back([&] {
+        if (csv_path) {
+            std::string o;
+            o.reserve((size_t)n * 700 + 1024);
+            const char* head = "miRNAID, Seqid(chromosome), start position, end position, strand, precursor sequence, secondary structure, mature sequence, star sequence, ";
+            o += head;
+            for (const std::string& s : samples) { o += s; o.push_back(','); o += s; o.push_back(','); o += s; o.push_back(','); o += s; o.push_back(','); }
+            o.push_back('\n');
+            o += head;
+            for (int s = 0; s < n_samples; s++) o += "reads mapped to precursor, reads mapped to mature, reads mapped to star, reads mapped to antisense region,";
+            o.push_back('\n');
+            for (int64_t k = 0; k < n; k++) {
+                const int32_t* m = loci + 10 * k;
+                const Txt& t = T[k];
+                if (k) o.push_back('\n');
+                name_of(o, "miRNA-precursor_", k); o += ", "; o += names[(size_t)m[0]]; o += ", "; put_int(o, m[1]); o += ", "; put_int(o, m[2]); o += ", "; o.push_back(m[7] ? '-' : '+');
+                o += ", "; o += t.pre; o += ", "; o.append(ssp[k], ssl[k]); o += ", "; o += t.mat; o += ", "; o += t.star;
+                for (int s = 0; s < n_samples; s++) for (int c = 0; c < 4; c++) { o += ", "; put_int(o, counts[((size_t)k * n_samples + s) * 4 + c]); }
+            }
+            if (n > 0) o.push_back('\n');
+            rcs[2] = write_whole(csv_path, o, &errs[2]);
+        }
+        if (!rcs[2] && stat_path) {
+            std::string o = "Total number of predicted miRNAs: ";
+            put_int(o, n); o += "\nDistribution of the length of the mature miRNAs:\n";
+            for (auto& x : dlen) { put_int(o, x.first); o += ": "; put_int(o, x.second); o.push_back('\n'); }
+            o += "Distribution of the nucleotide of the first base of the mature miRNAs:\n";
+            for (auto& x : dfirst) { o.push_back(x.first); o += ": "; put_int(o, x.second); o.push_back('\n'); }
+            rcs[2] = write_whole(stat_path, o, &errs[2]);
+        }
+    });
+    // ---- detail html
+    th.emplace_back([&] {
+        if (!html_path) return;
+        std::string o;
+        o.reserve((size_t)n * 3300 + 4096);
+        o += "<h1 > microRNAs predicted by miR-PREFeR </h1>\n<div>\n<h2 > Total number of prediction:"; put_int(o, n); o += "  </h2>\n";
+        auto table_head = [&](const char* title, const char* head) {
+            o += "<h3>"; o += title; o += "</h3>\n<table border=\"1\">\n\t<thead>\n\t\t<tr>\n\t\t<th>"; o += head; o += "</th>\n\t\t<th>Count</th>\n\t\t</tr>\n\t</thead>\n\t<tbody>\n";
+        };
+        table_head("Distribution of the lengths of the mature sequences", "Length");
+        for (auto& x : dlen) { o += "\t\t<tr>\n\t\t\t<td>"; put_int(o, x.first); o += " </td>\n\t\t\t<td>"; put_int(o, x.second); o += " </td>\n\t\t</tr>\n"; }
+        o += "\t</tbody>\n</table>\n</div>\n";
+        table_head("Distribution of the nucleotide of the first base of the mature sequences", "Nucleotide");
+        for (auto& x : dfirst) { o += "\t\t<tr>\n\t\t\t<td>"; o.push_back(x.first); o += " </td>\n\t\t\t<td>"; put_int(o, x.second); o += " </td>\n\t\t</tr>\n"; }
+        o += "\t</tbody>\n</table>\n</div>";
+        o += "<div><h3>Detailed infomation </h3>\n<table border=\"1\">\n<colgroup>\n\t<col span=8 style=\"background-color:#CECEF6\">\n";
+        static const char* colors[3] = {"#A9E2F3", "#ACFA58", "#F5A9BC"};
+        for (int s = 0; s < n_samples; s++) { o += "\t<col span=\"4\" style=\"background-color:"; o += colors[s % 3]; o += "\">"; }
+        o += "</colgroup>\n\t<thead>\n\t\t<tr>\n";
+        static const char* head1[8] = {"miRNA precursor ID", "Chromosome", "start position", "end position", "strand", "precursor sequence and secondary structure",
+                                       "mature sequence", "star sequence"};
+        for (const char* h : head1) { o += "\t\t\t<th rowspan=\"2\">"; o += h; o += "</th>\n"; }
+        for (const std::string& s : samples) { o += "\t\t\t<th colspan=\"4\">"; o += s; o += "</th>\n"; }
+        o += "\t\t\t<th colspan=\"2\">read mappings</th>\n\t\t</tr>\n\t\t<tr>\n";
+        static const char* per_sample[4] = {"precursor", "mature", "star", "antisense region"};
+        for (int s = 0; s < n_samples; s++) for (const char* w : per_sample) { o += "\t\t\t<th> reads mapped to "; o += w; o += " </th>\n"; }
+        o += "\t\t</tr>\n\t</thead>\n\t<tbody>\n";
+        auto td = [&](const std::string& c) { o += "\t\t\t<td nowrap>"; o += c; o += "</td>\n"; };
+        std::string tmp;
+        for (int64_t k = 0; k < n; k++) {
+            const int32_t* m = loci + 10 * k;
+            const Txt& t = T[k];
+            o += "\t\t<tr>\n";
+            tmp.clear(); name_of(tmp, "miRNA-precursor_", k); td(tmp);
+            td(names[(size_t)m[0]]);
+            tmp.clear(); put_int(tmp, m[1]); td(tmp);
+            tmp.clear(); put_int(tmp, m[2]); td(tmp);
+            tmp.assign(1, m[7] ? '-' : '+'); td(tmp);
+            o += "\t\t\t<td nowrap> <code>"; o += t.pre; o += "<BR>"; o.append(ssp[k], ssl[k]); o += " </code></td>";
+            o += "\t\t\t<td nowrap>"; o += t.mat; o += form[0]; o += t.mat; o += form[1]; o += form[2]; o += t.mat; o += form[3]; o += "</td>\n";
+            td(t.star);
+            for (int s = 0; s < n_samples; s++) for (int c = 0; c < 4; c++) { tmp.clear(); put_int(tmp, counts[((size_t)k * n_samples + s) * 4 + c]); td(tmp); }
+            o += "\t\t\t<td><a href=\"readmapping/"; name_of(o, "miRNA-precursor_", k); o += ".map.txt\" target=\"_blank\">Click to see detailed mapping.</a></td>\t\t</tr>\n";
+        }
+        o += "\t</tbody>\n</table>\n</div>\n";
+        rcs[3] = write_whole(html_path, o, &errs[3]);
+    });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < 4; k++) if (rcs[k]) return bail(rcs[k], "mirp_write_reports: " + errs[k]);
+    return 0;
+}

@@ -592,15 +592,12 @@ class Pipeline:
         counts = np.stack([x["counts"] for x in payloads])
         rm_thread = write_readmapping(result, payloads, None, None, self.data["samples"], counts, os.path.join(outdir, "readmapping"), background=True)
         gffname = os.path.join(outdir, prefix + "_miRNA.gff3")
-        write_gff(result, gffname)
         maturename = os.path.join(outdir, prefix + "_miRNA.mature.fa")
         stemloopname = os.path.join(outdir, prefix + "_miRNA.precursor.fa")
-        ssname = os.path.join(outdir, prefix + "_miRNA.precursor.ss")
-        write_fasta_ss(result, payloads, maturename, stemloopname, ssname)
-        texts = locus_texts(result, payloads)
-        write_csv_and_stat(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.csv"),
-                           os.path.join(outdir, "miRNA.stat.txt"), texts=texts)
-        write_html(result, payloads, self.data["samples"], counts, os.path.join(outdir, prefix + "_miRNA.detail.html"), texts=texts)
+        write_report_files(result, [x["pre"] for x in payloads], self.data["samples"], counts,
+                           {"gff": gffname, "mature": maturename, "precursor": stemloopname, "ss": os.path.join(outdir, prefix + "_miRNA.precursor.ss"),
+                            "csv": os.path.join(outdir, prefix + "_miRNA.detail.csv"), "html": os.path.join(outdir, prefix + "_miRNA.detail.html"),
+                            "stat": os.path.join(outdir, "miRNA.stat.txt")})
         with open(self._p(prefix + "_miRNA.info.dump"), "wb") as f:
             pickle.dump(result, f)
         rm_thread.join()
@@ -667,6 +664,25 @@ def adjust_mature_star(resultlist):
             m[3], m[5] = m[5], m[3]
             m[4], m[6] = m[6], m[4]
             e["switch"] = True
+
+
+def write_report_files(resultlist, pre_list, samples, counts, paths):
+    """gff3, mature / precursor FASTA, structure file, detail csv / html and miRNA.stat.txt of a SORTED result list in one native call
+    (mirp_write_reports: four threads format the seven files).  The writers below state the same formats in Python; tests/test_host_cpu.py holds
+    both against the reference's files."""
+    names, tid_of, loci = [], {}, []
+    for m in resultlist:
+        t = tid_of.setdefault(m[0], len(names))
+        if t == len(names):
+            names.append(m[0])
+        e = m[-1]
+        over = 0
+        if "max_imperfect_star" in e and e["max_imperfect_star"] != 0:
+            over = 2 if e["imperfect_star_which"] == 2 else 1
+        loci.append([t, m[1], m[2], m[3], m[4], m[5], m[6], 1 if m[8] == "-" else 0, 0 if e["total_depth_star"] == 0 else 1, over])
+    mark = "\x00SEQ\x00"
+    form = [p for taxon in ("Viridiplantae", "ALL") for p in _mirbase_form_text(mark, taxon).split(mark)]
+    capi.write_reports(np.array(loci, dtype=np.int32).reshape(-1, 10), names, [m[7] for m in resultlist], pre_list, samples, counts, form, paths)
 
 
 def write_gff(resultlist, gffname):

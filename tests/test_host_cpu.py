@@ -205,11 +205,61 @@ def test_report_writers_match_reference_files(name, tmp_path):
     assert open(tmp_path / "s.txt").read() == rep["stat_txt"]
     pipeline.write_html(result, contigs, c["sample_names"], counts, str(tmp_path / "d.html"))      # gen_html_table_file MP:2793-2904
     assert open(tmp_path / "d.html").read() == rep["detail_html"]
+    # the product's writer (mirp_write_reports, one native call for the seven files) against the same reference files
+    nat = {k: str(tmp_path / ("n_" + k)) for k in ("gff", "mature", "precursor", "ss", "csv", "html", "stat")}
+    pipeline.write_report_files(result, [pipeline._faidx(contigs, m[0], m[1], m[2] - 1) for m in result], c["sample_names"], counts, nat)
+    for k, want in (("gff", exp["gff3"]), ("mature", rep["mature_fa"]), ("precursor", rep["precursor_fa"]), ("ss", rep["precursor_ss"]), ("csv", rep["detail_csv"]),
+                    ("html", rep["detail_html"]), ("stat", rep["stat_txt"])):
+        assert open(nat[k]).read() == want, k
     # per-locus read layouts (gen_map_result MP:2907-2959); the synthetic reads are perfect matches, as bowtie -v 0 produces
     pipeline.write_readmapping(result, contigs, c["contig_names"], c["alns"], c["sample_names"], counts, str(tmp_path / "rm"))
     assert sorted(os.listdir(tmp_path / "rm")) == sorted(exp["readmapping"])
     for fn, text in exp["readmapping"].items():
         assert open(tmp_path / "rm" / fn).read() == text, fn
+
+
+def test_native_report_writer_equals_python_writers_on_random_loci(tmp_path):
+    """mirp_write_reports against the Python statement of the same formats on 3,000 random loci: both strands, star before / after the mature,
+    the three overhang forms, 1..3 samples, contig names in any order."""
+    import random
+    from mir_prefer_amd import pipeline
+    rnd = random.Random(5)
+    for ns in (1, 3):
+        samples = ["s%d.sam" % k for k in range(ns)]
+        result, pre = [], []
+        for _ in range(3000 if ns == 3 else 40):
+            fs = rnd.randrange(1, 10 ** 7)
+            ln = rnd.randrange(60, 300)
+            a, b = sorted(rnd.sample(range(0, ln - 25), 2))
+            if b - a < 26:
+                b = min(a + 26, ln - 25)
+            ml, sl = rnd.randrange(18, 25), rnd.randrange(18, 25)
+            arms = [(fs + a, fs + a + ml), (fs + b, fs + b + sl)]
+            if rnd.random() < 0.5:
+                arms.reverse()
+            e = {"total_depth_mature": rnd.randrange(1, 999), "total_depth_star": rnd.choice([0, 0, 5, 77])}
+            if rnd.random() < 0.5:
+                e["max_imperfect_star"] = rnd.choice([0, 1])
+                e["imperfect_star_which"] = rnd.choice([0, 1, 2])
+            result.append(["chr%d" % rnd.randrange(12), fs, fs + ln, arms[0][0], arms[0][1], arms[1][0], arms[1][1],
+                           "".join(rnd.choice("(.)") for _ in range(ln)), rnd.choice("+-"), bool(e["total_depth_star"]), e])
+        result.sort(key=lambda m: m[:10])
+        for m in result:
+            pre.append("".join(rnd.choice("ACGU") for _ in range(m[2] - m[1])))
+        counts = np.array([[[rnd.randrange(0, 10 ** rnd.randrange(1, 7)) for _ in range(4)] for _ in range(ns)] for _ in result], dtype=np.int64)
+        pay = [{"pre": x} for x in pre]
+        py = {k: str(tmp_path / ("p_%d_%s" % (ns, k))) for k in ("gff", "mature", "precursor", "ss", "csv", "html", "stat")}
+        pipeline.write_gff(list(result), py["gff"])
+        pipeline.write_fasta_ss(result, pay, py["mature"], py["precursor"], py["ss"])
+        pipeline.write_csv_and_stat(result, pay, samples, counts, py["csv"], py["stat"])
+        pipeline.write_html(result, pay, samples, counts, py["html"])
+        nat = {k: v.replace("p_", "n_") for k, v in py.items()}
+        pipeline.write_report_files(result, pre, samples, counts, nat)
+        for k in py:
+            assert open(nat[k], "rb").read() == open(py[k], "rb").read(), (ns, k)
+    # a path that cannot be opened is an error with the file's name, not a silent skip
+    with pytest.raises(Exception, match="no_such_dir"):
+        pipeline.write_report_files(result[:2], pre[:2], samples, counts[:2], {"gff": str(tmp_path / "no_such_dir" / "x.gff3")})
 
 
 def test_gff_keep_regions_match_the_reference_functions(tmp_path):
