@@ -620,7 +620,7 @@ def main():
                        "exchange": ("none (1 GPU)" if world == 1 else "mirp_gather_loci over the local transport (ranks share GPU 0: dev run)" if share_dir
                                     else "loci lists as host objects over gloo (RCCL communicator not available: %s)" % rccl_error if rccl_error
                                     else "mirp_gather_loci over RCCL (library-owned communicator), host objects over gloo")},
-            "roofline": {"kernel": "fold_lds_kernel<0, true>" if a.fold_model == "vienna-2.1.2" else "fold_lds_kernel<1, false>",
+            "roofline": {"kernel": "fold_lds_kernel<0, true>" if a.fold_model == "vienna-2.1.2" else "fold_lds_kernel<1, true>",
                          "bound": "lds", "achieved": achieved / 1e12, "peak": LDS_GUIDE_RELAX_PER_S / 1e12, "unit": "T relaxations/s",
                          "frac": achieved / LDS_GUIDE_RELAX_PER_S, "peak_measured": roof / 1e12, "frac_measured": achieved / roof if roof > 0 else None,
                          "bound_measured": "lds" if lds_roof <= valu_roof else "valu", "avg_launch_ms": fill_s * 1e3, "pipe_busy": pipe,

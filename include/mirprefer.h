@@ -344,6 +344,11 @@ int mirp_write_reports(int64_t n_loci, const int32_t* loci, const char* contig_n
                        const char* mature_fa_path, const char* precursor_fa_path, const char* ss_path, const char* csv_path, const char* html_path,
                        const char* stat_path, char* errbuf, size_t errbuf_len);
 
+/* Many small files at once -- the per-locus read-mapping files <folder>/miRNA-precursor_<k>.map.txt of gen_map_result (MP:2907-2959), one per
+ * locus: paths = n NUL-terminated file names back to back, file k holds text[offs[k] .. offs[k+1]).  Creating thousands of files is system-call
+ * time; up to 8 native threads share the list.  Host only.  0 = ok, -8 with the first failing name in errbuf. */
+int mirp_write_files(int64_t n_files, const char* paths, const char* text, const int64_t* offs, char* errbuf, size_t errbuf_len);
+
 #ifdef __cplusplus
 }
 #endif

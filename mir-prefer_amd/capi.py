@@ -81,6 +81,24 @@ def write_reports(loci, contig_names, ss_list, pre_list, sample_names, counts, m
         raise MirpError("%s (%d)" % (err.value.decode(), rc))
 
 
+def write_files(paths, texts):
+    """mirp_write_files: file paths[k] <- texts[k] (str), written by up to 8 native threads."""
+    lib = load_library()
+    n = len(paths)
+    if n == 0:
+        return
+    enc = [t.encode() for t in texts]
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=offs[1:])
+    err = C.create_string_buffer(512)
+    fn = lib.mirp_write_files
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int64, C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    rc = fn(n, b"".join(p.encode() + b"\0" for p in paths), b"".join(enc), offs.ctypes.data, err, 512)
+    if rc != 0:
+        raise MirpError("%s (%d)" % (err.value.decode(), rc))
+
+
 def read_fasta(path, want=None):
     """Native FASTA reader (mirp_read_fasta): -> list of (name, uint8 array) in file order; with `want` (names) only those sequences are
     materialised, the others come back as None."""

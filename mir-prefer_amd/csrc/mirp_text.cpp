@@ -631,3 +631,26 @@ extern "C" int mirp_write_reports(int64_t n, const int32_t* loci, const char* co
     for (int k = 0; k < 4; k++) if (rcs[k]) return bail(rcs[k], "mirp_write_reports: " + errs[k]);
     return 0;
 }
+
+extern "C" int mirp_write_files(int64_t n, const char* paths, const char* text, const int64_t* offs, char* errbuf, size_t errbuf_len) {
+    if (n < 0 || (n > 0 && (!paths || !text || !offs))) { if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "mirp_write_files: bad argument"); return -1; }
+    std::vector<const char*> name((size_t)n);
+    { const char* p = paths; for (int64_t k = 0; k < n; k++) { name[k] = p; p += std::strlen(p) + 1; } }
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 64));
+    std::vector<int64_t> bad((size_t)nt, -1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            for (int64_t k = n * t / nt; k < n * (t + 1) / nt; k++) {
+                FILE* f = std::fopen(name[k], "wb");
+                const size_t len = (size_t)(offs[k + 1] - offs[k]);
+                bool ok = f && (len == 0 || std::fwrite(text + offs[k], 1, len, f) == len);
+                if (f && std::fclose(f) != 0) ok = false;
+                if (!ok) { bad[t] = k; return; }
+            }
+        });
+    for (auto& t : th) t.join();
+    for (int t = 0; t < nt; t++)
+        if (bad[t] >= 0) { if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "mirp_write_files: cannot write %s", name[bad[t]]); return -8; }
+    return 0;
+}

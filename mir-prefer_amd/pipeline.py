@@ -804,19 +804,27 @@ def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder,
         mirname = "miRNA-precursor_%d" % idx
         jobs.append((os.path.join(folder, mirname + ".map.txt"), ">%s %s:%d-%d %s\n" % (mirname, m[0], m[1], m[2], m[8]) + bodies[idx]))
 
-    def put_all():          # thousands of small files: creating them is the cost, and the system calls release the interpreter lock
-        flags = os.O_WRONLY | os.O_CREAT | os.O_TRUNC
-        for path, text in jobs:
-            fd = os.open(path, flags, 0o644)
-            try:
-                os.write(fd, text.encode())
-            finally:
-                os.close(fd)
+    def put_all():          # thousands of small files: creating them is the cost -- native threads share the list (mirp_write_files)
+        capi.write_files([j[0] for j in jobs], [j[1] for j in jobs])
     if not background:
         put_all()
         return None
     import threading
-    th = threading.Thread(target=put_all)
+
+    class Writer(threading.Thread):          # join() re-raises what the writer hit: a report folder with files missing is not a finished stage
+        error = None
+
+        def run(self):
+            try:
+                put_all()
+            except BaseException as e:
+                self.error = e
+
+        def join(self, timeout=None):
+            threading.Thread.join(self, timeout)
+            if self.error is not None:
+                raise self.error
+    th = Writer()
     th.start()
     return th
 
