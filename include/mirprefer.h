@@ -346,7 +346,7 @@ int mirp_write_reports(int64_t n_loci, const int32_t* loci, const char* contig_n
 
 /* Many small files at once -- the per-locus read-mapping files <folder>/miRNA-precursor_<k>.map.txt of gen_map_result (MP:2907-2959), one per
  * locus: paths = n NUL-terminated file names back to back, file k holds text[offs[k] .. offs[k+1]).  Creating thousands of files is system-call
- * time; up to 8 native threads share the list.  Host only.  0 = ok, -8 with the first failing name in errbuf. */
+ * time spent in the kernel's directory lock, so one native thread writes them (MIRP_FILE_THREADS = n splits the list over n).  Host only.  0 = ok, -8 with the first failing name in errbuf. */
 int mirp_write_files(int64_t n_files, const char* paths, const char* text, const int64_t* offs, char* errbuf, size_t errbuf_len);
 
 #ifdef __cplusplus

@@ -82,7 +82,7 @@ def write_reports(loci, contig_names, ss_list, pre_list, sample_names, counts, m
 
 
 def write_files(paths, texts):
-    """mirp_write_files: file paths[k] <- texts[k] (str), written by up to 8 native threads."""
+    """mirp_write_files: file paths[k] <- texts[k] (str), written natively, outside the interpreter lock."""
     lib = load_library()
     n = len(paths)
     if n == 0:

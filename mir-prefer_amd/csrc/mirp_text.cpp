@@ -3,8 +3,12 @@
 // fold stage's RNALfold-format output (MP:3085-3098, consumed by MP:1541-1599).  These files are what the reference's stages exchange; on
 // the host they were the bulk of the end-to-end wall-clock (Python string formatting of 10^5..10^6 lines), here a stage formats its chunk of
 // lines per thread into memory and the file is written in one go.
+#include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 #include <algorithm>
 #include <memory>
 #include <string>
@@ -20,6 +24,32 @@ int n_workers(size_t items) {
     return (int)std::max<size_t>(1, std::min<size_t>((size_t)n, items / 256 + 1));
 }
 
+// The pieces, in order, into one file; -8 with a message on any failure.  One writer: buffered writes to ONE file serialise on the inode in the
+// kernel -- a thread per piece (pwrite at its offset) made the 135 MB fold text slower, not faster (tmpfs and overlay, round 4).
+int write_parts(const char* path, const std::vector<std::string>& parts, std::string* err) {
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { *err = std::string("cannot open ") + path; return -8; }
+    std::vector<size_t> off(parts.size() + 1, 0);
+    for (size_t k = 0; k < parts.size(); k++) off[k + 1] = off[k] + parts[k].size();
+    std::vector<char> bad(parts.size(), 0);
+    auto put = [&](size_t k) {
+        const char* p = parts[k].data();
+        size_t left = parts[k].size(), at = off[k];
+        while (left) {
+            const ssize_t w = ::pwrite(fd, p, left, (off_t)at);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) { bad[k] = 1; return; }
+            p += w; at += (size_t)w; left -= (size_t)w;
+        }
+    };
+    for (size_t k = 0; k < parts.size(); k++) put(k);
+    bool ok = true;
+    for (char b : bad) if (b) ok = false;
+    if (::close(fd) != 0) ok = false;
+    if (!ok) { *err = std::string("I/O error on ") + path; return -8; }
+    return 0;
+}
+
 // fn(first, last, std::string& out) formats items [first, last) into out; the pieces are written to path in order
 template <class F>
 int write_parallel(mirp_ctx* c, const char* path, size_t items, size_t bytes_per_item_hint, F fn, const char* who) {
@@ -33,13 +63,9 @@ int write_parallel(mirp_ctx* c, const char* path, size_t items, size_t bytes_per
             fn(a, b, parts[t]);
         });
     for (auto& t : th) t.join();
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return fail(c, -8, std::string(who) + ": cannot open " + path);
-    bool ok = true;
-    for (auto& p : parts)
-        if (!p.empty() && std::fwrite(p.data(), 1, p.size(), f) != p.size()) ok = false;
-    if (std::fclose(f) != 0) ok = false;
-    return ok ? 0 : fail(c, -8, std::string(who) + ": I/O error on " + path);
+    std::string err;
+    const int rc = write_parts(path, parts, &err);
+    return rc ? fail(c, rc, std::string(who) + ": " + err) : 0;
 }
 
 inline void put_int(std::string& o, long long v) {
@@ -281,13 +307,8 @@ static int write_fold_text_impl(mirp_ctx* c, const char* fasta_path, const char*
                 }
             });
         for (auto& t : th) t.join();
-        FILE* f = std::fopen(out.c_str(), "wb");
-        if (!f) { *err = "mirp_write_fold_text: cannot open " + out; return -8; }
-        bool ok = true;
-        for (auto& p : parts)
-            if (!p.empty() && std::fwrite(p.data(), 1, p.size(), f) != p.size()) ok = false;
-        if (std::fclose(f) != 0) ok = false;
-        if (!ok) { *err = "mirp_write_fold_text: I/O error on " + out; return -8; }
+        std::string werr;
+        if (const int rc = write_parts(out.c_str(), parts, &werr)) { *err = "mirp_write_fold_text: " + werr; return rc; }
         return 0;
     };
     if (!async) {
@@ -636,7 +657,11 @@ extern "C" int mirp_write_files(int64_t n, const char* paths, const char* text, 
     if (n < 0 || (n > 0 && (!paths || !text || !offs))) { if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "mirp_write_files: bad argument"); return -1; }
     std::vector<const char*> name((size_t)n);
     { const char* p = paths; for (int64_t k = 0; k < n; k++) { name[k] = p; p += std::strlen(p) + 1; } }
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 64));
+    const char* env = std::getenv("MIRP_FILE_THREADS");
+    // one writer unless told otherwise: creating files in ONE directory serialises on the directory in the kernel -- 1 / 2 / 4 / 8 threads measured
+    // the same on tmpfs (13-16 ms for 4,002 files) and no better on an overlay file system (profiles/tools/smallfiles.py)
+    const int cap = env && std::atoi(env) > 0 ? std::atoi(env) : 1;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(cap, n / 64));
     std::vector<int64_t> bad((size_t)nt, -1);
     std::vector<std::thread> th;
     for (int t = 0; t < nt; t++)

@@ -644,14 +644,15 @@ class Pipeline:
 def result_records(out, names):
     """`result` list of gen_miRNA_loci_nopredict (MP:2492-2496): [chr, fold_s, fold_e, mat_s, mat_e, star_s, star_e, ss, strand, has_star, exprinfo]."""
     res = []
-    for m, ss in zip(out["result"], out["ss"]):
-        f = int(m["reserved"])
-        info = {"total_depth_mature": int(m["total_depth_mature"]), "total_depth_star": int(m["total_depth_star"])}
+    R = out["result"]
+    col = [R[k].tolist() for k in ("tid", "fold_s", "fold_e", "mat_s", "mat_e", "star_s", "star_e", "strand", "has_star", "reserved", "total_depth_mature",
+                                   "total_depth_star")]          # columns as Python ints once, not one numpy scalar per field and locus
+    for tid, fs, fe, ms, me, s0, s1, strand, has_star, f, dm, dstar, ss in zip(*col, out["ss"]):
+        info = {"total_depth_mature": dm, "total_depth_star": dstar}
         if f & 1:
             info["max_imperfect_star"] = 1 if f & 8 else 0   # presence and zero/non-zero are what the gff writer reads (MP:2631)
             info["imperfect_star_which"] = ((f >> 1) & 3) - 1
-        res.append([names[m["tid"]], int(m["fold_s"]), int(m["fold_e"]), int(m["mat_s"]), int(m["mat_e"]), int(m["star_s"]), int(m["star_e"]), ss,
-                    records.STRAND[m["strand"]], bool(m["has_star"]), info])
+        res.append([names[tid], fs, fe, ms, me, s0, s1, ss, records.STRAND[strand], bool(has_star), info])
     return res
 
 
@@ -804,7 +805,7 @@ def write_readmapping(resultlist, contigs, names, alns, samples, counts, folder,
         mirname = "miRNA-precursor_%d" % idx
         jobs.append((os.path.join(folder, mirname + ".map.txt"), ">%s %s:%d-%d %s\n" % (mirname, m[0], m[1], m[2], m[8]) + bodies[idx]))
 
-    def put_all():          # thousands of small files: creating them is the cost -- native threads share the list (mirp_write_files)
+    def put_all():          # thousands of small files: creating them is the cost; done natively, outside the interpreter lock (mirp_write_files)
         capi.write_files([j[0] for j in jobs], [j[1] for j in jobs])
     if not background:
         put_all()
