@@ -149,6 +149,10 @@ int mirp_set_contig_shard(mirp_ctx* ctx, int32_t preceded_by_coverage_elsewhere)
  * to under-loaded ranks (host side: mir-prefer_amd/balance.py), which fold and filter them through mirp_fold_batch / mirp_predict_batch.
  * n_keep must not cut an L/R window pair.  The next mirp_candidate restores the full list. */
 int mirp_limit_windows(mirp_ctx* ctx, int64_t n_keep);
+/* The exclusive prefix sum every compaction of the candidate stage is built on (kept runs, region heads, window slots ...; the Python loops of
+ * MP:877-962 and MP:1246-1371 append to lists instead): out[k] = in[0] + .. + in[k-1] for k = 0 .. n, host arrays in and out, computed on the
+ * context's device by the kernels the stage uses (one workgroup up to 16,384 elements, a single-pass look-back scan beyond).  For tests. */
+int mirp_excl_scan_i32(mirp_ctx* ctx, const int32_t* in, int64_t n, int64_t* out);
 /* Replaces gen_contig_typeA + gen_candidate_region_typeA + dump_loci_seqs_and_alignment_multiprocess
  * (MP:877-962, 1246-1371, 1065-1244). contig_order = contig indices in the order sorted(dict_contigs) visits them (MP:1309). */
 int mirp_candidate(mirp_ctx* ctx, const MirpCandidateParams* params, const int32_t* contig_order, int64_t* n_peaks, int64_t* n_loci,

@@ -599,6 +599,16 @@ class Context:
     def last_fold_overflow(self):
         return int(self.lib.mirp_last_fold_overflow(self.h))
 
+    def excl_scan(self, values):
+        """Exclusive prefix sums of an int32 array on the device (mirp_excl_scan_i32, the scan of the candidate stage's compactions) -> int64 [n + 1]."""
+        v = np.ascontiguousarray(values, dtype=np.int32)
+        out = np.zeros(len(v) + 1, dtype=np.int64)
+        fn = self.lib.mirp_excl_scan_i32
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        self._check(fn(self.h, v.ctypes.data if len(v) else None, len(v), out.ctypes.data), "mirp_excl_scan_i32")
+        return out
+
     def limit_windows(self, n_keep):
         """Keeps the first n_keep windows of the last candidate() for the following stages (mirp_limit_windows)."""
         self._check(self.lib.mirp_limit_windows(self.h, int(n_keep)), "mirp_limit_windows")

@@ -10,6 +10,9 @@
 // Algorithmic traffic: 16 B per alignment record + 16 B per base (one 4-B write and one 4-B read
 // per base and strand: memset + single-pass decoupled-look-back scan), SURVEY.md section 8d.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
 #include "mirp_internal.h"
 
 namespace mirp {
@@ -144,13 +147,17 @@ __device__ __forceinline__ long long cov_start_slot(const MirpAln& r, const long
 // the few records whose two slots lie in different tiles (reads are tens of bases, a tile is 8192) touch it.  The exclusive prefix of those totals
 // is the depth carried into a tile -- the fused scan reads it instead of looking back for it.
 __global__ void __launch_bounds__(256) cov_tile_first_kernel(const MirpAln* __restrict__ alns, long long n, const long long* __restrict__ goff,
-                                                             const long long* __restrict__ clen, long long n_tiles, int cutoff, long long* __restrict__ first,
+                                                             const long long* __restrict__ clen, long long n_tiles, int cutoff, int max_len,
+                                                             long long* __restrict__ first, long long* __restrict__ back /* [n_tiles + 1] */,
                                                              int* __restrict__ agg /* [2][n_tiles], zero */) {
+    // back[t] = first record that can reach tile t: its start slot lies at most max_len (the longest record) before the tile.  A tile reads the records
+    // back[t] .. first[t + 1]: those of its own range plus the handful that hang over from the tile before (not that tile's whole record list).
     for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k <= n; k += (long long)gridDim.x * blockDim.x) {
-        long long t = n_tiles;
+        long long t = n_tiles, tb = n_tiles;
         if (k < n) {
             const MirpAln r = alns[k];
-            t = cov_start_slot(r, goff, clen) / SCAN_TILE;
+            const long long slot = cov_start_slot(r, goff, clen);
+            t = slot / SCAN_TILE; tb = (slot + max_len) / SCAN_TILE;
             int w = (int)(r.depth > (unsigned)cutoff ? (unsigned)cutoff : r.depth);
             const CovSlots c = cov_slots(r, goff, clen, nullptr, nullptr);
             const long long ta = c.i0 / SCAN_TILE, tb = c.i1 / SCAN_TILE;
@@ -161,8 +168,10 @@ __global__ void __launch_bounds__(256) cov_tile_first_kernel(const MirpAln* __re
                 atomicAdd(&a[tb], -w);
             }
         }
-        const long long tp = k > 0 ? cov_start_slot(alns[k - 1], goff, clen) / SCAN_TILE : -1;
+        const long long sp = k > 0 ? cov_start_slot(alns[k - 1], goff, clen) : 0;
+        const long long tp = k > 0 ? sp / SCAN_TILE : -1, tbp = k > 0 ? (sp + max_len) / SCAN_TILE : -1;
         for (long long x = tp + 1; x <= t && x <= n_tiles; x++) first[x] = k;
+        for (long long x = tbp + 1; x <= tb && x <= n_tiles; x++) back[x] = k;
     }
 }
 __global__ void __launch_bounds__(256) cov_maxlen_kernel(const MirpAln* __restrict__ alns, long long n, int* __restrict__ out) {
@@ -174,13 +183,15 @@ __global__ void __launch_bounds__(256) cov_maxlen_kernel(const MirpAln* __restri
 }
 
 // FUSED: the tile's difference values do not come from the dense arrays (one global atomic pair per record before, 8 bytes read per base here) but
-// are built in LDS from the sorted records themselves: the records that start in this tile or the one before it (first[]; no record is longer
-// than a tile -- checked on the host) add their +w / -w with LDS atomics.  A tile that holds a covered base, or continues a run, then writes its
+// are built in LDS from the sorted records themselves: the records that start in this tile or close enough before it to reach it (back[] / first[];
+// no record is longer than a tile -- checked on the host) add their +w / -w with LDS atomics.  A tile that holds a covered base, or continues a run, then writes its
 // values to the dense arrays once, with plain coalesced stores: that is all the run walk ever reads.  No clearing pass, no global atomics.
+#define COV_CT 256          // contigs whose {offset, length} fit the fused scan's LDS table (more: read from global memory)
 template <bool FUSED>
 __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ diff_p, int* __restrict__ diff_m, long long gtot,
                                                            const MirpAln* __restrict__ alns, const long long* __restrict__ goff, const long long* __restrict__ clen,
-                                                           const long long* __restrict__ first, const long long* __restrict__ carry_p,
+                                                           int n_contigs, const long long* __restrict__ first, const long long* __restrict__ back,
+                                                           const long long* __restrict__ carry_p,
                                                            const long long* __restrict__ carry_m,
                                                            int cutoff, unsigned long long* __restrict__ stat_d,
                                                            unsigned long long* __restrict__ stat_c, unsigned int* __restrict__ ticket,
@@ -193,14 +204,18 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ dif
     __shared__ int s_carry[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    extern __shared__ __align__(16) int ld[];          // FUSED: [2][SCAN_TILE]: + strand, - strand; then [2][COV_CT] contig offsets and lengths
+    // the contigs' {offset of the guarded slice, length} into LDS while the ticket is on its way: one dependent global round trip less per record batch
+    long long* ct = reinterpret_cast<long long*>(ld + 2 * SCAN_TILE);
+    const bool ct_lds = FUSED && n_contigs <= COV_CT;
+    if constexpr (FUSED) { if (ct_lds) for (int x = tid; x < n_contigs; x += SCAN_NT) { ct[x] = goff[x]; ct[COV_CT + x] = clen[x]; } }
     __syncthreads();
     const unsigned int tile = s_tile;
     const long long base = (long long)tile * SCAN_TILE;
     const long long wbase = base + (long long)wave * (64 * SCAN_IPT);
     int vp[SCAN_IPT], vm[SCAN_IPT];
     if constexpr (FUSED) {
-        extern __shared__ __align__(16) int ld[];          // [2][SCAN_TILE]: + strand, - strand
-        const long long k0 = first[tile > 0 ? tile - 1 : 0], k1 = first[tile + 1];
+        const long long k0 = back[tile], k1 = first[tile + 1];
         if (k0 == k1) {          // no record starts in this tile or the one before it: nothing can change here (most tiles of a sparse sample)
 #pragma unroll
             for (int v = 0; v < SCAN_IPT; v++) { vp[v] = 0; vm[v] = 0; }
@@ -216,7 +231,16 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ dif
                 for (int u = 0; u < RU; u++) {
                     if (kb + (long long)u * SCAN_NT >= k1) continue;
                     int w = (int)(r[u].depth > (unsigned)cutoff ? (unsigned)cutoff : r[u].depth);
-                    const CovSlots c = cov_slots(r[u], goff, clen, nullptr, nullptr);
+                    CovSlots c;
+                    if (ct_lds) {          // cov_slots with the table in LDS
+                        const long long L = ct[COV_CT + r[u].tid];
+                        long long s = r[u].pos, e = (long long)r[u].pos + r[u].len;
+                        if (s < 1) s = 1;
+                        if (e > L + 1) e = L + 1;
+                        c.ok = s < e;
+                        const long long o = ct[r[u].tid];
+                        c.i0 = o + s - 1; c.i1 = o + e - 1;
+                    } else c = cov_slots(r[u], goff, clen, nullptr, nullptr);
                     if (!c.ok || w == 0) continue;
                     if (r[u].strand & 2) w = -w;
                     int* d = ld + ((r[u].strand & 1) ? SCAN_TILE : 0);
@@ -476,6 +500,79 @@ __global__ void __launch_bounds__(1024) excl_scan_i32_kernel(const int* __restri
     if (tid == 0) out[n] = s_carry;
 }
 
+// The same scan over many workgroups for the arrays of a rank shard (10^5 .. 10^7 runs, regions, windows): single pass, decoupled look-back over
+// one 64-bit descriptor {flag:2 | partial sum:62, two's complement} per 4,096-element block; the launcher clears the ticket counter and the
+// descriptors of the blocks in use before every call (one fill of 8 bytes per block).
+#define MSCAN_NT 256
+#define MSCAN_IPT 16
+#define MSCAN_TILE (MSCAN_NT * MSCAN_IPT)
+#define MSCAN_MAX_BLOCKS 16384
+__device__ __forceinline__ unsigned long long mscan_pack(unsigned flag, long long v) {
+    return ((unsigned long long)flag << 62) | ((unsigned long long)v & 0x3fffffffffffffffull);
+}
+__global__ void __launch_bounds__(MSCAN_NT) excl_scan_i32_mb_kernel(const int* __restrict__ in, long long* __restrict__ out, long long n,
+                                                                    unsigned long long* __restrict__ scratch) {
+    __shared__ long long sh[MSCAN_NT / 64];
+    __shared__ unsigned s_tile;
+    __shared__ long long s_pre;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = (unsigned)atomicAdd(&scratch[0], 1ull);
+    __syncthreads();
+    const unsigned tile = s_tile;
+    unsigned long long* status = scratch + 1;
+    const long long k0 = (long long)tile * MSCAN_TILE + (long long)tid * MSCAN_IPT;
+    int v[MSCAN_IPT];
+    if (k0 + MSCAN_IPT <= n && (((size_t)(in + k0)) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < MSCAN_IPT / 4; q++) {
+            const int4 x = *reinterpret_cast<const int4*>(in + k0 + 4 * q);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < MSCAN_IPT; q++) v[q] = (k0 + q < n) ? in[k0 + q] : 0;
+    }
+    long long mine = 0;
+#pragma unroll
+    for (int q = 0; q < MSCAN_IPT; q++) mine += v[q];
+    long long iv = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const long long t = __shfl_up(iv, o); if (lane >= o) iv += t; }
+    if (lane == 63) sh[wave] = iv;
+    __syncthreads();
+    long long wpre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MSCAN_NT / 64; w++) { if (w < wave) wpre += sh[w]; tot += sh[w]; }
+    if (tid == 0) st_status(&status[tile], mscan_pack(tile == 0 ? 2u : 1u, tot));
+    if (tid < 64) {
+        long long pre = 0;
+        if (tile > 0) {
+            long long idx = (long long)tile - 1;
+            while (true) {
+                const long long j = idx - lane;
+                unsigned long long d = 0;
+                unsigned flag = 3;
+                if (j >= 0) { do { d = ld_status(&status[j]); flag = (unsigned)(d >> 62); } while (flag == 0); }
+                const unsigned long long pm = __ballot(flag == 2);
+                const int stop = pm ? (__ffsll((long long)pm) - 1) : 64;
+                long long a = (j >= 0 && lane <= stop) ? ((long long)(d << 2) >> 2) : 0;          // sign-extend the 62-bit partial sum
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                pre += a;
+                if (pm || idx - 64 < 0) break;
+                idx -= 64;
+            }
+            if (lane == 0) st_status(&status[tile], mscan_pack(2u, pre + tot));
+        }
+        if (lane == 0) s_pre = pre;
+    }
+    __syncthreads();
+    long long run = s_pre + wpre + iv - mine;
+#pragma unroll
+    for (int q = 0; q < MSCAN_IPT; q++) { if (k0 + q < n) out[k0 + q] = run; run += v[q]; }
+    if (tid == 0 && (long long)(tile + 1) * MSCAN_TILE >= n) out[n] = s_pre + tot;
+}
+
 // kept runs -> peaks in @SQ order (API output) and in sorted-contig order (pipeline order, MP:1309)
 __global__ void __launch_bounds__(256) contig_peak_ranges_kernel(const MirpPeak* __restrict__ runs, long long n_runs, const long long* __restrict__ kscan,
                                                                  int n_contigs, long long* __restrict__ csq /* [n_contigs+1] kept-start per contig */) {
@@ -612,7 +709,30 @@ __device__ __forceinline__ char rc_char(char c) {   // get_complement MP:232-235
     switch (c) { case 'A': return 'U'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G'; case 'U': return 'A'; default: return c; }
 }
 
+// first_rec[w] = index of the first (tid, pos)-sorted record at or after the start of window w: one thread per window, a plain binary search --
+// 2 x 10^5 independent searches in flight hide the chain of dependent loads that a search inside the payload kernel (one wave per window) paid in full.
+__global__ void __launch_bounds__(256) window_first_record_kernel(const MirpWindow* __restrict__ W, long long n_windows, const MirpAln* __restrict__ alns,
+                                                                  long long n_alns, long long* __restrict__ first_rec) {
+    for (long long w = blockIdx.x * (long long)blockDim.x + threadIdx.x; w < n_windows; w += (long long)gridDim.x * blockDim.x) {
+        const int tid = W[w].tid, ws = W[w].ws;
+        long long lo = 0, hi = n_alns;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            const int rt = alns[mid].tid, rp = alns[mid].pos;
+            if (rt < tid || (rt == tid && rp < ws)) lo = mid + 1; else hi = mid;
+        }
+        first_rec[w] = lo;
+    }
+}
+
+__device__ __forceinline__ int wave_max_i32(int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(x, o); x = t > x ? t : x; }
+    return x;
+}
+
 __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restrict__ W, long long n_windows, const MirpPeak* __restrict__ P,
+                                                            const long long* __restrict__ first_rec,
                                                             const MirpAln* __restrict__ alns, long long n_alns, const unsigned char* __restrict__ genome,
                                                             const long long* __restrict__ gboff, const long long* __restrict__ clen,
                                                             double min_mature_depth, int wmax,
@@ -634,27 +754,13 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
         char* dst = seqs + win.seq_off;
         if (strand == 0) for (int x = lane; x < len; x += 64) dst[x] = (char)g[s - 1 + x];
         else for (int x = lane; x < len; x += 64) dst[x] = rc_char((char)g[e - 1 - x]);
-        // ---- a5: per start position, most abundant read of the window's strand; first seen wins ties (MP:1457).  One 64-ary search of the
-        // (tid, pos)-sorted records for the window's first record, then the records of [ws, we] are walked 64 at a time; a record votes for its
-        // start position with the key (depth << 32 | ~index): the maximum is the deepest read and, among equals, the first in array order.
+        // ---- a5: per start position, most abundant read of the window's strand; first seen wins ties (MP:1457).  The window's first record in
+        // the (tid, pos)-sorted array comes from window_first_record_kernel; the records of [ws, we] are walked 64 at a time and a record votes for
+        // its start position with the key (depth << 32 | ~index): the maximum is the deepest read and, among equals, the first in array order.
         // (Round 3 ran one binary search over ALL records per start position: 326 x 25 dependent loads per window, 3.6 ms at a config[4] shard.)
         const int width = we - ws + 1;
         for (int x = lane; x < width; x += 64) { best[x] = 0ull; tot[x] = 0; }
-        long long lo = 0, hi = n_alns;
-        auto less = [&](long long k) { const MirpAln r = alns[k]; return r.tid < tid || (r.tid == tid && r.pos < ws); };
-        while (hi - lo > 64) {
-            const long long step = (hi - lo + 63) >> 6;
-            const long long k = lo + (long long)(lane + 1) * step - 1;
-            const bool lt = k < hi ? less(k) : false;
-            const int c = __popcll(__ballot(lt));          // probes are ascending: the first c are below the key
-            const long long nlo = lo + (long long)c * step;
-            hi = (nlo + step < hi) ? nlo + step : hi;      // probe c (if any) is not below the key: the bound lies in (probe c-1, probe c]
-            lo = nlo;
-        }
-        {
-            const bool lt = lo + lane < hi ? less(lo + lane) : false;
-            lo += __popcll(__ballot(lt));
-        }
+        const long long lo = first_rec[w];
         __syncthreads();
         for (long long k0 = lo;; k0 += 64) {
             const long long k = k0 + lane;
@@ -683,35 +789,59 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
             }
         }
         __syncthreads();
-        // ---- a6: gen_matures_one_peak per same-strand peak of the region (MP:1472-1510)
-        if (lane == 0) {
+        // ---- a6: gen_matures_one_peak per same-strand peak of the region (MP:1472-1510).  The reference walks the positions of [peak start - 20,
+        // peak end) in order: the first two with a read deeper than the bound are kept, the second is replaced by any later one that is strictly deeper
+        // (so it ends as the FIRST deepest position behind the first kept one); with none above the bound the first deepest position of all stands
+        // in.  Here a lane takes a position, 64 at a time, and the order-dependent picks are first-set-lane / first-lane-at-the-maximum.
+        {
             int nm = 0;
             const long long f = win.pad0;
             const int npk = win.pad1;
             MirpMature* out = matures + win.mature_off;
             for (int k = 0; k < npk; k++) {
-                MirpPeak pk = P[f + k];
+                const MirpPeak pk = P[f + k];
                 if (pk.strand != strand) continue;
-                MirpMature cand[2];
-                int n = 0;
-                MirpMature hi; hi.start = 0; hi.end = 0; hi.strand = -1; hi.depth = 0;
-                for (int pos = pk.start - 20; pos < pk.end; pos++) {
-                    if (pos < ws || pos > we) continue;
-                    int d = dmax[pos - ws];
-                    if (d <= 0) continue;
-                    int l = lmax[pos - ws];
-                    if (d > hi.depth) { hi.start = pos; hi.end = pos + l; hi.strand = strand; hi.depth = d; }
-                    if ((double)d > min_mature_depth) {
-                        MirpMature m; m.start = pos; m.end = pos + l; m.strand = strand; m.depth = d;
-                        if (n < 2) cand[n++] = m;
-                        else if (d > cand[n - 1].depth) cand[n - 1] = m;
+                int n = 0, c_pos[2] = {0, 0}, c_d[2] = {0, 0}, c_l[2] = {0, 0};
+                int hi_pos = 0, hi_d = 0, hi_l = 0;
+                const int p0 = pk.start - 20 > ws ? pk.start - 20 : ws, p1 = pk.end - 1 < we ? pk.end - 1 : we;      // inclusive
+                for (int b = p0; b <= p1; b += 64) {
+                    const int pos = b + lane;
+                    const int d = pos <= p1 ? dmax[pos - ws] : 0;
+                    const int l = pos <= p1 ? (int)lmax[pos - ws] : 0;
+                    const int dm = wave_max_i32(d);
+                    if (dm > hi_d) {
+                        const int fl = __ffsll((long long)__ballot(d == dm)) - 1;
+                        hi_pos = b + fl; hi_d = dm; hi_l = __shfl(l, fl);
+                    }
+                    unsigned long long q = __ballot(d > 0 && (double)d > min_mature_depth);
+                    while (n < 2 && q) {
+                        const int fl = __ffsll((long long)q) - 1;
+                        c_pos[n] = b + fl; c_d[n] = __shfl(d, fl); c_l[n] = __shfl(l, fl);
+                        n++;
+                        q &= q - 1;
+                    }
+                    if (q) {          // n == 2: a later position replaces the second pick only if strictly deeper
+                        const bool mine = (q >> lane) & 1ull;
+                        const int m = wave_max_i32(mine ? d : 0);
+                        if (m > c_d[1]) {
+                            const int fl = __ffsll((long long)__ballot(mine && d == m)) - 1;
+                            c_pos[1] = b + fl; c_d[1] = m; c_l[1] = __shfl(l, fl);
+                        }
                     }
                 }
-                if (n == 0) cand[n++] = hi;
-                for (int x = 0; x < n; x++) out[nm++] = cand[x];
+                if (lane == 0) {
+                    if (n == 0) {
+                        MirpMature m; m.start = hi_d > 0 ? hi_pos : 0; m.end = hi_d > 0 ? hi_pos + hi_l : 0; m.strand = hi_d > 0 ? strand : -1; m.depth = hi_d;
+                        out[nm] = m;
+                    }
+                    for (int x = 0; x < n; x++) { MirpMature m; m.start = c_pos[x]; m.end = c_pos[x] + c_l[x]; m.strand = strand; m.depth = c_d[x]; out[nm + x] = m; }
+                }
+                nm += n == 0 ? 1 : n;
             }
-            win.n_matures = nm; win.seq_len = len;
-            if (!rt_out) { win.pad0 = 0; win.pad1 = 0; W[w] = win; }   // inspection mode re-runs on finished windows: leave them untouched
+            if (lane == 0) {
+                win.n_matures = nm; win.seq_len = len;
+                if (!rt_out) { win.pad0 = 0; win.pad1 = 0; W[w] = win; }   // inspection mode re-runs on finished windows: leave them untouched
+            }
         }
         __syncthreads();
     }
@@ -741,32 +871,33 @@ void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long 
                      long long depth_cap, long long* depth_gx, unsigned long long* totals) {
     long long tiles = cov_scan_tiles(gtot);
     hipLaunchKernelGGL(cov_scan_kernel<false>, dim3((unsigned)tiles), dim3(SCAN_NT), 0, st, const_cast<int*>(diff_p), const_cast<int*>(diff_m), gtot, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, cutoff, stat_d, stat_c, ticket, (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
+                       nullptr, 0, nullptr, nullptr, nullptr, nullptr, cutoff, stat_d, stat_c, ticket, (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
 }
 int cov_scan_tile_positions() { return SCAN_TILE; }
 void launch_cov_maxlen(hipStream_t st, const MirpAln* alns, long long n, int* out) {
     if (n <= 0) return;
     hipLaunchKernelGGL(cov_maxlen_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, alns, n, out);
 }
-size_t cov_fused_aux_bytes(long long gtot) { const size_t t = (size_t)cov_scan_tiles(gtot); return 8 * (t + 2) + 4 * 2 * t + 16 + 8 * 2 * (t + 2); }
-hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, void* aux, int* diff_p,
+size_t cov_fused_aux_bytes(long long gtot) { const size_t t = (size_t)cov_scan_tiles(gtot); return 8 * (t + 2) + 4 * 2 * t + 16 + 8 * 3 * (t + 2); }
+hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, int max_len, const long long* goff, const long long* clen, int n_contigs, void* aux, int* diff_p,
                                  int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d, unsigned long long* stat_c, unsigned int* ticket, void* starts,
                                  long long starts_cap, MirpDepthPos* depth_out, long long depth_cap, long long* depth_gx, unsigned long long* totals) {
     const long long tiles = cov_scan_tiles(gtot);
-    const size_t lds = 2 * (size_t)SCAN_TILE * sizeof(int);
+    const size_t lds = 2 * (size_t)SCAN_TILE * sizeof(int) + 2 * COV_CT * sizeof(long long);
     hipError_t e = hipFuncSetAttribute((const void*)cov_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    // aux: first[tiles + 2] | agg[2][tiles] (+ pad) | carry_p[tiles + 2] | carry_m[tiles + 2]
+    // aux: first[tiles + 2] | agg[2][tiles] (+ pad) | carry_p[tiles + 2] | carry_m[tiles + 2] | back[tiles + 2]
     long long* first = (long long*)aux;
     int* agg = (int*)(first + tiles + 2);
     long long* carry_p = (long long*)(((uintptr_t)(agg + 2 * tiles) + 15) & ~(uintptr_t)15);
     long long* carry_m = carry_p + tiles + 2;
+    long long* back = carry_m + tiles + 2;
     e = hipMemsetAsync(agg, 0, 4 * 2 * (size_t)tiles, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cov_tile_first_kernel, dim3(grid_for(n + 1, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, tiles, cutoff, first, agg);
+    hipLaunchKernelGGL(cov_tile_first_kernel, dim3(grid_for(n + 1, 256, 8192)), dim3(256), 0, st, alns, n, goff, clen, tiles, cutoff, max_len, first, back, agg);
     launch_excl_scan(st, agg, carry_p, tiles);
     launch_excl_scan(st, agg + tiles, carry_m, tiles);
-    hipLaunchKernelGGL(cov_scan_kernel<true>, dim3((unsigned)tiles), dim3(SCAN_NT), lds, st, diff_p, diff_m, gtot, alns, goff, clen, first, carry_p, carry_m, cutoff, stat_d, stat_c, ticket,
+    hipLaunchKernelGGL(cov_scan_kernel<true>, dim3((unsigned)tiles), dim3(SCAN_NT), lds, st, diff_p, diff_m, gtot, alns, goff, clen, n_contigs, first, back, carry_p, carry_m, cutoff, stat_d, stat_c, ticket,
                        (RunStart*)starts, starts_cap, depth_out, depth_cap, depth_gx, totals);
     return hipGetLastError();
 }
@@ -781,7 +912,32 @@ void launch_depth_fix(hipStream_t st, MirpDepthPos* d, const long long* gx, long
     if (n <= 0) return;
     hipLaunchKernelGGL(depth_fix_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, d, gx, n, goff, n_contigs);
 }
+// Scratch of the many-workgroup scan, one per stream (calls on a stream are ordered, so its descriptors and ticket counter have one user at a time);
+// released by release_scan_scratch when the stream's owner goes away.
+namespace {
+struct ScanScratch { unsigned long long* dev = nullptr; };
+std::mutex g_scan_mu;
+std::map<hipStream_t, ScanScratch> g_scan;
+}  // namespace
+void release_scan_scratch(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_scan_mu);
+    auto it = g_scan.find(st);
+    if (it == g_scan.end()) return;
+    if (it->second.dev) (void)hipFree(it->second.dev);
+    g_scan.erase(it);
+}
 void launch_excl_scan(hipStream_t st, const int* in, long long* out, long long n) {
+    const long long blocks = (n + MSCAN_TILE - 1) / MSCAN_TILE;
+    if (n > 1024 * SCAN1_NT && blocks <= MSCAN_MAX_BLOCKS) {
+        std::lock_guard<std::mutex> lk(g_scan_mu);
+        ScanScratch& s = g_scan[st];
+        const size_t bytes = 8 * (size_t)(MSCAN_MAX_BLOCKS + 1);
+        if (!s.dev && hipMalloc((void**)&s.dev, bytes) != hipSuccess) { s.dev = nullptr; (void)hipGetLastError(); }
+        if (s.dev && hipMemsetAsync(s.dev, 0, 8 * (size_t)(blocks + 1), st) == hipSuccess) {
+            hipLaunchKernelGGL(excl_scan_i32_mb_kernel, dim3((unsigned)blocks), dim3(MSCAN_NT), 0, st, in, out, n, s.dev);
+            return;
+        }
+    }
     hipLaunchKernelGGL(excl_scan_i32_kernel, dim3(1), dim3(1024), 0, st, in, out, n);
 }
 void launch_peak_compact(hipStream_t st, const MirpPeak* runs, const int* keep, const long long* kscan, long long n_runs, int n_contigs,
@@ -812,10 +968,11 @@ void launch_region_emit(hipStream_t st, const MirpPeak* P, const long long* rfir
 }
 void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, const MirpPeak* P, const MirpAln* alns, long long n_alns,
                            const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
-                           MirpMature* matures, int* rt_out) {
+                           MirpMature* matures, long long* first_rec, int* rt_out) {
     if (n_windows <= 0) return;
     size_t lds = (size_t)wmax * 18 + 32;
-    hipLaunchKernelGGL(window_payload_kernel, dim3(grid_for(n_windows, 1, 16384)), dim3(64), lds, st, W, n_windows, P, alns, n_alns, genome, gboff, clen,
+    hipLaunchKernelGGL(window_first_record_kernel, dim3(grid_for(n_windows, 256, 8192)), dim3(256), 0, st, W, n_windows, alns, n_alns, first_rec);
+    hipLaunchKernelGGL(window_payload_kernel, dim3(grid_for(n_windows, 1, 16384)), dim3(64), lds, st, W, n_windows, P, first_rec, alns, n_alns, genome, gboff, clen,
                        min_mature_depth, wmax, seqs, matures, rt_out);
 }
 

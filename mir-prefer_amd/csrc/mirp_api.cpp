@@ -107,7 +107,7 @@ extern "C" void mirp_destroy(mirp_ctx* c) {
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_params185) (void)hipFree(c->d_params185);
     if (c->d_params185l) (void)hipFree(c->d_params185l);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) { mirp::release_scan_scratch(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
 }
 

@@ -70,7 +70,7 @@ size_t run_start_bytes();
 int cov_scan_tile_positions();
 void launch_cov_maxlen(hipStream_t st, const MirpAln* alns, long long n, int* out);
 size_t cov_fused_aux_bytes(long long gtot);
-hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, const long long* goff, const long long* clen, void* aux, int* diff_p,
+hipError_t launch_cov_scan_fused(hipStream_t st, const MirpAln* alns, long long n, int max_len /* longest record */, const long long* goff, const long long* clen, int n_contigs, void* aux, int* diff_p,
                                  int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d, unsigned long long* stat_c, unsigned int* ticket, void* starts,
                                  long long starts_cap, MirpDepthPos* depth_out, long long depth_cap, long long* depth_gx, unsigned long long* totals);
 void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long long gtot, int cutoff, unsigned long long* stat_d,
@@ -79,7 +79,8 @@ void launch_cov_scan(hipStream_t st, const int* diff_p, const int* diff_m, long 
 void launch_run_walk(hipStream_t st, const void* starts, long long n_runs, const int* diff_p, const int* diff_m, long long gtot, int cutoff,
                      const long long* goff, int n_contigs, int min_len, MirpPeak* runs, int* keep, int first_run_double);
 void launch_depth_fix(hipStream_t st, MirpDepthPos* d, const long long* gx, long long n, const long long* goff, int n_contigs);
-void launch_excl_scan(hipStream_t st, const int* in, long long* out, long long n);
+void launch_excl_scan(hipStream_t st, const int* in, long long* out, long long n);      // out[n + 1]; arrays beyond 16,384 elements: many-workgroup look-back scan
+void release_scan_scratch(hipStream_t st);                                              // frees that scan's per-stream descriptors (before the stream is destroyed)
 void launch_peak_compact(hipStream_t st, const MirpPeak* runs, const int* keep, const long long* kscan, long long n_runs, int n_contigs,
                          const int* order, long long* csq, long long* cdest, MirpPeak* peaks_sq, MirpPeak* peaks_sorted);
 void launch_region_head(hipStream_t st, const MirpPeak* P, long long n, int max_gap, int* head);
@@ -91,6 +92,6 @@ void launch_region_emit(hipStream_t st, const MirpPeak* P, const long long* rfir
                         int* roles, int seq_stride);
 void launch_window_payload(hipStream_t st, MirpWindow* W, long long n_windows, const MirpPeak* P, const MirpAln* alns, long long n_alns,
                            const unsigned char* genome, const long long* gboff, const long long* clen, double min_mature_depth, int wmax, char* seqs,
-                           MirpMature* matures, int* rt_out = nullptr);
+                           MirpMature* matures, long long* first_rec /* scratch, n_windows entries */, int* rt_out = nullptr);
 
 }  // namespace mirp

@@ -169,8 +169,8 @@ static int run_coverage(mirp_ctx* c, MirpDepthPos* depth_out, long long depth_ca
     if (c->cov_fused) {
         if (c->tile_first.ensure(mirp::cov_fused_aux_bytes(gtot))) return fail(c, -6, "device allocation failed (coverage)");
         c->diff_clean_ptr = nullptr;          // the dense arrays hold the written tiles' values from now on: the atomic path clears them before it runs again
-        HIPCHK(c, mirp::launch_cov_scan_fused(c->stream, (const MirpAln*)c->alns.p, c->n_alns, (const long long*)c->goff.p, (const long long*)c->clen.p,
-                                              c->tile_first.p, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p,
+        HIPCHK(c, mirp::launch_cov_scan_fused(c->stream, (const MirpAln*)c->alns.p, c->n_alns, c->max_aln_len, (const long long*)c->goff.p, (const long long*)c->clen.p,
+                                              c->n_contigs, c->tile_first.p, diff_p, diff_m, gtot, c->cand.cutoff, stat_d, stat_c, ticket, c->starts.p,
                                               std::max<long long>(c->n_alns + c->n_segs, 1), depth_out, depth_cap, depth_gx, (unsigned long long*)c->totals.p));
         return 0;
     }
@@ -219,6 +219,22 @@ extern "C" int mirp_limit_windows(mirp_ctx* c, int64_t n_keep) {
     // every later stage reads the window arrays as prefixes of length n_windows (offsets into wpeaks / matures / sequences stay valid)
     c->n_windows = n_keep;
     c->have_fold = false; c->have_result = false;
+    return 0;
+}
+
+extern "C" int mirp_excl_scan_i32(mirp_ctx* c, const int32_t* in, int64_t n, int64_t* out) {
+    if (!c) return -1;
+    if (n < 0 || !out || (n > 0 && !in)) return fail(c, -1, "mirp_excl_scan_i32: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    TmpDevice T;
+    int* d_in = (int*)T.get(4 * (size_t)std::max<int64_t>(n, 1));
+    long long* d_out = (long long*)T.get(8 * (size_t)(n + 1));
+    if (!d_in || !d_out) return fail(c, -6, "device allocation failed");
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(d_in, in, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    mirp::launch_excl_scan(c->stream, d_in, d_out, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, d_out, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -300,7 +316,7 @@ extern "C" int mirp_candidate(mirp_ctx* c, const MirpCandidateParams* params, co
     const int wmax = c->cand.precursor_len + 52;
     mirp::launch_window_payload(st, (MirpWindow*)c->windows.p, nw, P, (const MirpAln*)c->alns.p, c->n_alns, (const unsigned char*)c->genome.p,
                                 (const long long*)c->gboff.p, (const long long*)c->clen.p, c->cand.cutoff * 0.5 /* MP:3404 */, wmax, (char*)c->wseqs.p,
-                                (MirpMature*)c->matures.p);
+                                (MirpMature*)c->matures.p, (long long*)c->woffs.p /* scratch here: window_index_kernel fills it below */);
     if (nw > 0)
         hipLaunchKernelGGL(mirp::window_index_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, st,
                            (const MirpWindow*)c->windows.p, nw, (long long*)c->woffs.p, (int*)c->wlens.p);
@@ -391,9 +407,11 @@ extern "C" int mirp_get_window_readtable(mirp_ctx* c, int32_t** table, int32_t* 
     int* d = (int*)T.get(sizeof(int) * 3 * (size_t)wmax * (size_t)std::max<long long>(nw, 1));
     if (!d) return fail(c, -6, "device allocation failed (read table)");
     HIPCHK(c, hipMemsetAsync(d, 0, sizeof(int) * 3 * (size_t)wmax * (size_t)std::max<long long>(nw, 1), c->stream));
+    long long* first_rec = (long long*)T.get(8 * (size_t)std::max<long long>(nw, 1));
+    if (!first_rec) return fail(c, -6, "device allocation failed (read table)");
     mirp::launch_window_payload(c->stream, (MirpWindow*)c->windows.p, nw, (const MirpPeak*)c->peaks_sorted.p, (const MirpAln*)c->alns.p, c->n_alns,
                                 (const unsigned char*)c->genome.p, (const long long*)c->gboff.p, (const long long*)c->clen.p, c->cand.cutoff * 0.5, wmax,
-                                (char*)c->wseqs.p, (MirpMature*)c->matures.p, d);
+                                (char*)c->wseqs.p, (MirpMature*)c->matures.p, first_rec, d);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     int32_t* h = host_copy<int32_t>(c, d, 3 * (size_t)wmax * (size_t)nw);

@@ -410,3 +410,23 @@ def test_fused_coverage_scan_equals_atomic_path_and_brute_force(gpu_ctx):
             assert got[mode][0] == want, (seed, mode)
         assert got[1][1] == got[0][1], seed
     gpu_ctx.set_coverage_path(-1)
+
+
+@pytest.mark.gpu
+def test_exclusive_scan_single_block_and_lookback_paths(gpu_ctx):
+    """The prefix sum under every compaction of the candidate stage, both kernels: one workgroup (<= 16,384 elements) and the single-pass look-back
+    scan over 4,096-element blocks (beyond): sizes on the block edges, negative values (the tile aggregates of a difference array are signed),
+    large partial sums, and 300 back-to-back calls on one stream (the descriptors are never cleared between calls: each call has its own epoch)."""
+    rng = np.random.RandomState(3)
+    for n in (0, 1, 5, 1024, 16383, 16384, 16385, 16384 + 4095, 5 * 4096, 5 * 4096 + 1, 300001, 4096 * 700 + 17, 20000003):
+        for lo, hi in ((0, 2), (-1000, 1001), (2 ** 30, 2 ** 31 - 1)):
+            if n > 4000000 and lo != -1000:
+                continue
+            v = rng.randint(lo, hi, size=n).astype(np.int32)
+            want = np.concatenate([[0], np.cumsum(v.astype(np.int64))])
+            got = gpu_ctx.excl_scan(v)
+            assert np.array_equal(got, want), (n, lo)
+    v = rng.randint(0, 7, size=70001).astype(np.int32)
+    want = np.concatenate([[0], np.cumsum(v.astype(np.int64))])
+    for k in range(300):
+        assert np.array_equal(gpu_ctx.excl_scan(v[:70001 - 97 * (k % 5)]), want[:70001 - 97 * (k % 5) + 1]), k
