@@ -337,11 +337,15 @@ __global__ void __launch_bounds__(SCAN_NT) cov_scan_kernel(int* __restrict__ dif
     tile_excl_scan2<SCAN_NV>(ns, na, es, ea, ts, ta, sh);
     if constexpr (FUSED) {
         // ta = covered bases of the tile; a run can also reach in from the tile before (depth carried in above the threshold) and its walk then reads
-        // this tile's first values
+        // this tile's first values.  Written per ROW of 256 positions (one coalesced kilobyte per array and wave): a run walk reads the positions of
+        // its run and the one that ends it, so a row is needed if it holds a covered base or the depth just before it is above the threshold --
+        // at a config[4] shard every tile holds a locus, but two rows in three hold none.
         const bool carried = (int)(((unsigned)s_carry[0] + (unsigned)s_carry[1]) & 0x7fffffffu) > cutoff;
         if (ta > 0 || carried) {
 #pragma unroll
             for (int v = 0; v < SCAN_NV; v++) {
+                const int before = (int)(((unsigned)s_carry[0] + (unsigned)ep[v]) & 0x7fffffffu) + (int)(((unsigned)s_carry[1] + (unsigned)em[v]) & 0x7fffffffu);
+                if (__ballot(((abovemask >> (v * 4)) & 15u) != 0) == 0ull && __builtin_amdgcn_readfirstlane(before) <= cutoff) continue;
                 const long long x = wbase + v * 256 + lane * 4;
                 if (x + 3 < gtot) {
                     *reinterpret_cast<int4*>(diff_p + x) = make_int4(vp[v * 4], vp[v * 4 + 1], vp[v * 4 + 2], vp[v * 4 + 3]);
@@ -427,9 +431,18 @@ __global__ void __launch_bounds__(256) run_walk_kernel(const RunStart* __restric
         RunStart r = starts[k];
         int dp = r.dp, dm = r.dm;
         long long sum_p = dp, sum_m = dm, x = r.gx + 1;
-        for (; x < gtot; x++) {
-            dp += diff_p[x]; dm += diff_m[x];
-            if (dp + dm > cutoff) { sum_p += dp; sum_m += dm; } else break;
+        // the walk is a chain of dependent steps, but the LOADS need not be: eight positions of both arrays are fetched at once, then stepped through
+        // (one load pair per step made the kernel as long as its longest run times the memory latency: 0.24 ms at a config[4] shard)
+        for (bool open = true; open && x < gtot;) {
+            int vp[8], vm[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const long long xx = x + q < gtot ? x + q : gtot - 1; vp[q] = diff_p[xx]; vm[q] = diff_m[xx]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (!open || x >= gtot) break;
+                dp += vp[q]; dm += vm[q];
+                if (dp + dm > cutoff) { sum_p += dp; sum_m += dm; x++; } else open = false;
+            }
         }
         int t = contig_of(goff, n_contigs, r.gx);
         if (k > 0) {
@@ -743,6 +756,7 @@ __global__ void __launch_bounds__(64) window_payload_kernel(MirpWindow* __restri
     int* tot = dmax + wmax;                       // [wmax]  total depth of the reads that start at pos (inspection copy only)
     unsigned short* lmax = (unsigned short*)(tot + wmax);   // [wmax]
     const int lane = threadIdx.x;
+    // (fetching the next window's record, index and first 64 records while this one is worked on made the kernel slower: 0.47 -> 0.53 ms at a config[4] shard)
     for (long long w = blockIdx.x; w < n_windows; w += gridDim.x) {
         MirpWindow win = W[w];
         const int tid = win.tid, ws = win.ws, we = win.we, strand = win.strand;
