@@ -24,6 +24,9 @@ namespace v185 {
 #define V_NT 256
 #define V_G 8
 #define V_BT_STACK 192
+#ifndef MIRP_EPI_DMAX
+#define MIRP_EPI_DMAX 300   // largest pair distance a tiled archive holds (fold_epilogue.h)
+#endif
 #define V_BT_LINE 16     // cells of a helix line fetched per round trip (every further cell is one more tile of the archive)
 
 struct GTab185 {   // int32 tables in a global workspace (fold185_kernel)
@@ -492,6 +495,137 @@ __device__ int backtrack_tiled(const Ctx<PT>& X, const TabT& T, int start, int m
     return L;
 }
 
+// Exterior sweep over the TILED archive (TabT::kTiled: 8 x 8 tiles over (row, diagonal), 16 bytes = the 8 rows of one diagonal), the layout of
+// f3_sweep_tiled of the default model: a wave takes one row block of 8 rows and has all of its tiles in flight at once, lane = diagonal, a wave-wide
+// load is 1 KB of consecutive tiles.  What dangles 1 adds is the c(i+1, j) term: cell (i+1, j) is row + 1 on diagonal - 1, i.e. the NEXT row of the
+// PREVIOUS lane's vector -- one lane shift of the loaded vectors (lane 0 takes lane 63 of the group before), and for the block's last row the first
+// row of the next row block on the previous lane's diagonal (a ninth, 2-byte value per lane).  (The row-per-lane sweep this replaces read 16 bytes
+// of a 128-byte tile per access: 4.7 of the epilogue's 10.1 ms.)  Partners whose f3 is final go into the lane's eight running minima, which meet
+// in LDS; partners inside the block of 8 x (waves) rows park their two terms in LDS by the row whose f3 they wait for; wave 0 then runs the chain
+// through the block in registers.
+template <class PT, class TabT, int NT>
+__device__ void sweep_tiled(const Ctx<PT>& X, const TabT& T, int* f3, int* scratch) {
+    constexpr int NW = NT / 64, RBK = 8 * NW;
+    constexpr int NG = (MIRP_EPI_DMAX + 1 - V_TURN - 1) / 64 + 1;      // groups of 64 partner distances 4 .. span (c reaches span - 1, the c(i+1, j) term one further)
+    static_assert(RBK <= 64, "the chain maps the rows of a block onto the lanes of one wave");
+    static_assert(RBK <= 64 + V_TURN, "only the first group of distances has partners inside the block");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = X.n, D = T.D;
+    const unsigned char* S = X.S;
+    int* part = scratch;                      // [RBK] per-row minimum over the partners whose f3 is final
+    int* innerA = scratch + RBK;              // [RBK (row waited for)][RBK (row)] term continued by f3[j+1]
+    int* innerB = innerA + RBK * RBK;         // the same for the 3' dangle term, continued by f3[j+2]
+    const int tau = X.P->TerminalAU;
+    const int top = n - V_TURN - 1;           // highest row that can pair
+    for (int g = top >= 1 ? (top - 1) / RBK : -1; g >= 0; g--) {
+        const int blk_lo = g * RBK + 1, blk_hi = blk_lo + RBK - 1;
+        const int tb = g * NW + wave, i0 = 8 * tb + 1;
+        const int dmax_b = D < n - i0 ? D : n - i0;                    // wave-uniform: the block's first row reaches furthest
+        const uint4* base = reinterpret_cast<const uint4*>(T.carch + T.off[tb]) + lane;
+        const unsigned short* nbase = reinterpret_cast<const unsigned short*>(T.carch) + (i0 + 8 <= n ? T.off[tb + 1] : 0) + 8 * lane;
+        // two groups of 64 distances in flight (the one at hand and the next): all five at once cost 25 registers under this kernel's budget of 64
+        auto load = [&](int u, uint4& c4, unsigned& x1) {
+            const int d = V_TURN + 1 + 64 * u + lane;
+            c4 = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+            x1 = 0x7fffu;
+            if (d <= dmax_b) c4 = base[64 * u];
+            if (d <= D && i0 + 8 + d <= n) x1 = nbase[8 * 64 * u];
+        };
+        uint4 cnext; unsigned xnext;
+        load(0, cnext, xnext);
+        for (int x = tid; x < RBK + 2 * RBK * RBK; x += NT) part[x] = V_INF;
+        __syncthreads();
+        {
+            int best[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; rr++) best[rr] = V_INF;
+            const int vS = S[i0 + lane <= n + 1 ? i0 + lane : n + 1];      // lanes 0 .. 8: the bases of rows i0 .. i0 + 8 (wave-uniform per row: v_readlane)
+            unsigned last[5] = {0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fffu};      // lane 63 of the group before (scalars); distance 3 does not pair
+#pragma unroll 1
+            for (int u = 0; u < NG; u++) {
+                const uint4 cgu = cnext; const unsigned nxu = xnext;
+                if (u + 1 < NG && V_TURN + 1 + 64 * (u + 1) <= dmax_b + 1) load(u + 1, cnext, xnext);
+                if (V_TURN + 1 + 64 * u <= dmax_b + 1) {              // wave-uniform (distance dmax_b + 1 still has its c(i+1, j) term)
+                    const int d = V_TURN + 1 + 64 * u + lane;
+                    const int j0 = i0 + d;                            // partner of row i0; row i0 + rr pairs with j0 + rr
+                    // the previous lane's vector: rows i0 .. i0 + 8 of diagonal d - 1
+                    unsigned pw[5];
+                    {
+                        const unsigned own[5] = {cgu.x, cgu.y, cgu.z, cgu.w, nxu};
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const unsigned v = (unsigned)__shfl_up((int)own[q], 1);
+                            pw[q] = lane == 0 ? last[q] : v;
+                            last[q] = (unsigned)__builtin_amdgcn_readlane((int)own[q], 63);
+                        }
+                    }
+                    const unsigned cw[4] = {cgu.x, cgu.y, cgu.z, cgu.w};
+                    int sjn = S[j0 <= n + 1 ? j0 : n + 1];           // base of j (carried from row to row), then of j + 1 (out of range: never used)
+#pragma unroll
+                    for (int rr = 0; rr < 8; rr++) {
+                        const int i = i0 + rr, j = j0 + rr;
+                        const int sj0 = sjn;
+                        sjn = S[j + 1 <= n + 1 ? j + 1 : n + 1];
+                        const int ca = (int)(short)((rr & 1) ? cw[rr >> 1] >> 16 : cw[rr >> 1] & 0xffffu);
+                        const int r1 = rr + 1;
+                        const int cb = r1 < 8 ? (int)(short)((r1 & 1) ? pw[r1 >> 1] >> 16 : pw[r1 >> 1] & 0xffffu) : (int)(short)(pw[4] & 0xffffu);
+                        const bool inw = j <= n;
+                        const int si = __builtin_amdgcn_readlane(vS, rr), si1 = __builtin_amdgcn_readlane(vS, rr + 1);
+                        int a = V_INF, b = V_INF;
+                        if (inw && ca != 0x7fff && d <= D) {          // c is finite only where the two bases pair
+                            const int t = pair_type(si, sj0);
+                            const int e = ca + (t > 2 ? tau : 0);
+                            a = e;
+                            if (j < n) b = e + D3(X, t, sjn);
+                        }
+                        if (inw && cb != 0x7fff && d - 1 > V_TURN && d - 1 <= D) {
+                            const int t = pair_type(si1, sj0);
+                            const int e = cb + D5(X, t, si) + (t > 2 ? tau : 0);
+                            a = e < a ? e : a;
+                            if (j < n) { const int v = e + D3(X, t, sjn); b = v < b ? v : b; }
+                        }
+                        if (a < V_INF) {
+                            if (j >= blk_hi) {                        // f3[j+1], f3[j+2] final (f3[n+1] = f3[n+2] = 0)
+                                int v = f3[j + 1] + a; best[rr] = v < best[rr] ? v : best[rr];
+                                if (j < n) { v = f3[j + 2] + b; best[rr] = v < best[rr] ? v : best[rr]; }
+                            } else {                                  // continued by rows of this block (first group of distances only)
+                                innerA[(j + 1 - blk_lo) * RBK + (i - blk_lo)] = a;
+                                if (j + 2 > blk_hi) { const int v = f3[j + 2] + b; best[rr] = v < best[rr] ? v : best[rr]; }
+                                else innerB[(j + 2 - blk_lo) * RBK + (i - blk_lo)] = b;
+                            }
+                        }
+                    }
+                }
+            }
+            // hand-issued ds_min: the compiler's atomic optimizer would turn each atomicMin into a loop over the active lanes
+            {
+                const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) int*)(part + 8 * wave);
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) asm volatile("ds_min_i32 %0, %1 offset:%2" : : "v"(pa), "v"(best[rr]), "n"(4 * rr) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int r = lane & (RBK - 1);
+            int best = part[r];
+            int fx = f3[blk_hi + 1 <= n + 2 ? blk_hi + 1 : n + 2], fo = 0;
+#pragma unroll 4
+            for (int xr = RBK - 1; xr >= 0; xr--) {
+                const int bx = __builtin_amdgcn_readlane(best, xr);
+                fx = bx < fx ? bx : fx;                                // f3 of row blk_lo + xr
+                fo = lane == xr ? fx : fo;
+                const int ea = innerA[xr * RBK + r], eb = innerB[xr * RBK + r];      // terms of row r that wait for this row
+                int v = ea + fx; v = ea < V_INF ? v : V_INF; best = v < best ? v : best;
+                v = eb + fx; v = eb < V_INF ? v : V_INF; best = v < best ? v : best;
+            }
+            if (lane < RBK && blk_lo + lane <= n) f3[blk_lo + lane] = fo;
+        }
+        __syncthreads();
+    }
+}
+
 // Exterior sweep (sequential in i, partners reduced in parallel), enumeration of the structure starts, one backtrack per start and wave,
 // RNALfold's "print prev unless contained in new" rule, output records.  Called by all NT threads of the workgroup; f3 must be zero-filled.
 template <class PT, class TabT, int NT>
@@ -508,7 +642,10 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
         // diagonal by diagonal -- its 32 cells of one archived diagonal are one contiguous read.  Partners at or above the block top have
         // final f3 values and are reduced to one minimum per row; the few partners inside the block leave their two terms in LDS.  Step 2
         // (wave 0): the short sequential chain through the block touches LDS only.  The backtrack stacks are idle here and serve as scratch.
-        {
+        if constexpr (TabT::kTiled) {
+            static_assert((NT / 64) * 8 + 2 * (NT / 64) * 8 * (NT / 64) * 8 <= (NT / 64) * 3 * V_BT_STACK, "exterior-sweep scratch must fit the backtrack stacks");
+            sweep_tiled<PT, TabT, NT>(X, T, f3, btstk);
+        } else {
             constexpr int NW = NT / 64, RB = 32;
             static_assert(RB + 2 * RB * RB <= NW * 3 * V_BT_STACK, "exterior-sweep scratch must fit the backtrack stacks");
             int* part = btstk;                  // [RB] per-row minimum over the partners with final f3
@@ -652,11 +789,6 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
             const bool anyd = __ballot(differ) != 0ull;
             const bool print = (i + Ln < prev_i + lp) || anyd;
             if (lane == 0 && !print) out_lines[(size_t)win * max_lines + k].printed = 0;
-        }
-        if (tid == 0) {
-            out_nlines[win] = red[9] ? red[11] : nst;      // over capacity (status 1): the number of lines the window needs
-            out_mfe[win] = f3[1];
-            out_status[win] = red[10] ? red[10] : (red[9] ? 1 : 0);
         }
         if (tid == 0) {
             out_nlines[win] = red[9] ? red[11] : nst;      // over capacity (status 1): the number of lines the window needs

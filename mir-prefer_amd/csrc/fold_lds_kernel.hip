@@ -1195,7 +1195,10 @@ struct LTab185 {
     __device__ __forceinline__ int TB(int i, int j) const { return tb[at(j - i, i)]; }
 };
 
-__global__ void __launch_bounds__(ENT, 8) fold185_lds_epilogue_kernel(
+#ifndef MIRP_EPI185_WGS
+#define MIRP_EPI185_WGS 8
+#endif
+__global__ void __launch_bounds__(ENT, MIRP_EPI185_WGS) fold185_lds_epilogue_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int span, const short* __restrict__ slabs, size_t slab_shorts, const int* __restrict__ win_state, unsigned int* __restrict__ work_counter,
     int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss, int* __restrict__ out_nlines,
