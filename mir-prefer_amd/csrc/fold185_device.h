@@ -742,14 +742,19 @@ __device__ void epilogue(const Ctx<PT>& X, const TabT& T, int* f3, int* starts, 
                 if (lane == 0 && cnt < max_lines) starts[cnt] = 1;
                 cnt++;
             }
-            if (lane == 0) { red[8] = cnt < max_lines ? cnt : max_lines; red[9] = cnt > max_lines ? 1 : 0; red[10] = 0; red[11] = cnt; }
+            if (lane == 0) { red[8] = cnt < max_lines ? cnt : max_lines; red[9] = cnt > max_lines ? 1 : 0; red[10] = 0; red[11] = cnt; red[7] = 0; }
         }
         __syncthreads();
         const int nst = red[8];
         V185_T(1);
         char* mybuf = btbuf + wave * (nc + 8);
         int* mystk = btstk + wave * 3 * V_BT_STACK;
-        for (int k = wave; k < nst; k += NT / 64) {
+        // structures differ a lot in length: the waves draw them from a counter (red[7]) instead of striding (bounded trip count, as in fold_epilogue.h)
+        for (int it = 0; it <= nst; it++) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&red[7], 1);
+            const int k = __builtin_amdgcn_readfirstlane(t);
+            if (k >= nst) break;
             const int lind = starts[k];
             int L;
             if constexpr (TabT::kTiled) L = backtrack_tiled(X, T, lind, lind == 1 ? M : M + 1, mybuf, nc + 8, mystk);
