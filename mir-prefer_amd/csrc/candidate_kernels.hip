@@ -431,14 +431,17 @@ __global__ void __launch_bounds__(256) run_walk_kernel(const RunStart* __restric
         RunStart r = starts[k];
         int dp = r.dp, dm = r.dm;
         long long sum_p = dp, sum_m = dm, x = r.gx + 1;
-        // the walk is a chain of dependent steps, but the LOADS need not be: eight positions of both arrays are fetched at once, then stepped through
+        // the walk is a chain of dependent steps, but the LOADS need not be: RW_B positions of both arrays are fetched at once, then stepped through
         // (one load pair per step made the kernel as long as its longest run times the memory latency: 0.24 ms at a config[4] shard)
+#ifndef RW_B
+#define RW_B 8
+#endif
         for (bool open = true; open && x < gtot;) {
-            int vp[8], vm[8];
+            int vp[RW_B], vm[RW_B];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { const long long xx = x + q < gtot ? x + q : gtot - 1; vp[q] = diff_p[xx]; vm[q] = diff_m[xx]; }
+            for (int q = 0; q < RW_B; q++) { const long long xx = x + q < gtot ? x + q : gtot - 1; vp[q] = diff_p[xx]; vm[q] = diff_m[xx]; }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < RW_B; q++) {
                 if (!open || x >= gtot) break;
                 dp += vp[q]; dm += vm[q];
                 if (dp + dm > cutoff) { sum_p += dp; sum_m += dm; x++; } else open = false;
