@@ -81,7 +81,7 @@ def write_reports(loci, contig_names, ss_list, pre_list, sample_names, counts, m
         raise MirpError("%s (%d)" % (err.value.decode(), rc))
 
 
-def write_files(paths, texts):
+def write_files(paths, texts, n_threads=1):
     """mirp_write_files: file paths[k] <- texts[k] (str), written natively, outside the interpreter lock."""
     lib = load_library()
     n = len(paths)
@@ -93,8 +93,8 @@ def write_files(paths, texts):
     err = C.create_string_buffer(512)
     fn = lib.mirp_write_files
     fn.restype = C.c_int
-    fn.argtypes = [C.c_int64, C.c_char_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
-    rc = fn(n, b"".join(p.encode() + b"\0" for p in paths), b"".join(enc), offs.ctypes.data, err, 512)
+    fn.argtypes = [C.c_int64, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]
+    rc = fn(n, b"".join(p.encode() + b"\0" for p in paths), b"".join(enc), offs.ctypes.data, int(n_threads), err, 512)
     if rc != 0:
         raise MirpError("%s (%d)" % (err.value.decode(), rc))
 

@@ -653,14 +653,13 @@ extern "C" int mirp_write_reports(int64_t n, const int32_t* loci, const char* co
     return 0;
 }
 
-extern "C" int mirp_write_files(int64_t n, const char* paths, const char* text, const int64_t* offs, char* errbuf, size_t errbuf_len) {
+extern "C" int mirp_write_files(int64_t n, const char* paths, const char* text, const int64_t* offs, int32_t n_threads, char* errbuf, size_t errbuf_len) {
     if (n < 0 || (n > 0 && (!paths || !text || !offs))) { if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "mirp_write_files: bad argument"); return -1; }
     std::vector<const char*> name((size_t)n);
     { const char* p = paths; for (int64_t k = 0; k < n; k++) { name[k] = p; p += std::strlen(p) + 1; } }
-    const char* env = std::getenv("MIRP_FILE_THREADS");
     // one writer unless told otherwise: creating files in ONE directory serialises on the directory in the kernel -- 1 / 2 / 4 / 8 threads measured
     // the same on tmpfs (13-16 ms for 4,002 files) and no better on an overlay file system (profiles/tools/smallfiles.py)
-    const int cap = env && std::atoi(env) > 0 ? std::atoi(env) : 1;
+    const int cap = n_threads > 1 ? (n_threads < 64 ? n_threads : 64) : 1;
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(cap, n / 64));
     std::vector<int64_t> bad((size_t)nt, -1);
     std::vector<std::thread> th;

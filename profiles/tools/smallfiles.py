@@ -14,7 +14,7 @@ for base in (tempfile.gettempdir(), "/dev/shm"):
                 fd = os.open(p, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
                 os.write(fd, x.encode()); os.close(fd)
         else:
-            capi.write_files(paths, texts)
+            capi.write_files(paths, texts, int(os.environ.get("MIRP_FILE_THREADS", "1")))
         w = time.time() - t
         t = time.time(); shutil.rmtree(d); r = time.time() - t
         print("%-10s %-7s threads=%s create %.3f s  rmtree %.3f s" % (base, how, os.environ.get("MIRP_FILE_THREADS", "default"), w, r))
