@@ -429,6 +429,12 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     const int ka = lane - (64 - room);
                     if (ka >= 0 && ka < take2) aent = list[((d + 1) % 3) * LSEG + ka];
                 }
+#ifndef MIRP_ROLEMAP
+#define MIRP_ROLEMAP 1
+#endif
+#define MIRP_XROWS15 9, 7
+#define MIRP_XROWS8 8
+#define MIRP_XROWS9 10
                 // roles (0-7: generic rows, 8-13: bulges / 1xn, 14-15: small shapes), measured job costs (MIRP_FOLD_CLOCKS): generic 2-row < small
                 // shapes < generic 4-row < bulges / 1xn.  Phase B of the previous diagonal runs on waves 0-5 (one thread per cell, wave 0 always,
                 // wave 5 rarely), so those waves take the cheapest jobs.
@@ -460,7 +466,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                     // the terms of the outer pair that turn a job's running minimum into the cell's key: fetched before the shape code, so that
                     // their two round trips (bases, then tables) overlap the job's own reads instead of following them
                     int au1 = 0, mmo = 0, mm1 = 0;
-                    if (role < 14) {
+                    if (role < 14 || (MIRP_ROLEMAP && MODEL == 0)) {
                         au1 = type > 2 ? tau_s : 0;
                         mmo = ((int)(ent << 10)) >> 22; mm1 = ((int)ent) >> 22;          // the 10-bit signed fields of the entry
                     }
@@ -472,10 +478,19 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     case 1: res = MIRP_A1G<CK MIRP_A1WD, 29, 24>(a, i, j, mmo); if (CK || slow) a1_i1<CK, 25, 27>(a, i, j, xi); else a1_i1f<25, 27>(a, i, j, xi); break;      \
     case 2: res = MIRP_A1G<CK MIRP_A1WD, 28, 25>(a, i, j, mmo); if (CK || slow) a1_i0<CK, 26, 29>(a, i, j, xi); else a1_i0f<26, 29>(a, i, j, xi); break;      \
     case 3: res = MIRP_A1G<CK MIRP_A1WD, 27, 26>(a, i, j, mmo); if (CK || slow) a1_b1<CK, 26, 30>(a, i, j, xb); else a1_b1f<26, 30>(a, i, j, xb); break;      \
-    case 4: res = MIRP_A1G<CK MIRP_A1WD, 22, 17, 12, 7>(a, i, j, mmo); break;                    \
-    case 5: res = MIRP_A1G<CK MIRP_A1WD, 21, 18, 11, 8>(a, i, j, mmo); break;                    \
-    case 6: res = MIRP_A1G<CK MIRP_A1WD, 20, 16, 13, 9>(a, i, j, mmo); break;                    \
-    default: res = MIRP_A1G<CK MIRP_A1WD, 19, 15, 14, 10, 6>(a, i, j, mmo); break;               \
+    case 4: res = MIRP_A1G<CK MIRP_A1WD, MIRP_ROWS4>(a, i, j, mmo); break;                    \
+    case 5: res = MIRP_A1G<CK MIRP_A1WD, MIRP_ROWS5>(a, i, j, mmo); break;                    \
+    case 6: res = MIRP_A1G<CK MIRP_A1WD, MIRP_ROWS6>(a, i, j, mmo); break;                    \
+    default: res = MIRP_A1G<CK MIRP_A1WD, MIRP_ROWS7>(a, i, j, mmo); break;               \
+    }
+// generic rows that ride on the waves of other jobs (MIRP_ROLEMAP 1): with the split loop sparse, the 4-5-row generic groups were the busiest waves of an
+// interval (90 % busy against 56-65 % on the small-shape and bulge waves, profiles/tools/wave_busy.sh); a row can run anywhere -- the key carries the shape
+#define MIRP_XGEN(CK)                                                                     \
+    switch (role) {                                                                       \
+    case 15: rx = MIRP_A1G<CK MIRP_A1WD, MIRP_XROWS15>(a, i, j, mmo); break;                         \
+    case 8: rx = MIRP_A1G<CK MIRP_A1WD, MIRP_XROWS8>(a, i, j, mmo); break;                           \
+    case 9: rx = MIRP_A1G<CK MIRP_A1WD, MIRP_XROWS9>(a, i, j, mmo); break;                           \
+    default: break;                                                                       \
     }
                             // the 2-row generic groups run on the phase-B waves, which have slack left: they also take a few bulge / 1xn shapes
                             unsigned xb = KEY_INF, xi = KEY_INF;
@@ -483,15 +498,38 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                             if constexpr (MODEL == 0) {
 #define MIRP_A1G a1_generic_w
 #define MIRP_A1WD , GEN_WD
+#if MIRP_ROLEMAP              // rows 7 - 10 ride on the small-shape and bulge waves (MIRP_XGEN below)
+#define MIRP_ROWS4 22, 17, 12
+#define MIRP_ROWS5 21, 18, 11
+#define MIRP_ROWS6 20, 16, 13
+#define MIRP_ROWS7 19, 15, 14, 6
+#else
+#define MIRP_ROWS4 22, 17, 12, 7
+#define MIRP_ROWS5 21, 18, 11, 8
+#define MIRP_ROWS6 20, 16, 13, 9
+#define MIRP_ROWS7 19, 15, 14, 10, 6
+#endif
                                 if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
 #undef MIRP_A1G
 #undef MIRP_A1WD
-                            } else {
+#undef MIRP_ROWS4
+#undef MIRP_ROWS5
+#undef MIRP_ROWS6
+#undef MIRP_ROWS7
+                            } else {          // vienna-1.8.5 keeps all generic rows on roles 4 - 7 (the other map measured +0.6 ms there)
 #define MIRP_A1G a1_generic
 #define MIRP_A1WD
+#define MIRP_ROWS4 22, 17, 12, 7
+#define MIRP_ROWS5 21, 18, 11, 8
+#define MIRP_ROWS6 20, 16, 13, 9
+#define MIRP_ROWS7 19, 15, 14, 10, 6
                                 if (a.um >= MAXLOOP) { MIRP_GEN(false) } else { MIRP_GEN(true) }
 #undef MIRP_A1G
 #undef MIRP_A1WD
+#undef MIRP_ROWS4
+#undef MIRP_ROWS5
+#undef MIRP_ROWS6
+#undef MIRP_ROWS7
                             }
                             if (role < 4) {
                                 const unsigned rb = a1_key(xb, -32768 - OTH_BIAS + au1);
@@ -554,6 +592,19 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                         if (ca < INF) { const unsigned k = ((unsigned)(ra + ca + KEY_BIAS) << 10) | ka; res = k < res ? k : res; }
                         if (cb2 < INF) { const unsigned k = ((unsigned)(rb2 + cb2 + KEY_BIAS) << 10) | kb2; res = k < res ? k : res; }
                     }
+#if MIRP_ROLEMAP
+                    if constexpr (MODEL == 0) {
+                        if (role >= 8 && !(dbg_flags & 4)) {
+                            unsigned rx = KEY_NONE;
+#define MIRP_A1G a1_generic_w
+#define MIRP_A1WD , GEN_WD
+                            if (a.um >= MAXLOOP) { MIRP_XGEN(false) } else { MIRP_XGEN(true) }
+#undef MIRP_A1G
+#undef MIRP_A1WD
+                            res = rx < res ? rx : res;
+                        }
+                    }
+#endif
 #ifdef MIRP_X_NOATOM            // timing experiment: a plain store instead of the block's atomic minimum
                     if (act && res != KEY_NONE) ck[i] = res;
 #else
