@@ -457,10 +457,22 @@ def main():
         # the library's RCCL communicator, one rank per GPU.  Should it not come up on some node (every rank must agree, so the outcome is shared over
         # the host group), the loci lists are gathered as host objects over gloo instead -- the line then says so; the measured step is the same.
         why = None
+        import threading
+        # ncclCommInitRank can also HANG (a rank that never joins, a fabric that does not come up): a stuck native call cannot be cancelled, so a
+        # watchdog ends the process with a message instead of leaving the launcher to its own timeout
+        joined = threading.Event()
+
+        def _watchdog():
+            if not joined.wait(float(os.environ.get("MIRP_BENCH_RCCL_TIMEOUT", "300"))):
+                sys.stderr.write("[bench] rank %d: the RCCL communicator did not come up within the time limit (MIRP_BENCH_RCCL_TIMEOUT) -- giving up\n" % rank)
+                sys.stderr.flush()
+                os._exit(5)
+        threading.Thread(target=_watchdog, daemon=True).start()
         try:
             mdist.init_context(ctx, rank, world)
         except Exception as e:          # capi.MirpError: dlopen / ncclCommInitRank failed
             why = "%s" % (e,)
+        joined.set()
         box = [None] * world
         tdist.all_gather_object(box, why)
         bad = [w for w in box if w]
