@@ -156,8 +156,12 @@ __host__ __device__ inline int arch_rowblk_off(int b, int n, int dcap) {
 }
 
 struct LdsLayout {
-    unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total, fml_bytes;
+    unsigned fml, aux, S, seq, pax, qb2, list, tabs, misc, total, fml_bytes, code4;
 };
+#ifndef MIRP_A1_CODES4
+#define MIRP_A1_CODES4 0      // fold_lds_kernel.hip sets it: the bulge / 1xn jobs read their pair codes four per ds_read_b32 (see a1_codes4)
+#endif
+#define CODE_STR 368          // bytes per shifted copy of a pair-code array (LCAP + 8 codes + the last job's over-read of 3), a multiple of 16
 __host__ __device__ constexpr unsigned lds_al(unsigned x) { return (x + 15u) & ~15u; }
 // SPARSE: the multiloop splits run over a pool of split candidates (see "sparse splits" in fold_lds_kernel.hip): a third mdec buffer, and the pool
 // lives behind the window's fML triangle inside the fml region, which then takes everything the other arrays leave of the 160 KB.
@@ -171,8 +175,15 @@ __host__ __device__ constexpr LdsLayout lds_layout() {
     L.aux = o; o += lds_al(CRING_ROWS * CSTR * 2 + (MODEL ? 5 : 3) * LCAP * 2 + (SPARSE ? 6 : 5) * LCAP * 4);   // c ring (32 diagonals + mirror row), DML ring (3; 5 in the vienna-1.8.5 model), 3 x ckey, 2 (sparse: 3) x mdec
     L.S = o; o += lds_al(LCAP + 8);
     L.seq = o; o += lds_al(LCAP + 8);
-    L.pax = o; o += lds_al((LCAP + 8) * 2);
-    L.qb2 = o; o += lds_al(LCAP + 8);
+    if (MIRP_A1_CODES4 && SPARSE) {      // 4 byte-shifted copies of the q codes, then 4 of the p codes (bytes); copy 0 of each IS the array
+        L.code4 = o; L.qb2 = o; L.pax = o + 4 * CODE_STR; o += 8 * CODE_STR;
+    } else if (MIRP_A1_CODES4) {         // the dense instantiations (overflow pass) have no room for the copies: byte arrays, codes read one by one
+        L.pax = o; o += CODE_STR;
+        L.qb2 = o; o += CODE_STR;
+    } else {
+        L.pax = o; o += lds_al((LCAP + 8) * 2);
+        L.qb2 = o; o += lds_al(LCAP + 8);
+    }
     L.list = o; o += lds_al(3 * LSEG * 4);      // 32-bit entries (see `list` in the kernel)
     L.tabs = o; o += lds_al((unsigned)sizeof(LdsTables));
     L.misc = o; o += lds_al((48 + ARCH_RB + ((SPARSE && MODEL) ? 48 : 0)) * 4);      // (vienna-1.8.5 candidate pass: + the 4 x 11-word bitmap of pooled pairs)
@@ -187,13 +198,21 @@ static_assert(lds_layout<0>().total <= 160 * 1024 && lds_layout<1>().total <= 16
 typedef const volatile __attribute__((address_space(3))) unsigned short* lds_vu16;   // LDS reads that must stay narrow (see a1_gen_row)
 typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8;
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#if MIRP_A1_CODES4
+typedef unsigned char pax_t;          // the p codes (xt_pcode < 256) as bytes: copy 0 of their four shifted copies
+typedef lds_vu8 lds_vpax;
+#else
+typedef unsigned short pax_t;
+typedef lds_vu16 lds_vpax;
+#endif
 struct A1 {
     const FoldParams* __restrict__ P;
     const LdsTables* T;
     const unsigned char* S;
     const unsigned short* cring;
-    const unsigned short* pax;     // xt_pcode(S[x], S[x-1])
+    const pax_t* pax;              // xt_pcode(S[x], S[x-1])
     const unsigned char* qbr;      // xt_qcode(S[x], S[x+1]) at n + 1 - x: the q side is walked downwards, so it is stored reversed (ascending immediates)
+    const unsigned char* code4 = nullptr;      // MIRP_A1_CODES4: [4][CODE_STR] copy c of qbr shifted by c bytes, then the same of the p codes as bytes
     int r0, um, n;
     const int* __restrict__ rowtab;    // FoldParams::ring_rowoff[r0 & 31]: ring-row offset (shorts) of loop size u, i.e. ((r0 - u) & 31) * CSTR
 };
@@ -297,7 +316,7 @@ __device__ __forceinline__ void a1_b0(const A1& a, int i, int j, unsigned& best)
 template <bool CHECK, int LO, int HI>
 __device__ __forceinline__ void a1_b1(const A1& a, int i, int j, unsigned& best) {
     const unsigned idxq = a.qbr[a.n + 2 - j];
-    lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+    lds_vpax pl = (lds_vpax)(a.pax + i + 1);
     const unsigned short* rb = a.cring + i + 1;
     const unsigned char* xb = a.T->XB;
 #pragma unroll
@@ -333,7 +352,7 @@ __device__ __forceinline__ void a1_i0(const A1& a, int i, int j, unsigned& best)
 template <bool CHECK, int LO, int HI>
 __device__ __forceinline__ void a1_i1(const A1& a, int i, int j, unsigned& best) {
     const unsigned idxq = a.qbr[a.n + 3 - j];
-    lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+    lds_vpax pl = (lds_vpax)(a.pax + i + 1);
     const unsigned short* rb = a.cring + i + 1;
     const unsigned char* xb = a.T->X1;
 #pragma unroll
@@ -395,6 +414,39 @@ __device__ __forceinline__ void a1_small_g(const A1& a, int i, int j, int type, 
 #define MIRP_XIDX(e) (e)
 #endif
 #define A1_CHUNK 10
+// N consecutive pair codes starting at byte A of a code array, four per read.  A lane's A has any alignment (consecutive cells have consecutive
+// columns) and a ds_read_b32 off its alignment costs several aligned ones (profiles/tools/lds_unaligned.hip), so the array exists four times, copy c
+// shifted by c bytes: the dword at (A - c) of copy c = A & 3 holds codes A .. A + 3 and is aligned.  The byte selects fold into the adds that use
+// the codes (v_add_u32_sdwa).  which = 0: q codes (qbr), 1: p codes (pax; they fit a byte).
+// base + byte K of w in one instruction (the compiler extracts with v_bfe_u32 first when the sum is an LDS address)
+template <int K>
+__device__ __forceinline__ unsigned a1_add_byte(unsigned base, unsigned w) {
+    unsigned r;
+    if constexpr (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(w));
+    else if constexpr (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(w));
+    else if constexpr (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(w));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(w));
+    return r;
+}
+// x[k] = tab[idx + code k] for the N codes starting at byte A of code array `which`
+template <int N, int K = 0>
+__device__ __forceinline__ void a1_gather4(unsigned tab_idx, const unsigned (&dw)[(N + 3) / 4], int (&x)[N]) {
+    if constexpr (K < N) {
+        x[K] = *(lds_vu8)(size_t)a1_add_byte<K & 3>(tab_idx, dw[K >> 2]);
+        a1_gather4<N, K + 1>(tab_idx, dw, x);
+    }
+}
+template <int N>
+__device__ __forceinline__ void a1_codes4(const A1& a, int which, int A, const unsigned char* tab, unsigned idx, int (&x)[N]) {
+    typedef const volatile __attribute__((address_space(3))) unsigned* lds_vu32;
+    const int c = A & 3;
+    lds_vu32 p = (lds_vu32)(a.code4 + which * 4 * CODE_STR + c * (CODE_STR - 1) + A);      // copy c, byte A - c
+    unsigned dw[(N + 3) / 4];
+#pragma unroll
+    for (int t = 0; t < (N + 3) / 4; t++) dw[t] = p[t];
+    const unsigned tab_idx = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)tab + idx;      // LDS address of tab[idx]
+    a1_gather4<N>(tab_idx, dw, x);
+}
 template <int LO, int HI>
 __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best) {
     if constexpr (HI - LO + 1 > A1_CHUNK) { a1_b0f<LO, LO + A1_CHUNK - 1>(a, i, j, best); a1_b0f<LO + A1_CHUNK, HI>(a, i, j, best); }
@@ -416,10 +468,13 @@ __device__ __forceinline__ void a1_b0f(const A1& a, int i, int j, unsigned& best
 #ifdef MIRP_NOCODE_READ
         for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
 #else
-        for (int k = 0; k < N; k++) code[k] = ql[LO + k];
+        for (int k = 0; k < N; k++) if (!(MIRP_A1_CODES4 && a.code4)) code[k] = ql[LO + k];
 #endif
+        if (MIRP_A1_CODES4 && a.code4) a1_codes4<N>(a, 0, a.n + 2 - j + LO, xb, idxp, x);
+        else {
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
+            for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
+        }
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb0_key[LO + k]; best = e < best ? e : best; }
@@ -431,7 +486,7 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
     else {
         constexpr int N = HI - LO + 1;
         const unsigned idxq = a.qbr[a.n + 2 - j];
-        lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+        lds_vpax pl = (lds_vpax)(a.pax + i + 1);
         const unsigned short* rb = a.cring + i + 1;
         const unsigned char* xb = a.T->XB;
         unsigned code[N], g[N];
@@ -446,10 +501,13 @@ __device__ __forceinline__ void a1_b1f(const A1& a, int i, int j, unsigned& best
 #ifdef MIRP_NOCODE_READ
         for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
 #else
-        for (int k = 0; k < N; k++) code[k] = pl[LO + k];
+        for (int k = 0; k < N; k++) if (!(MIRP_A1_CODES4 && a.code4)) code[k] = pl[LO + k];
 #endif
+        if (MIRP_A1_CODES4 && a.code4) a1_codes4<N>(a, 1, i + 1 + LO, xb, idxq, x);
+        else {
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
+            for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
+        }
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->kb1_key[LO + k]; best = e < best ? e : best; }
@@ -476,10 +534,13 @@ __device__ __forceinline__ void a1_i0f(const A1& a, int i, int j, unsigned& best
 #ifdef MIRP_NOCODE_READ
         for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
 #else
-        for (int k = 0; k < N; k++) code[k] = ql[LO + k];
+        for (int k = 0; k < N; k++) if (!(MIRP_A1_CODES4 && a.code4)) code[k] = ql[LO + k];
 #endif
+        if (MIRP_A1_CODES4 && a.code4) a1_codes4<N>(a, 0, a.n + 2 - j + LO, xb, idxp, x);
+        else {
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
+            for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxp + code[k])];
+        }
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n0_key[LO + k]; best = e < best ? e : best; }
@@ -491,7 +552,7 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
     else {
         constexpr int N = HI - LO + 1;
         const unsigned idxq = a.qbr[a.n + 3 - j];
-        lds_vu16 pl = (lds_vu16)(a.pax + i + 1);
+        lds_vpax pl = (lds_vpax)(a.pax + i + 1);
         const unsigned short* rb = a.cring + i + 1;
         const unsigned char* xb = a.T->X1;
         unsigned code[N], g[N];
@@ -506,10 +567,13 @@ __device__ __forceinline__ void a1_i1f(const A1& a, int i, int j, unsigned& best
 #ifdef MIRP_NOCODE_READ
         for (int k = 0; k < N; k++) code[k] = 3 * (LO + k);
 #else
-        for (int k = 0; k < N; k++) code[k] = pl[LO + k];
+        for (int k = 0; k < N; k++) if (!(MIRP_A1_CODES4 && a.code4)) code[k] = pl[LO + k];
 #endif
+        if (MIRP_A1_CODES4 && a.code4) a1_codes4<N>(a, 1, i + 1 + LO, xb, idxq, x);
+        else {
 #pragma unroll
-        for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
+            for (int k = 0; k < N; k++) x[k] = xb[MIRP_XIDX(idxq + code[k])];
+        }
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) { const unsigned e = ((g[k] + (unsigned)x[k]) << 10) + a.P->k1n1_key[LO + k]; best = e < best ? e : best; }

@@ -21,6 +21,7 @@
 //     INF is >= 65535 and can never beat the 65535 start value of a running minimum;
 //   * windows whose energies leave the 16-bit ranges are flagged and re-run by the generic kernel.
 // No MFMA: integer min-plus DP with irregular table lookups.
+#define MIRP_A1_CODES4 1
 #include "fold_lds_common.h"
 
 namespace mirp {
@@ -78,8 +79,9 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
     auto mdec_of = [&](int d) -> int* { return acc + (3 + (SPARSE ? d % 3 : (d & 1))) * LCAP; };
     unsigned char* S = smem + LY.S;
     unsigned char* seq = smem + LY.seq;
-    unsigned short* pax = (unsigned short*)(smem + LY.pax);
+    pax_t* pax = (pax_t*)(smem + LY.pax);
     unsigned char* qbr = smem + LY.qb2;
+    unsigned char* code4 = SPARSE ? smem + LY.code4 : nullptr;      // [2][4][CODE_STR]: shifted byte copies of the q codes, then of the p codes (a1_codes4)
     // special-hairpin energies by start position (tri-, tetra-, hexaloops): only read on diagonals 4, 5 and 7, so they borrow the ring rows
     // of diagonals 29-31, which are first written on diagonal 29
     short* spec = (short*)(cring + 29 * CSTR);
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
             // combined pair codes (only interior positions are ever read: p - 1 >= 1, q + 1 <= n)
             if (x >= 1) {
-                pax[x] = (unsigned short)xt_pcode(S[x], x > 1 ? (int)S[x - 1] : 0);
+                pax[x] = (pax_t)xt_pcode(S[x], x > 1 ? (int)S[x - 1] : 0);
                 qbr[n + 1 - x] = (unsigned char)xt_qcode(S[x], x < n ? (int)S[x + 1] : 0);
             }
         }
@@ -209,6 +211,14 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
             list_append(dd, tid + 1, t, oi);
         }
         __syncthreads();
+        // byte-shifted copies 1 - 3 of both pair-code arrays (copy 0 = the arrays themselves, a1_codes4); entries past the ends are never used as codes
+        if constexpr (SPARSE) {
+            for (int x = tid; x < 8 * CODE_STR; x += LNT) {
+                const int which = x / (4 * CODE_STR), c = (x / CODE_STR) & 3, y = x % CODE_STR + c;
+                if (c) code4[x] = y < CODE_STR ? (which ? (unsigned char)pax[y] : qbr[y]) : (unsigned char)0;
+            }
+            __syncthreads();
+        }
 
         if (dbg_cycles && tid == 0) { long long t = clock64(); tS += t - t0; t0 = t; }
         // ---- anti-diagonal wavefront, software-pipelined: phase B of diagonal d (one thread per cell) runs in the same barrier
@@ -440,7 +450,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
                 // wave 5 rarely), so those waves take the cheapest jobs.
                 const int role = wave < 4 ? wave : wave < 6 ? wave + 10 : wave < 12 ? wave + 2 : wave - 8;
                 A1 a;
-                a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.n = n;
+                a.P = P; a.T = &T; a.S = S; a.cring = cring; a.pax = pax; a.qbr = qbr; a.code4 = code4; a.n = n;
                 const bool slow = (dbg_flags & 8192) != 0;     // diagnostics build: the one-round-trip-per-candidate versions of the jobs
                 {
                 for (int blk = 0; blk < nblk; blk++) {
