@@ -117,7 +117,7 @@ def parse_args():
     ap.add_argument("--micro-windows", type=int, default=1 << 16, help="windows per family of the fold micro-benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-child", default=None, help=argparse.SUPPRESS)      # internal: this process only runs the CLI leg under the given directory ("-" = default) and prints its record
+    ap.add_argument("--e2e-runs", type=int, default=3, help="fresh CLI processes per end-to-end leg (the first one is the reported figure)")
     ap.add_argument("--no-cov-shard", action="store_true", help="skip the coverage-stage measurement at a config[4] rank shard's size (configs.coverage_config4_shard)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of wall-clock per CPU-baseline leg")
     ap.add_argument("--no-ingest", action="store_true")
@@ -276,12 +276,14 @@ def relaxation_count(seq_bytes, offs, lens, span):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-def e2e_cli(ds, fold_model, base=None):
-    """The product CLI's `pipeline` verb on files of the bench workload: SAM + FASTA in -> gff3 / fasta / ss / csv / html / readmapping out.
-    base = the directory the input and output files live under (default: the system's temporary directory)."""
+def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg=""):
+    """The product CLI the way a user runs it: a FRESH `python -m mir_prefer_amd.cli pipeline <config>` process per run, clocked by this (parent)
+    process from spawn to exit -- interpreter start, imports, library load, device context, first-touch of every allocation and code object, the four
+    stages, every report file, the removal of the temporary folder and process teardown are all inside.  SAM + FASTA in -> gff3 / fasta / ss / csv /
+    html / readmapping out (MP:3728-3739).  base = the directory the files live under (None: the system's temporary directory).  The child's own
+    stamps (MIRP_CLI_TIMINGS) give the breakdown; nothing of it enters the headline figure."""
     import shutil
     import tempfile
-    from mir_prefer_amd import config, pipeline
     tmp = tempfile.mkdtemp(prefix="mirp_e2e_", dir=base)
     try:
         sams = ds.write_sams(tmp)
@@ -289,45 +291,47 @@ def e2e_cli(ds, fold_model, base=None):
         ds.write_fasta(fa)
         cfg = os.path.join(tmp, "config")
         with open(cfg, "w") as f:
-            f.write("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = bench\nPRECURSOR_LEN = %d\nREADS_DEPTH_CUTOFF = %d\nMAX_GAP = %d\n"
-                    % (fa, ", ".join(sams), os.path.join(tmp, "out"), L, CUT, GAP))
+            f.write("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = bench\nPRECURSOR_LEN = %d\nREADS_DEPTH_CUTOFF = %d\nMAX_GAP = %d\n%s"
+                    % (fa, ", ".join(sams), os.path.join(tmp, "out"), L, CUT, GAP, extra_cfg))
         in_bytes = sum(os.path.getsize(p) for p in sams) + os.path.getsize(fa)
-        so = sys.stdout
-        sys.stdout = open(os.devnull, "w")
-        first_wall = None
-        try:
-          for rep in range(2):      # two in-process runs, the second is reported (the first one's wall-clock is kept beside it: it pays the device allocations
-            shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)      # of a new context, which vary with what the process did before)
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        env["MIRP_CLI_TIMINGS"] = os.path.join(tmp, "timings.json")
+        recs = []
+        for rep in range(runs):
+            shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
             t0 = time.time()
-            opt = config.parse_configfile(cfg)
-            opt["OUTPUT_DETAILS_FOR_DEBUG"] = False
-            p = pipeline.Pipeline(opt, 0, fold_model=fold_model)
-            stages = {}
-            # the stage sequence of the `pipeline` verb (Pipeline.run_pipeline): the candidate stage's host artefacts and the fold text are
-            # written behind the next stage's device work
-            gpu = {}
-            for st, kw in (("prepare", {}), ("candidate", {"defer": True}), ("fold", {"defer": True}), ("predict", {})):
-                t = time.time()
-                res = getattr(p, "run_" + st)(**kw)
-                stages[st] = time.time() - t
-                tm = p.ctx.last_timings()
-                if st == "candidate":
-                    gpu[st] = (tm["coverage_ms"] + tm["candidate_rest_ms"]) / 1e3
-                elif st in ("fold", "predict"):
-                    gpu[st] = tm[st + "_ms"] / 1e3
+            r = subprocess.run([sys.executable, "-m", "mir_prefer_amd.cli", "--fold-model", fold_model, "pipeline", cfg], env=env, cwd=tmp,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
             wall = time.time() - t0
-            p.ctx.close()
-            if rep == 0:
-                first_wall = wall
-        finally:
-            sys.stdout.close()
-            sys.stdout = so
+            if r.returncode != 0:
+                return {"error": "CLI exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+            marks = json.load(open(env["MIRP_CLI_TIMINGS"]))
+            seg, prev, dev = {}, t0, {}
+            for m in marks:
+                seg[m["name"]] = m["t"] - prev
+                prev = m["t"]
+                if "device_ms" in m:
+                    dev[m["name"]] = m["device_ms"] / 1e3
+            seg["exit"] = t0 + wall - prev
+            loci = None
+            for ln in r.stdout.splitlines():
+                if ln.endswith(" miRNAs identified."):
+                    loci = int(ln.split()[0])
+            recs.append({"process_wall_s": wall, "segments_s": {k: round(v, 4) for k, v in seg.items()}, "device_s": {k: round(v, 4) for k, v in dev.items()}, "loci": loci})
         out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs)
-        return {"wall_s": wall, "wall_s_first_run": first_wall, "files_under": os.path.dirname(tmp), "stage_s": stages, "stage_gpu_s": gpu, "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": len(res or []),
-                "note": "in-process CLI stage drivers in the `pipeline` verb's sequence (config parse -> prepare -> candidate -> fold -> predict incl. every stage "
-                        "artefact and report file; stage_gpu_s = the device time inside each stage, the rest is host); the second of two runs, each with a "
-                        "context of its own (wall_s_first_run: the first, which pays the process' first device allocations and code loads), in a child process "
-                        "of the bench (a CLI user's process has one context); interpreter start-up and imports not included"}
+        first = recs[0]
+        dev_total = sum(first["device_s"].values())
+        return {"process_wall_s": first["process_wall_s"], "process_wall_s_all_runs": [round(x["process_wall_s"], 4) for x in recs],
+                "device_s": dev_total, "host_s": first["process_wall_s"] - dev_total, "host_over_device": (first["process_wall_s"] - dev_total) / dev_total if dev_total else None,
+                "segments_s": first["segments_s"], "stage_device_s": first["device_s"], "files_under": os.path.dirname(tmp),
+                "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": first["loci"],
+                "note": "parent-side clock around a fresh `python -m mir_prefer_amd.cli pipeline <config>` process: interpreter start, imports, library load, "
+                        "device context, first touch of allocations and code objects, stages, report files, removal of the temporary folder and exit all "
+                        "included; process_wall_s = the FIRST of the runs (each a new process, inputs in the page cache); segments_s = the child's own stamps: "
+                        "main = spawn -> entry of main() (interpreter + package import), imports = capi / numpy / pipeline, context = config parse + "
+                        "library load + device context, then the four stages, removetmp, exit = end of main() -> process gone; stage_device_s = device time "
+                        "inside each stage"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -422,27 +426,9 @@ def fold_microbench(ctx, n_windows):
     return out
 
 
-def e2e_in_child(a, base):
-    """The CLI leg in a process of its own: a CLI user's process has ONE context, and a second context in a process that already folded pays a one-off
-    0.1 - 0.4 s on its first fold (profiles/tools/idle_probe.py: first context 66 ms, second context 187 ms, then 65) that no user ever sees.  The
-    child generates the same seeded workload, runs the stage drivers twice (fresh output folder each time) and prints the record; interpreter
-    start-up and imports are outside its clock, as before."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--e2e-child", base or "-", "--fold-model", a.fold_model, "--genome", str(a.genome), "--loci", str(a.loci)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    if r.returncode != 0:
-        return {"error": "CLI child exited with %d: %s" % (r.returncode, r.stderr[-300:])}
-    return json.loads(r.stdout.strip().splitlines()[-1])
-
-
 def main():
     a = parse_args()
     a.workload = a.workload.replace("cfg", "config")
-    if a.e2e_child is not None:
-        from mir_prefer_amd import synth
-        specs, n_samples, background, _, _ = workload_specs("config1", 1, a.genome, a.loci)
-        contigs, alns, sample_names = build_shard(specs, {0}, n_samples, background)
-        print(json.dumps(e2e_cli(synth.Dataset(contigs, sample_names, alns, []), a.fold_model, base=None if a.e2e_child == "-" else a.e2e_child)))
-        return
     if a.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start one worker process per GPU under torch.distributed.run BEFORE anything touches the GPU
         # (no HIP call has happened in this process; it only waits for the child and passes its exit code on)
@@ -590,11 +576,16 @@ def main():
     ranks = None
     if world > 1:
         box = [None] * world
-        tdist.all_gather_object(box, (elapsed, float(nwin), t_own, len(alns), len(owned), moved[0], moved[1]))
+        info = ctx.dist_comm_info()
+        tdist.all_gather_object(box, (elapsed, float(nwin), t_own, len(alns), len(owned), moved[0], moved[1], info["comm_count"], info["comm_device"], ctx.device, os.getpid()))
         elapsed = max(x[0] for x in box)
         total_windows = sum(x[1] for x in box)
         ranks = {"own_ms_per_step": [1e3 * x[2] / a.steps for x in box], "windows": [int(x[1]) for x in box], "alignments": [int(x[3]) for x in box],
-                 "contigs": [int(x[4]) for x in box], "windows_shipped": [int(x[5]) for x in box], "windows_received": [int(x[6]) for x in box]}
+                 "contigs": [int(x[4]) for x in box], "windows_shipped": [int(x[5]) for x in box], "windows_received": [int(x[6]) for x in box],
+                 # what RCCL itself reports on every rank (ncclCommCount / ncclCommCuDevice; -1 = no RCCL communicator: local transport or gloo), the HIP
+                 # device of the rank's context and its process id: N processes, N devices, one communicator of N ranks
+                 "rccl_comm_count": [int(x[7]) for x in box], "rccl_comm_device": [int(x[8]) for x in box], "context_device": [int(x[9]) for x in box],
+                 "pid": [int(x[10]) for x in box]}
         ranks["max_over_mean_time"] = max(ranks["own_ms_per_step"]) / (sum(ranks["own_ms_per_step"]) / world)
     else:
         total_windows = float(nwin)
@@ -747,22 +738,31 @@ def main():
                 ctx.load_genome(contigs)          # back to the headline workload for the baselines below
                 ctx.load_alignments(alns)
             ds = synth.Dataset(contigs, sample_names, alns, [])
-            if not a.no_e2e and headline:
-                try:
-                    # the files of the run live on the in-memory file system when there is one: 4,000 small report files + a 135 MB fold text
-                    # measure the container's overlay file system otherwise (the same 4,002 creates took 0.04 .. 0.5 s there from one second to
-                    # the next, profiles/tools/smallfiles.py); the same run under the default temporary directory is reported beside it
-                    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-                    line["e2e"] = e2e_in_child(a, shm)
-                    line["e2e_wall_s"] = line["e2e"].get("wall_s")
-                    if shm and "error" not in line["e2e"]:
-                        other = e2e_in_child(a, None)
-                        if "error" not in other:
-                            line["e2e"]["default_tmpdir"] = {k: other[k] for k in ("wall_s", "wall_s_first_run", "stage_s", "files_under")}
-                except SystemExit as e:
-                    line["e2e"] = {"error": "CLI exited with %r" % (e.code,)}
             if not a.no_ingest and headline:
                 line["ingest"] = ingest_leg(ctx, a.ingest_records)
+            if not a.no_e2e and headline:
+                # End-to-end wall-clock, the second half of BASELINE's metric: the CLI in a fresh process, files under the default temporary directory
+                # (what a user gets); the same on the in-memory file system beside it (the container's overlay file system creates 4,002 small
+                # report files in 0.04 .. 0.5 s from one second to the next, profiles/tools/smallfiles.py); then config[2] (3 SAM files, 119 Mb FASTA).
+                ctx.close()          # a CLI user's GPU is not shared with a bench process that holds 20 GB of it
+                ctx = None
+                line["e2e"] = e2e_process(ds, a.fold_model, None, a.e2e_runs)
+                line["e2e_wall_s"] = line["e2e"].get("process_wall_s")
+                shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+                if shm and "error" not in line["e2e"]:
+                    other = e2e_process(ds, a.fold_model, shm, a.e2e_runs)
+                    line["e2e"]["files_on_tmpfs"] = {k: other.get(k) for k in ("process_wall_s", "process_wall_s_all_runs", "segments_s", "files_under", "error") if k in other}
+                if not a.no_configs:
+                    sp2, ns2, bg2, _, d2 = workload_specs("config2", 1)
+                    c2, a2, sn2 = build_shard(sp2, set(range(len(sp2))), ns2, bg2)
+                    r2 = e2e_process(synth.Dataset(c2, sn2, a2, []), a.fold_model, None, max(1, a.e2e_runs - 1))
+                    r2["workload"] = d2
+                    if r2.get("loci") is not None and r2["loci"] != EXPECTED_LOCI[("config2", a.fold_model)] and a.fold_model == "vienna-2.1.2":
+                        r2["error"] = "result check failed: %d loci" % r2["loci"]
+                    line["e2e_config2"] = r2
+                    del c2, a2
+                if line["e2e"].get("loci") is not None and line["e2e"]["loci"] != EXPECTED_LOCI.get(("config1", a.fold_model), line["e2e"]["loci"]):
+                    line["e2e"]["error"] = "result check failed: %d loci" % line["e2e"]["loci"]
             if not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(ds, alns, order, a.cpu_budget)
         print(json.dumps(line))
@@ -770,7 +770,8 @@ def main():
         tdist.barrier()
         if rccl_error is None:
             ctx.dist_finalize()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         tdist.destroy_process_group()
 

@@ -267,6 +267,13 @@ int mirp_dist_init_local(mirp_ctx* ctx, const char* dir, int32_t rank, int32_t w
 int mirp_dist_finalize(mirp_ctx* ctx);
 int mirp_dist_rank(const mirp_ctx* ctx);
 int mirp_dist_world(const mirp_ctx* ctx);
+/* What RCCL reports about the context's communicator: info = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice}; {-1, -1, -1} without a RCCL
+ * communicator (one rank, or mirp_dist_init_local).  (The reference's pool has no analogue; it lets a scaling record prove N ranks on N devices.)
+ * Every wait on a peer inside the mirp_dist_* / mirp_gather_* / mirp_exchange_bytes / mirp_ingest_sams_shard calls has a deadline of
+ * MIRP_DIST_TIMEOUT_S seconds (environment, default 600): on expiry, or on an asynchronous RCCL error, the communicator is aborted (ncclCommAbort)
+ * and the call -- and every later exchange on the context -- returns -7, where the reference's parent waits for ever on a crashed child
+ * (result queue, MP:2461-2499). */
+int mirp_dist_comm_info(mirp_ctx* ctx, int32_t info[3]);
 /* Sum over the ranks of a small int64 vector, in place (n <= 1024); every rank gets the sums.  mirp_dist_barrier = one such reduction. */
 int mirp_dist_allreduce_sum(mirp_ctx* ctx, int64_t* v, int32_t n);
 int mirp_dist_barrier(mirp_ctx* ctx);

@@ -292,6 +292,8 @@ def load_library():
     for f in ("mirp_dist_finalize", "mirp_dist_barrier", "mirp_dist_rank", "mirp_dist_world"):
         getattr(lib, f).argtypes = [vp]
         getattr(lib, f).restype = C.c_int
+    lib.mirp_dist_comm_info.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.mirp_dist_comm_info.restype = C.c_int
     lib.mirp_dist_allreduce_sum.argtypes = [vp, vp, C.c_int32]
     lib.mirp_dist_allreduce_sum.restype = C.c_int
     lib.mirp_gather_loci.argtypes = [vp, C.c_int32, C.POINTER(vp), i64p, C.POINTER(vp), i32p]
@@ -323,6 +325,7 @@ class Context:
         if rc != 0:
             raise MirpError("mirp_create(device=%d) failed with code %d (no usable GPU?)" % (device, rc))
         self.h = h
+        self.device = int(device)
 
     def close(self):
         if getattr(self, "h", None):
@@ -504,6 +507,12 @@ class Context:
 
     def dist_world(self):
         return int(self.lib.mirp_dist_world(self.h))
+
+    def dist_comm_info(self):
+        """{ncclCommCount, ncclCommUserRank, ncclCommCuDevice} of the context's RCCL communicator; -1s without one."""
+        v = (C.c_int32 * 3)()
+        self._check(self.lib.mirp_dist_comm_info(self.h, v), "mirp_dist_comm_info")
+        return {"comm_count": int(v[0]), "comm_rank": int(v[1]), "comm_device": int(v[2])}
 
     def dist_barrier(self):
         self._check(self.lib.mirp_dist_barrier(self.h), "mirp_dist_barrier")

@@ -32,8 +32,31 @@ def parse_option_optparse(argv=None):
             "device": options.device, "fold_model": options.fold_model}
 
 
+class _Clock:
+    """MIRP_CLI_TIMINGS=<file>: where the process spent its wall-clock, as JSON (bench.py's end-to-end leg reads it; times are time.time() stamps,
+    so a parent can place its own spawn stamp in front).  Without the variable nothing is recorded."""
+
+    def __init__(self):
+        self.path = os.environ.get("MIRP_CLI_TIMINGS")
+        self.marks = []
+
+    def mark(self, name, **extra):
+        if self.path:
+            import time
+            self.marks.append(dict(extra, name=name, t=time.time()))
+
+    def dump(self):
+        if self.path:
+            import json
+            with open(self.path, "w") as f:
+                json.dump(self.marks, f)
+
+
 def main(argv=None):
+    clock = _Clock()
+    clock.mark("main")
     from . import capi, config, pipeline
+    clock.mark("imports")
     o = parse_option_optparse(argv)
     opt = config.parse_configfile(o["config"])
     opt["OUTPUT_DETAILS_FOR_DEBUG"] = o["debug"]
@@ -83,6 +106,8 @@ def main(argv=None):
             from . import dist
             dctx = dist.init_context(capi.Context(o["device"]), rank, world)
         p = pipeline.Pipeline(opt, o["device"], fold_model=o["fold_model"], rank=rank, world=world, ctx=dctx)
+        p.clock = clock
+        clock.mark("context")
         def removetmp():                        # run_removetmp (MP:3630-3639): unless -k; DELETE_IF_SUCCESS is parsed but unused, as in the reference
             if not o["keeptmp"]:
                 if world > 1:
@@ -94,7 +119,9 @@ def main(argv=None):
                     sys.stdout.write("Temporary folder removed.\n\n")
         if o["action"] == "pipeline":
             p.run_pipeline()
+            clock.mark("stages")
             removetmp()
+            clock.mark("removetmp")
         elif o["action"] == "recover":
             if p.run_recover():
                 removetmp()
@@ -107,6 +134,8 @@ def main(argv=None):
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
+    clock.mark("end")
+    clock.dump()
     return 0
 
 

@@ -23,6 +23,14 @@
 // No MFMA: integer min-plus DP with irregular table lookups.
 #define MIRP_A1_CODES4 1
 #include "fold_lds_common.h"
+// In-place compaction of the split-candidate pool, period in diagonals per model (0 = never) and the number of 64-entry rounds a wave holds in registers.
+#ifndef MIRP_CPERIOD0
+#define MIRP_CPERIOD0 0       // default model: never (925 entries: a compaction's two barriers cost more than the dead lanes; measured 60.9 / 61.7 / 62.1 / 62.9 ms at never / 128 / 64 / 32)
+#endif
+#ifndef MIRP_CPERIOD1
+#define MIRP_CPERIOD1 64      // vienna-1.8.5 (1,283 pair entries, 70 instructions per visit): 89.5 ms without, 87.3 / 85.9 / 85.6 / 85.0 at 8 / 16 / 32 / 64
+#endif
+#define CPOOL_ROUNDS 4
 
 namespace mirp {
 
@@ -142,7 +150,11 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // sparse splits: the candidate pool (u32 {s-1, j << 9} + u16 fML(s,j) per entry) takes what the window's triangle leaves of the fml region
         const int pool_off = SPARSE ? (int)lds_al(2u * (unsigned)(tri_off(((span < n - 1) ? span : n - 1) + 1, n > 5 ? n : 5) + 2)) : 0;
         // (vienna-1.8.5: 8-byte entries, one per PAIR -- see "pair pool" at splits_sparse185)
-        const int pool_cap = SPARSE ? ((((int)LY.fml_bytes - pool_off) / (MODEL ? 8 : 6)) & ~63) : 0;
+        // A model whose pool is compacted in place (compact_pool: every wave keeps its slice in CPOOL_ROUNDS x 64 registers) cannot hold more than
+        // LNW x CPOOL_ROUNDS x 64 entries: short windows leave room for more behind their triangle, the capacity stops there and a larger pool takes
+        // the overflow hand-off to the dense instantiation (misc[2]) like any other.
+        const int pool_room = SPARSE ? ((((int)LY.fml_bytes - pool_off) / (MODEL ? 8 : 6)) & ~63) : 0;
+        const int pool_cap = (SPARSE && (MODEL ? MIRP_CPERIOD1 : MIRP_CPERIOD0) > 0 && pool_room > LNW * CPOOL_ROUNDS * 64) ? LNW * CPOOL_ROUNDS * 64 : pool_room;
         unsigned* poolA = (unsigned*)(smem + LY.fml + pool_off);
         unsigned short* poolB = (unsigned short*)(poolA + (pool_cap > 0 ? pool_cap : 0));
         unsigned* poolB32 = poolA + (pool_cap > 0 ? pool_cap : 0);
@@ -1038,7 +1050,7 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         // readers a lane each.  Every MIRP_CPERIOD diagonals the pool is compacted in place: every wave keeps its slice in registers across a barrier, the
         // survivors move left behind the survivors of the lower waves.  (Between two barriers of its own: phase B of this interval appends after it.)
         auto compact_pool = [&](const int d) {
-            constexpr int CR = 4;                  // rounds of 64 entries per wave: 16 x 4 x 64 = 4096 >= any pool capacity
+            constexpr int CR = CPOOL_ROUNDS;       // rounds of 64 entries per wave: 16 x 4 x 64 = 4096 = the capacity pool_cap is clamped to
             int* cnts = misc + 22;                 // [16]
             int total = misc[3];
             total = total < pool_cap ? total : pool_cap;
@@ -1081,12 +1093,6 @@ __global__ void __launch_bounds__(LNT) fold_lds_kernel(
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
         for (int d = 4; d <= Dm; d++) {
-#ifndef MIRP_CPERIOD0
-#define MIRP_CPERIOD0 0       // default model: never (925 entries: a compaction's two barriers cost more than the dead lanes; measured 60.9 / 61.7 / 62.1 / 62.9 ms at never / 128 / 64 / 32)
-#endif
-#ifndef MIRP_CPERIOD1
-#define MIRP_CPERIOD1 64      // vienna-1.8.5 (1,283 pair entries, 70 instructions per visit): 89.5 ms without, 87.3 / 85.9 / 85.6 / 85.0 at 8 / 16 / 32 / 64
-#endif
             if constexpr (SPARSE) { constexpr int CP = MODEL ? MIRP_CPERIOD1 : MIRP_CPERIOD0; if (CP > 0 && (d & (CP - 1)) == 0 && d >= 32) compact_pool(d); }
             if (dbg_cycles && lane == 0) wt = clock64();
             if constexpr (MODEL != 0) {   // the length of the list phase A1 of this interval looks ahead to (diagonal d+2, built in the previous interval): read

@@ -84,6 +84,7 @@ struct mirp_ctx {
     int dist_rank = 0, dist_world = 1;
     std::string dist_dir;             // local transport (mirp_dist_init_local): ranks that share a GPU exchange through files in this directory
     long long dist_seq = 0;
+    bool dist_broken = false;         // a wait on a peer expired (or RCCL reported an asynchronous error): the communicator was aborted, every later exchange fails at once
     DevBuf dist_tmp;
     struct TextJob { std::thread th; int rc = 0; std::string err; };
     std::vector<std::shared_ptr<TextJob>> text_jobs;      // text artefacts still being formatted / written behind the caller (mirp_wait_text)
@@ -117,6 +118,7 @@ int dist_gatherv_bytes(mirp_ctx* c, const void* d_src, long long mine, int dst, 
 int dist_alltoallv_bytes(mirp_ctx* c, const void* d_send, const std::vector<long long>& send_off, const std::vector<long long>& send_cnt, void* d_recv,
                          const std::vector<long long>& recv_off, const std::vector<long long>& recv_cnt);
 int dist_allgather_ll(mirp_ctx* c, const long long* mine, int n, std::vector<long long>& out);
+int dist_agree(mirp_ctx* c, int local_rc, const char* what);
 }  // namespace mirp
 
 int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_offs, const int* d_lens, int n_work, int n_cap, int span,

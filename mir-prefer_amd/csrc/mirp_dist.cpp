@@ -24,6 +24,11 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string err;
     bool load() {
         if (h) return true;
@@ -50,11 +55,27 @@ struct Rccl {
         MIRP_SYM(GetUniqueId, "ncclGetUniqueId") MIRP_SYM(CommInitRank, "ncclCommInitRank") MIRP_SYM(CommDestroy, "ncclCommDestroy")
         MIRP_SYM(AllGather, "ncclAllGather") MIRP_SYM(AllReduce, "ncclAllReduce") MIRP_SYM(Send, "ncclSend") MIRP_SYM(Recv, "ncclRecv")
         MIRP_SYM(GroupStart, "ncclGroupStart") MIRP_SYM(GroupEnd, "ncclGroupEnd") MIRP_SYM(GetErrorString, "ncclGetErrorString")
+        MIRP_SYM(CommGetAsyncError, "ncclCommGetAsyncError") MIRP_SYM(CommAbort, "ncclCommAbort") MIRP_SYM(CommCount, "ncclCommCount")
+        MIRP_SYM(CommCuDevice, "ncclCommCuDevice") MIRP_SYM(CommUserRank, "ncclCommUserRank")
 #undef MIRP_SYM
         return true;
     }
 };
 Rccl g_rccl;
+
+// Deadline of every wait on a peer (a collective's completion on the stream, a block of the local transport): MIRP_DIST_TIMEOUT_S seconds, default
+// 600.  A rank that died (OOM kill, a failed allocation that made it leave before the collective, a lost GPU) never joins; without a deadline its
+// peers would sit in hipStreamSynchronize for ever -- the reference's parent does exactly that on a crashed child.
+double dist_timeout_s() {
+    const char* e = std::getenv("MIRP_DIST_TIMEOUT_S");
+    const double v = e ? std::atof(e) : 0.0;
+    return v > 0.0 ? v : 600.0;
+}
+double mono_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 // ---- local transport: ranks that share one GPU (RCCL refuses two ranks on one device) exchange through files in a directory they all see.
 // Every collective draws the next sequence number; rank s leaves its block for rank q in <dir>/x<seq>.<s>.<q> (written under a temporary
@@ -77,8 +98,9 @@ int local_exchange(mirp_ctx* c, const std::vector<std::pair<const void*, long lo
         if (s2 == me) continue;
         const std::string fn = name(s2, me);
         FILE* f = nullptr;
-        for (long long spin = 0; !(f = std::fopen(fn.c_str(), "rb")); spin++) {
-            if (spin > 600000) return fail(c, -7, "local transport: timed out waiting for rank " + std::to_string(s2));
+        const double t_end = mono_now() + dist_timeout_s();
+        while (!(f = std::fopen(fn.c_str(), "rb"))) {
+            if (mono_now() > t_end) { c->dist_broken = true; return fail(c, -7, "local transport: timed out waiting for rank " + std::to_string(s2) + " (MIRP_DIST_TIMEOUT_S)"); }
             struct timespec ts = {0, 1000000};
             nanosleep(&ts, nullptr);
         }
@@ -93,6 +115,40 @@ int local_exchange(mirp_ctx* c, const std::vector<std::pair<const void*, long lo
     return 0;
 }
 }  // namespace
+
+// Completion of what was enqueued on the context's stream, with the deadline: polls the stream and the communicator's asynchronous error state
+// instead of blocking in hipStreamSynchronize.  On expiry (or an asynchronous RCCL error) the communicator is ABORTED -- its kernels on the stream
+// are torn down, later collectives on this context fail at once (dist_broken) -- and the call returns -7, so the run ends non-zero on every rank
+// that is still alive.
+static int dist_wait(mirp_ctx* c, const char* what) {
+    if (!c->comm || c->dist_world == 1) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    const double t_end = mono_now() + dist_timeout_s();
+    long spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(c, -2, std::string(what) + ": " + hipGetErrorString(q));
+        ncclResult_t ae = ncclSuccess;
+        const ncclResult_t r = g_rccl.CommGetAsyncError((ncclComm_t)c->comm, &ae);
+        const bool late = mono_now() > t_end;
+        if (r != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress) || late) {
+            const std::string why = late ? std::string("no completion within MIRP_DIST_TIMEOUT_S = ") + std::to_string((int)dist_timeout_s()) + " s (a rank is missing or stuck)"
+                                         : std::string("RCCL reported ") + g_rccl.GetErrorString(r != ncclSuccess ? r : ae);
+            (void)g_rccl.CommAbort((ncclComm_t)c->comm);
+            c->comm = nullptr; c->dist_broken = true;
+            return fail(c, -7, std::string(what) + ": " + why + "; communicator aborted");
+        }
+        if (++spins < 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }        // 40 ms of fine polling, then 1 ms steps
+        else { struct timespec ts = {0, 1000000}; nanosleep(&ts, nullptr); }
+    }
+}
+#define DIST_LIVE(c, what)                                                                                                    \
+    do {                                                                                                                      \
+        if ((c)->dist_broken) return fail((c), -7, std::string(what) + ": the communicator was aborted by an earlier failure"); \
+    } while (0)
 
 #define NCCLCHK(c, call)                                                                                                      \
     do {                                                                                                                      \
@@ -153,7 +209,21 @@ extern "C" int mirp_dist_finalize(mirp_ctx* c) {
         (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
         c->comm = nullptr;
     }
-    c->dist_rank = 0; c->dist_world = 1; c->dist_dir.clear();
+    c->dist_rank = 0; c->dist_world = 1; c->dist_dir.clear(); c->dist_broken = false;
+    return 0;
+}
+
+// What RCCL itself says about the communicator: info[0] = ncclCommCount (ranks it connected), info[1] = ncclCommUserRank, info[2] = ncclCommCuDevice
+// (the HIP device it runs on); all -1 without a RCCL communicator (one rank, or the local transport).  bench.py prints them per rank, so that a
+// scaling record shows that RCCL -- not a fallback -- saw N ranks on N devices.
+extern "C" int mirp_dist_comm_info(mirp_ctx* c, int32_t info[3]) {
+    if (!c || !info) return -1;
+    info[0] = info[1] = info[2] = -1;
+    if (!c->comm) return 0;
+    int v = -1;
+    NCCLCHK(c, g_rccl.CommCount((ncclComm_t)c->comm, &v)); info[0] = v;
+    NCCLCHK(c, g_rccl.CommUserRank((ncclComm_t)c->comm, &v)); info[1] = v;
+    NCCLCHK(c, g_rccl.CommCuDevice((ncclComm_t)c->comm, &v)); info[2] = v;
     return 0;
 }
 
@@ -165,6 +235,7 @@ extern "C" int mirp_dist_allreduce_sum(mirp_ctx* c, int64_t* v, int32_t n) {
     if (!c) return -1;
     if (n < 0 || n > 1024 || (n > 0 && !v)) return fail(c, -1, "mirp_dist_allreduce_sum: bad argument");
     if (c->dist_world == 1 || n == 0) return 0;
+    DIST_LIVE(c, "mirp_dist_allreduce_sum");
     if (!c->comm) {
         std::vector<long long> all;
         if (int rc = mirp::dist_allgather_ll(c, (const long long*)v, n, all)) return rc;
@@ -175,6 +246,7 @@ extern "C" int mirp_dist_allreduce_sum(mirp_ctx* c, int64_t* v, int32_t n) {
     if (c->dist_tmp.ensure(8 * 1024)) return fail(c, -6, "device allocation failed (dist)");
     HIPCHK(c, hipMemcpyAsync(c->dist_tmp.p, v, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, g_rccl.AllReduce(c->dist_tmp.p, c->dist_tmp.p, (size_t)n, ncclInt64, ncclSum, (ncclComm_t)c->comm, c->stream));
+    if (int rc = dist_wait(c, "mirp_dist_allreduce_sum")) return rc;      // before the copy back: a pageable D2H copy blocks in the runtime, without a deadline
     HIPCHK(c, hipMemcpyAsync(v, c->dist_tmp.p, 8 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -186,6 +258,21 @@ extern "C" int mirp_dist_barrier(mirp_ctx* c) {
 }
 
 namespace mirp {
+// Every rank learns whether any rank failed in its rank-local preparation (allocation, upload) BEFORE a grouped send / recv: a rank that returned
+// early would leave its peers waiting for a block that never comes.  Returns local_rc when this rank failed, -7 naming the first failed rank when
+// another one did, 0 when all are ready.
+int dist_agree(mirp_ctx* c, int local_rc, const char* what) {
+    if (c->dist_world == 1) return local_rc;
+    const long long flag = local_rc ? 1 : 0;
+    const std::string keep = c->err;
+    std::vector<long long> flags;
+    if (int rc = dist_allgather_ll(c, &flag, 1, flags)) return local_rc ? (c->err = keep, local_rc) : rc;
+    if (local_rc) { c->err = keep; return local_rc; }
+    for (int r = 0; r < c->dist_world; r++)
+        if (flags[(size_t)r]) return fail(c, -7, std::string(what) + ": rank " + std::to_string(r) + " failed before the exchange");
+    return 0;
+}
+
 // counts[world] (records of `rec_bytes` bytes each) of every rank, on every rank
 int dist_all_counts(mirp_ctx* c, long long mine, std::vector<long long>& counts) { return dist_allgather_ll(c, &mine, 1, counts); }
 
@@ -196,6 +283,7 @@ int dist_gatherv_bytes(mirp_ctx* c, const void* d_src, long long mine, int dst, 
         if (mine) HIPCHK(c, hipMemcpyAsync(d_dst, d_src, (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
         return 0;
     }
+    DIST_LIVE(c, "gather of device blocks");
     if (!c->comm) {      // local transport, host-staged
         std::vector<char> h((size_t)std::max<long long>(mine, 1));
         if (mine) HIPCHK(c, hipMemcpyAsync(h.data(), d_src, (size_t)mine, hipMemcpyDeviceToHost, c->stream));
@@ -227,6 +315,7 @@ int dist_gatherv_bytes(mirp_ctx* c, const void* d_src, long long mine, int dst, 
         GROUPOP(g_rccl.Send(d_src, (size_t)mine, ncclUint8, dst, comm, c->stream));
     }
     if (int rc = group_end(c, g_first, g_what)) return rc;
+    if (int rc = dist_wait(c, "gather of device blocks")) return rc;
     if (c->dist_rank == dst && mine) {
         long long off = 0;
         for (int r = 0; r < dst; r++) off += counts[r];
@@ -244,6 +333,7 @@ int dist_alltoallv_bytes(mirp_ctx* c, const void* d_send, const std::vector<long
         if (send_cnt[0]) HIPCHK(c, hipMemcpyAsync((char*)d_recv + recv_off[0], (const char*)d_send + send_off[0], (size_t)send_cnt[0], hipMemcpyDeviceToDevice, c->stream));
         return 0;
     }
+    DIST_LIVE(c, "all-to-all of device blocks");
     if (!c->comm) {      // local transport, host-staged
         long long tot = 0;
         for (int r = 0; r < W; r++) tot = std::max(tot, send_off[r] + send_cnt[r]);
@@ -269,6 +359,7 @@ int dist_alltoallv_bytes(mirp_ctx* c, const void* d_send, const std::vector<long
         if (recv_cnt[r]) GROUPOP(g_rccl.Recv((char*)d_recv + recv_off[r], (size_t)recv_cnt[r], ncclUint8, r, comm, c->stream));
     }
     if (int rc = group_end(c, g_first, g_what)) return rc;
+    if (int rc = dist_wait(c, "all-to-all of device blocks")) return rc;
     if (send_cnt[me]) HIPCHK(c, hipMemcpyAsync((char*)d_recv + recv_off[me], (const char*)d_send + send_off[me], (size_t)send_cnt[me], hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
@@ -278,6 +369,7 @@ int dist_allgather_ll(mirp_ctx* c, const long long* mine, int n, std::vector<lon
     const int W = c->dist_world;
     out.assign((size_t)W * n, 0);
     if (W == 1) { for (int k = 0; k < n; k++) out[k] = mine[k]; return 0; }
+    DIST_LIVE(c, "all-gather of counts");
     if (!c->comm) {
         std::vector<std::pair<const void*, long long>> send((size_t)W, {mine, 8LL * n});
         std::vector<std::vector<char>> recv;
@@ -292,6 +384,7 @@ int dist_allgather_ll(mirp_ctx* c, const long long* mine, int n, std::vector<lon
     long long* d = (long long*)c->dist_tmp.p;
     HIPCHK(c, hipMemcpyAsync(d + (size_t)W * n, mine, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, g_rccl.AllGather(d + (size_t)W * n, d, (size_t)n, ncclInt64, (ncclComm_t)c->comm, c->stream));
+    if (int rc = dist_wait(c, "all-gather of counts")) return rc;
     HIPCHK(c, hipMemcpyAsync(out.data(), d, 8 * (size_t)W * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -311,12 +404,17 @@ extern "C" int mirp_gather_records(mirp_ctx* c, const void* rec, int64_t n, int3
     TmpDevice T;
     void* d_src = T.get((size_t)n * rec_bytes + 16);
     void* d_dst = c->dist_rank == dst ? T.get((size_t)total + 16) : nullptr;
-    if (!d_src || (c->dist_rank == dst && !d_dst)) return fail(c, -6, "device allocation failed (gather)");
-    if (n) HIPCHK(c, hipMemcpyAsync(d_src, rec, (size_t)n * rec_bytes, hipMemcpyHostToDevice, c->stream));
-    if (int rc = mirp::dist_gatherv_bytes(c, d_src, (long long)n * rec_bytes, dst, d_dst, counts)) return rc;
+    void* h = c->dist_rank == dst ? std::malloc((size_t)std::max<long long>(total, 1)) : nullptr;
+    int prep_rc = 0;
+    if (!d_src || (c->dist_rank == dst && (!d_dst || !h))) prep_rc = fail(c, -6, "allocation failed (gather)");
+    if (!prep_rc && n) {
+        hipError_t he = hipMemcpyAsync(d_src, rec, (size_t)n * rec_bytes, hipMemcpyHostToDevice, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+        if (he != hipSuccess) prep_rc = fail(c, -2, std::string("mirp_gather_records: upload failed: ") + hipGetErrorString(he));
+    }
+    if (int rc = mirp::dist_agree(c, prep_rc, "mirp_gather_records")) { std::free(h); return rc; }
+    if (int rc = mirp::dist_gatherv_bytes(c, d_src, (long long)n * rec_bytes, dst, d_dst, counts)) { std::free(h); return rc; }
     if (c->dist_rank == dst) {
-        void* h = std::malloc((size_t)std::max<long long>(total, 1));
-        if (!h) return fail(c, -6, "host allocation failed (gather)");
         hipError_t he = total ? hipMemcpyAsync(h, d_dst, (size_t)total, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) { std::free(h); return fail(c, -2, std::string("mirp_gather_records: ") + hipGetErrorString(he)); }
@@ -359,13 +457,7 @@ extern "C" int mirp_exchange_bytes(mirp_ctx* c, const void* send, const int64_t*
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
         if (he != hipSuccess) prep_rc = fail(c, -2, std::string("mirp_exchange_bytes: upload failed: ") + hipGetErrorString(he));
     }
-    {
-        const long long flag = prep_rc ? 1 : 0;
-        std::vector<long long> flags;
-        int rc = mirp::dist_allgather_ll(c, &flag, 1, flags);
-        if (!rc) for (int r = 0; r < W && !rc; r++) if (flags[(size_t)r]) rc = prep_rc ? prep_rc : fail(c, -7, "mirp_exchange_bytes: rank " + std::to_string(r) + " failed before the exchange");
-        if (rc) { std::free(h); return prep_rc ? prep_rc : rc; }
-    }
+    if (int rc = mirp::dist_agree(c, prep_rc, "mirp_exchange_bytes")) { std::free(h); return rc; }
     if (int rc = mirp::dist_alltoallv_bytes(c, d_send, soff, scnt, d_recv, roff, rcnt)) { std::free(h); return rc; }
     hipError_t he = hipSuccess;
     long long o = 0;
@@ -401,13 +493,14 @@ extern "C" int mirp_gather_loci(mirp_ctx* c, int32_t dst, MirpMirna** result, in
     const bool root = c->dist_rank == dst;
     void* d_rec = root ? T.get((size_t)total * sizeof(MirpMirna) + 16) : nullptr;
     void* d_txt = root ? T.get((size_t)total * c->fold_stride + 16) : nullptr;
-    if (root && (!d_rec || !d_txt)) return fail(c, -6, "device allocation failed (gather)");
-    if (int rc = mirp::dist_gatherv_bytes(c, c->p_res.p, mine * (long long)sizeof(MirpMirna), dst, d_rec, crec)) return rc;
-    if (int rc = mirp::dist_gatherv_bytes(c, c->p_text.p, mine * c->fold_stride, dst, d_txt, ctxt)) return rc;
+    MirpMirna* hr = root ? (MirpMirna*)std::calloc((size_t)std::max<long long>(total, 1), sizeof(MirpMirna)) : nullptr;
+    char* ht = root ? (char*)std::calloc((size_t)std::max<long long>(total, 1), (size_t)c->fold_stride) : nullptr;
+    // a root that cannot allocate must not leave the other ranks in ncclSend: agree first
+    const int prep_rc = (root && (!d_rec || !d_txt || !hr || !ht)) ? fail(c, -6, "allocation failed (gather of the loci list)") : 0;
+    if (int rc = mirp::dist_agree(c, prep_rc, "mirp_gather_loci")) { std::free(hr); std::free(ht); return rc; }
+    if (int rc = mirp::dist_gatherv_bytes(c, c->p_res.p, mine * (long long)sizeof(MirpMirna), dst, d_rec, crec)) { std::free(hr); std::free(ht); return rc; }
+    if (int rc = mirp::dist_gatherv_bytes(c, c->p_text.p, mine * c->fold_stride, dst, d_txt, ctxt)) { std::free(hr); std::free(ht); return rc; }
     if (root) {
-        MirpMirna* hr = (MirpMirna*)std::calloc((size_t)std::max<long long>(total, 1), sizeof(MirpMirna));
-        char* ht = (char*)std::calloc((size_t)std::max<long long>(total, 1), (size_t)c->fold_stride);
-        if (!hr || !ht) { std::free(hr); std::free(ht); return fail(c, -6, "host allocation failed (gather)"); }
         hipError_t he = hipSuccess;
         if (total) {
             he = hipMemcpyAsync(hr, d_rec, (size_t)total * sizeof(MirpMirna), hipMemcpyDeviceToHost, c->stream);

@@ -509,13 +509,8 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
             if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
             if (he != hipSuccess) prep_rc = fail(c, -2, std::string(who) + ": upload of the exchange buffer failed: " + hipGetErrorString(he));
         }
-        {   // the outcome is collective: one flag per rank, every rank returns an error if any rank has one
-            const long long flag = prep_rc ? 1 : 0;
-            std::vector<long long> flags;
-            if (int rc = mirp::dist_allgather_ll(c, &flag, 1, flags)) return prep_rc ? prep_rc : rc;
-            for (int r = 0; r < W; r++)
-                if (flags[(size_t)r]) return prep_rc ? prep_rc : fail(c, -7, std::string(who) + ": rank " + std::to_string(r) + " failed before the record exchange");
-        }
+        // the outcome is collective: one flag per rank, every rank returns an error if any rank has one
+        if (int rc = mirp::dist_agree(c, prep_rc, who)) return rc;
         if (int rc = mirp::dist_alltoallv_bytes(c, d_send, soff, scnt, d_recv, roff, rcnt)) return rc;
         // unpack into (file, source) order; segment owners are re-based to the record's index in this rank's array
         owner.resize(std::max<size_t>((size_t)ns, 1)); span.resize(std::max<size_t>((size_t)ns, 1));

@@ -315,8 +315,8 @@ class Pipeline:
         ok, res = True, None
         try:
             res = balance.exchange(xchg, self.rank, self.world, self.ctx.get_windows, self.data["alns"], counts)
-        except capi.MirpError as e:
-            sys.stderr.write(str(e) + "\n")
+        except Exception as e:          # any failure of one rank (library error, a payload that does not unpack) must reach the agreement below:
+            sys.stderr.write("%s: %s\n" % (type(e).__name__, e))      # a rank that died here would leave the others inside the next collective
             ok = False
         self._agree_ok(ok, "window re-balancing")
         keep, self._imported, self._moves = res
@@ -427,8 +427,8 @@ class Pipeline:
         for p in self._imported:          # windows received from over-loaded ranks (balance.py): folded through the batch entry point
             try:
                 balance.fold_imported(self.ctx, p, self.opt["PRECURSOR_LEN"])
-            except (RuntimeError, capi.MirpError) as e:
-                sys.stderr.write(str(e) + "\n")
+            except Exception as e:
+                sys.stderr.write("%s: %s\n" % (type(e).__name__, e))
                 status = np.concatenate([status, np.array([-1], dtype=status.dtype)])
         return status
 
@@ -497,9 +497,13 @@ class Pipeline:
         if pending is None and not previous_stage_saved(self.recovername, "fold"):
             self._fail_stage()
         self._say("Starting predicting miRNAs.")
-        if self.state != "fold":
+        if self.state != "fold":          # the `predict` verb in a process of its own: the fold is redone on the device (0.07 s), its status checked as run_fold does
             self._ensure_candidate()
-            self._fold_device()
+            status = self._fold_device()
+            badf = np.nonzero(status != 0)[0]
+            if len(badf):
+                sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (badf[0], status[badf[0]]))
+            self._agree_ok(len(badf) == 0, "fold")
             self.state = "fold"
         ns = len(self.data["samples"])
         out = self.ctx.predict(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
@@ -512,7 +516,7 @@ class Pipeline:
                 params = (ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], 1 if self.opt["ALLOW_3NT_OVERHANG"] else 0,
                           1 if self.opt["ALLOW_NO_STAR_EXPRESSION"] else 0, 55)
                 imp = [balance.predict_imported(self.ctx, p, params) for p in self._imported]
-            except (RuntimeError, capi.MirpError) as e:
+            except Exception as e:
                 sys.stderr.write("Error occurred when predicting miRNAs (imported windows): %s\n" % e)
                 bad = [0]
         self._agree_ok(len(bad) == 0, "predict")
@@ -613,11 +617,22 @@ class Pipeline:
         self._barrier()
         return result
 
+    def _mark(self, stage):
+        c = getattr(self, "clock", None)
+        if c is not None and c.path:
+            tm = self.ctx.last_timings()
+            c.mark(stage, device_ms={"candidate": tm["coverage_ms"] + tm["candidate_rest_ms"], "fold": tm["fold_ms"], "predict": tm["predict_ms"]}.get(stage, 0.0))
+
     def run_pipeline(self):
         self.run_prepare()
+        self._mark("prepare")
         self.run_candidate(defer=True)
+        self._mark("candidate")
         self.run_fold(defer=True)
-        return self.run_predict()
+        self._mark("fold")
+        res = self.run_predict()
+        self._mark("predict")
+        return res
 
     def run_recover(self):
         """The `recover` verb (MP:3740-3774): continue after the last recorded stage; nothing recorded -> a message, no action.  Returns True

@@ -1,5 +1,7 @@
+"""Dev tool: cost of the first fold of a second context in a process that already folded (first context / second context / again).
+usage (GPU box): python profiles/tools/idle_probe.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mir_prefer_amd import synth, capi
 ds = synth.make_dataset([30427671], 12000, n_samples=1, seed=2, contig_names=["Chr1"])

@@ -183,6 +183,43 @@ def test_stress_families(gpu_ctx, model, count):
     assert not bad, [seqs[k] for k in bad[:3]]
 
 
+def _microsatellites():
+    """Low-complexity windows whose vienna-1.8.5 pair pools outgrow what one in-place compaction holds (4,096 entries) long before they outgrow the
+    room behind a short window's triangle: (AU)k, (AU)k GCGC (AU)k, (GU)k, (ACGU)k at window lengths 100 .. 300."""
+    out = []
+    for n in list(range(100, 301, 10)) + [150, 199, 201, 290]:
+        out.append(("AU" * 200)[:n])
+        half = (n - 4) // 2
+        out.append(("AU" * 200)[:half] + "GCGC" + ("AU" * 200)[:half])
+        out.append(("GU" * 200)[:n])
+        out.append(("ACGU" * 100)[:n])
+        out.append(("AAUU" * 100)[:n])
+    return out
+
+
+@pytest.mark.parametrize("model", ["vienna-1.8.5", "vienna-2.1.2"])
+@pytest.mark.parametrize("span", [300, 150])
+def test_microsatellite_pools_take_the_dense_hand_off(gpu_ctx, model, span):
+    """a pool larger than the compaction's register slice must be handed to the dense kernel, never truncated.  Sparse pass ==
+    dense split loop == oracle on microsatellite windows, and the hand-off is seen to happen."""
+    seqs = _microsatellites()
+    try:
+        gpu_ctx.set_fold_model(model)
+        a = gpu_ctx.fold_batch(seqs, span, max_lines=352)
+        n_dense = gpu_ctx.last_fold_dense()
+        gpu_ctx.set_fold_split_path(1)
+        b = gpu_ctx.fold_batch(seqs, span, max_lines=352)
+    finally:
+        gpu_ctx.set_fold_split_path(0)
+        gpu_ctx.set_fold_model("vienna-2.1.2")
+    assert n_dense > 0
+    want = oracle_fold_all(seqs, span, model)
+    for k, s in enumerate(seqs):
+        assert a[k]["status"] == 0 and b[k]["status"] == 0, s
+        assert (a[k]["lines"], a[k]["mfe"]) == (b[k]["lines"], b[k]["mfe"]), s
+        assert (a[k]["lines"], a[k]["mfe"]) == (want[k][0], want[k][1]), s
+
+
 def test_config2_slice_of_12000_windows_lines_and_records(gpu_ctx, oracle):
     """BASELINE config[2] (TAIR10-sized, 5 contigs, 3 samples, 70,244 windows): the candidate stage against the oracle over the whole genome, and a
     contiguous slice of 12,000 windows (it crosses a contig boundary) line by line and record by record -- fold text through the batch entry
