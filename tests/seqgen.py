@@ -32,3 +32,40 @@ def window(r, lo, hi):
 def windows(seed, count, lo, hi):
     r = random.Random(seed)
     return [window(r, lo, hi) for _ in range(count)]
+
+
+def stress_family(r, k):
+    """The five sequence families of the differential stress: 0 mixed (window()), 1 short tandem repeats, 2 two- / three-letter alphabets (energy
+    ties), 3 perfect / near-perfect long hairpins, 4 N-rich."""
+    n = r.randint(40, 350)
+    if k == 0:
+        return window(r, 60, 350)
+    if k == 1:      # short tandem repeats
+        unit = "".join(r.choice("ACGU") for _ in range(r.randint(1, 7)))
+        return (unit * (n // len(unit) + 1))[:n]
+    if k == 2:      # two-letter alphabets
+        ab = r.choice(["GC", "AU", "GU", "ACG", "AGU"])
+        return "".join(r.choice(ab) for _ in range(n))
+    if k == 3:      # perfect / near-perfect long hairpins
+        arm = r.randint(20, 160)
+        a = "".join(r.choice("ACGU") for _ in range(arm))
+        rc = {"A": "U", "C": "G", "G": "C", "U": "A"}
+        b = [rc[c] for c in reversed(a)]
+        for _ in range(r.randint(0, 6)):
+            b[r.randrange(arm)] = r.choice("ACGU")
+        return (a + "".join(r.choice("ACGU") for _ in range(r.randint(3, 12))) + "".join(b))[:350]
+    return "".join(r.choice("ACGUN") if r.random() < 0.3 else r.choice("ACGU") for _ in range(n))      # N-rich
+
+
+def microsatellites():
+    """Low-complexity windows whose vienna-1.8.5 pair pools outgrow what one in-place compaction holds (4,096 entries) long before they outgrow the
+    room behind a short window's triangle: (AU)k, (AU)k GCGC (AU)k, (GU)k, (ACGU)k at window lengths 100 .. 300."""
+    out = []
+    for n in list(range(100, 301, 10)) + [150, 199, 201, 290]:
+        out.append(("AU" * 200)[:n])
+        half = (n - 4) // 2
+        out.append(("AU" * 200)[:half] + "GCGC" + ("AU" * 200)[:half])
+        out.append(("GU" * 200)[:n])
+        out.append(("ACGU" * 100)[:n])
+        out.append(("AAUU" * 100)[:n])
+    return out

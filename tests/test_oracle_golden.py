@@ -323,3 +323,96 @@ def test_structure_rules_match_direct_reference_calls(oracle):
         assert code == (MS_CODE[want] if want else 0), c
         fails += want is not None
     assert fails > 200
+
+
+# ---- the wider pin (tests/golden/tools/gen_headline_golden.py): real RNALfold 2.1.2 / 1.8.5 on the benchmark's own window distribution and on the
+# stress families, and the whole reference pipeline on a mid-size dataset under both folders
+def headline_fold_groups():
+    """-> {group: [sequences]} regenerated from the seeds, checked against the fixture's input digests."""
+    import base64
+    import random
+    from tests import seqgen
+    from tests.golden.tools_digest import seq_digest
+    fix = gu.load_json("headline_folds.json.gz")
+    import bench
+    from tests import oracle_binding
+    o = oracle_binding.load()
+    specs, ns, bg, _, _ = bench.workload_specs("config1", 1)
+    contigs, alns, _ = bench.build_shard(specs, {0}, ns, bg)
+    lens = np.array([len(s) for _, s in contigs], dtype=np.int64)
+    _, peaks = o.coverage_peaks(alns, lens, bench.CUT)
+    win = o.make_windows(peaks, alns, contigs, np.arange(len(contigs), dtype=np.int32), bench.GAP, bench.L, bench.CUT * 0.5)
+    W = win["windows"]
+    assert len(W) == fix["headline_windows_total"]
+    r = random.Random(fix["stress_seed"])
+    groups = {"headline": [win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes().decode() for b in W[::fix["headline_step"]]],
+              "stress": [seqgen.stress_family(r, i % 5) for i in range(fix["stress_count"])] + seqgen.microsatellites()}
+    for name, seqs in groups.items():
+        g = fix["groups"][name]
+        assert len(seqs) == g["n"]
+        assert b"".join(seq_digest(s) for s in seqs) == base64.b64decode(g["seq_digests"]), name          # the same windows the real binaries folded
+    return fix, groups
+
+
+def check_headline_folds(fix, groups, fold_many):
+    """fold_many(seqs, span, model) -> [(lines, mfe)]; every (window, model, span) digest of the real binaries' output must be reproduced."""
+    import base64
+    from tests.golden.tools_digest import fold_digest
+    n = 0
+    for name, seqs in groups.items():
+        for key, exp in fix["groups"][name]["folds"].items():
+            model, span = key.split("/")
+            got = fold_many(seqs, int(span), model)
+            want = base64.b64decode(exp["digests"])
+            for k, (lines, mfe) in enumerate(got):
+                assert mfe == exp["mfe"][k], (name, key, k, seqs[k])
+                assert fold_digest(lines, mfe) == want[6 * k:6 * k + 6], (name, key, k, seqs[k])
+                n += 1
+    return n
+
+
+def test_headline_and_stress_windows_match_real_rnalfold(oracle):
+    """2,188 windows of the headline workload + 725 stress windows, both models, spans 300 and 150: the oracle against digests of the REAL binaries' output."""
+    from tests.test_whole_workload_gpu import oracle_fold_all
+    fix, groups = headline_fold_groups()
+    n = check_headline_folds(fix, groups, lambda seqs, span, model: oracle_fold_all(seqs, span, model))
+    assert n >= 4 * (2000 + 500)
+
+
+def mid_case(oracle):
+    from mir_prefer_amd import synth
+    from tests.golden.tools_digest import array_digest
+    exp = gu.load_json("mid/expected.json.gz")
+    d = exp["dataset"]
+    ds = synth.make_dataset(d["lens"], d["loci"], n_samples=d["samples"], seed=d["seed"], contig_names=d["names"], edge_cases=True)
+    alns = ds.sorted_alns()
+    assert [array_digest(s) for _, s in ds.contigs] == d["genome_sha256"] and array_digest(alns) == d["alns_sha256"]
+    return exp, ds, alns
+
+
+@pytest.mark.parametrize("model", ["vienna-2.1.2", "vienna-1.8.5"])
+def test_mid_dataset_whole_reference_pipeline(oracle, model):
+    """The whole py3-shimmed reference (bundled samtools + RNALfold 2.1.2 / 1.8.5) on a dataset no other fixture holds: FASTA headers of all windows,
+    the pass / fail decision of every region and the raw result list against the oracle chain."""
+    import hashlib
+    from tests.test_whole_workload_gpu import oracle_fold_all
+    exp, ds, alns = mid_case(oracle)
+    run = exp["runs"][model]
+    cfg = run["config"]
+    names = ds.contig_names
+    _, peaks = oracle.coverage_peaks(alns, ds.contig_lens, cfg["READS_DEPTH_CUTOFF"])
+    order = np.argsort(np.array(names, dtype=object), kind="stable").astype(np.int32)
+    win = oracle.make_windows(peaks, alns, ds.contigs, order, cfg["MAX_GAP"], cfg["PRECURSOR_LEN"], cfg["READS_DEPTH_CUTOFF"] * 0.5)
+    W = win["windows"]
+    assert len(W) == run["n_windows"] >= 600
+    heads = [records.fasta_header(w, win["wpeaks"], win["matures"], names) for w in W]
+    assert hashlib.sha256("\n".join(heads).encode()).hexdigest() == run["fasta_headers_sha256"]
+    seqs = [win["seq"][w["seq_off"]:w["seq_off"] + w["seq_len"]].tobytes() for w in W]
+    structs = [oracle.structures_from_lines(l, 55) for l, _ in oracle_fold_all(seqs, cfg["PRECURSOR_LEN"], model)]
+    case = {"cfg": cfg, "win": win, "sample_names": ds.sample_names, "alns": alns}
+    decisions, result = run_predict(case, oracle, structs)
+    assert [len(d) for d in decisions] == run["decisions"]
+    exp_res = gu.unjson(run["result_raw"])
+    assert len(exp_res) >= 100
+    assert [mirna_record(m, names) for _, m in result] == [e[:10] for e in exp_res]
+    assert [(m.total_depth_mature, m.total_depth_star) for _, m in result] == [(e[10]["total_depth_mature"], e[10]["total_depth_star"]) for e in exp_res]

@@ -139,25 +139,7 @@ def test_config1_slice_dense_split_path_equals_candidate_pool_pass(gpu_ctx, conf
         assert np.array_equal(a[key], b[key]), key
 
 
-def _family(r, k):
-    n = r.randint(40, 350)
-    if k == 0:
-        return seqgen.window(r, 60, 350)
-    if k == 1:      # short tandem repeats
-        unit = "".join(r.choice("ACGU") for _ in range(r.randint(1, 7)))
-        return (unit * (n // len(unit) + 1))[:n]
-    if k == 2:      # two-letter alphabets
-        ab = r.choice(["GC", "AU", "GU", "ACG", "AGU"])
-        return "".join(r.choice(ab) for _ in range(n))
-    if k == 3:      # perfect / near-perfect long hairpins
-        arm = r.randint(20, 160)
-        a = "".join(r.choice("ACGU") for _ in range(arm))
-        rc = {"A": "U", "C": "G", "G": "C", "U": "A"}
-        b = [rc[c] for c in reversed(a)]
-        for _ in range(r.randint(0, 6)):
-            b[r.randrange(arm)] = r.choice("ACGU")
-        return (a + "".join(r.choice("ACGU") for _ in range(r.randint(3, 12))) + "".join(b))[:350]
-    return "".join(r.choice("ACGUN") if r.random() < 0.3 else r.choice("ACGU") for _ in range(n))      # N-rich
+_family = seqgen.stress_family
 
 
 @pytest.mark.parametrize("model,count", [("vienna-2.1.2", 5000), ("vienna-1.8.5", 1500)])
@@ -183,18 +165,7 @@ def test_stress_families(gpu_ctx, model, count):
     assert not bad, [seqs[k] for k in bad[:3]]
 
 
-def _microsatellites():
-    """Low-complexity windows whose vienna-1.8.5 pair pools outgrow what one in-place compaction holds (4,096 entries) long before they outgrow the
-    room behind a short window's triangle: (AU)k, (AU)k GCGC (AU)k, (GU)k, (ACGU)k at window lengths 100 .. 300."""
-    out = []
-    for n in list(range(100, 301, 10)) + [150, 199, 201, 290]:
-        out.append(("AU" * 200)[:n])
-        half = (n - 4) // 2
-        out.append(("AU" * 200)[:half] + "GCGC" + ("AU" * 200)[:half])
-        out.append(("GU" * 200)[:n])
-        out.append(("ACGU" * 100)[:n])
-        out.append(("AAUU" * 100)[:n])
-    return out
+_microsatellites = seqgen.microsatellites
 
 
 @pytest.mark.parametrize("model", ["vienna-1.8.5", "vienna-2.1.2"])
