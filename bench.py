@@ -56,8 +56,13 @@ TAIR10 = [30427671, 19698289, 23459830, 18585056, 26975502]
 MSU7 = [43300000, 35900000, 36400000, 35500000, 30000000, 31200000, 29700000, 28400000, 23000000, 23200000, 29000000, 27500000]
 
 
-def workload_specs(name, world, genome=CHR1_LEN, loci=N_LOCI):
-    """-> (contig specs [(name, length, loci, seed)], n_samples, background records per contig, scaling, description)"""
+def workload_specs(name, world, genome=CHR1_LEN, loci=N_LOCI, scale=1.0):
+    """-> (contig specs [(name, length, loci, seed)], n_samples, background records per contig, scaling, description).  scale (tests only): contig
+    lengths, loci and background records of config2-4 multiplied by it -- the same shape at a size a test can afford."""
+    if scale != 1.0 and name != "config1":
+        specs, ns, bg, scaling, desc = workload_specs(name, world, genome, loci)
+        return ([(n, max(20000, int(l * scale)), max(4, int(k * scale)), sd) for n, l, k, sd in specs], ns, int(bg * scale), scaling,
+                desc + " -- SCALED by %g (test size, not a benchmark configuration)" % scale)
     if name == "config1":
         return ([("Chr%d" % (r + 1), genome, loci, 2 + r) for r in range(world)], 1, 0, "weak",
                 "BASELINE config[1]: A. thaliana chr1-sized contig per GPU (%d bp), 1 sample, L=300, %d synthetic loci per contig" % (genome, loci))
@@ -113,6 +118,7 @@ def parse_args():
                     help="BASELINE.json configs[k] (cfgK = configK); config1 is the headline and the default")
     ap.add_argument("--loci", type=int, default=N_LOCI, help="config1: loci per contig")
     ap.add_argument("--genome", type=int, default=CHR1_LEN, help="config1: contig length")
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="tests only: config2-4 at this fraction of their size (the line says so; no expected-result check)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (config2, vienna-1.8.5, fold micro-benchmark)")
     ap.add_argument("--micro-windows", type=int, default=1 << 16, help="windows per family of the fold micro-benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,7 +500,7 @@ def main():
     ctx.set_fold_model(a.fold_model)
 
     # ---- synthetic workload: every rank generates and holds only the contigs it owns
-    specs, n_samples, background, scaling, desc = workload_specs(a.workload, world, a.genome, a.loci)
+    specs, n_samples, background, scaling, desc = workload_specs(a.workload, world, a.genome, a.loci, a.genome_scale)
     if a.workload == "config1":
         owned = [rank]
     else:
@@ -621,7 +627,7 @@ def main():
         except Exception:
             pass
         headline = a.workload == "config1" and a.genome == CHR1_LEN and a.loci == N_LOCI
-        loci_expected = EXPECTED_LOCI.get((a.workload, a.fold_model)) if (world == 1 and (headline or a.workload != "config1")) else None
+        loci_expected = EXPECTED_LOCI.get((a.workload, a.fold_model)) if (world == 1 and a.genome_scale == 1.0 and (headline or a.workload != "config1")) else None
         if loci_expected is not None and int(nres) != loci_expected:
             sys.stderr.write("[bench] RESULT CHECK FAILED: %d miRNA loci, expected %d for (%s, %s) -- no line printed\n" % (nres, loci_expected, a.workload, a.fold_model))
             ctx.close()

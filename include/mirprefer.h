@@ -362,6 +362,19 @@ int mirp_write_reports(int64_t n_loci, const int32_t* loci, const char* contig_n
  * failing name in errbuf. */
 int mirp_write_files(int64_t n_files, const char* paths, const char* text, const int64_t* offs, int32_t n_threads, char* errbuf, size_t errbuf_len);
 
+/* The tail of run_predict in ONE call (MP:3545-3627; host only): from a result list as mirp_predict / mirp_gather_loci return it (records + structure
+ * text rows of ss_stride bytes) to the readmapping/ folder and the seven report files under outdir.  Inside: the more abundant arm becomes the mature
+ * (MP:2611-2617), the list is put in the order of resultlist.sort() (MP:2622: [chr, fold_s, fold_e, mat_s, mat_e, star_s, star_e, ss, strand, has_star],
+ * element by element, stable), the per-sample read counts of gen_mirna_info (MP:2644-2728) are taken from the (tid, pos)-sorted records, then
+ * mirp_report_readmapping + mirp_write_files (on a thread of their own) and mirp_write_reports do the formatting.  contig_seq[t] / contig_len[t] = the
+ * bases of contig t on the host (NULL where not held: a locus there is an error).  Optional outputs (NULL to skip): order_out[n] = input index of
+ * list position i, sorted_out[n] = the records in list order after the swap, counts_out[n][n_samples][4].  n = 0 writes nothing (the reference prints
+ * "0 miRNA identified. No result files generated.", MP:3547-3550).  0 = ok, < 0 with a message in errbuf. */
+int mirp_write_result_reports(const MirpMirna* result, int64_t n, const char* ss_text, int32_t ss_stride, const char* contig_names, int32_t n_contigs,
+                              const uint8_t* const* contig_seq, const int64_t* contig_len, const MirpAln* alns, int64_t n_alns, const char* sample_names,
+                              int32_t n_samples, const char* mirbase_form, const char* outdir, const char* prefix, int32_t* order_out,
+                              MirpMirna* sorted_out, int64_t* counts_out, char* errbuf, size_t errbuf_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,8 +6,8 @@ import os
 
 import numpy as np
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MIRP_LIB") or os.path.join(_HERE, "libmirprefer.so")   # MIRP_LIB: dev tools load the diagnostics build (make DIAG=1)
+from . import early
+from .early import LIB_PATH, FastaData
 ABI_VERSION = 6      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
 
 
@@ -26,10 +26,6 @@ class SamData(C.Structure):
 
 class Region(C.Structure):
     _fields_ = [("tid", C.c_int32), ("start", C.c_int32), ("end", C.c_int32)]
-
-
-class FastaData(C.Structure):
-    _fields_ = [("n_contigs", C.c_int32), ("names", C.c_void_p), ("len", C.POINTER(C.c_int64)), ("seq", C.c_void_p), ("n_bytes", C.c_int64)]
 
 
 def report_readmapping(loci, ss_list, alns, contig_arrays, sample_names, counts0):
@@ -81,6 +77,36 @@ def write_reports(loci, contig_names, ss_list, pre_list, sample_names, counts, m
         raise MirpError("%s (%d)" % (err.value.decode(), rc))
 
 
+def write_result_reports(result, text, contig_names, contig_arrays, alns, sample_names, mirbase_form, outdir, prefix):
+    """The tail of the predict stage in one native call (mirp_write_result_reports, host only): result = MIRNA_DTYPE records and text = their structure
+    rows as Context.predict_raw returns them, contig_arrays[t] = uint8 bases of contig t (None / empty where not held).  Writes readmapping/ and the
+    seven report files under outdir.  -> (records in list order after the mature/star swap, order[n] = input index of list position i,
+    counts int64 [n, n_samples, 4])."""
+    lib = load_library()
+    result = np.ascontiguousarray(result)
+    n = len(result)
+    text = np.ascontiguousarray(text, dtype=np.uint8).reshape(n, -1) if n else np.zeros((0, 1), np.uint8)
+    alns = np.ascontiguousarray(alns)
+    keep = [np.ascontiguousarray(a, dtype=np.uint8) if a is not None and len(a) else None for a in contig_arrays]
+    ptrs = (C.c_void_p * max(len(keep), 1))(*[a.ctypes.data if a is not None else None for a in keep])
+    lens = np.array([len(a) if a is not None else 0 for a in keep] or [0], dtype=np.int64)
+    blob = lambda xs: b"".join(x.encode() + b"\0" for x in xs)
+    order = np.zeros(max(n, 1), dtype=np.int32)
+    out = np.zeros(max(n, 1), dtype=result.dtype)
+    counts = np.zeros((max(n, 1), len(sample_names), 4), dtype=np.int64)
+    err = C.create_string_buffer(512)
+    fn = lib.mirp_write_result_reports
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int32, C.c_char_p,
+                   C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    rc = fn(result.ctypes.data if n else None, n, text.ctypes.data if n else None, int(text.shape[1]), blob(contig_names), len(contig_names), ptrs, lens.ctypes.data,
+            alns.ctypes.data if len(alns) else None, len(alns), blob(sample_names), len(sample_names), blob(mirbase_form), str(outdir).encode(), str(prefix).encode(),
+            order.ctypes.data, out.ctypes.data, counts.ctypes.data, err, 512)
+    if rc != 0:
+        raise MirpError("%s (%d)" % (err.value.decode(), rc))
+    return out[:n], order[:n], counts[:n]
+
+
 def write_files(paths, texts, n_threads=1):
     """mirp_write_files: file paths[k] <- texts[k] (str), written natively, outside the interpreter lock."""
     lib = load_library()
@@ -103,12 +129,18 @@ def read_fasta(path, want=None):
     """Native FASTA reader (mirp_read_fasta): -> list of (name, uint8 array) in file order; with `want` (names) only those sequences are
     materialised, the others come back as None."""
     lib = load_library()
-    d = FastaData()
-    err = C.create_string_buffer(512)
-    nw = len(want) if want else 0
-    arr = (C.c_char_p * max(nw, 1))(*[str(w).encode() for w in (want or [])])
-    if lib.mirp_read_fasta(str(path).encode(), arr, nw, C.byref(d), err, 512) != 0:
-        raise ValueError(err.value.decode())
+    got = early.take_fasta(path) if not want else None      # the CLI may have started this read before the heavy imports (early.py)
+    if got is not None:
+        rc, d, msg = got
+        if rc != 0:
+            raise ValueError(msg)
+    else:
+        d = FastaData()
+        err = C.create_string_buffer(512)
+        nw = len(want) if want else 0
+        arr = (C.c_char_p * max(nw, 1))(*[str(w).encode() for w in (want or [])])
+        if lib.mirp_read_fasta(str(path).encode(), arr, nw, C.byref(d), err, 512) != 0:
+            raise ValueError(err.value.decode())
     try:
         blob = np.frombuffer((C.c_char * d.n_bytes).from_address(d.seq), dtype=np.uint8, count=d.n_bytes).copy() if d.n_bytes else np.zeros(0, np.uint8)
         out, off, o = [], 0, 0
@@ -180,7 +212,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise MirpError("libmirprefer.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU fallback for the product path)")
-    lib = C.CDLL(LIB_PATH)
+    lib = early.cdll()
     lib.mirp_abi_version.argtypes = []
     lib.mirp_abi_version.restype = C.c_int
     if lib.mirp_abi_version() != ABI_VERSION:      # a stale build (or a stale MIRP_LIB variant) would be called through the wrong signatures
@@ -320,8 +352,12 @@ class Context:
 
     def __init__(self, device=0):
         self.lib = load_library()
-        h = C.c_void_p()
-        rc = self.lib.mirp_create(int(device), C.byref(h))
+        got = early.take_context(int(device))      # the CLI may have started the context before the heavy imports (early.py)
+        if got is not None:
+            rc, h = got
+        else:
+            h = C.c_void_p()
+            rc = self.lib.mirp_create(int(device), C.byref(h))
         if rc != 0:
             raise MirpError("mirp_create(device=%d) failed with code %d (no usable GPU?)" % (device, rc))
         self.h = h
@@ -710,6 +746,20 @@ class Context:
         a_s = _copy_out(self.lib, ss, np.uint8, n * ml * stride).reshape(n, ml, stride)
         _copy_out(self.lib, nl, np.int32, n)
         return {int(w): (a_l[k], a_s[k]) for k, w in enumerate(wins)}
+
+    def predict_raw(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
+        """mirp_predict with the result left in flat arrays: {"result": MIRNA_DTYPE[n], "text": uint8[n, stride] structure rows, "n_passed", "status"};
+        nothing is turned into Python objects per locus (write_result_reports takes the arrays as they are)."""
+        from . import records
+        pp = (C.c_int32 * 6)(int(n_samples), int(min_mature_len), int(max_mature_len), 1 if allow_3nt else 0, 1 if allow_no_star else 0, int(minlen))
+        vp = C.c_void_p
+        res, text, npass, stat = vp(), vp(), vp(), vp()
+        nres, nw, stride = C.c_int64(), C.c_int64(), C.c_int32()
+        self._check(self.lib.mirp_predict(self.h, pp, C.byref(res), C.byref(nres), C.byref(text), C.byref(stride), C.byref(npass), C.byref(stat), C.byref(nw)),
+                    "mirp_predict")
+        r = _copy_out(self.lib, res, records.MIRNA_DTYPE, nres.value)
+        t = _copy_out(self.lib, text, np.uint8, nres.value * stride.value).reshape(nres.value, max(stride.value, 1))
+        return {"result": r, "text": t, "n_passed": _copy_out(self.lib, npass, np.int32, nw.value), "status": _copy_out(self.lib, stat, np.int32, nw.value)}
 
     def predict(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
         from . import records

@@ -1,6 +1,5 @@
 """`KEY=VALUE` configuration file: same keys, defaults and validation as the reference's parse_configfile
 (/root/reference/miR_PREFeR.py:80-186); errors go to stderr and exit with status -1 like the reference."""
-import multiprocessing
 import os
 import sys
 
@@ -41,7 +40,7 @@ def parse_configfile(configfile):
                     _die("File " + val + " does not exist!!\n")
                 opt[key] = os.path.expanduser(val)
             elif key == "NUM_OF_CORE":
-                cpucount, n = multiprocessing.cpu_count(), int(val)
+                cpucount, n = os.cpu_count() or 1, int(val)
                 if 2 * cpucount < n:
                     sys.stderr.write("Warnning: 2*NUM_OF_CORE is larger than CPUS/Cores on the machine. Use " + str(2 * cpucount) + " instead.\n")
                     n = 2 * cpucount

@@ -63,11 +63,20 @@ class Pipeline:
     (stage verbs): a stage that finds no device-resident state re-creates it from the previous stages' artefacts."""
 
     _imported, _moves = (), None          # window-level re-balancing (balance.py): payloads received, the plan (None: not decided yet)
+    lean, _prepared = False, None
 
-    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2", rank=0, world=1, ctx=None):
+    def __init__(self, dict_option, device=0, fold_model="vienna-2.1.2", rank=0, world=1, ctx=None, lean=False):
         """rank / world: contig sharding over one process per GPU (`torch.distributed` initialised by the caller, see cli.py).  Every rank
-        runs the stages on its own contigs (dist.partition_contigs); rank 0 merges the artefacts and writes the result files."""
+        runs the stages on its own contigs (dist.partition_contigs); rank 0 merges the artefacts and writes the result files.
+        lean (the `pipeline` verb of ONE process without -k and without -d, cli.py): the run ends by deleting its temporary folder (run_removetmp,
+        MP:3630-3639), so the stage artefacts nobody will read are not made at all -- prepared.npz, the depth file, the window FASTA, the loci dump,
+        ExRegionA.gff3, the window dump, the RNALfold-format text (135 MB at config[1]) and the result pickle -- the stages hand their state on in
+        memory, and the report files come from one native call.  No stage is recorded in `<prefix>_recover`: a lean run that dies leaves nothing to
+        recover from and is simply run again (0.5 s); every other way of running -- stage verbs, `recover`, -k, -d, several ranks -- writes every
+        file as before."""
         self.rank, self.world = rank, world
+        self.lean = bool(lean) and world == 1 and not dict_option.get("OUTPUT_DETAILS_FOR_DEBUG")
+        self._prepared = None
         self.opt = dict_option
         self.tmp = dict_option["TMPFOLDER"] or os.path.join(dict_option["OUTFOLDER"], dict_option["NAME_PREFIX"] + "_tmp")
         os.makedirs(dict_option["OUTFOLDER"], exist_ok=True)
@@ -228,6 +237,10 @@ class Pipeline:
         except ValueError as e:
             sys.stderr.write(str(e) + "\n")
             sys.exit(-1)
+        if getattr(self, "lean", False):          # handed to the candidate stage in memory (_load_inputs)
+            self._prepared = {"contig_names": names, "contig_lens": lens, "sample_names": samples, "alns": alns, "segs": segs}
+            _msg("Done (prepare stage)\n")
+            return
         prepared = self._p("prepared.npz")
         np.savez(prepared, contig_names=np.array(names, dtype=object), contig_lens=lens, sample_names=np.array(samples, dtype=object), alns=alns,
                  segs=segs, allow_pickle=True)
@@ -238,15 +251,20 @@ class Pipeline:
     def _load_inputs(self):
         if self.data is not None:
             return
-        d = load_recover_file(self.recovername)
-        if d.get("world", 1) != self.world:      # piece files and contig shards are laid out per rank: the stages of one run share one world size
-            if self.rank == 0:
-                sys.stderr.write("Error: the stage files in %s were written by a run with %d rank(s); this run has %d. Run the stages with the same "
-                                 "number of ranks, or start again from 'prepare'.\n" % (self.tmp, d.get("world", 1), self.world))
-            sys.exit(-1)
-        prep = d["finished_stages"]["prepare"]["preparedname"]
-        sharded = isinstance(prep, (list, tuple))          # one file per rank, each with the records of the rank's own contigs
-        z = np.load(prep[self.rank] if sharded else prep, allow_pickle=True)
+        if self._prepared is not None:          # lean run: the prepare stage's result, still in memory
+            z, sharded = self._prepared, False
+            self._prepared = None
+        else:
+            d = load_recover_file(self.recovername)
+            if d.get("world", 1) != self.world:      # piece files and contig shards are laid out per rank: the stages of one run share one world size
+                if self.rank == 0:
+                    sys.stderr.write("Error: the stage files in %s were written by a run with %d rank(s); this run has %d. Run the stages with the same "
+                                     "number of ranks, or start again from 'prepare'.\n" % (self.tmp, d.get("world", 1), self.world))
+                sys.exit(-1)
+            prep = d["finished_stages"]["prepare"]["preparedname"]
+            sharded = isinstance(prep, (list, tuple))          # one file per rank, each with the records of the rank's own contigs
+            z = np.load(prep[self.rank] if sharded else prep, allow_pickle=True)
+            z = {k: z[k] for k in z.files}
         names = [str(x) for x in z["contig_names"]]
         lens = z["contig_lens"]
         mine = np.ones(len(names), dtype=bool)
@@ -268,7 +286,7 @@ class Pipeline:
                 sys.stderr.write("Error: sequence %s of the SAM header is not in the FASTA file\n" % missing[0])
             sys.exit(-1)
         alns = z["alns"]
-        segs = z["segs"] if "segs" in z.files else alns[:0]
+        segs = z["segs"] if "segs" in z else alns[:0]
         if self.world > 1 and not sharded:
             alns = alns[mine[alns["tid"]]]
             segs = segs[mine[segs["tid"]]]
@@ -330,11 +348,15 @@ class Pipeline:
         """defer (the `pipeline` verb on one rank): the Python-side artefacts of the stage -- the pickled dict_loci, ExRegionA.gff3, the window
         dump and the checkpoint record -- are written by a host thread behind the fold kernels (the device call releases the interpreter
         lock); run_fold joins it once the fold is done.  Ranks > 1 exchange objects in that code, which must stay on the main thread."""
-        if not previous_stage_saved(self.recovername, "prepare"):
+        if self._prepared is None and not previous_stage_saved(self.recovername, "prepare"):
             self._fail_stage()
         self._say("Starting identifying candidate regions")
         self.state = None
         self._ensure_candidate()
+        if self.lean:          # no artefact of this stage outlives the run: the windows stay on the device for the fold
+            sys.stdout.write("%d candidate loci generated, %d regions to fold.\n" % (int(self.counts[1]), int(self.counts[2])))
+            self._say("Done (candidate stage)\n")
+            return
         names, prefix, r = self.data["names"], self.opt["NAME_PREFIX"], self.rank
         depthname = self._p("bam.depth.cut%d" % self.opt["READS_DEPTH_CUTOFF"])
         if self.world == 1:
@@ -436,7 +458,7 @@ class Pipeline:
     def run_fold(self, write_text=True, defer=False):
         """defer (the `pipeline` verb): the RNALfold-format text is formatted and written behind the predict stage's device and report work;
         the fold stage is recorded in the checkpoint file once that file is complete (run_predict joins the writer before it records itself)."""
-        if getattr(self, "_cand_thread", None) is None and not previous_stage_saved(self.recovername, "candidate"):
+        if not (self.lean and self.state == "candidate") and getattr(self, "_cand_thread", None) is None and not previous_stage_saved(self.recovername, "candidate"):
             self._fail_stage()
         self._say("Starting folding candidate sequences.")
         self._ensure_candidate()
@@ -449,6 +471,10 @@ class Pipeline:
         if len(bad):
             sys.stderr.write("Error occurred when folding sequences (window %d, status %d).\n" % (bad[0], status[bad[0]]))
         self._agree_ok(len(bad) == 0, "fold")
+        if self.lean:          # the structure lines stay on the device for the filter; mirp_write_fold_text remains the export for every other way of running
+            self._pending_fold = None
+            self._say("Done (fold stage)\n")
+            return
         if write_text:
             d = load_recover_file(self.recovername)
             self.ctx.write_fold_text(d["finished_stages"]["candidate"]["fasta"][self.rank], foldname, wait=not defer)
@@ -494,6 +520,8 @@ class Pipeline:
 
     def _run_predict(self):
         pending = getattr(self, "_pending_fold", None)
+        if self.lean and self.state == "fold":
+            return self._run_predict_lean()
         if pending is None and not previous_stage_saved(self.recovername, "fold"):
             self._fail_stage()
         self._say("Starting predicting miRNAs.")
@@ -617,6 +645,29 @@ class Pipeline:
         self._barrier()
         return result
 
+    def _run_predict_lean(self):
+        """One process, no -k, no -d: the filter's flat result goes straight into the native report writer (mirp_write_result_reports: swap, list order,
+        read counts, readmapping/ and the seven report files); no Python object per locus, no result pickle, no checkpoint record."""
+        self._say("Starting predicting miRNAs.")
+        ns = len(self.data["samples"])
+        out = self.ctx.predict_raw(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
+        bad = np.nonzero(out["status"] != 0)[0]
+        if len(bad):
+            sys.stderr.write("Error occurred when predicting miRNAs: window %d exceeds the capacity of the filter kernel (status %d).\n" % (bad[0], out["status"][bad[0]]))
+            sys.exit(-1)
+        if len(out["result"]) == 0:
+            _msg("0 miRNA identified. No result files generated.")
+            return out["result"]
+        prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
+        mark = "\x00SEQ\x00"
+        form = [p for taxon in ("Viridiplantae", "ALL") for p in _mirbase_form_text(mark, taxon).split(mark)]
+        res, _, _ = capi.write_result_reports(out["result"], out["text"], self.data["names"], [sq for _, sq in self.data["contigs"]], self.data["alns"],
+                                              self.data["samples"], form, outdir, prefix)
+        _msg("The output files are in " + outdir)
+        sys.stdout.write("%d miRNAs identified.\n" % len(res))
+        _msg("Done (predict stage)\n")
+        return res
+
     def _mark(self, stage):
         c = getattr(self, "clock", None)
         if c is not None and c.path:
@@ -626,9 +677,9 @@ class Pipeline:
     def run_pipeline(self):
         self.run_prepare()
         self._mark("prepare")
-        self.run_candidate(defer=True)
+        self.run_candidate(defer=not self.lean)
         self._mark("candidate")
-        self.run_fold(defer=True)
+        self.run_fold(defer=not self.lean)
         self._mark("fold")
         res = self.run_predict()
         self._mark("predict")

@@ -80,6 +80,38 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     assert rec["last_stage"] == "predict" and set(rec["finished_stages"]) == {"prepare", "candidate", "fold", "predict"}
 
 
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
+def test_lean_pipeline_process_reproduces_reference_outputs(name, tmp_path):
+    """`python -m mir_prefer_amd.cli pipeline <config>` as a user runs it -- a fresh process, no -k, no -d: the device context and the genome read start
+    before the heavy imports (early.py), no stage artefact is written (they would be deleted at the end, MP:3630-3639), the report files come from one
+    native call.  The outputs are the reference's byte for byte, the temporary folder is gone, the exit status is 0."""
+    import subprocess
+    import sys
+    exp, cfg, out = _setup(name, tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "mir_prefer_amd.cli", "--fold-model", exp.get("fold_model", "vienna-2.1.2"), "pipeline", cfg], cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    prefix = exp["config"]["NAME_PREFIX"]
+    rep = exp["reports"]
+    for fn, want in ((prefix + "_miRNA.gff3", exp["gff3"]), (prefix + "_miRNA.mature.fa", rep["mature_fa"]), (prefix + "_miRNA.precursor.fa", rep["precursor_fa"]),
+                     (prefix + "_miRNA.precursor.ss", rep["precursor_ss"]), (prefix + "_miRNA.detail.csv", rep["detail_csv"]), (prefix + "_miRNA.detail.html", rep["detail_html"]),
+                     ("miRNA.stat.txt", rep["stat_txt"])):
+        assert open(out / fn).read() == want, fn
+    assert sorted(os.listdir(out / "readmapping")) == sorted(exp["readmapping"])
+    for fn, text in exp["readmapping"].items():
+        assert open(out / "readmapping" / fn).read() == text, fn
+    assert not os.path.exists(out / (prefix + "_tmp"))
+    n = len(exp["readmapping"])
+    assert ("%d miRNAs identified." % n) in r.stdout and "Temporary folder removed." in r.stdout
+    for stage in ("prepare", "candidate", "fold", "predict"):
+        assert ("Done (%s stage)" % stage) in r.stdout
+    # the same verb in-process: the stage drivers behave the same without the early start
+    shutil.rmtree(out)
+    assert cli.main(["--fold-model", exp.get("fold_model", "vienna-2.1.2"), "pipeline", cfg]) == 0
+    assert open(out / (prefix + "_miRNA.gff3")).read() == exp["gff3"] and not os.path.exists(out / (prefix + "_tmp"))
+
+
 def test_stage_verbs_and_recover(tmp_path):
     exp, cfg, out = _setup("mini", tmp_path)
     with pytest.raises(SystemExit):          # fold before candidate: refused like the reference (MP:3446-3448)

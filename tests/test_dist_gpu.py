@@ -199,3 +199,63 @@ def test_exported_window_payload_through_the_batch_path_equals_the_resident_path
     balance.fold_imported(gpu_ctx, p, cfg["PRECURSOR_LEN"])
     head = gpu_ctx.predict(ns, cfg["MIN_MATURE_LEN"], cfg["MAX_MATURE_LEN"], a3, ans)
     assert head["result"].tobytes() == full["result"][~tail].tobytes() and head["ss"] == [s for s, t in zip(full["ss"], tail) if not t]
+
+
+def _bench_line(args, env=None, timeout=900):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_gpus_n_on_one_gpu(tmp_path):
+    """`python bench.py --gpus N` end to end, the way the driver's scaling runs start it (the relaunch under torch.distributed.run, the gloo host
+    group, the library's exchanges -- here over the local transport because RCCL refuses two ranks on one device): a scaled-down config[2] (5 contigs,
+    3 samples, sharded by contig, windows re-balanced) at N = 1, 2, 3 must report the same windows and the same number of miRNA loci, and a JSON
+    line whose `ranks` block accounts for every window."""
+    common = ["--workload", "config2", "--genome-scale", "0.04", "--steps", "2", "--warmup", "1", "--no-configs", "--no-e2e", "--no-cpu-baseline", "--no-ingest"]
+    one = _bench_line(["--gpus", "1"] + common)
+    assert one["n_gpus"] == 1 and one["config"]["loci_found"] > 50 and "SCALED" in one["config"]["workload"]
+    for n in (2, 3):
+        share = tmp_path / ("share%d" % n)
+        share.mkdir()
+        line = _bench_line(["--gpus", str(n)] + common, env={"MIRP_BENCH_SHARE_GPU": str(share)})
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and line["steps"] == 2
+        assert line["config"]["windows_total"] == one["config"]["windows_total"]
+        assert line["config"]["loci_found"] == one["config"]["loci_found"]
+        rk = line["ranks"]
+        assert len(rk["windows"]) == n and sum(rk["windows"]) == one["config"]["windows_total"]
+        assert sum(rk["windows_shipped"]) == sum(rk["windows_received"])
+        assert sum(rk["contigs"]) == 5 and len(set(rk["pid"])) == n
+        assert rk["rccl_comm_count"] == [-1] * n and rk["context_device"] == [0] * n          # local transport: no RCCL communicator on a shared GPU
+        assert line["value"] > 0 and abs(line["ms_per_step"] * line["value"] / 1e3 - line["config"]["windows_total"]) < 1e-6 * line["config"]["windows_total"] + 1
+
+
+def test_lost_rank_ends_the_exchange_with_an_error(tmp_path):
+    """A rank that never joins: the waiting rank's exchange returns an error after MIRP_DIST_TIMEOUT_S instead of hanging (the reference's parent waits
+    for ever on a crashed child), and every later exchange on the context fails at once."""
+    code = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from mir_prefer_amd import capi
+ctx = capi.Context(0)
+ctx.dist_init_local(sys.argv[2], 0, 2)          # rank 1 never starts
+t = time.time()
+try:
+    ctx.gather_records(np.arange(8, dtype=np.int32).reshape(2, 4))
+    print("NOERROR")
+except capi.MirpError as e:
+    print("ERROR1 %.1f %s" % (time.time() - t, e))
+t = time.time()
+try:
+    ctx.dist_barrier()
+    print("NOERROR")
+except capi.MirpError as e:
+    print("ERROR2 %.1f %s" % (time.time() - t, e))
+"""
+    r = subprocess.run([sys.executable, "-c", code, ROOT, str(tmp_path)], env=dict(os.environ, MIRP_DIST_TIMEOUT_S="2"), capture_output=True, text=True, timeout=120)
+    out = r.stdout.splitlines()
+    assert r.returncode == 0 and len(out) == 2, (r.stdout, r.stderr[-1500:])
+    assert out[0].startswith("ERROR1 ") and 1.5 < float(out[0].split()[1]) < 10 and "timed out waiting for rank 1" in out[0]
+    assert out[1].startswith("ERROR2 0.0") and "aborted by an earlier failure" in out[1]

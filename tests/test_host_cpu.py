@@ -218,6 +218,53 @@ def test_report_writers_match_reference_files(name, tmp_path):
         assert open(tmp_path / "rm" / fn).read() == text, fn
 
 
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
+def test_result_reports_one_call_matches_reference_files(name, tmp_path):
+    """mirp_write_result_reports (the lean `pipeline` run's report path): the reference's RAW result list -- queue order, mature / star as the filter
+    found them -- as flat records, shuffled; one native call must produce the reference's gff3, fasta / ss / csv / html / stat files and every
+    read-mapping file byte for byte (swap MP:2611-2617, resultlist.sort() MP:2622, gen_mirna_info MP:2644-2728, gen_map_result MP:2907-2959)."""
+    import random
+    from mir_prefer_amd import capi, pipeline, records
+    from tests import golden_util as gu
+    c = gu.load_pipeline_case(name)
+    exp = c["exp"]
+    raw = [list(m[:10]) + [dict(m[10])] for m in gu.unjson(exp["result_raw"])]
+    random.Random(3).shuffle(raw)
+    tid_of = {n: t for t, n in enumerate(c["contig_names"])}
+    stride = max(len(m[7]) for m in raw) + 3
+    rec = np.zeros(len(raw), dtype=records.MIRNA_DTYPE)
+    text = np.zeros((len(raw), stride), dtype=np.uint8)
+    for k, m in enumerate(raw):
+        e = m[10]
+        rec[k] = (k, tid_of[m[0]], m[1], m[2], m[3], m[4], m[5], m[6], 1 if m[8] == "-" else 0, 1 if m[9] else 0, 0, 0, len(m[7]), 0,
+                  e["total_depth_mature"], e["total_depth_star"])
+        text[k, :len(m[7])] = np.frombuffer(m[7].encode(), dtype=np.uint8)
+        text[k, len(m[7]):] = ord("#")          # a row is not NUL-terminated: the record's ss_len bounds it
+    mark = "\x00SEQ\x00"
+    form = [p for taxon in ("Viridiplantae", "ALL") for p in pipeline._mirbase_form_text(mark, taxon).split(mark)]
+    out = tmp_path / "out"
+    res, order, counts = capi.write_result_reports(rec, text, c["contig_names"], [sq for _, sq in c["contigs"]], c["alns"], c["sample_names"], form, str(out), name)
+    rep = exp["reports"]
+    for fn, want in ((name + "_miRNA.gff3", exp["gff3"]), (name + "_miRNA.mature.fa", rep["mature_fa"]), (name + "_miRNA.precursor.fa", rep["precursor_fa"]),
+                     (name + "_miRNA.precursor.ss", rep["precursor_ss"]), (name + "_miRNA.detail.csv", rep["detail_csv"]), (name + "_miRNA.detail.html", rep["detail_html"]),
+                     ("miRNA.stat.txt", rep["stat_txt"])):
+        assert open(out / fn).read() == want, fn
+    assert sorted(os.listdir(out / "readmapping")) == sorted(exp["readmapping"])
+    for fn, want in exp["readmapping"].items():
+        assert open(out / "readmapping" / fn).read() == want, fn
+    # the optional outputs: list order, records after the swap, counts as the Python statement computes them
+    ref = [list(m[:10]) + [dict(m[10])] for m in raw]
+    pipeline.adjust_mature_star(ref)
+    want_order = sorted(range(len(ref)), key=lambda k: ref[k][:10])
+    assert order.tolist() == want_order
+    assert [[c["contig_names"][r["tid"]], int(r["fold_s"]), int(r["fold_e"]), int(r["mat_s"]), int(r["mat_e"]), int(r["star_s"]), int(r["star_e"])] for r in res] == \
+           [ref[k][:7] for k in want_order]
+    assert np.array_equal(counts, pipeline.mirna_read_counts([ref[k] for k in want_order], c["contig_names"], c["alns"], len(c["sample_names"])))
+    # no loci: nothing is written, nothing fails
+    res0, _, _ = capi.write_result_reports(rec[:0], text[:0], c["contig_names"], [sq for _, sq in c["contigs"]], c["alns"], c["sample_names"], form, str(tmp_path / "none"), name)
+    assert len(res0) == 0 and not os.path.exists(tmp_path / "none")
+
+
 def test_native_report_writer_equals_python_writers_on_random_loci(tmp_path):
     """mirp_write_reports against the Python statement of the same formats on 3,000 random loci: both strands, star before / after the mature,
     the three overhang forms, 1..3 samples, contig names in any order."""
