@@ -282,7 +282,7 @@ def relaxation_count(seq_bytes, offs, lens, span):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg=""):
+def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
     """The product CLI the way a user runs it: a FRESH `python -m mir_prefer_amd.cli pipeline <config>` process per run, clocked by this (parent)
     process from spawn to exit -- interpreter start, imports, library load, device context, first-touch of every allocation and code object, the four
     stages, every report file, the removal of the temporary folder and process teardown are all inside.  SAM + FASTA in -> gff3 / fasta / ss / csv /
@@ -306,6 +306,8 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg=""):
         recs = []
         for rep in range(runs):
             shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
+            if pause_s:
+                time.sleep(pause_s)
             t0 = time.time()
             r = subprocess.run([sys.executable, "-m", "mir_prefer_amd.cli", "--fold-model", fold_model, "pipeline", cfg], env=env, cwd=tmp,
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -326,12 +328,20 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg=""):
                     loci = int(ln.split()[0])
             recs.append({"process_wall_s": wall, "segments_s": {k: round(v, 4) for k, v in seg.items()}, "device_s": {k: round(v, 4) for k, v in dev.items()}, "loci": loci})
         out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs)
+        n_small = len(os.listdir(os.path.join(tmp, "out", "readmapping"))) if os.path.isdir(os.path.join(tmp, "out", "readmapping")) else 0
+        probe = os.path.join(tmp, "fsprobe")          # what this file system charges for creating a small file right now (one per miRNA locus is the reference's
+        os.makedirs(probe)                             # output format: readmapping/<id>.map.txt); it varies 12 .. 100 us from one second to the next on an overlay
+        t = time.time()
+        for k in range(2000):
+            os.close(os.open(os.path.join(probe, "f%d" % k), os.O_WRONLY | os.O_CREAT, 0o644))
+        fs_us = (time.time() - t) / 2000 * 1e6
         first = recs[0]
         dev_total = sum(first["device_s"].values())
         return {"process_wall_s": first["process_wall_s"], "process_wall_s_all_runs": [round(x["process_wall_s"], 4) for x in recs],
+                "device_s_all_runs": [round(sum(x["device_s"].values()), 4) for x in recs], "segments_s_all_runs": [x["segments_s"] for x in recs],
                 "device_s": dev_total, "host_s": first["process_wall_s"] - dev_total, "host_over_device": (first["process_wall_s"] - dev_total) / dev_total if dev_total else None,
                 "segments_s": first["segments_s"], "stage_device_s": first["device_s"], "files_under": os.path.dirname(tmp),
-                "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": first["loci"],
+                "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": first["loci"], "small_report_files": n_small, "fs_create_us_per_file": round(fs_us, 1),
                 "note": "parent-side clock around a fresh `python -m mir_prefer_amd.cli pipeline <config>` process: interpreter start, imports, library load, "
                         "device context, first touch of allocations and code objects, stages, report files, removal of the temporary folder and exit all "
                         "included; process_wall_s = the FIRST of the runs (each a new process, inputs in the page cache); segments_s = the child's own stamps: "
@@ -744,8 +754,6 @@ def main():
                 ctx.load_genome(contigs)          # back to the headline workload for the baselines below
                 ctx.load_alignments(alns)
             ds = synth.Dataset(contigs, sample_names, alns, [])
-            if not a.no_ingest and headline:
-                line["ingest"] = ingest_leg(ctx, a.ingest_records)
             if not a.no_e2e and headline:
                 # End-to-end wall-clock, the second half of BASELINE's metric: the CLI in a fresh process, files under the default temporary directory
                 # (what a user gets); the same on the in-memory file system beside it (the container's overlay file system creates 4,002 small
@@ -769,6 +777,10 @@ def main():
                     del c2, a2
                 if line["e2e"].get("loci") is not None and line["e2e"]["loci"] != EXPECTED_LOCI.get(("config1", a.fold_model), line["e2e"]["loci"]):
                     line["e2e"]["error"] = "result check failed: %d loci" % line["e2e"]["loci"]
+            if not a.no_ingest and headline:          # after the end-to-end legs: this one writes 0.6 GB of SAM text, and a file system that is flushing it
+                if ctx is None:                       # creates the CLI's thousands of small report files several times slower (fs_create_us_per_file)
+                    ctx = capi.Context(local_rank)
+                line["ingest"] = ingest_leg(ctx, a.ingest_records)
             if not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(ds, alns, order, a.cpu_budget)
         print(json.dumps(line))

@@ -141,8 +141,10 @@ def read_fasta(path, want=None):
         arr = (C.c_char_p * max(nw, 1))(*[str(w).encode() for w in (want or [])])
         if lib.mirp_read_fasta(str(path).encode(), arr, nw, C.byref(d), err, 512) != 0:
             raise ValueError(err.value.decode())
-    try:
-        blob = np.frombuffer((C.c_char * d.n_bytes).from_address(d.seq), dtype=np.uint8, count=d.n_bytes).copy() if d.n_bytes else np.zeros(0, np.uint8)
+    keep = got is not None          # the CLI's early read: the process is short-lived, the arrays below are views of the library's buffer (no 119 MB copy
+    try:                            # at config[2]); the buffer is never handed back -- _FASTA_KEEP holds the descriptor until the process ends
+        raw = np.frombuffer((C.c_char * d.n_bytes).from_address(d.seq), dtype=np.uint8, count=d.n_bytes) if d.n_bytes else np.zeros(0, np.uint8)
+        blob = raw if keep else raw.copy()
         out, off, o = [], 0, 0
         for k in range(d.n_contigs):
             nm = C.string_at(d.names + off)
@@ -153,8 +155,14 @@ def read_fasta(path, want=None):
             else:
                 out.append((nm.decode(), blob[o:o + L])); o += L
     finally:
-        lib.mirp_free_fasta_data(C.byref(d))
+        if keep:
+            _FASTA_KEEP.append(d)
+        else:
+            lib.mirp_free_fasta_data(C.byref(d))
     return out
+
+
+_FASTA_KEEP = []
 
 
 def _unpack_sam_data(lib, d):
@@ -472,8 +480,15 @@ class Context:
     def load_genome(self, contigs):
         """contigs: list of (name, uint8 array) in @SQ order."""
         lens = np.array([len(s) for _, s in contigs], dtype=np.int64)
-        blob = np.concatenate([s for _, s in contigs]) if contigs else np.zeros(0, np.uint8)
-        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        arrs = [s for _, s in contigs]
+        base = arrs[0].base if arrs and isinstance(arrs[0], np.ndarray) else None
+        if (isinstance(base, np.ndarray) and base.ndim == 1 and base.dtype == np.uint8 and base.flags.c_contiguous and len(base) == int(lens.sum()) and
+                all(isinstance(a, np.ndarray) and a.dtype == np.uint8 for a in arrs) and arrs[0].ctypes.data == base.ctypes.data and
+                all(a.ctypes.data + len(a) == b.ctypes.data for a, b in zip(arrs, arrs[1:]))):
+            blob = base          # the contigs are consecutive slices of one buffer (capi.read_fasta): upload it as it is
+        else:
+            blob = np.concatenate(arrs) if contigs else np.zeros(0, np.uint8)
+            blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self._check(self.lib.mirp_load_genome(self.h, len(contigs), lens.ctypes.data, blob.ctypes.data), "mirp_load_genome")
 
     def load_alignments(self, alns):
