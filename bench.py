@@ -748,6 +748,24 @@ def main():
                                                  "reach over a tile edge), a 256-position row of the dense arrays is written only if a run walk can read it (all rows counted "
                                                  "here; the counter-based bytes are in profiles/*_coverage_shard_pmc.json)"}
                     del c4, a4
+                # PRECURSOR_LEN beyond what the LDS-resident fill kernel holds (span <= 300, windows <= 350 nt): the same seeded workload at
+                # PRECURSOR_LEN = 400 (the reference accepts 60 .. 3000, MP:167-184) -- every window goes through the generic kernel, tables in HBM
+                ctx.load_genome(contigs)
+                ctx.load_alignments(alns)
+
+                def step400():
+                    _, _, nw4 = ctx.candidate(CUT, GAP, 400, order)
+                    ctx.fold(400)
+                    f4 = ctx.last_fold_fallbacks()
+                    r4 = ctx.predict(n_samples, 18, 23, False, True)
+                    return nw4, len(r4["result"]), f4, ctx.last_timings()
+                step400()
+                t = time.time()
+                k4 = [step400() for _ in range(2)]
+                el = time.time() - t
+                cfgs["L400"] = {"workload": "config1 generator at PRECURSOR_LEN = 400 (windows of 400 / 425 nt): fold_generic_kernel, DP tables in HBM",
+                                "windows_per_s": k4[-1][0] * 2 / el, "ms_per_step": 1e3 * el / 2, "windows": int(k4[-1][0]), "loci_found": int(k4[-1][1]),
+                                "fold_generic_fallback_windows": int(k4[-1][2]), "fold_ms": float(np.mean([x[3]["fold_ms"] for x in k4]))}
                 cfgs["note"] = ("config3 / config4 are multi-GPU workloads: `python bench.py --gpus 8 --workload config3|config4` (a rank's shard of either is covered at "
                                 "full size by tests/test_configs_gpu.py); the headline above stays config1")
                 line["configs"] = cfgs

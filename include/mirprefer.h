@@ -53,7 +53,7 @@ typedef struct {
 } MirpWindow;
 typedef struct { int32_t tid, start, end, n_windows; int32_t w[2][2]; int64_t peak_first; int32_t n_peaks; int32_t pad; } MirpLocus; /* dict_loci entry (MP:1312-1316) */
 
-#define MIRP_MAX_SAMPLES 16
+#define MIRP_MAX_SAMPLES 255     /* ALIGNMENT_FILEs of one run (MP:3300-3308 has no limit; a record's sample index is 8 bits wide) */
 #define MIRP_MAX_MIRNA_PER_WINDOW 8
 typedef struct { int32_t n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen; } MirpPredictParams;
 /* One entry of check_loci's `miRNAs` list (MP:2296-2343); the structure text is line `line` of the window's fold

@@ -196,33 +196,64 @@ __device__ __forceinline__ long long aln_lower_bound(const MirpAln* __restrict__
 struct ExprRes {
     long long total_this, total_mature, total_iso, total_star; // total_star = after max with imperfect (when key present)
     long long raw_star, total_anti, imp[3];                    // reasons mode: star before the imperfect maximum, antisense depth, the three imperfect-star depths
-    int mature_each[MIRP_MAX_SAMPLES];                          // reasons mode: mature depth per sample
     int distance, has_imp_key, imp_start, imp_end, imp_which /* -1 none */;
     double ratio_total, ratio_iso;
     bool too_many_start, expressed_all, exception;
 };
 
 // check_expression_new (MP:2037-2163) on reads kept by gen_mapinfo_each_sample (MP:2021)
+// Sample sets as bit masks over the 8-bit sample index of a record (any number of ALIGNMENT_FILEs up to MIRP_MAX_SAMPLES, MP:3300-3308): eight words,
+// indexed through compile-time selects so that they stay in registers.
+struct SampleSet {
+    unsigned int w[8];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = 0u;
+    }
+    __device__ __forceinline__ bool test_and_set(int s) {          // -> was the bit clear?
+        const unsigned int bit = 1u << (s & 31);
+        const int wi = s >> 5;
+        bool fresh = false;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i == wi) { fresh = !(w[i] & bit); w[i] |= bit; }
+        return fresh;
+    }
+    __device__ __forceinline__ bool holds_first(int n) const {       // bits 0 .. n-1 all set
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int lo = 32 * i;
+            if (n > lo) { const unsigned int want = (n - lo >= 32) ? 0xffffffffu : ((1u << (n - lo)) - 1u); ok = ok && ((w[i] & want) == want); }
+        }
+        return ok;
+    }
+};
+
+// mature_each (reasons mode): where the per-sample mature depths go -- the tail of the thread's own reasons record, already zeroed; nullptr otherwise
 template <bool REASONS>
 __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_samples, int tid, int ws, int we, int fold_s, int fold_e,
-                             int m0, int m1, int star_s, int star_e, int strand, int allow_3nt, ExprRes& o) {
+                             int m0, int m1, int star_s, int star_e, int strand, int allow_3nt, ExprRes& o, int* mature_each, int mature_each_cap) {
     const int mature_len = m1 - m0, star_len = star_e - star_s, pre_len = fold_e - fold_s;
     long long k0 = aln_lower_bound(a, na, tid, fold_s > ws ? fold_s : ws), k1 = aln_lower_bound(a, na, tid, fold_e);
     long long tot_pre = 0, tot_mat = 0, tot_iso = 0, tot_star = 0, imp[3] = {0, 0, 0};
-    unsigned int mature_mask = 0;   // samples with reads_mature > 0
-    int starts = 0;
-    int last_pos[MIRP_MAX_SAMPLES];
-    for (int s = 0; s < MIRP_MAX_SAMPLES; s++) last_pos[s] = -1;
+    SampleSet mature_set;          // samples with reads_mature > 0
+    SampleSet seen;                // samples with a read on this strand starting at cur_pos (the records are sorted by position)
+    mature_set.clear(); seen.clear();
+    int starts = 0, cur_pos = -1;
     long long tot_anti = 0;
-    if (REASONS) for (int s = 0; s < MIRP_MAX_SAMPLES; s++) o.mature_each[s] = 0;
     for (long long k = k0; k < k1; k++) {
         MirpAln r = a[k];
         if (r.pos < ws || r.pos + (int)r.len > we) continue;
         if ((int)r.strand != strand) { if (REASONS) tot_anti += (int)r.depth; continue; }   // antisense reads do not enter any rule used by check_loci
         int d = (int)r.depth, rl = r.len, sp = r.pos, sm = r.sample;
-        if (last_pos[sm] != sp) { last_pos[sm] = sp; starts++; }
+        if (sp != cur_pos) { cur_pos = sp; seen.clear(); }
+        if (seen.test_and_set(sm)) starts++;          // once per (start position, sample with reads there), MP:2066-2068
         tot_pre += d;
-        if (sp == m0 && rl == mature_len) { tot_mat += d; if (d > 0) mature_mask |= 1u << sm; if (REASONS) o.mature_each[sm] += d; }
+        if (sp == m0 && rl == mature_len) {
+            tot_mat += d;
+            if (d > 0) (void)mature_set.test_and_set(sm);
+            if (REASONS) { if (mature_each && sm < mature_each_cap) mature_each[sm] += d; }
+        }
         if (sp == star_s && rl == star_len) tot_star += d;
         int dx = sp - m0, dl = rl - mature_len;
         if (dx >= -3 && dx <= 3 && dl >= -3 && dl <= 3) tot_iso += d;
@@ -256,7 +287,7 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
     o.ratio_iso = o.exception ? 0.0 : (double)(tot_iso + st) / (double)tot_pre;
     // only the LAST sample's start counter is ever non-zero (stale loop variable, MP:2046/2068)
     o.too_many_start = ((double)starts / pre_len) > 0.5;
-    o.expressed_all = (mature_mask == ((n_samples >= 32) ? 0xffffffffu : ((1u << n_samples) - 1u)));
+    o.expressed_all = mature_set.holds_first(n_samples);
 }
 
 // REASONS: the -d mode of the reference (check_loci's dict_why_not_miRNA_reasons, MP:2206-2347): every evaluated (mature, structure) pair is
@@ -429,10 +460,15 @@ __global__ void __launch_bounds__(64, MIRP_PRED_WPS) predict_kernel(
                         long long tm = 0, ts = 0;
                         ExprRes rx;
                         rx.exception = true;
+                        int* rrec = nullptr;          // reasons mode: this (mature, structure) pair's record, claimed before the expression test fills its tail
+                        if (REASONS) {
+                            const unsigned int ridx = atomicAdd(rcount, 1u);
+                            if (ridx < rcap) { rrec = rpool + (size_t)ridx * rstride; for (int q = 12; q < rstride; q++) rrec[q] = 0; }
+                        }
                         if (ms.code == 0) {
                             ExprRes& ex = rx;
                             d_expression<REASONS>(alns, n_alns, pp.n_samples, W.tid, W.ws, W.we, ms.fold_s, ms.fold_e, m.start, m.end, ms.star_s, ms.star_e,
-                                         m.strand, pp.allow_3nt, ex);
+                                         m.strand, pp.allow_3nt, ex, (REASONS && rrec && rstride > 21) ? rrec + 21 : nullptr, rstride - 21);
                             tm = ex.total_mature; ts = ex.total_star;
                             // 'max_imperfect_star' in exprinfo (MP:2161, 2631-2635): bit0 key present, bits1-2 which+1, bit3 max > 0
                             impf = (ex.has_imp_key ? 1 : 0) | ((ex.imp_which + 1) << 1) | ((ex.imp_which >= 0) ? 8 : 0);
@@ -451,16 +487,13 @@ __global__ void __launch_bounds__(64, MIRP_PRED_WPS) predict_kernel(
                             int flags = 0;
                             ExprRes* exp_ = nullptr;
                             (void)exp_;
-                            const unsigned int ridx = atomicAdd(rcount, 1u);
-                            if (ridx < rcap) {
-                                int* r = rpool + (size_t)ridx * rstride;
+                            if (rrec) {
+                                int* r = rrec;
                                 r[0] = w; r[1] = mi; r[2] = s; r[3] = p.line; r[4] = p.off; r[5] = p.len; r[6] = ms.code; r[8] = ms.fold_s; r[9] = ms.fold_e;
                                 r[10] = ms.star_s; r[11] = ms.star_e;
-                                for (int q = 12; q < rstride; q++) r[q] = 0;
                                 if (ms.code == 0) {
                                     r[12] = (int)rx.total_this; r[13] = (int)rx.total_anti; r[14] = (int)rx.total_mature; r[15] = (int)rx.total_iso; r[16] = (int)rx.raw_star;
                                     r[17] = (int)rx.imp[0]; r[18] = (int)rx.imp[1]; r[19] = (int)rx.imp[2]; r[20] = rx.distance;
-                                    for (int q = 0; q < pp.n_samples && 21 + q < rstride; q++) r[21 + q] = rx.mature_each[q];
                                     if (rx.exception) flags |= 256;
                                     else if (rx.distance <= 4) flags |= 1;
                                     else if (rx.total_star > 0) { if (rx.ratio_total < 0.2) flags |= 2; else flags |= 128; }

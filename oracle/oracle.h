@@ -66,7 +66,7 @@ typedef struct { int32_t code; int32_t star_s, star_e, fold_s, fold_e; int32_t p
 int oracle_duplex_code(const char *mature, int ml, const char *star, int sl);   /* stat_duplex + pass_stat_duplex alone: MS_* code */
 int oracle_maturestar(const char *ss, int len, int m0, int m1, int foldstart, int regionstart, int regionend, int strand, OracleMatureStar *out);
 
-#define ORACLE_MAX_SAMPLES 16
+#define ORACLE_MAX_SAMPLES 256
 typedef struct {
     int32_t reads_pre[ORACLE_MAX_SAMPLES], reads_mature[ORACLE_MAX_SAMPLES], reads_star[ORACLE_MAX_SAMPLES], reads_antisense[ORACLE_MAX_SAMPLES];
     int32_t reads_isoform[ORACLE_MAX_SAMPLES], reads_inside[ORACLE_MAX_SAMPLES], bases_with_reads_start[ORACLE_MAX_SAMPLES];

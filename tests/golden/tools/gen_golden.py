@@ -215,6 +215,10 @@ if __name__ == "__main__":
     if "mini185" in what:
         # the "mini" dataset with the RNALfold the reference bundles for Linux (1.8.5) on PATH instead of 2.1.2
         gen_pipeline_golden("mini185", [120000, 60000, 90000], ["Chr2", "Chr10", "Chr1"], 130, 2, 5, None, {}, rnalfold="RNALfold185")
+    if "mini24" in what:
+        # 24 ALIGNMENT_FILEs: more samples than one 16-entry register array held in rounds 1-4 (the reference has no limit, MP:3300-3308); both
+        # no-star rules that look at every sample (MP:2316-2330) are in play with ALLOW_NO_STAR_EXPRESSION = Y
+        gen_pipeline_golden("mini24", [70000, 40000], ["ctgY", "ctgX"], 70, 24, 11, None, {})
     if "mini3" in what:
         gen_pipeline_golden("mini3", [80000, 50000], ["ctgB", "ctgA"], 70, 3, 9, [1, 0],
                             {"ALLOW_3NT_OVERHANG": "Y", "ALLOW_NO_STAR_EXPRESSION": "N", "MAX_MATURE_LEN": 24})

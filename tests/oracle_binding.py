@@ -25,7 +25,7 @@ def build():
 
 
 MAX_STRUCTS = 512
-MAX_SAMPLES = 16
+MAX_SAMPLES = 256
 
 
 class Struct(C.Structure):

@@ -19,7 +19,7 @@ def _gpu_record(m, ss, names):
             records.STRAND[m["strand"]], bool(m["has_star"])]
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3", "mini185"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
 def test_pipeline_matches_reference_fixture(name, gpu_ctx):
     c = gu.load_pipeline_case(name)
     gpu_ctx.set_fold_model(c["exp"].get("fold_model", "vienna-2.1.2"))
@@ -108,3 +108,44 @@ def test_pipeline_matches_oracle_on_larger_dataset(gpu_ctx, oracle):
     want = [mirna_record(m, names) for _, m in result]
     got = [_gpu_record(m, ss, names) for m, ss in zip(out["result"], out["ss"])]
     assert got == want and len(got) > 50
+
+
+@pytest.mark.parametrize("n_samples,allow3,no_star", [(40, False, True), (70, True, True), (255, False, True)])
+def test_many_samples_match_oracle(gpu_ctx, oracle, n_samples, allow3, no_star):
+    """More ALIGNMENT_FILEs than 16 / 32 / 64 (the reference has no limit, MP:3300-3308; a record's sample index is 8 bits): the per-sample rules of the
+    expression test -- mature reads in EVERY sample, start positions per sample (MP:2066-2068, 2316-2330) -- through the filter kernel's sample sets
+    (eight mask words), result list and the -d records' per-sample mature depths against the oracle."""
+    ds = synth.make_dataset([160000, 90000], 170, n_samples=n_samples, seed=100 + n_samples, contig_names=["k2", "k1"], edge_cases=True)
+    names, alns = ds.contig_names, ds.sorted_alns()
+    assert int(alns["sample"].max()) == n_samples - 1
+    cut, gap, L = 10, 100, 300
+    order = _sorted_order(names)
+    _, peaks = oracle.coverage_peaks(alns, ds.contig_lens, cut)
+    win = oracle.make_windows(peaks, alns, ds.contigs, order, gap, L, cut * 0.5)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(cut, gap, L, order)
+    assert nwin == len(win["windows"]) > 100
+    gpu_ctx.fold(L)
+    out = gpu_ctx.predict(n_samples, 18, 23, allow3, no_star)
+    structs = [oracle.structures_from_lines(oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L)["lines"], 55) for b in win["windows"]]
+    case = {"cfg": {"MIN_MATURE_LEN": 18, "MAX_MATURE_LEN": 23, "ALLOW_3NT_OVERHANG": "Y" if allow3 else "N", "ALLOW_NO_STAR_EXPRESSION": "Y" if no_star else "N"},
+            "win": win, "sample_names": ds.sample_names, "alns": alns}
+    _, result = run_predict(case, oracle, structs)
+    want = [mirna_record(m, names) for _, m in result]
+    got = [_gpu_record(m, ss, names) for m, ss in zip(out["result"], out["ss"])]
+    assert got == want and len(got) > 10
+    # -d records: the per-sample mature depths of every evaluated (mature, structure) pair sum to its total, and name only real samples
+    rec = gpu_ctx.predict_reasons(n_samples, 18, 23, allow3, no_star)
+    pairs = rec[(rec[:, 1] >= 0) & (rec[:, 6] == 0)]
+    assert rec.shape[1] == 21 + n_samples and len(pairs) > 20
+    assert (pairs[:, 21:].sum(axis=1) == pairs[:, 14]).all()
+    # one pair recomputed by the oracle, sample by sample
+    w = win["windows"]
+    for r in pairs[:: max(1, len(pairs) // 25)]:
+        b = w[int(r[0])]
+        m = win["matures"][b["mature_off"] + int(r[1])]
+        e = oracle.expression(alns, n_samples, int(b["tid"]), int(b["ws"]), int(b["we"]), int(r[8]), int(r[9]), int(m["start"]), int(m["end"]), int(r[10]), int(r[11]),
+                              int(m["strand"]), allow3)
+        assert [int(x) for x in r[21:]] == [int(e.reads_mature[s]) for s in range(n_samples)]
+        assert int(r[12]) == e.total_this_strand and int(r[14]) == e.total_mature
