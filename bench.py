@@ -295,17 +295,20 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
         sams = ds.write_sams(tmp)
         fa = os.path.join(tmp, "genome.fa")
         ds.write_fasta(fa)
-        cfg = os.path.join(tmp, "config")
-        with open(cfg, "w") as f:
-            f.write("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = bench\nPRECURSOR_LEN = %d\nREADS_DEPTH_CUTOFF = %d\nMAX_GAP = %d\n%s"
-                    % (fa, ", ".join(sams), os.path.join(tmp, "out"), L, CUT, GAP, extra_cfg))
+        cfg_text = ("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %%s\nNAME_PREFIX = bench\nPRECURSOR_LEN = %d\nREADS_DEPTH_CUTOFF = %d\nMAX_GAP = %d\n%s"
+                    % (fa, ", ".join(sams), L, CUT, GAP, extra_cfg))
         in_bytes = sum(os.path.getsize(p) for p in sams) + os.path.getsize(fa)
         env = dict(os.environ)
         env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
         env["MIRP_CLI_TIMINGS"] = os.path.join(tmp, "timings.json")
         recs = []
         for rep in range(runs):
-            shutil.rmtree(os.path.join(tmp, "out"), ignore_errors=True)
+            # every run writes into a folder of its own and NOTHING is deleted until the whole bench is done (_E2E_TRASH): on the box's overlay file
+            # system a burst of deletions makes the next seconds' file creations 6 - 9 x slower (10 -> 65 .. 97 us per file, profiles/tools/fs_regime.py),
+            # which would charge the harness's own clean-up to the next run's 4,002 / 16,016 report files
+            cfg = os.path.join(tmp, "config%d" % rep)
+            with open(cfg, "w") as f:
+                f.write(cfg_text % os.path.join(tmp, "out%d" % rep))
             if pause_s:
                 time.sleep(pause_s)
             t0 = time.time()
@@ -327,8 +330,8 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
                 if ln.endswith(" miRNAs identified."):
                     loci = int(ln.split()[0])
             recs.append({"process_wall_s": wall, "segments_s": {k: round(v, 4) for k, v in seg.items()}, "device_s": {k: round(v, 4) for k, v in dev.items()}, "loci": loci})
-        out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs)
-        n_small = len(os.listdir(os.path.join(tmp, "out", "readmapping"))) if os.path.isdir(os.path.join(tmp, "out", "readmapping")) else 0
+        out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(tmp, "out0")) for f in fs)
+        n_small = len(os.listdir(os.path.join(tmp, "out0", "readmapping"))) if os.path.isdir(os.path.join(tmp, "out0", "readmapping")) else 0
         probe = os.path.join(tmp, "fsprobe")          # what this file system charges for creating a small file right now (one per miRNA locus is the reference's
         os.makedirs(probe)                             # output format: readmapping/<id>.map.txt); it varies 12 .. 100 us from one second to the next on an overlay
         t = time.time()
@@ -349,7 +352,16 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
                         "library load + device context, then the four stages, removetmp, exit = end of main() -> process gone; stage_device_s = device time "
                         "inside each stage"}
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        _E2E_TRASH.append(tmp)
+
+
+_E2E_TRASH = []          # directories of the end-to-end legs, removed when the bench is done (see e2e_process)
+
+
+def e2e_cleanup():
+    import shutil
+    while _E2E_TRASH:
+        shutil.rmtree(_E2E_TRASH.pop(), ignore_errors=True)
 
 
 def ingest_leg(ctx, n_records):
@@ -802,6 +814,8 @@ def main():
             if not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(ds, alns, order, a.cpu_budget)
         print(json.dumps(line))
+        sys.stdout.flush()
+        e2e_cleanup()
     if world > 1:
         tdist.barrier()
         if rccl_error is None:

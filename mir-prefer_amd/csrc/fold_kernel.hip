@@ -32,6 +32,29 @@ struct GTab {
 #define GEN_NT 256
 #define GEN_G 8   // lanes cooperating on one cell
 
+__host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines) {
+    const int nc = n_cap + 8;
+    size_t b = 0;
+    b += sizeof(int) * nc;                          // f3
+    b += sizeof(int) * 2 * max_lines;               // starts, lens
+    b += sizeof(int) * (GEN_NT / 64) * 3 * BT_STACK;
+    b += sizeof(int) * 8;
+    b += sizeof(short) * 3 * nc;
+    b += 2 * nc;
+    b += (GEN_NT / 64) * nc;
+    return (b + 15) & ~(size_t)15;
+}
+
+// one table (c or fML) of a workspace slot, in ints
+__host__ __device__ size_t fold_generic_table_ints(int n_cap, int span) {
+    size_t D = (size_t)(span < n_cap ? span : n_cap) + 1;
+    size_t per = D * (size_t)(n_cap + 2);
+    return (per + 63) & ~(size_t)63;
+}
+
+// split candidates a column can hold: one per diagonal at most
+__host__ __device__ int fold_generic_pool_cap(int n_cap, int span) { return (span < n_cap ? span : n_cap) + 1; }
+
 __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs,
     const int* __restrict__ win_lens, const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints,
@@ -49,6 +72,10 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     unsigned char* S = (unsigned char*)(spec + 3 * nc);    // nc
     unsigned char* seq = S + nc;                           // nc
     char* btbuf = (char*)(seq + nc);                       // (NT/64)*nc
+    int* pcnt = (int*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines));      // nc: split candidates of every column so far
+    int* cbest = pcnt + nc;                                // nc: interior-loop minimum of the diagonal's cells
+    unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
+    unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
 
     const int tid = threadIdx.x;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
@@ -100,71 +127,115 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
         }
         GTab T;
         T.ld = n_cap + 2;
+        const size_t tab_ints = fold_generic_table_ints(n_cap, span);
         T.c = ws + (size_t)blockIdx.x * ws_slot_ints;
-        T.m = T.c + ws_slot_ints / 2;
+        T.m = T.c + tab_ints;
+        // Multiloop splits (round 5): DML(i,j) = min_s fML(i,s-1) + fML(s,j) is kept for the last four diagonals (the cell's own fML needs DML(i,j), the
+        // closing term of (i,j) is DML(i+1,j-1) of diagonal d-2 -- the dense kernel recomputed that loop), and a diagonal's DML comes from
+        // DML(i,j-1) and the SPLIT CANDIDATES of column j only: the cells (s,j) whose fML is realised strictly by their pair term (exact with
+        // ML_BASE = 0: any other split is dominated, DESIGN.md 4 / tests/tools/splitcand_gate.c).  Column j's candidates {s, fML(s,j)} are appended to
+        // pool[j] by the one cell of the column on each diagonal (no contention), counts in LDS.
+        int* dml = T.m + tab_ints;                              // [4][ld]
+        int2* pool = reinterpret_cast<int2*>(dml + 4 * (size_t)T.ld);      // [ld][pcap]
+        const int pcap = fold_generic_pool_cap(n_cap, span);
         // diagonal TURN of fML must read as INF
         for (int x = tid; x <= n; x += GEN_NT) T.m[(size_t)TURN * T.ld + x] = INF;
+        for (int x = tid; x < 4 * T.ld; x += GEN_NT) dml[x] = INF;
+        for (int x = tid; x <= n + 1; x += GEN_NT) pcnt[x] = 0;
         __syncthreads();
         WinCtx X;
         X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D;
 
-        // ---- anti-diagonal wavefront fill: all cells with the same d = j - i are independent
-        const int sub = tid % GEN_G;
+        // ---- anti-diagonal wavefront fill: all cells with the same d = j - i are independent.  Three intervals per diagonal:
+        //  0  pair types of the diagonal's cells, the paired ones compacted into a list;
+        //  A  interior loops with LANE = PAIRED CELL and a wave-uniform loop shape: a task is (block of 64 paired cells, n1), the n2 loop runs in lockstep,
+        //     so every lane of a wave evaluates the same (n1, n2) form of the loop energy (no divergence inside e_intloop) and the lanes' reads of
+        //     c(p, q) are neighbours on ONE diagonal (d - n1 - n2 - 2); the minimum per cell is merged with an LDS atomic;
+        //  B  a thread per cell: hairpin, multiloop closing from the DML ring, DML(i,j) from DML(i,j-1) and the column's split candidates, fML.
+        const int lane = tid & 63, wave = tid >> 6;
         for (int d = TURN + 1; d <= D; d++) {
             const int ncell = n - d;
-            for (int cell = tid / GEN_G; cell < ((ncell + GEN_NT / GEN_G - 1) / (GEN_NT / GEN_G)) * (GEN_NT / GEN_G); cell += GEN_NT / GEN_G) {
-                const bool live = cell < ncell;
-                const int i = cell + 1, j = i + d;
+            if (tid == 0) sh_misc[7] = 0;
+            __syncthreads();
+            for (int base = 0; base < ncell; base += GEN_NT) {
+                const int cell = base + tid;
                 int type = 0;
-                int best = INF, mdec = INF;
-                if (live) {
-                    type = pair_type(S[i], S[j]);
-                    if (type) {
-                        if (sub == 0) best = e_hairpin(X, i, j, type);
-                        const int si1 = S[i + 1], sj1 = S[j - 1];
-                        const int pmax = (j - 2 - TURN < i + MAXLOOP + 1) ? j - 2 - TURN : i + MAXLOOP + 1;
-                        for (int p = i + 1 + sub; p <= pmax; p += GEN_G) {
-                            int minq = j - i + p - MAXLOOP - 2;
-                            if (minq < p + 1 + TURN) minq = p + 1 + TURN;
-                            const int sp1 = S[p - 1], Sp = S[p];
-                            for (int q = minq; q < j; q++) {
-                                int t2 = pair_type(Sp, S[q]);
-                                if (!t2) continue;
-                                t2 = rtype_of(t2);
-                                int e = e_intloop(P, p - i - 1, j - q - 1, type, t2, si1, sj1, sp1, S[q + 1]) + T.C(q - p, p);
-                                best = e < best ? e : best;
-                            }
+                if (cell < ncell) { type = pair_type(S[cell + 1], S[cell + 1 + d]); ctype[cell] = (unsigned char)type; cbest[cell] = INF; }
+                const unsigned long long bal = __ballot(type != 0);
+                int wbase = 0;
+                if (lane == 0 && bal) wbase = atomicAdd(&sh_misc[7], (int)__popcll(bal));
+                wbase = __shfl(wbase, 0);
+                if (type) plist[wbase + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+            }
+            __syncthreads();
+            const int np = sh_misc[7];
+            const int n1max = (d - 2 - (TURN + 1) < MAXLOOP) ? d - 2 - (TURN + 1) : MAXLOOP;      // q - p = d - n1 - n2 - 2 >= TURN + 1
+            if (n1max >= 0) {
+                const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
+                for (int t = wave; t < ntask; t += GEN_NT / 64) {
+                    const int blk = t / (n1max + 1), n1 = t - blk * (n1max + 1);
+                    const int k = blk * 64 + lane;
+                    if (k < np) {
+                        const int cell = plist[k];
+                        const int i = cell + 1, j = i + d, p = i + 1 + n1;
+                        const int type = ctype[cell];
+                        const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1], Sp = S[p];
+                        int n2max = MAXLOOP - n1;
+                        if (n2max > d - n1 - 2 - (TURN + 1)) n2max = d - n1 - 2 - (TURN + 1);
+                        int best = INF;
+                        for (int n2 = 0; n2 <= n2max; n2++) {
+                            const int q = j - 1 - n2;
+                            int t2 = pair_type(Sp, S[q]);
+                            if (!t2) continue;
+                            t2 = rtype_of(t2);
+                            const int e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, S[q + 1]) + T.C(q - p, p);
+                            best = e < best ? e : best;
                         }
-                        // multiloop closed by (i,j): DML(i+1, j-1)
-                        int dec = INF;
-                        for (int k = i + 2 + TURN + sub; k <= j - 3 - TURN; k += GEN_G) {
-                            int e = T.M(k - i - 1, i + 1) + T.M(j - k - 2, k + 1);
-                            dec = e < dec ? e : dec;
-                        }
-                        dec += P->ML_closing + e_mlstem(P, rtype_of(type), sj1, si1);
-                        best = dec < best ? dec : best;
-                    }
-                    for (int k = i + 1 + TURN + sub; k <= j - 2 - TURN; k += GEN_G) {
-                        int e = T.M(k - i, i) + T.M(j - k - 1, k + 1);
-                        mdec = e < mdec ? e : mdec;
+                        if (best < INF) atomicMin(&cbest[cell], best);
                     }
                 }
-#pragma unroll
-                for (int o = GEN_G / 2; o > 0; o >>= 1) {
-                    int t = __shfl_xor(best, o); best = t < best ? t : best;
-                    int u = __shfl_xor(mdec, o); mdec = u < mdec ? u : mdec;
-                }
-                if (live && sub == 0) {
+            }
+            __syncthreads();
+            for (int cell = tid; cell < ncell; cell += GEN_NT) {
+                const int i = cell + 1, j = i + d;
+                const int type = ctype[cell];
+                int best = INF;
+                if (type) {
+                    best = e_hairpin(X, i, j, type);
+                    const int il = cbest[cell];
+                    best = il < best ? il : best;
+                    // multiloop closed by (i,j): DML(i+1, j-1), kept from diagonal d-2
+                    int dec = dml[(size_t)((d - 2) & 3) * T.ld + i + 1];
+                    dec += P->ML_closing + e_mlstem(P, rtype_of(type), S[j - 1], S[i + 1]);
+                    best = dec < best ? dec : best;
                     if (best > INF) best = INF;
-                    int mm = T.M(d - 1, i + 1);
-                    int m2 = T.M(d - 1, i);
-                    mm = m2 < mm ? m2 : mm;
-                    if (type) { int e = best + ml_term(X, i, j, type); mm = e < mm ? e : mm; }
-                    mm = mdec < mm ? mdec : mm;
-                    if (mm > INF) mm = INF;
-                    T.c[(size_t)d * T.ld + i] = type ? best : INF;
-                    T.m[(size_t)d * T.ld + i] = mm;
                 }
+                // DML(i,j): DML(i,j-1) and the candidates of column j (those far enough from i for fML(i,s-1) to exist)
+                int mdec = dml[(size_t)((d - 1) & 3) * T.ld + i];
+                const int pn = pcnt[j];
+                const int2* pj = pool + (size_t)j * pcap;
+                for (int k = 0; k < pn; k++) {
+                    const int2 en = pj[k];
+                    if (en.x < i + TURN + 2) continue;
+                    const int e = T.M(en.x - 1 - i, i) + en.y;
+                    mdec = e < mdec ? e : mdec;
+                }
+                if (mdec > INF) mdec = INF;
+                int mm = T.M(d - 1, i + 1);
+                const int m2 = T.M(d - 1, i);
+                mm = m2 < mm ? m2 : mm;
+                mm = mdec < mm ? mdec : mm;
+                if (type) {
+                    const int e = best + ml_term(X, i, j, type);
+                    if (e < mm) {          // realised strictly by the pair term: (i,j) is a split candidate of column j
+                        mm = e;
+                        if (pn < pcap) { pool[(size_t)j * pcap + pn] = make_int2(i, e); pcnt[j] = pn + 1; }
+                    }
+                }
+                if (mm > INF) mm = INF;
+                T.c[(size_t)d * T.ld + i] = type ? best : INF;
+                T.m[(size_t)d * T.ld + i] = mm;
+                dml[(size_t)(d & 3) * T.ld + i] = mdec;
             }
             __syncthreads();
         }
@@ -173,23 +244,13 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     }
 }
 
-size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
-    const int nc = n_cap + 8;
-    size_t b = 0;
-    b += sizeof(int) * nc;                          // f3
-    b += sizeof(int) * 2 * max_lines;               // starts, lens
-    b += sizeof(int) * (GEN_NT / 64) * 3 * BT_STACK;
-    b += sizeof(int) * 8;
-    b += sizeof(short) * 3 * nc;
-    b += 2 * nc;
-    b += (GEN_NT / 64) * nc;
-    return (b + 15) & ~(size_t)15;
-}
+// split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
+size_t fold_generic_lds_bytes(int n_cap, int max_lines) { return fold_generic_lds_bytes_base(n_cap, max_lines) + (size_t)(4 + 4 + 2 + 1) * (size_t)(n_cap + 8) + 16; }
 
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
-    size_t D = (size_t)(span < n_cap ? span : n_cap) + 1;
-    size_t per = D * (size_t)(n_cap + 2);
-    return 2 * ((per + 63) & ~(size_t)63);
+    // c, fML, four diagonals of DML, the candidate pool (two ints per entry)
+    const size_t ld = (size_t)n_cap + 2;
+    return 2 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63);
 }
 
 void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs,

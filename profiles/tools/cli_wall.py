@@ -12,3 +12,4 @@ specs, ns, bg, _, _ = bench.workload_specs(wl, 1)
 contigs, alns, samples = bench.build_shard(specs, set(range(len(specs))), ns, bg)
 r = bench.e2e_process(synth.Dataset(contigs, samples, alns, []), "vienna-2.1.2", base, runs, pause_s=pause)
 print(json.dumps(r, indent=1))
+bench.e2e_cleanup()
