@@ -513,11 +513,17 @@ class Context:
             reg[k].tid, reg[k].start, reg[k].end = int(regions[k][0]), int(regions[k][1]), int(regions[k][2])
         d = SamData()
         sec = (C.c_double * 4)()
+        import time
+        t0 = time.time()
         rc = self.lib.mirp_ingest_sams_gpu(self.h, arr, len(paths), int(n_threads), C.cast(reg, C.c_void_p), nreg, C.byref(d), sec)
+        t1 = time.time()
         if rc != 0:
             raise ValueError(self.lib.mirp_last_error(self.h).decode())
         cn, lens, sn, alns, segs = _unpack_sam_data(self.lib, d)
-        return cn, lens, sn, alns, segs, {"tokenize_s": sec[0], "upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3]}
+        # native_other_s: what the library call spends outside its four phases (opening / mapping the files, the host buffers of the result);
+        # host_copy_s: the records copied out of the library's buffer into numpy arrays and the buffer released
+        return cn, lens, sn, alns, segs, {"tokenize_s": sec[0], "upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3],
+                                          "native_other_s": max(0.0, (t1 - t0) - sum(sec)), "host_copy_s": time.time() - t1}
 
     def ingest_sams_shard(self, paths, owner_of_tid, regions=None, n_threads=0):
         """Sharded ingest (mirp_ingest_sams_shard): this rank tokenizes its byte range of every file, records travel to the rank that owns their

@@ -20,7 +20,7 @@
 #include <string.h>
 #include <math.h>
 #include <ctype.h>
-#include "energy_params_t2004.h"
+#include "../mir-prefer_amd/csrc/energy_params_t2004.h"   /* the one copy of the extracted Turner-2004 tables (data; tests/golden/tools/extract_params.py) */
 #include "oracle.h"
 
 #define TURN 3

@@ -17,7 +17,7 @@
 #include <string.h>
 #include <math.h>
 #include <ctype.h>
-#include "energy_params_t1999.h"
+#include "../mir-prefer_amd/csrc/energy_params_t1999.h"   /* the one copy of the extracted Turner-1999 tables (data; tests/golden/tools/extract_params_t1999.py) */
 #include "oracle.h"
 
 #define TURN 3

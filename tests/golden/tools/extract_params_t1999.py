@@ -4,7 +4,7 @@ reference's bundled Linux RNALfold ELF binary and emit them as a plain C header 
 
 Runs only in the build container (needs /root/reference). Output is committed:
   mir-prefer_amd/csrc/energy_params_t1999.h   (product copy)
-  oracle/energy_params_t1999.h                (oracle copy, identical bytes)
+  (oracle/lfold185.c includes that file: one copy of the data)
 """
 import os, re, struct, subprocess, sys
 
@@ -98,6 +98,6 @@ for k, v in scal.items():
 out.append("#define T99_LXC %r" % lxc)
 text = "\n".join(out) + "\n"
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-for dst in ("mir-prefer_amd/csrc/energy_params_t1999.h", "oracle/energy_params_t1999.h"):
+for dst in ("mir-prefer_amd/csrc/energy_params_t1999.h",):          # the one copy: the oracle includes it from there
     open(os.path.join(root, dst), "w").write(text)
 print(scal, lxc, len(tetra), tetra[:5], T["Tetraloop_E"][:5], len(tri), T["hairpin"][:10], T["stack"][8:16])
