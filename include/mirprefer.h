@@ -375,6 +375,24 @@ int mirp_write_result_reports(const MirpMirna* result, int64_t n, const char* ss
                               int32_t n_samples, const char* mirbase_form, const char* outdir, const char* prefix, int32_t* order_out,
                               MirpMirna* sorted_out, int64_t* counts_out, char* errbuf, size_t errbuf_len);
 
+/* Window view: the fold and the filter (mirp_fold, mirp_predict, mirp_predict_reasons) run on windows [first, first + count) of the candidate stage's
+ * list until the view is changed; count < 0 restores the whole list.  Window indices in the results are relative to `first`.  The getters and text
+ * writers of the candidate stage are not affected by a view and must not be called while one is active.  (Analogue in the reference: the pieces
+ * its folder and filter processes work through one after the other, MP:1329-1354, 2468-2480.) */
+int mirp_select_windows(mirp_ctx* ctx, int64_t first, int64_t count);
+
+/* The fold, the filter and the report files of a single-process run as ONE pipelined call (replaces run_fold + run_predict of the `pipeline` verb,
+ * MP:3441-3627, when no stage artefact is to be kept): the window list is cut into about n_chunks chunks at places where the windows alone decide
+ * the list order of the results (no window before the cut reaches the first window behind it, or the contig changes; an (L, R) pair is never split),
+ * every chunk is folded and filtered (mirp_select_windows + mirp_fold + mirp_predict), and a host thread turns a chunk's loci into read-mapping files
+ * (mirp_write_result_reports' steps) WHILE THE DEVICE FOLDS THE NEXT CHUNK; the seven report files follow at the end.  Arguments as
+ * mirp_write_result_reports; max_lines as mirp_fold.  Out: n_loci, the number of chunks used, device_ms = {fold, filter} summed over the chunks.
+ * Afterwards the context holds the whole window list again, without a fold (mirp_fold must run before any getter of the fold stage). */
+int mirp_fold_predict_report_stream(mirp_ctx* ctx, int32_t span, int32_t max_lines, const MirpPredictParams* pp, int32_t n_chunks, const char* contig_names,
+                                    int32_t n_contigs, const uint8_t* const* contig_seq, const int64_t* contig_len, const MirpAln* alns, int64_t n_alns,
+                                    const char* sample_names, int32_t n_samples, const char* mirbase_form, const char* outdir, const char* prefix,
+                                    int64_t* n_loci, int32_t* n_chunks_used, double device_ms[2]);
+
 #ifdef __cplusplus
 }
 #endif

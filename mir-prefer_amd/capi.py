@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 from . import early
-from .early import LIB_PATH, FastaData
+from .early import LIB_PATH, FastaData, SamData
 ABI_VERSION = 6      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
 
 
@@ -17,11 +17,6 @@ class MirpError(RuntimeError):
 
 class FoldLine(C.Structure):
     _fields_ = [("start", C.c_int32), ("len", C.c_int32), ("energy", C.c_int32), ("printed", C.c_int32)]
-
-
-class SamData(C.Structure):
-    _fields_ = [("n_contigs", C.c_int32), ("contig_names", C.c_void_p), ("contig_len", C.POINTER(C.c_int64)), ("n_samples", C.c_int32),
-                ("sample_names", C.c_void_p), ("alns", C.c_void_p), ("n_alns", C.c_int64), ("segs", C.c_void_p), ("n_segs", C.c_int64)]
 
 
 class Region(C.Structure):
@@ -187,13 +182,20 @@ def _unpack_sam_data(lib, d):
 
 
 def ingest_sams(paths, n_threads=0, with_segments=False):
-    """Native multi-threaded SAM ingest, host sort (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns[, segs])."""
+    """Native multi-threaded SAM ingest, host sort (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns[, segs]).  An ingest of the
+    same files that the CLI started before its heavy imports (early.start_ingest) is adopted instead of run again."""
     lib = load_library()
-    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
-    d = SamData()
-    err = C.create_string_buffer(512)
-    if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
-        raise ValueError(err.value.decode())
+    got = early.take_ingest(paths)
+    if got is not None:
+        rc, d, msg = got
+        if rc != 0:
+            raise ValueError(msg)
+    else:
+        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+        d = SamData()
+        err = C.create_string_buffer(512)
+        if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
+            raise ValueError(err.value.decode())
     out = _unpack_sam_data(lib, d)
     return out if with_segments else out[:4]
 
@@ -781,6 +783,32 @@ class Context:
         r = _copy_out(self.lib, res, records.MIRNA_DTYPE, nres.value)
         t = _copy_out(self.lib, text, np.uint8, nres.value * stride.value).reshape(nres.value, max(stride.value, 1))
         return {"result": r, "text": t, "n_passed": _copy_out(self.lib, npass, np.int32, nw.value), "status": _copy_out(self.lib, stat, np.int32, nw.value)}
+
+    def fold_predict_report_stream(self, span, params, n_chunks, contig_names, contig_arrays, alns, sample_names, mirbase_form, outdir, prefix, max_lines=96):
+        """mirp_fold_predict_report_stream: fold + filter of the resident windows in chunks, a chunk's read-mapping files written by a host thread while the
+        device folds the next chunk, the seven report files at the end.  params = (n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star,
+        minlen).  -> (number of miRNA loci, chunks used, device seconds {fold, predict})."""
+        pp = (C.c_int32 * 6)(*[int(x) for x in params])
+        alns = np.ascontiguousarray(alns)
+        keep = [np.ascontiguousarray(a, dtype=np.uint8) if a is not None and len(a) else None for a in contig_arrays]
+        ptrs = (C.c_void_p * max(len(keep), 1))(*[a.ctypes.data if a is not None else None for a in keep])
+        lens = np.array([len(a) if a is not None else 0 for a in keep] or [0], dtype=np.int64)
+        blob = lambda xs: b"".join(x.encode() + b"\0" for x in xs)
+        nl, nc, ms = C.c_int64(), C.c_int32(), (C.c_double * 2)()
+        fn = self.lib.mirp_fold_predict_report_stream
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int32,
+                       C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        self._check(fn(self.h, int(span), int(max_lines), pp, int(n_chunks), blob(contig_names), len(contig_names), ptrs, lens.ctypes.data,
+                       alns.ctypes.data if len(alns) else None, len(alns), blob(sample_names), len(sample_names), blob(mirbase_form), str(outdir).encode(), str(prefix).encode(),
+                       C.byref(nl), C.byref(nc), ms), "mirp_fold_predict_report_stream")
+        return int(nl.value), int(nc.value), {"fold_s": ms[0] / 1e3, "predict_s": ms[1] / 1e3}
+
+    def select_windows(self, first, count):
+        """mirp_select_windows: the fold and the filter run on windows [first, first + count) until changed; count < 0 = the whole list again."""
+        self.lib.mirp_select_windows.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        self.lib.mirp_select_windows.restype = C.c_int
+        self._check(self.lib.mirp_select_windows(self.h, int(first), int(count)), "mirp_select_windows")
 
     def predict(self, n_samples, min_mature_len, max_mature_len, allow_3nt, allow_no_star, minlen=55):
         from . import records

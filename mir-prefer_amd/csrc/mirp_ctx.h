@@ -88,6 +88,13 @@ struct mirp_ctx {
     DevBuf dist_tmp;
     struct TextJob { std::thread th; int rc = 0; std::string err; };
     std::vector<std::shared_ptr<TextJob>> text_jobs;      // text artefacts still being formatted / written behind the caller (mirp_wait_text)
+    // window view (mirp_select_windows): the fold and the filter run on windows [win_first, win_first + n_windows) of the candidate stage's list;
+    // sel_total = the list's length while a view is active, -1 otherwise
+    long long win_first = 0, sel_total = -1;
+    const MirpWindow* v_windows() const { return (const MirpWindow*)windows.p + win_first; }
+    const int* v_roles() const { return (const int*)roles.p + win_first; }
+    const long long* v_woffs() const { return (const long long*)woffs.p + win_first; }
+    const int* v_wlens() const { return (const int*)wlens.p + win_first; }
     long long n_result = 0;           // records of the last mirp_predict (p_res / p_text), what mirp_gather_loci sends
     bool have_result = false;
 };

@@ -212,11 +212,26 @@ extern "C" int mirp_set_contig_shard(mirp_ctx* c, int32_t preceded_by_coverage_e
     return 0;
 }
 
+extern "C" int mirp_select_windows(mirp_ctx* c, int64_t first, int64_t count) {
+    if (!c) return -1;
+    if (!c->have_candidate) return fail(c, -1, "mirp_select_windows: run mirp_candidate first");
+    const long long total = c->sel_total >= 0 ? c->sel_total : c->n_windows;
+    if (count < 0) {          // back to the whole list
+        c->win_first = 0; c->n_windows = total; c->sel_total = -1;
+    } else {
+        if (first < 0 || first + count > total) return fail(c, -1, "mirp_select_windows: range outside the window list");
+        c->sel_total = total; c->win_first = first; c->n_windows = count;
+    }
+    c->have_fold = false; c->have_result = false;
+    return 0;
+}
+
 extern "C" int mirp_limit_windows(mirp_ctx* c, int64_t n_keep) {
     if (!c) return -1;
     if (!c->have_candidate) return fail(c, -1, "mirp_limit_windows: run mirp_candidate first");
     if (n_keep < 0 || n_keep > c->n_windows) return fail(c, -1, "mirp_limit_windows: n_keep out of range");
     // every later stage reads the window arrays as prefixes of length n_windows (offsets into wpeaks / matures / sequences stay valid)
+    if (c->sel_total >= 0) return fail(c, -1, "mirp_limit_windows: a window view is active (mirp_select_windows)");
     c->n_windows = n_keep;
     c->have_fold = false; c->have_result = false;
     return 0;
@@ -437,7 +452,7 @@ extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
     c->n_side = 0; c->side_max_lines = 0;
     long long fallbacks = 0;
     {
-        int rc = mirp_run_fold(c, (const unsigned char*)c->wseqs.p, (const long long*)c->woffs.p, (const int*)c->wlens.p, (int)nw, n_cap, span, max_lines,
+        int rc = mirp_run_fold(c, (const unsigned char*)c->wseqs.p, c->v_woffs(), c->v_wlens(), (int)nw, n_cap, span, max_lines,
                                stride, (MirpFoldLine*)c->lines.p, (char*)c->ss.p, (int*)c->nlines.p, (int*)c->mfe.p, (int*)c->status.p);
         if (rc) return rc;
         fallbacks = c->last_fallback;
@@ -469,8 +484,8 @@ extern "C" int mirp_fold(mirp_ctx* c, int32_t span, int32_t max_lines) {
                 c->ss2.ensure((size_t)ns * per2) || c->nlines2.ensure(4 * (size_t)ns) || c->mfe2.ensure(4 * (size_t)ns) || c->status2.ensure(4 * (size_t)ns))
                 return fail(c, -6, "device allocation failed (fold overflow buffers)");
             const dim3 g((ns + 255) / 256), b(256);
-            hipLaunchKernelGGL(mirp::side_gather_kernel, g, b, 0, c->stream, (const int*)c->side_list.p, (int)ns, (const long long*)c->woffs.p,
-                               (const int*)c->wlens.p, (long long*)c->side_offs.p, (int*)c->side_lens.p);
+            hipLaunchKernelGGL(mirp::side_gather_kernel, g, b, 0, c->stream, (const int*)c->side_list.p, (int)ns, c->v_woffs(),
+                               c->v_wlens(), (long long*)c->side_offs.p, (int*)c->side_lens.p);
             int rc = mirp_run_fold(c, (const unsigned char*)c->wseqs.p, (const long long*)c->side_offs.p, (const int*)c->side_lens.p, (int)ns, n_cap, span, big,
                                    stride, (MirpFoldLine*)c->lines2.p, (char*)c->ss2.p, (int*)c->nlines2.p, (int*)c->mfe2.p, (int*)c->status2.p);
             if (rc) return rc;
@@ -549,14 +564,14 @@ static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, uns
     if (c->p_need.ensure(12 * (size_t)std::max<long long>(nw, 1))) return fail(c, -6, "device allocation failed (predict)");
     // every launch re-runs the windows that exceeded a capacity of the kernel (structures, pieces per line, candidate matures) at capacities
     // sized for them (run_predict_launch): the reference has no such limits
-    if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+    if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, c->v_windows(), (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
                                           (const MirpFoldLine*)c->lines.p, (const char*)c->ss.p, c->fold_stride, c->fold_max_lines, (const int*)c->nlines.p, pp,
                                           (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip, &err, (int*)c->p_need.p))
         return fail(c, rc, "mirp_predict: " + err);
     if (c->n_side > 0) {
         if (mirp::predict_lds_bytes(c->side_max_lines, c->fold_stride) > 160 * 1024)
             return fail(c, -5, "mirp_predict: a window with more structure lines than the default capacity exceeds the LDS budget of the predict kernel at this PRECURSOR_LEN");
-        if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, (const MirpWindow*)c->windows.p, (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
+        if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, c->v_windows(), (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
                                               (const MirpFoldLine*)c->lines2.p, (const char*)c->ss2.p, c->fold_stride, c->side_max_lines, (const int*)c->nlines2.p, pp,
                                               (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, (const int*)c->side_list.p,
                                               (int)c->n_side, nullptr, &err, (int*)c->p_need.p))
@@ -585,7 +600,7 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
     if (nw > 0) {
         if (int rc = launch_predict_resident(c, *pp, nullptr, nullptr, 0u, 0)) return rc;
         HIPCHK(c, hipEventRecord(c->ev[1], st));
-        hipLaunchKernelGGL(mirp::result_keep_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, st, (const int*)c->roles.p,
+        hipLaunchKernelGGL(mirp::result_keep_kernel, dim3((unsigned)std::min<long long>((nw + 255) / 256, 4096)), dim3(256), 0, st, c->v_roles(),
                            (const int*)c->p_nout.p, nw, (int*)c->p_keep.p);
         mirp::launch_excl_scan(st, (const int*)c->p_keep.p, (long long*)c->p_kscan.p, nw);
         if (read_ll(c, (const long long*)c->p_kscan.p + nw, &nres)) return fail(c, -2, "D2H failed");

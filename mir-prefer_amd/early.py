@@ -17,9 +17,15 @@ class FastaData(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("names", C.c_void_p), ("len", C.POINTER(C.c_int64)), ("seq", C.c_void_p), ("n_bytes", C.c_int64)]
 
 
+class SamData(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("contig_names", C.c_void_p), ("contig_len", C.POINTER(C.c_int64)), ("n_samples", C.c_int32),
+                ("sample_names", C.c_void_p), ("alns", C.c_void_p), ("n_alns", C.c_int64), ("segs", C.c_void_p), ("n_segs", C.c_int64)]
+
+
 _lib = None
 _contexts = {}      # device -> (thread, handle, result box)
 _fastas = {}        # path -> (thread, FastaData, error buffer, result box)
+_ingests = {}       # tuple of SAM paths -> (thread, SamData, error buffer, result box)
 
 
 def cdll():
@@ -75,6 +81,40 @@ def start_fasta(path):
 def take_fasta(path):
     """-> (return code of mirp_read_fasta, FastaData, error text) of the read started for `path`, or None; handed out once (the caller frees)."""
     ent = _fastas.pop(path, None)
+    if ent is None:
+        return None
+    th, d, err, box = ent
+    th.join()
+    return box.get("rc", -1), d, err.value.decode()
+
+
+def start_ingest(paths):
+    """The host ingest of the SAM files (mirp_ingest_sams: tokenizer threads + stable host sort by (tid, pos)) while the device is still being opened;
+    the prepare stage adopts the records (pipeline.Pipeline._prepare_rank0) and only uploads them."""
+    lib = cdll()
+    key = tuple(str(p) for p in paths)
+    if lib is None or not key or key in _ingests or any(p.endswith(".gz") for p in key):
+        return
+    fn = lib.mirp_ingest_sams
+    fn.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(SamData), C.c_char_p, C.c_size_t]      # as capi.load_library declares it
+    fn.restype = C.c_int
+    arr = (C.c_char_p * len(key))(*[p.encode() for p in key])
+    d, err, box = SamData(), C.create_string_buffer(512), {}
+
+    def run():
+        box["rc"] = fn(arr, len(key), 0, C.byref(d), err, 512)
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    _ingests[key] = (th, d, err, box)
+
+
+def has_ingest(paths):
+    return tuple(str(p) for p in paths) in _ingests
+
+
+def take_ingest(paths):
+    """-> (return code of mirp_ingest_sams, SamData, error text) of the ingest started for these paths, or None; handed out once (the caller frees)."""
+    ent = _ingests.pop(tuple(str(p) for p in paths), None)
     if ent is None:
         return None
     th, d, err, box = ent

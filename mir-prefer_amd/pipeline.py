@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-from . import balance, capi, dist, gffmask, ingest, records
+from . import balance, capi, dist, early, gffmask, ingest, records
 
 STAGES = ["prepare", "candidate", "fold", "predict"]
 
@@ -232,6 +232,8 @@ class Pipeline:
         try:
             if any(str(p).endswith(".gz") for p in paths):        # compressed inputs: host parser (same rules), host filter and sort
                 names, lens, samples, alns, segs = ingest.read_sams(paths, regions=regions, with_segments=True)
+            elif regions is None and early.has_ingest(paths):      # the CLI started the host ingest while the device was being opened: adopt it
+                names, lens, samples, alns, segs = capi.ingest_sams(paths, with_segments=True)
             else:       # tokenizer on the host threads; keep-region filter and the stable (tid, pos) sort on the GPU (mirp_ingest_sams_gpu)
                 names, lens, samples, alns, segs, self.ingest_seconds = self.ctx.ingest_sams(paths, regions=regions)
         except ValueError as e:
@@ -462,6 +464,12 @@ class Pipeline:
             self._fail_stage()
         self._say("Starting folding candidate sequences.")
         self._ensure_candidate()
+        if self.lean and self.state == "candidate":
+            # lean run: the fold, the filter and the report files are ONE pipelined native call (mirp_fold_predict_report_stream, run by the predict
+            # stage below): chunks of the window list are folded and filtered while a host thread writes the previous chunk's read-mapping files
+            self.state = "fold"
+            self._stream = True
+            return
         status = self._fold_device()
         self._join_candidate()          # the candidate stage's host artefacts were being written behind the fold kernels (`pipeline` verb)
         self.state = "fold"
@@ -648,8 +656,33 @@ class Pipeline:
     def _run_predict_lean(self):
         """One process, no -k, no -d: the filter's flat result goes straight into the native report writer (mirp_write_result_reports: swap, list order,
         read counts, readmapping/ and the seven report files); no Python object per locus, no result pickle, no checkpoint record."""
-        self._say("Starting predicting miRNAs.")
         ns = len(self.data["samples"])
+        prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
+        mark = "\x00SEQ\x00"
+        form = [p for taxon in ("Viridiplantae", "ALL") for p in _mirbase_form_text(mark, taxon).split(mark)]
+        if getattr(self, "_stream", False):
+            self._stream = False
+            nwin = int(self.counts[2])
+            chunks = int(os.environ.get("MIRP_STREAM_CHUNKS", "0")) or max(1, min(12, (nwin + 3000) // 6000))      # about 6,000 windows a chunk: 23 per CU
+            params = (ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], 1 if self.opt["ALLOW_3NT_OVERHANG"] else 0,
+                      1 if self.opt["ALLOW_NO_STAR_EXPRESSION"] else 0, 55)
+            try:
+                n, used, self.stream_device_s = self.ctx.fold_predict_report_stream(self.opt["PRECURSOR_LEN"], params, chunks, self.data["names"],
+                                                                                   [sq for _, sq in self.data["contigs"]], self.data["alns"], self.data["samples"],
+                                                                                   form, outdir, prefix)
+            except capi.MirpError as e:
+                sys.stderr.write(str(e) + "\n")
+                sys.exit(-1)
+            self._say("Done (fold stage)\n")
+            self._say("Starting predicting miRNAs.")
+            if n == 0:
+                _msg("0 miRNA identified. No result files generated.")
+                return []
+            _msg("The output files are in " + outdir)
+            sys.stdout.write("%d miRNAs identified.\n" % n)
+            _msg("Done (predict stage)\n")
+            return range(n)
+        self._say("Starting predicting miRNAs.")
         out = self.ctx.predict_raw(ns, self.opt["MIN_MATURE_LEN"], self.opt["MAX_MATURE_LEN"], self.opt["ALLOW_3NT_OVERHANG"], self.opt["ALLOW_NO_STAR_EXPRESSION"])
         bad = np.nonzero(out["status"] != 0)[0]
         if len(bad):
@@ -658,9 +691,6 @@ class Pipeline:
         if len(out["result"]) == 0:
             _msg("0 miRNA identified. No result files generated.")
             return out["result"]
-        prefix, outdir = self.opt["NAME_PREFIX"], self.opt["OUTFOLDER"]
-        mark = "\x00SEQ\x00"
-        form = [p for taxon in ("Viridiplantae", "ALL") for p in _mirbase_form_text(mark, taxon).split(mark)]
         res, _, _ = capi.write_result_reports(out["result"], out["text"], self.data["names"], [sq for _, sq in self.data["contigs"]], self.data["alns"],
                                               self.data["samples"], form, outdir, prefix)
         _msg("The output files are in " + outdir)
@@ -672,7 +702,10 @@ class Pipeline:
         c = getattr(self, "clock", None)
         if c is not None and c.path:
             tm = self.ctx.last_timings()
-            c.mark(stage, device_ms={"candidate": tm["coverage_ms"] + tm["candidate_rest_ms"], "fold": tm["fold_ms"], "predict": tm["predict_ms"]}.get(stage, 0.0))
+            sd = getattr(self, "stream_device_s", None)          # lean run: fold + filter ran inside the predict stage's one pipelined call
+            dev = {"candidate": tm["coverage_ms"] + tm["candidate_rest_ms"], "fold": 0.0 if (sd or self.lean) else tm["fold_ms"],
+                   "predict": (sd["fold_s"] + sd["predict_s"]) * 1e3 if sd else tm["predict_ms"]}
+            c.mark(stage, device_ms=dev.get(stage, 0.0))
 
     def run_pipeline(self):
         self.run_prepare()

@@ -80,8 +80,9 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     assert rec["last_stage"] == "predict" and set(rec["finished_stages"]) == {"prepare", "candidate", "fold", "predict"}
 
 
+@pytest.mark.parametrize("chunks", [0, 7])
 @pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
-def test_lean_pipeline_process_reproduces_reference_outputs(name, tmp_path):
+def test_lean_pipeline_process_reproduces_reference_outputs(name, chunks, tmp_path):
     """`python -m mir_prefer_amd.cli pipeline <config>` as a user runs it -- a fresh process, no -k, no -d: the device context and the genome read start
     before the heavy imports (early.py), no stage artefact is written (they would be deleted at the end, MP:3630-3639), the report files come from one
     native call.  The outputs are the reference's byte for byte, the temporary folder is gone, the exit status is 0."""
@@ -90,7 +91,9 @@ def test_lean_pipeline_process_reproduces_reference_outputs(name, tmp_path):
     exp, cfg, out = _setup(name, tmp_path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "mir_prefer_amd.cli", "--fold-model", exp.get("fold_model", "vienna-2.1.2"), "pipeline", cfg], cwd=str(tmp_path),
-                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, PYTHONPATH=root, MIRP_STREAM_CHUNKS=str(chunks)), capture_output=True, text=True, timeout=600)
+    # chunks = 7: the fold / filter / report pipeline (mirp_fold_predict_report_stream) cut into seven chunks of ~40 windows, read-mapping files of one chunk
+    # written while the next is folded; 0 = the default (one chunk at this size)
     assert r.returncode == 0, r.stderr[-2000:]
     prefix = exp["config"]["NAME_PREFIX"]
     rep = exp["reports"]

@@ -149,3 +149,55 @@ def test_many_samples_match_oracle(gpu_ctx, oracle, n_samples, allow3, no_star):
                               int(m["strand"]), allow3)
         assert [int(x) for x in r[21:]] == [int(e.reads_mature[s]) for s in range(n_samples)]
         assert int(r[12]) == e.total_this_strand and int(r[14]) == e.total_mature
+
+
+def test_window_views_and_streamed_reports_equal_the_whole_run(gpu_ctx, oracle, tmp_path):
+    """mirp_select_windows: folding and filtering the window list view by view gives the whole run's result list; mirp_fold_predict_report_stream
+    (chunks cut where the windows decide the list order, files of a chunk written while the next folds) writes the same files as the one-call writer
+    on the whole run's result, for 1, 3 and 9 chunks."""
+    import filecmp
+    import os
+    from mir_prefer_amd import capi, pipeline
+    ds = synth.make_dataset([400000, 250000], 420, n_samples=2, seed=4242, contig_names=["Chr2", "Chr10"], edge_cases=True)      # the `mid` dataset
+    names, alns = ds.contig_names, ds.sorted_alns()
+    order = _sorted_order(names)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(10, 100, 300, order)
+    gpu_ctx.fold(300)
+    whole = gpu_ctx.predict_raw(2, 18, 23, False, True)
+    assert len(whole["result"]) > 100
+    w = gpu_ctx.get_windows()["windows"]
+    # views at L/R-pair boundaries (tag 0 = single window, 1 = L, 2 = R)
+    cuts = [0]
+    for target in (nwin // 3, 2 * nwin // 3):
+        k = target
+        while w[k]["tag"] == 2:
+            k += 1
+        cuts.append(k)
+    cuts.append(nwin)
+    parts = []
+    for a, b in zip(cuts, cuts[1:]):
+        gpu_ctx.select_windows(a, b - a)
+        gpu_ctx.fold(300)
+        out = gpu_ctx.predict_raw(2, 18, 23, False, True)
+        r = out["result"].copy()
+        r["window"] += a
+        parts.append((r, out["text"]))
+    gpu_ctx.select_windows(0, -1)
+    got = np.concatenate([p[0] for p in parts])
+    assert got.tobytes() == whole["result"].tobytes()
+    assert np.concatenate([p[1] for p in parts]).tobytes() == whole["text"].tobytes()
+    mark = "\x00SEQ\x00"
+    form = [p for taxon in ("Viridiplantae", "ALL") for p in pipeline._mirbase_form_text(mark, taxon).split(mark)]
+    ref_dir = tmp_path / "whole"
+    capi.write_result_reports(whole["result"], whole["text"], names, [sq for _, sq in ds.contigs], alns, ds.sample_names, form, str(ref_dir), "x")
+    for chunks in (1, 3, 9):
+        d = tmp_path / ("stream%d" % chunks)
+        n, used, dev = gpu_ctx.fold_predict_report_stream(300, (2, 18, 23, 0, 1, 55), chunks, names, [sq for _, sq in ds.contigs], alns, ds.sample_names, form, str(d), "x")
+        assert n == len(whole["result"]) and 1 <= used <= chunks and (chunks == 1 or used > 1) and dev["fold_s"] > 0
+        cmp = filecmp.dircmp(str(ref_dir), str(d))
+        assert not cmp.left_only and not cmp.right_only
+        for sub, files in ((".", cmp.common_files), ("readmapping", os.listdir(ref_dir / "readmapping"))):
+            match, mismatch, errors = filecmp.cmpfiles(str(ref_dir / sub), str(d / sub), files, shallow=False)
+            assert not mismatch and not errors and len(match) == len(files)
