@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sched.h>
 #include <thread>
 #include <vector>
 #include "mirp_ctx.h"
@@ -215,8 +216,26 @@ struct Parsed {
 // header + threaded tokenizer over every file; records stay in per-chunk vectors (sample, then file order)
 // (part, n_parts): this caller tokenizes the part-th of n_parts equal byte ranges of every file's body (cut at line starts): the sharded ingest
 // of one process per GPU; (0, 1) = the whole file.
+
+// CPUs this process may actually use: the affinity mask and the cgroup quota, not the box's core count (a container on a 256-thread host is often granted
+// 8 or 16; 256 tokenizer threads on 16 CPUs only add switches).
+static int usable_cpus() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0 && k < n) n = k; }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = ""; long long per = 0;
+        if (std::fscanf(f, "%31s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) {
+            const int k = (int)((std::atoll(q) + per - 1) / per);
+            if (k > 0 && k < n) n = k;
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 int parse_all(const char* const* paths, int32_t n_paths, int32_t n_threads, Parsed* P, std::string* err, int part = 0, int n_parts = 1) {
-    if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads < 1) n_threads = usable_cpus();
     NameTable tab;
     P->per_file.resize(n_paths);
     for (int fi = 0; fi < n_paths; fi++) {
@@ -347,7 +366,7 @@ extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32
     if (!paths || n_paths < 1 || !out) return fail("mirp_ingest_sams: bad argument");
     if (n_paths > MIRP_MAX_SAMPLES) return fail("mirp_ingest_sams: too many samples");
     std::memset(out, 0, sizeof(*out));
-    if (n_threads < 1) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads < 1) n_threads = usable_cpus();
     Parsed P;
     std::string err;
     if (parse_all(paths, n_paths, n_threads, &P, &err)) return fail(err);
