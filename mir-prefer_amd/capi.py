@@ -160,24 +160,42 @@ def read_fasta(path, want=None):
 _FASTA_KEEP = []
 
 
-def _unpack_sam_data(lib, d):
-    from .synth import ALN_DTYPE
-    try:
-        def names(ptr, n):
-            out, off = [], 0
-            for _ in range(n):
-                s = C.string_at(ptr + off)
-                out.append(s.decode()); off += len(s) + 1
-            return out
-        cn = names(d.contig_names, d.n_contigs)
-        sn = names(d.sample_names, d.n_samples)
-        lens = np.array([d.contig_len[k] for k in range(d.n_contigs)], dtype=np.int64)
+class _SamHold:
+    """Owns the buffers of one MirpSamData until the record arrays that view them are gone (mirp_free_sam_data then)."""
 
-        def recs(ptr, n):
-            return np.frombuffer((C.c_char * (n * 16)).from_address(ptr), dtype=ALN_DTYPE, count=n).copy() if n else np.zeros(0, dtype=ALN_DTYPE)
-        alns, segs = recs(d.alns, d.n_alns), recs(d.segs, d.n_segs)
-    finally:
-        lib.mirp_free_sam_data(C.byref(d))
+    def __init__(self, lib, d):
+        self.lib, self.d = lib, d
+
+    def __del__(self):
+        try:
+            self.lib.mirp_free_sam_data(C.byref(self.d))
+        except Exception:
+            pass
+
+
+def _unpack_sam_data(lib, d):
+    """-> (contig names, lengths, sample names, alns, segs).  The record arrays are VIEWS of the library's buffers (no copy of 16 bytes x 10^7 records:
+    the copy was half of the ingest leg's wall-clock); the buffers are released when the last array viewing them is collected."""
+    from .synth import ALN_DTYPE
+    hold = _SamHold(lib, d)
+
+    def names(ptr, n):
+        out, off = [], 0
+        for _ in range(n):
+            s = C.string_at(ptr + off)
+            out.append(s.decode()); off += len(s) + 1
+        return out
+    cn = names(d.contig_names, d.n_contigs)
+    sn = names(d.sample_names, d.n_samples)
+    lens = np.array([d.contig_len[k] for k in range(d.n_contigs)], dtype=np.int64)
+
+    def recs(ptr, n):
+        if not n:
+            return np.zeros(0, dtype=ALN_DTYPE)
+        buf = (C.c_char * (n * 16)).from_address(ptr)
+        buf._hold = hold          # the array's base keeps the owner alive
+        return np.frombuffer(buf, dtype=ALN_DTYPE, count=n)
+    alns, segs = recs(d.alns, d.n_alns), recs(d.segs, d.n_segs)
     return cn, lens, sn, alns, segs
 
 

@@ -11,6 +11,13 @@
 namespace mirp {
 namespace v185 {
 
+__host__ __device__ inline size_t fold185_lds_bytes_base(int n_cap, int max_lines) {
+    const size_t nc = (size_t)n_cap + 8;
+    size_t b = sizeof(int) * (nc + 8 + 2 * (size_t)max_lines + (V_NT / 64) * 3 * V_BT_STACK + V_NT / 64 + 8);
+    b += sizeof(short) * nc + 2 * nc + (V_NT / 64) * (nc + 8);
+    return (b + 15) & ~(size_t)15;
+}
+
 __global__ void __launch_bounds__(V_NT) fold185_kernel(
     const FoldParams185* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
@@ -26,6 +33,9 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
     unsigned char* S = (unsigned char*)(tetra + nc);       // nc
     unsigned char* seq = S + nc;                           // nc
     char* btbuf = (char*)(seq + nc);                       // (NT/64) * (nc + 8)
+    int* cbest = (int*)(smem + fold185_lds_bytes_base(n_cap, max_lines));      // nc: interior-loop minimum of the diagonal's cells
+    unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
+    unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = span;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
@@ -70,31 +80,62 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
 
         // ---- anti-diagonal wavefront fill; cells at distance M hold c = INF but a finite fML
         const int Dmax = M < n - 1 ? M : n - 1;
+        // Three intervals per diagonal (round 5, as fold_generic_kernel): pair types + the list of paired cells; interior loops with LANE = PAIRED CELL and a
+        // wave-uniform (n1, n2) shape (task = block of 64 paired cells x n1; no divergence inside loopE, neighbouring reads of c on one diagonal), merged per
+        // cell by an LDS atomic minimum; then the cells in groups of V_G lanes: hairpin, multiloop closing, the dense split loop, fML.
         const int sub = tid % V_G;
         for (int d = V_TURN + 1; d <= Dmax; d++) {
             const int ncell = n - d;
+            if (tid == 0) red[V_NT / 64 + 7] = 0;
+            __syncthreads();
+            for (int base = 0; base < ncell; base += V_NT) {
+                const int cell = base + tid;
+                int type = 0;
+                if (cell < ncell) { type = ptype(X, cell + 1, cell + 1 + d); ctype[cell] = (unsigned char)type; cbest[cell] = V_INF; }
+                const unsigned long long bal = __ballot(type != 0);
+                int wbase = 0;
+                if (lane == 0 && bal) wbase = atomicAdd(&red[V_NT / 64 + 7], (int)__popcll(bal));
+                wbase = __shfl(wbase, 0);
+                if (type) plist[wbase + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+            }
+            __syncthreads();
+            const int np = red[V_NT / 64 + 7];
+            const int n1max = (d - 2 - (V_TURN + 1) < V_MAXLOOP) ? d - 2 - (V_TURN + 1) : V_MAXLOOP;
+            if (n1max >= 0 && np > 0) {
+                const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
+                for (int t = wave; t < ntask; t += V_NT / 64) {
+                    const int blk = t / (n1max + 1), n1 = t - blk * (n1max + 1);
+                    const int k = blk * 64 + lane;
+                    if (k < np) {
+                        const int cell = plist[k];
+                        const int i = cell + 1, j = i + d, p = i + 1 + n1;
+                        const int type = ctype[cell];
+                        const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1];
+                        int n2max = V_MAXLOOP - n1;
+                        if (n2max > d - n1 - 2 - (V_TURN + 1)) n2max = d - n1 - 2 - (V_TURN + 1);
+                        int best = V_INF;
+                        for (int n2 = 0; n2 <= n2max; n2++) {
+                            const int q = j - 1 - n2;
+                            int t2 = ptype(X, p, q);
+                            if (!t2) continue;
+                            t2 = rtype_of(t2);
+                            const int e = loopE(X, n1, n2, type, t2, si1, sj1, sp1, S[q + 1]) + T.C(p, q);
+                            best = e < best ? e : best;
+                        }
+                        if (best < V_INF) atomicMin(&cbest[cell], best);
+                    }
+                }
+            }
+            __syncthreads();
             for (int cell = tid / V_G; cell < ((ncell + V_NT / V_G - 1) / (V_NT / V_G)) * (V_NT / V_G); cell += V_NT / V_G) {
                 const bool live = cell < ncell;
                 const int i = cell + 1, j = i + d;
                 int type = 0, best = V_INF, mdec = V_INF;
                 if (live) {
-                    type = ptype(X, i, j);
+                    type = ctype[cell];
                     if (type) {
-                        if (sub == 0) best = hairpin(X, i, j, type);
+                        if (sub == 0) { best = hairpin(X, i, j, type); const int il = cbest[cell]; best = il < best ? il : best; }
                         const int si1 = S[i + 1], sj1 = S[j - 1];
-                        const int pmax = (j - 2 - V_TURN < i + V_MAXLOOP + 1) ? j - 2 - V_TURN : i + V_MAXLOOP + 1;
-                        for (int p = i + 1 + sub; p <= pmax; p += V_G) {
-                            int minq = j - i + p - V_MAXLOOP - 2;
-                            if (minq < p + 1 + V_TURN) minq = p + 1 + V_TURN;
-                            const int sp1 = S[p - 1];
-                            for (int q = minq; q < j; q++) {
-                                int t2 = ptype(X, p, q);
-                                if (!t2) continue;
-                                t2 = rtype_of(t2);
-                                const int e = loopE(X, p - i - 1, j - q - 1, type, t2, si1, sj1, sp1, S[q + 1]) + T.C(p, q);
-                                best = e < best ? e : best;
-                            }
-                        }
                         if (sub == 1 % V_G) {
                             const int tt = rtype_of(type);
                             const int e3 = P->dangle3[tt][si1], e5 = P->dangle5[tt][sj1];
@@ -143,12 +184,7 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
 
 }  // namespace v185
 
-size_t fold185_lds_bytes(int n_cap, int max_lines) {
-    const size_t nc = (size_t)n_cap + 8;
-    size_t b = sizeof(int) * (nc + 8 + 2 * (size_t)max_lines + (V_NT / 64) * 3 * V_BT_STACK + V_NT / 64 + 8);
-    b += sizeof(short) * nc + 2 * nc + (V_NT / 64) * (nc + 8);
-    return (b + 15) & ~(size_t)15;
-}
+size_t fold185_lds_bytes(int n_cap, int max_lines) { return v185::fold185_lds_bytes_base(n_cap, max_lines) + (size_t)(4 + 2 + 1) * ((size_t)n_cap + 8) + 16; }
 
 size_t fold185_ws_slot_ints(int n_cap, int span) {
     size_t per = (size_t)(span + 2) * (size_t)(n_cap + 2);
