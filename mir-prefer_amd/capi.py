@@ -8,7 +8,7 @@ import numpy as np
 
 from . import early
 from .early import LIB_PATH, FastaData, SamData
-ABI_VERSION = 6      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
+ABI_VERSION = 7      # include/mirprefer.h as this binding was written against (mirp_abi_version of the library must match)
 
 
 class MirpError(RuntimeError):

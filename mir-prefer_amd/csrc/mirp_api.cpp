@@ -10,7 +10,7 @@
 #include <vector>
 #include "mirp_internal.h"
 
-#define MIRP_ABI_VERSION 6   // 6: mirp_last_coverage_fused, mirp_fold_batch_summary, mirp_predict_batch_reasons, text writers; 5: mirp_dist_*, mirp_gather_loci / mirp_gather_records, mirp_read_fasta, mirp_ingest_sams_shard; 4: MirpSamData.segs, mirp_ingest_sams_gpu, mirp_load_coverage_segments; 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
+#define MIRP_ABI_VERSION 7   // 7: mirp_write_result_reports, mirp_fold_predict_report_stream, mirp_select_windows, mirp_dist_comm_info, MIRP_MAX_SAMPLES 255; 6: mirp_last_coverage_fused, mirp_fold_batch_summary, mirp_predict_batch_reasons, text writers; 5: mirp_dist_*, mirp_gather_loci / mirp_gather_records, mirp_read_fasta, mirp_ingest_sams_shard; 4: MirpSamData.segs, mirp_ingest_sams_gpu, mirp_load_coverage_segments; 2: mirp_set_fold_model, mirp_ingest_sams; 3: mirp_predict returns the per-window capacity status, mirp_get_fold_overflow
 #define MIRP_NMAX 3096
 
 #include "mirp_ctx.h"
