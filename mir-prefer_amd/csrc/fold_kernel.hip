@@ -76,6 +76,19 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     int* cbest = pcnt + nc;                                // nc: interior-loop minimum of the diagonal's cells
     unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
     unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
+    // inner-pair terms of the interior-loop energies, [t2][sq1][sp1] as shorts, and the stacking table: read per candidate -- out of LDS, not through
+    // the texture addresser (the interval was bound by vector-memory instructions: one per table look-up and lane, profiles/EXPERIMENT... DESIGN.md 4)
+    short* l_mmI = (short*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines) + ((size_t)(4 + 4 + 2 + 1) * (size_t)nc + 15) / 16 * 16);
+    short* l_mm1n = l_mmI + 200;
+    short* l_mm23 = l_mm1n + 200;
+    short* l_stack = l_mm23 + 200;                         // 64
+    for (int x = threadIdx.x; x < 200; x += GEN_NT) {
+        const int t = x / 25, a = (x / 5) % 5, b = x % 5;
+        // (the rows of pair type 0 hold INF and are never read: an interior candidate has a pair on both sides)
+        l_mmI[x] = (short)min(P->mismatchI[t][a][b], 32767); l_mm1n[x] = (short)min(P->mismatch1nI[t][a][b], 32767); l_mm23[x] = (short)min(P->mismatch23I[t][a][b], 32767);
+    }
+    for (int x = threadIdx.x; x < 64; x += GEN_NT) l_stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
+    __syncthreads();
 
     const int tid = threadIdx.x;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
@@ -173,22 +186,45 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
             if (n1max >= 0) {
                 const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
                 for (int t = wave; t < ntask; t += GEN_NT / 64) {
-                    const int blk = t / (n1max + 1), n1 = t - blk * (n1max + 1);
+                    const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: loop shape and size terms in scalar registers
+                    const int blk = tu / (n1max + 1), n1 = tu - blk * (n1max + 1);
                     const int k = blk * 64 + lane;
                     if (k < np) {
                         const int cell = plist[k];
                         const int i = cell + 1, j = i + d, p = i + 1 + n1;
                         const int type = ctype[cell];
                         const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1], Sp = S[p];
+                        const int ij = type * 25 + si1 * 5 + sj1;
+                        const int o_mmI = l_mmI[ij], o_mm1n = l_mm1n[ij], o_mm23 = l_mm23[ij];      // the outer pair's terms: once per task
                         int n2max = MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (TURN + 1)) n2max = d - n1 - 2 - (TURN + 1);
+                        const int* crow = T.c + (size_t)(d - n1 - 2) * T.ld + p;          // c(p, q) = crow[-n2 * ld]
                         int best = INF;
                         for (int n2 = 0; n2 <= n2max; n2++) {
                             const int q = j - 1 - n2;
                             int t2 = pair_type(Sp, S[q]);
                             if (!t2) continue;
                             t2 = rtype_of(t2);
-                            const int e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, S[q + 1]) + T.C(q - p, p);
+                            const int sq1 = S[q + 1];
+                            const int pq = t2 * 25 + sq1 * 5 + sp1;
+                            const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
+                            int e;
+                            if (ns >= 2 && !(ns == 2 && nl <= 3)) {                             // generic loop (375 of the 496 shapes)
+                                const int x = (nl - ns) * P->ninio;
+                                e = P->internal_loop[nl + ns] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + l_mmI[pq];
+                            } else if (nl == 0) {
+                                e = l_stack[type * 8 + t2];
+                            } else if (ns == 0) {
+                                e = P->bulge[nl] + (nl == 1 ? (int)l_stack[type * 8 + t2] : ((type > 2 ? P->TerminalAU : 0) + (t2 > 2 ? P->TerminalAU : 0)));
+                            } else if (ns == 1 && nl >= 3) {
+                                const int x = (nl - 1) * P->ninio;
+                                e = P->internal_loop[nl + 1] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mm1n + l_mm1n[pq];
+                            } else if (ns == 2 && nl == 3) {
+                                e = P->internal_loop[5] + P->ninio + o_mm23 + l_mm23[pq];
+                            } else {
+                                e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, sq1);         // 1x1, 1x2, 2x1, 2x2: the big tables
+                            }
+                            e += crow[-(ptrdiff_t)n2 * T.ld];
                             best = e < best ? e : best;
                         }
                         if (best < INF) atomicMin(&cbest[cell], best);
@@ -249,7 +285,9 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
 }
 
 // split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
-size_t fold_generic_lds_bytes(int n_cap, int max_lines) { return fold_generic_lds_bytes_base(n_cap, max_lines) + (size_t)(4 + 4 + 2 + 1) * (size_t)(n_cap + 8) + 16; }
+size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
+    return fold_generic_lds_bytes_base(n_cap, max_lines) + ((size_t)(4 + 4 + 2 + 1) * (size_t)(n_cap + 8) + 15) / 16 * 16 + sizeof(short) * (3 * 200 + 64) + 16;
+}
 
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
     // c, fML, four diagonals of DML, the candidate pool (two ints per entry)

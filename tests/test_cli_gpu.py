@@ -279,3 +279,67 @@ def test_sharded_run_fails_on_every_rank_together(tmp_path):
     assert all(c == 0 for c in codes), logs
     with pytest.raises(SystemExit):
         cli.main(["candidate", cfg])
+
+
+def _run_cli(args, cwd, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-m", "mir_prefer_amd.cli"] + args, cwd=str(cwd), env=dict(os.environ, PYTHONPATH=root, **(env or {})), capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_lean_pipeline_edge_cases(tmp_path):
+    """The lean `pipeline` process on inputs that end early: (1) a SAM file with a malformed read id -- the early host ingest's error surfaces as the
+    reference's message and exit status -1 (MP:242-253) while the device-open thread is still running; (2) reads that never reach the depth cutoff -- no
+    candidate, "0 miRNA identified", no result files, exit 0; (3) a window over the default line capacity (a planted tandem repeat) -- the streamed fold /
+    filter / report call re-folds it like the stage-by-stage run: same files as `-k pipeline`."""
+    from mir_prefer_amd import synth
+    exp, cfg, out = _setup("mini", tmp_path)
+    # (1)
+    sam = tmp_path / "S1.sam"
+    lines = open(sam).read().splitlines()
+    k = next(i for i, l in enumerate(lines) if not l.startswith("@"))
+    lines[k + 5] = "badid" + lines[k + 5][lines[k + 5].index("\t"):]
+    sam.write_text("\n".join(lines) + "\n")
+    r = _run_cli(["pipeline", cfg], tmp_path)
+    assert r.returncode == 255 and "Read id must be in" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not os.path.exists(out / "mini_miRNA.gff3")
+    # (2)
+    d2 = tmp_path / "low"
+    d2.mkdir()
+    ds = synth.make_dataset([50000], 0, n_samples=1, seed=4, contig_names=["c1"])
+    alns = ds.alns.copy()
+    ds2 = synth.Dataset(ds.contigs, ds.sample_names, alns[:0], [])
+    sams = ds2.write_sams(str(d2))
+    ds2.write_fasta(str(d2 / "g.fa"))
+    (d2 / "config").write_text("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = low\n" % (d2 / "g.fa", sams[0], d2 / "out"))
+    with open(sams[0], "a") as f:          # one read, depth 3: below READS_DEPTH_CUTOFF
+        f.write("S1_r0_x3\t0\tc1\t1000\t255\t21M\t*\t0\t0\t%s\t%s\n" % ("A" * 21, "I" * 21))
+    r = _run_cli(["pipeline", str(d2 / "config")], d2)
+    assert r.returncode == 0, r.stderr[-800:]
+    assert "0 miRNA identified. No result files generated." in r.stdout and not os.path.exists(d2 / "out" / "low_miRNA.gff3")
+    # (3)
+    d3 = tmp_path / "rep"
+    d3.mkdir()
+    ds = synth.make_dataset([120000], 40, n_samples=1, seed=8, contig_names=["c1"], edge_cases=True)
+    g = ds.contigs[0][1].copy()
+    a0 = ds.alns[ds.alns["depth"] > 20][0]          # a covered locus: overwrite its surroundings with a dinucleotide repeat (one structure line per start position)
+    lo = max(0, int(a0["pos"]) - 160)
+    g[lo:lo + 340] = np.frombuffer((b"AT" * 170), dtype=np.uint8)
+    ds3 = synth.Dataset([("c1", g)], ds.sample_names, ds.alns, [])
+    sams = ds3.write_sams(str(d3))
+    ds3.write_fasta(str(d3 / "g.fa"))
+    for name, extra in (("lean", []), ("keep", ["-k"])):
+        (d3 / ("config_" + name)).write_text("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = rep\n" % (d3 / "g.fa", sams[0], d3 / name))
+        r = _run_cli(extra + ["pipeline", str(d3 / ("config_" + name))], d3, env={"MIRP_STREAM_CHUNKS": "3"})
+        assert r.returncode == 0, r.stderr[-800:]
+    import filecmp
+    files = [f for f in os.listdir(d3 / "keep") if os.path.isfile(d3 / "keep" / f)]
+    assert "rep_miRNA.gff3" in files
+    match, mismatch, errors = filecmp.cmpfiles(str(d3 / "keep"), str(d3 / "lean"), files, shallow=False)
+    assert not mismatch and not errors, (mismatch, errors)
+    rm = sorted(os.listdir(d3 / "keep" / "readmapping"))
+    assert rm == sorted(os.listdir(d3 / "lean" / "readmapping"))
+    match, mismatch, errors = filecmp.cmpfiles(str(d3 / "keep" / "readmapping"), str(d3 / "lean" / "readmapping"), rm, shallow=False)
+    assert not mismatch and not errors
