@@ -18,6 +18,9 @@ __host__ __device__ inline size_t fold185_lds_bytes_base(int n_cap, int max_line
     return (b + 15) & ~(size_t)15;
 }
 
+// PHASE 1 = fill, PHASE 2 = exterior sweep + backtracks, launched back to back over batches of `grid` windows (slot = blockIdx.x), as fold_generic_kernel:
+// the fill needs half the registers of the epilogue.
+template <int PHASE>
 __global__ void __launch_bounds__(V_NT) fold185_kernel(
     const FoldParams185* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
@@ -43,7 +46,7 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
         if (n < 1 || n > n_cap) {
-            if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = n < 1 ? 0 : -40; }
+            if (PHASE == 2 && tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = n < 1 ? 0 : -40; }
             continue;
         }
         for (int x = tid; x <= n + 1; x += V_NT) {
@@ -80,6 +83,7 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
 
         // ---- anti-diagonal wavefront fill; cells at distance M hold c = INF but a finite fML
         const int Dmax = M < n - 1 ? M : n - 1;
+        if constexpr (PHASE == 1) {
         // Three intervals per diagonal (round 5, as fold_generic_kernel): pair types + the list of paired cells; interior loops with LANE = PAIRED CELL and a
         // wave-uniform (n1, n2) shape (task = block of 64 paired cells x n1; no divergence inside loopE, neighbouring reads of c on one diagonal), merged per
         // cell by an LDS atomic minimum; then the cells in groups of V_G lanes: hairpin, multiloop closing, the dense split loop, fML.
@@ -177,8 +181,10 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
             __syncthreads();
         }
 
+        } else {
         epilogue<FoldParams185, GTab185, V_NT>(X, T, f3, starts, lens, btstk, red, btbuf, nc, win, max_lines, ss_stride, out_lines, out_ss, out_nlines,
                                                 out_mfe, out_status);
+        }
     }
 }
 
@@ -197,11 +203,25 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
                           int* out_nlines, int* out_mfe, int* out_status) {
     const size_t lds = fold185_lds_bytes(n_cap, max_lines);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)v185::fold185_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)v185::fold185_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)v185::fold185_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(v185::fold185_kernel, dim3(grid), dim3(V_NT), lds, stream, P, seqs, offs, lens, work_list, n_work, span, n_cap, ws, ws_slot_ints, max_lines,
-                       ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
+    for (int b = 0; b < n_work; b += grid) {          // batches of `grid` windows: window b + k owns workspace slot k in both kernels
+        const int nb = n_work - b < grid ? n_work - b : grid;
+        const int* wl = work_list ? work_list + b : nullptr;
+        const long long* o2 = work_list ? offs : offs + b;
+        const int* l2 = (work_list || !lens) ? lens : lens + b;
+        MirpFoldLine* ol = work_list ? out_lines : out_lines + (size_t)b * max_lines;
+        char* os = work_list ? out_ss : out_ss + (size_t)b * max_lines * ss_stride;
+        int* on = work_list ? out_nlines : out_nlines + b;
+        int* om = work_list ? out_mfe : out_mfe + b;
+        int* ost = work_list ? out_status : out_status + b;
+        hipLaunchKernelGGL(v185::fold185_kernel<1>, dim3(nb), dim3(V_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride, ol, os, on,
+                           om, ost);
+        hipLaunchKernelGGL(v185::fold185_kernel<2>, dim3(nb), dim3(V_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride, ol, os, on,
+                           om, ost);
+    }
     return hipGetLastError();
 }
 

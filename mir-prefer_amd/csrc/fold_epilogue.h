@@ -909,7 +909,11 @@ __device__ void fold_epilogue(const WinCtx& X, const Tab& T, int span, int* f3 /
 #else
             if constexpr (Tab::kTiled) L = backtrack_wave_tiled(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
 #endif
+#ifdef MIRP_X_GEN_NOBT              // timing experiment (generic path): sweep and enumeration only
+            else L = -10;
+#else
             else L = backtrack_wave(X, T, lind, (pp + 2 < n ? pp + 2 : n), span, mybuf, mystk);
+#endif
         }
         EPI_T(3);
         if (L < 0) {

@@ -20,16 +20,20 @@ struct GTab {
     static constexpr bool kTiled = false;
     int* __restrict__ c;
     int* __restrict__ m;
+    unsigned short* __restrict__ tb;
     int ld;
     __device__ __forceinline__ int C(int d, int i) const { return c[(size_t)d * ld + i]; }
     __device__ __forceinline__ int M(int d, int i) const { return m[(size_t)d * ld + i]; }
-    __device__ __forceinline__ int TB(int, int) const { return -1; }   // no trace-back codes: the backtrack searches
+    // trace-back code of a pair (round 5): 1 + (n1 << 5 | n2) = the interior loop the backtrack's search (p ascending, q descending) would find first,
+    // 0 = the hairpin realises c(i,j), or no interior loop does (multiloop)
+    __device__ __forceinline__ int TB(int d, int i) const { return tb[(size_t)d * ld + i]; }
 };
 
 // ------------------------------------------------------------------------------------------
 // Generic kernel: tables in global workspace.
 // ------------------------------------------------------------------------------------------
 #define GEN_NT 256
+#define GEN_AUX_BYTES(nc) ((((size_t)(4 + 8 + 2 + 1) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (64-bit keys, 8-aligned), plist (short), ctype (byte) per position
 #define GEN_G 8   // lanes cooperating on one cell
 
 __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines) {
@@ -55,6 +59,10 @@ __host__ __device__ size_t fold_generic_table_ints(int n_cap, int span) {
 // split candidates a column can hold: one per diagonal at most
 __host__ __device__ int fold_generic_pool_cap(int n_cap, int span) { return (span < n_cap ? span : n_cap) + 1; }
 
+// PHASE 1 = fill (tables into the window's workspace slot), PHASE 2 = exterior sweep + structure enumeration + backtracks out of the slot.  Two
+// instantiations, launched back to back over a batch of at most `grid` windows (slot = blockIdx.x): the fill needs 74 VGPRs, the epilogue 163 -- as one
+// kernel the fill ran at the epilogue's occupancy (3 workgroups per CU instead of 6).
+template <int PHASE>
 __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs,
     const int* __restrict__ win_lens, const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints,
@@ -73,12 +81,13 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     unsigned char* seq = S + nc;                           // nc
     char* btbuf = (char*)(seq + nc);                       // (NT/64)*nc
     int* pcnt = (int*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines));      // nc: split candidates of every column so far
-    int* cbest = pcnt + nc;                                // nc: interior-loop minimum of the diagonal's cells
+    unsigned long long* cbest = (unsigned long long*)(pcnt + nc + (nc & 1));      // nc: interior-loop minimum of the diagonal's cells as a key
+                                                           // (energy + 2^30) << 10 | n1 << 5 | n2: the minimum names the first loop in the backtrack's search order
     unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
     unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
     // inner-pair terms of the interior-loop energies, [t2][sq1][sp1] as shorts, and the stacking table: read per candidate -- out of LDS, not through
     // the texture addresser (the interval was bound by vector-memory instructions: one per table look-up and lane, profiles/EXPERIMENT... DESIGN.md 4)
-    short* l_mmI = (short*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines) + ((size_t)(4 + 4 + 2 + 1) * (size_t)nc + 15) / 16 * 16);
+    short* l_mmI = (short*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)nc));
     short* l_mm1n = l_mmI + 200;
     short* l_mm23 = l_mm1n + 200;
     short* l_stack = l_mm23 + 200;                         // 64
@@ -96,7 +105,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
         const long long o0 = offs[win];
         const int n = win_lens ? win_lens[win] : (int)(offs[win + 1] - o0);
         if (n < 1 || n > n_cap) {
-            if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = n < 1 ? 0 : -40; }
+            if (PHASE == 2 && tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = n < 1 ? 0 : -40; }
             continue;
         }
         const int D = (span - 1 < n - 1) ? span - 1 : n - 1;
@@ -151,13 +160,17 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
         int* dml = T.m + tab_ints;                              // [4][ld]
         int2* pool = reinterpret_cast<int2*>(dml + 4 * (size_t)T.ld);      // [ld][pcap]
         const int pcap = fold_generic_pool_cap(n_cap, span);
-        // diagonal TURN of fML must read as INF
-        for (int x = tid; x <= n; x += GEN_NT) T.m[(size_t)TURN * T.ld + x] = INF;
-        for (int x = tid; x < 4 * T.ld; x += GEN_NT) dml[x] = INF;
-        for (int x = tid; x <= n + 1; x += GEN_NT) pcnt[x] = 0;
+        T.tb = reinterpret_cast<unsigned short*>(pool + (size_t)T.ld * pcap);      // [D + 1][ld] shorts
+        if constexpr (PHASE == 1) {
+            // diagonal TURN of fML must read as INF
+            for (int x = tid; x <= n; x += GEN_NT) T.m[(size_t)TURN * T.ld + x] = INF;
+            for (int x = tid; x < 4 * T.ld; x += GEN_NT) dml[x] = INF;
+            for (int x = tid; x <= n + 1; x += GEN_NT) pcnt[x] = 0;
+        }
         __syncthreads();
         WinCtx X;
         X.P = P; X.S = S; X.seq = seq; X.f3 = f3; X.spec = spec; X.ldspec = nc; X.n = n; X.D = D;
+        if constexpr (PHASE == 1) {
 
         // ---- anti-diagonal wavefront fill: all cells with the same d = j - i are independent.  Three intervals per diagonal:
         //  0  pair types of the diagonal's cells, the paired ones compacted into a list;
@@ -173,7 +186,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
             for (int base = 0; base < ncell; base += GEN_NT) {
                 const int cell = base + tid;
                 int type = 0;
-                if (cell < ncell) { type = pair_type(S[cell + 1], S[cell + 1 + d]); ctype[cell] = (unsigned char)type; cbest[cell] = INF; }
+                if (cell < ncell) { type = pair_type(S[cell + 1], S[cell + 1 + d]); ctype[cell] = (unsigned char)type; cbest[cell] = ~0ull; }
                 const unsigned long long bal = __ballot(type != 0);
                 int wbase = 0;
                 if (lane == 0 && bal) wbase = atomicAdd(&sh_misc[7], (int)__popcll(bal));
@@ -199,7 +212,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                         int n2max = MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (TURN + 1)) n2max = d - n1 - 2 - (TURN + 1);
                         const int* crow = T.c + (size_t)(d - n1 - 2) * T.ld + p;          // c(p, q) = crow[-n2 * ld]
-                        int best = INF;
+                        int best = INF, best_n2 = 0;
                         for (int n2 = 0; n2 <= n2max; n2++) {
                             const int q = j - 1 - n2;
                             int t2 = pair_type(Sp, S[q]);
@@ -225,9 +238,9 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                                 e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, sq1);         // 1x1, 1x2, 2x1, 2x2: the big tables
                             }
                             e += crow[-(ptrdiff_t)n2 * T.ld];
-                            best = e < best ? e : best;
+                            if (e < best) { best = e; best_n2 = n2; }          // strict: the first n2 (largest q) among equals
                         }
-                        if (best < INF) atomicMin(&cbest[cell], best);
+                        if (best < INF) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(n1 << 5 | best_n2));
                     }
                 }
             }
@@ -236,14 +249,17 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                 const int i = cell + 1, j = i + d;
                 const int type = ctype[cell];
                 int best = INF;
+                int code = 0;
                 if (type) {
-                    best = e_hairpin(X, i, j, type);
-                    const int il = cbest[cell];
-                    best = il < best ? il : best;
+                    const int hp = e_hairpin(X, i, j, type);
+                    best = hp;
+                    const unsigned long long key = cbest[cell];
+                    const int il = key == ~0ull ? INF : (int)(unsigned)(key >> 10) - (1 << 30);
+                    if (il < best) { best = il; code = 1 + (int)(key & 1023u); }          // the hairpin does not realise c and this loop does (unless the multiloop below wins)
                     // multiloop closed by (i,j): DML(i+1, j-1), kept from diagonal d-2
                     int dec = dml[(size_t)((d - 2) & 3) * T.ld + i + 1];
                     dec += P->ML_closing + e_mlstem(P, rtype_of(type), S[j - 1], S[i + 1]);
-                    best = dec < best ? dec : best;
+                    if (dec < best) { best = dec; code = 0; }          // strictly better than every interior loop: the backtrack finds no loop and searches the split
                     if (best > INF) best = INF;
                 }
                 // DML(i,j): DML(i,j-1) and the candidates of column j (those far enough from i for fML(i,s-1) to exist)
@@ -270,37 +286,56 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                 }
                 if (mm > INF) mm = INF;
                 T.c[(size_t)d * T.ld + i] = type ? best : INF;
+                T.tb[(size_t)d * T.ld + i] = (unsigned short)code;
                 T.m[(size_t)d * T.ld + i] = mm;
                 dml[(size_t)(d & 3) * T.ld + i] = mdec;
             }
             __syncthreads();
         }
+        } else {
 #ifdef MIRP_X_GEN_NOEPI             // timing experiment: fill only (results are empty)
         if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; }
 #else
         fold_epilogue<GTab, GEN_NT>(X, T, span, f3, starts, lens, btbuf, nc, btstk, sh_misc, win, max_lines, ss_stride,
                                    out_lines, out_ss, out_nlines, out_mfe, out_status);
 #endif
+        }
     }
 }
 
 // split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
 size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
-    return fold_generic_lds_bytes_base(n_cap, max_lines) + ((size_t)(4 + 4 + 2 + 1) * (size_t)(n_cap + 8) + 15) / 16 * 16 + sizeof(short) * (3 * 200 + 64) + 16;
+    return fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (3 * 200 + 64) + 16;
 }
 
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
-    // c, fML, four diagonals of DML, the candidate pool (two ints per entry)
+    // c, fML, four diagonals of DML, the candidate pool (two ints per entry), the trace-back codes (a short per cell)
     const size_t ld = (size_t)n_cap + 2;
-    return 2 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63);
+    return 2 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63) +
+           ((fold_generic_table_ints(n_cap, span) / 2 + 63) & ~(size_t)63);
 }
 
 void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs,
                          const int* lens, const int* work_list, int n_work, int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines,
                          int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status) {
-    size_t lds = fold_generic_lds_bytes(n_cap, max_lines);
-    hipLaunchKernelGGL(fold_generic_kernel, dim3(grid), dim3(GEN_NT), lds, stream, P, seqs, offs, lens, work_list, n_work, span, n_cap, ws,
-                       ws_slot_ints, max_lines, ss_stride, out_lines, out_ss, out_nlines, out_mfe, out_status);
+    // batches of `grid` windows: window b + k of the batch owns workspace slot k in both kernels (without a work list the kernels index the windows
+    // directly, so the batch is addressed by shifted array bases; with one, by the shifted list)
+    const size_t lds = fold_generic_lds_bytes(n_cap, max_lines);
+    for (int b = 0; b < n_work; b += grid) {
+        const int nb = n_work - b < grid ? n_work - b : grid;
+        const int* wl = work_list ? work_list + b : nullptr;
+        const long long* o2 = work_list ? offs : offs + b;
+        const int* l2 = (work_list || !lens) ? lens : lens + b;
+        MirpFoldLine* ol = work_list ? out_lines : out_lines + (size_t)b * max_lines;
+        char* os = work_list ? out_ss : out_ss + (size_t)b * max_lines * ss_stride;
+        int* on = work_list ? out_nlines : out_nlines + b;
+        int* om = work_list ? out_mfe : out_mfe + b;
+        int* ost = work_list ? out_status : out_status + b;
+        hipLaunchKernelGGL(fold_generic_kernel<1>, dim3(nb), dim3(GEN_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride,
+                           ol, os, on, om, ost);
+        hipLaunchKernelGGL(fold_generic_kernel<2>, dim3(nb), dim3(GEN_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride,
+                           ol, os, on, om, ost);
+    }
 }
 
 }  // namespace mirp
