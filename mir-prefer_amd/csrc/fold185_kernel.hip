@@ -118,12 +118,14 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                         int n2max = V_MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (V_TURN + 1)) n2max = d - n1 - 2 - (V_TURN + 1);
                         int best = V_INF;
+#pragma unroll 8
                         for (int n2 = 0; n2 <= n2max; n2++) {
                             const int q = j - 1 - n2;
+                            const int cv = T.C(p, q);          // before the pair test: the loads of an unrolled group are in flight together
                             int t2 = ptype(X, p, q);
                             if (!t2) continue;
                             t2 = rtype_of(t2);
-                            const int e = loopE(X, n1, n2, type, t2, si1, sj1, sp1, S[q + 1]) + T.C(p, q);
+                            const int e = loopE(X, n1, n2, type, t2, si1, sj1, sp1, S[q + 1]) + cv;
                             best = e < best ? e : best;
                         }
                         if (best < V_INF) atomicMin(&cbest[cell], best);

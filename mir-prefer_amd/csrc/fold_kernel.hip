@@ -207,17 +207,21 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                         const int i = cell + 1, j = i + d, p = i + 1 + n1;
                         const int type = ctype[cell];
                         const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1], Sp = S[p];
+                        // reversed pair type of (p, q) for this lane's p as five 3-bit fields indexed by the base code of q: {N A C G U} -> 0 or rtype (the loop
+                        // below would otherwise spend a quarter of its instructions in pair_type's 64-bit shifts)
+                        const unsigned prow = Sp == 1 ? (6u << 12) : Sp == 2 ? (2u << 9) : Sp == 3 ? ((1u << 6) | (4u << 12)) : Sp == 4 ? ((5u << 3) | (3u << 9)) : 0u;
                         const int ij = type * 25 + si1 * 5 + sj1;
                         const int o_mmI = l_mmI[ij], o_mm1n = l_mm1n[ij], o_mm23 = l_mm23[ij];      // the outer pair's terms: once per task
                         int n2max = MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (TURN + 1)) n2max = d - n1 - 2 - (TURN + 1);
                         const int* crow = T.c + (size_t)(d - n1 - 2) * T.ld + p;          // c(p, q) = crow[-n2 * ld]
                         int best = INF, best_n2 = 0;
+#pragma unroll 8
                         for (int n2 = 0; n2 <= n2max; n2++) {
                             const int q = j - 1 - n2;
-                            int t2 = pair_type(Sp, S[q]);
+                            const int cv = crow[-(ptrdiff_t)n2 * T.ld];          // before the pair test: the loads of an unrolled group are in flight together
+                            const int t2 = (int)((prow >> (3 * S[q])) & 7u);
                             if (!t2) continue;
-                            t2 = rtype_of(t2);
                             const int sq1 = S[q + 1];
                             const int pq = t2 * 25 + sq1 * 5 + sp1;
                             const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
@@ -237,7 +241,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                             } else {
                                 e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, sq1);         // 1x1, 1x2, 2x1, 2x2: the big tables
                             }
-                            e += crow[-(ptrdiff_t)n2 * T.ld];
+                            e += cv;
                             if (e < best) { best = e; best_n2 = n2; }          // strict: the first n2 (largest q) among equals
                         }
                         if (best < INF) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(n1 << 5 | best_n2));
