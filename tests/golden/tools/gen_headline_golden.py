@@ -150,8 +150,26 @@ def gen_mid():
     gen_golden.dump_gz(exp, os.path.join(GOLD, "mid", "expected.json.gz"))
 
 
+def gen_long():
+    """tests/golden/long_folds.json.gz: both RNALfold binaries at spans 400 and 330 on 160 windows of 360 .. 480 nt (tests/seqgen.windows, seed 4001) and 40
+    windows of the stress families stretched to that length -- PRECURSOR_LEN beyond what the LDS-resident kernels hold: the generic kernels' domain
+    (fold_generic_kernel / fold185_kernel, rewritten in round 5)."""
+    seqs = seqgen.long_windows()
+    fix = {"generator": "RNALfold 2.1.2 / 1.8.5 (bundled binaries), -L span, default dangles; digests as headline_folds.json.gz", "seed": 4001, "n": len(seqs),
+           "seq_digests": base64.b64encode(b"".join(seq_digest(s) for s in seqs)).decode(), "folds": {}}
+    for model, binary in MODELS:
+        for span in (400, 330):
+            res = real_folds(os.path.join(ORA_BIN, binary), seqs, span)
+            fix["folds"]["%s/%d" % (model, span)] = {"digests": base64.b64encode(b"".join(fold_digest(x["lines"], x["mfe"]) for x in res)).decode(),
+                                                     "mfe": [x["mfe"] for x in res], "n_lines": [len(x["lines"]) for x in res]}
+            print("long", model, span, len(res), "windows,", sum(len(x["lines"]) for x in res), "lines")
+    gen_golden.dump_gz(fix, os.path.join(GOLD, "long_folds.json.gz"))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["folds", "mid"]
+    if "long" in what:
+        gen_long()
     if "folds" in what:
         gen_folds()
     if "mid" in what:

@@ -69,3 +69,14 @@ def microsatellites():
         out.append(("ACGU" * 100)[:n])
         out.append(("AAUU" * 100)[:n])
     return out
+
+
+def long_windows():
+    """Windows beyond the LDS-resident fold kernels' reach (360 .. 480 nt; folded at spans 400 and 330 in tests/golden/long_folds.json.gz): 160 mixed ones
+    and 40 of the stress families stretched to that length."""
+    seqs = windows(4001, 160, 360, 480)
+    r = random.Random(4002)
+    for i in range(40):
+        s = stress_family(r, i % 5)
+        seqs.append((s + "".join(r.choice("ACGU") for _ in range(r.randint(20, 90))) + s[::-1] + s)[:r.randint(360, 470)])
+    return seqs

@@ -155,3 +155,20 @@ def test_fold_vienna212_matches_the_bundled_binary(gpu_ctx):
             assert [list(l) for l in g["lines"]] == exp["lines"], seq
             n += 1
     assert n >= 300 and {300, 100, 40, 20} <= spans
+
+
+def test_generic_kernels_match_the_real_binaries_beyond_300(gpu_ctx):
+    """The generic kernels (span > 300, windows > 350 nt; fill with split candidates, lane = paired cell, trace-back codes; fill and epilogue as two kernels)
+    against digests of the real RNALfold 2.1.2 / 1.8.5 output: 200 windows of 360 .. 480 nt at spans 400 and 330 (tests/golden/long_folds.json.gz)."""
+    from tests.test_oracle_golden import check_long_folds, long_fold_fixture
+    fix, seqs = long_fold_fixture()
+
+    def fold_many(s, span, model):
+        gpu_ctx.set_fold_model(model)
+        out = gpu_ctx.fold_batch(s, span, max_lines=500)
+        assert all(g["status"] == 0 for g in out)
+        return [(g["lines"], g["mfe"]) for g in out]
+    try:
+        assert check_long_folds(fix, seqs, fold_many) == 800
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")

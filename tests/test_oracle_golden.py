@@ -416,3 +416,34 @@ def test_mid_dataset_whole_reference_pipeline(oracle, model):
     assert len(exp_res) >= 100
     assert [mirna_record(m, names) for _, m in result] == [e[:10] for e in exp_res]
     assert [(m.total_depth_mature, m.total_depth_star) for _, m in result] == [(e[10]["total_depth_mature"], e[10]["total_depth_star"]) for e in exp_res]
+
+
+def long_fold_fixture():
+    import base64
+    from tests import seqgen
+    from tests.golden.tools_digest import seq_digest
+    fix = gu.load_json("long_folds.json.gz")
+    seqs = seqgen.long_windows()
+    assert len(seqs) == fix["n"] and b"".join(seq_digest(s) for s in seqs) == base64.b64decode(fix["seq_digests"])
+    return fix, seqs
+
+
+def check_long_folds(fix, seqs, fold_many):
+    import base64
+    from tests.golden.tools_digest import fold_digest
+    n = 0
+    for key, exp in fix["folds"].items():
+        model, span = key.split("/")
+        want = base64.b64decode(exp["digests"])
+        for k, (lines, mfe) in enumerate(fold_many(seqs, int(span), model)):
+            assert mfe == exp["mfe"][k] and fold_digest(lines, mfe) == want[6 * k:6 * k + 6], (key, k, seqs[k])
+            n += 1
+    return n
+
+
+def test_long_windows_match_real_rnalfold(oracle):
+    """PRECURSOR_LEN beyond 300 (the reference accepts 60 .. 3000, MP:167-184): 200 windows of 360 .. 480 nt at spans 400 and 330, both models, the oracle
+    against digests of the real binaries' output."""
+    from tests.test_whole_workload_gpu import oracle_fold_all
+    fix, seqs = long_fold_fixture()
+    assert check_long_folds(fix, seqs, lambda s, span, model: oracle_fold_all(s, span, model)) == 800
