@@ -343,3 +343,16 @@ def test_lean_pipeline_edge_cases(tmp_path):
     assert rm == sorted(os.listdir(d3 / "lean" / "readmapping"))
     match, mismatch, errors = filecmp.cmpfiles(str(d3 / "keep" / "readmapping"), str(d3 / "lean" / "readmapping"), rm, shallow=False)
     assert not mismatch and not errors
+
+
+def test_lean_pipeline_relative_paths_and_log(tmp_path):
+    """Relative OUTFOLDER / input paths and -L in a lean run: the native report writer creates the folders it needs, the log file is written
+    (MP:60-66), the result is the reference's."""
+    exp, cfg, out = _setup("mini", tmp_path)
+    text = open(cfg).read().replace(str(tmp_path) + "/", "")
+    (tmp_path / "rel.cfg").write_text(text.replace("OUTFOLDER = out", "OUTFOLDER = res/deep"))
+    r = _run_cli(["-L", "pipeline", "rel.cfg"], tmp_path)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert open(tmp_path / "res" / "deep" / "mini_miRNA.gff3").read() == exp["gff3"]
+    assert os.path.exists(tmp_path / "res" / "deep" / "mini.log")
+    assert sorted(os.listdir(tmp_path / "res" / "deep" / "readmapping")) == sorted(exp["readmapping"])
