@@ -354,8 +354,9 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
                         "device context, first touch of allocations and code objects, stages, report files, removal of the temporary folder and exit all "
                         "included; process_wall_s = the FIRST of the runs (each a new process, inputs in the page cache); segments_s = the child's own stamps: "
                         "main = spawn -> entry of main() (interpreter + package import), imports = capi / numpy / pipeline, context = config parse + "
-                        "library load + device context, then the four stages, removetmp, exit = end of main() -> process gone; stage_device_s = device time "
-                        "inside each stage"}
+                        "library load + device context (the join on the early device-open thread), then the four stages -- a lean run (no -k, no -d) does fold + filter + "
+                        "report files as ONE pipelined call inside the predict segment, so `fold` is 0 and `predict` carries the fold's device time --, "
+                        "removetmp, exit = end of main() -> process gone; stage_device_s = device time inside each stage"}
     finally:
         _E2E_TRASH.append(tmp)
 
@@ -547,12 +548,17 @@ def main():
 
     def step():
         npk, nloci, nwin = ctx.candidate(CUT, GAP, L, order)
-        imported = []
+        imported, plan_moves = [], []
         if world > 1:
             # even out the window lists before the fold: whole contigs per rank leave the ranks uneven (config3: 1.23 x the mean on the fullest
             # rank), windows are independent.  Every rank computes the same plan from the counts; the payloads go over the library's communicator.
-            counts = [None] * world
-            tdist.all_gather_object(counts, int(nwin))
+            if rccl_error is None:          # one small all-reduce on the library's communicator (every rank fills its own slot) instead of a pickled object gather over gloo
+                slot = np.zeros(world, dtype=np.int64)
+                slot[rank] = int(nwin)
+                counts = [int(x) for x in ctx.dist_allreduce_sum(slot)]
+            else:
+                counts = [None] * world
+                tdist.all_gather_object(counts, int(nwin))
             if rccl_error is None:
                 xchg = ctx.exchange_bytes
             else:
@@ -560,7 +566,7 @@ def main():
                     box = [None] * world
                     tdist.all_gather_object(box, blocks)
                     return [b[rank] for b in box]
-            keep, imported, _ = balance.exchange(xchg, rank, world, ctx.get_windows, alns, counts)
+            keep, imported, plan_moves = balance.exchange(xchg, rank, world, ctx.get_windows, alns, counts)
             moved[0], moved[1] = int(nwin) - keep, sum(len(p["windows"]) for p in imported)
             if keep != nwin:
                 ctx.limit_windows(keep)
@@ -578,9 +584,10 @@ def main():
         if world > 1 and rccl_error is None:          # the exchange step of the path: loci lists of all ranks on rank 0, over RCCL from the device-resident result
             g = ctx.gather_loci(0)
             total = len(g["result"])
-            extra = np.concatenate([x["result"] for x in imp]) if imp else np.zeros(0, dtype=records.MIRNA_DTYPE)      # loci of imported windows
-            ge = ctx.gather_records(extra.view(np.int32).reshape(len(extra), records.MIRNA_DTYPE.itemsize // 4))
-            total += 0 if ge is None else len(ge)
+            if plan_moves:          # every rank computed the same plan: without a transfer nobody holds imported windows and the second gather has nothing to carry
+                extra = np.concatenate([x["result"] for x in imp]) if imp else np.zeros(0, dtype=records.MIRNA_DTYPE)      # loci of imported windows
+                ge = ctx.gather_records(extra.view(np.int32).reshape(len(extra), records.MIRNA_DTYPE.itemsize // 4))
+                total += 0 if ge is None else len(ge)
         elif world > 1:
             parts = [None] * world if rank == 0 else None
             tdist.gather_object(np.concatenate([out["result"]] + [x["result"] for x in imp]), parts, dst=0)

@@ -2,11 +2,12 @@
 // One precursor window per workgroup.  Replaces `RNALfold -L <PRECURSOR_LEN>`
 // (/root/reference/miR_PREFeR.py:3047-3119, command line :3053) for gfx950.
 //
-// This file holds the GENERIC kernel: DP tables (c, fML) live in a per-workgroup global
-// workspace laid out diagonal-major ((d, i) -> d*ld + i) so that every table read of the
-// anti-diagonal wavefront fill is coalesced across the lanes that own consecutive cells.
-// It supports any window length up to MIRP_NMAX and any span, and is the fallback for
-// windows the LDS-resident fast kernel (fold_lds_kernel.hip) flags as out of its range.
+// This file holds the GENERIC kernels: DP tables (c, fML, trace-back codes, a DML ring and the split-candidate pool) live in a
+// per-window global workspace slot laid out diagonal-major ((d, i) -> d*ld + i) so that the reads of the anti-diagonal wavefront
+// fill are neighbours across the lanes that own neighbouring cells.  Any window length and any span (PRECURSOR_LEN 60 .. 3000,
+// MP:167-184): the path of every window when span > 300, and the fallback for windows the LDS-resident kernels
+// (fold_lds_kernel.hip) hand back (longer than 350 nt, energies outside the 16-bit range).  Two kernels per batch of windows:
+// fold_generic_kernel<1> fills the tables, <2> runs the exterior sweep, the enumeration and the backtracks (fold_epilogue.h).
 #include <hip/hip_runtime.h>
 #include "fold_epilogue.h"
 
@@ -34,7 +35,6 @@ struct GTab {
 // ------------------------------------------------------------------------------------------
 #define GEN_NT 256
 #define GEN_AUX_BYTES(nc) ((((size_t)(4 + 8 + 2 + 1) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (64-bit keys, 8-aligned), plist (short), ctype (byte) per position
-#define GEN_G 8   // lanes cooperating on one cell
 
 __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines) {
     const int nc = n_cap + 8;
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
     unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
     // inner-pair terms of the interior-loop energies, [t2][sq1][sp1] as shorts, and the stacking table: read per candidate -- out of LDS, not through
-    // the texture addresser (the interval was bound by vector-memory instructions: one per table look-up and lane, profiles/EXPERIMENT... DESIGN.md 4)
+    // the texture addresser (the interval was bound by vector-memory instructions, one per table look-up and lane: DESIGN.md 4, "Generic kernels")
     short* l_mmI = (short*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)nc));
     short* l_mm1n = l_mmI + 200;
     short* l_mm23 = l_mm1n + 200;

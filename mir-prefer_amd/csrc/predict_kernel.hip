@@ -193,6 +193,36 @@ __device__ __forceinline__ long long aln_lower_bound(const MirpAln* __restrict__
     return lo;
 }
 
+// lower bound inside [lo, hi) (the window's own records: tens to hundreds, found once per window by the whole wave)
+__device__ __forceinline__ long long aln_lower_bound_in(const MirpAln* __restrict__ a, long long lo, long long hi, int tid, long long pos) {
+    while (lo < hi) {
+        long long mid = (lo + hi) >> 1;
+        MirpAln r = a[mid];
+        if (r.tid < tid || (r.tid == tid && r.pos < pos)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// the same lower bound over the whole record array with all 64 lanes probing at once: 3 round trips for 10^5 records, 5 for 10^7 (a lane's own binary
+// search takes 17 .. 25 dependent ones, and every (mature, structure) pair of the window used to pay two of them)
+__device__ __forceinline__ long long wave_lower_bound(const MirpAln* __restrict__ a, long long n, int tid, long long pos) {
+    const int lane = threadIdx.x & 63;
+    long long lo = 0, hi = n;
+    while (hi - lo > 64) {
+        const long long step = (hi - lo + 63) / 64;
+        const long long idx = lo + step * (lane + 1) - 1;
+        bool less = false;
+        if (idx < hi) { const MirpAln r = a[idx]; less = r.tid < tid || (r.tid == tid && r.pos < pos); }
+        const long long cnt = (long long)__popcll(__ballot(less));          // the probes below the key are a prefix of the lanes
+        const long long nlo = lo + step * cnt, nhi = lo + step * (cnt + 1) - 1;
+        lo = nlo;
+        hi = nhi < hi ? nhi : hi;
+    }
+    bool less = false;
+    if (lo + lane < hi) { const MirpAln r = a[lo + lane]; less = r.tid < tid || (r.tid == tid && r.pos < pos); }
+    return lo + (long long)__popcll(__ballot(less));
+}
+
 struct ExprRes {
     long long total_this, total_mature, total_iso, total_star; // total_star = after max with imperfect (when key present)
     long long raw_star, total_anti, imp[3];                    // reasons mode: star before the imperfect maximum, antisense depth, the three imperfect-star depths
@@ -232,9 +262,12 @@ struct SampleSet {
 // mature_each (reasons mode): where the per-sample mature depths go -- the tail of the thread's own reasons record, already zeroed; nullptr otherwise
 template <bool REASONS>
 __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_samples, int tid, int ws, int we, int fold_s, int fold_e,
-                             int m0, int m1, int star_s, int star_e, int strand, int allow_3nt, ExprRes& o, int* mature_each, int mature_each_cap) {
+                             int m0, int m1, int star_s, int star_e, int strand, int allow_3nt, ExprRes& o, int* mature_each, int mature_each_cap,
+                             long long wk0, long long wk1) {
     const int mature_len = m1 - m0, star_len = star_e - star_s, pre_len = fold_e - fold_s;
-    long long k0 = aln_lower_bound(a, na, tid, fold_s > ws ? fold_s : ws), k1 = aln_lower_bound(a, na, tid, fold_e);
+    // [wk0, wk1) = the records that start inside the window [ws, we); a record that starts at or behind we fails the test below anyway
+    (void)na;
+    long long k0 = aln_lower_bound_in(a, wk0, wk1, tid, fold_s > ws ? fold_s : ws), k1 = aln_lower_bound_in(a, wk0, wk1, tid, fold_e);
     long long tot_pre = 0, tot_mat = 0, tot_iso = 0, tot_star = 0, imp[3] = {0, 0, 0};
     SampleSet mature_set;          // samples with reads_mature > 0
     SampleSet seen;                // samples with a read on this strand starting at cur_pos (the records are sorted by position)
@@ -434,6 +467,7 @@ __global__ void __launch_bounds__(64, MIRP_PRED_WPS) predict_kernel(
         }
         __syncthreads();
         int nout = 0;
+        const long long wk0 = wave_lower_bound(alns, n_alns, W.tid, W.ws), wk1 = wave_lower_bound(alns, n_alns, W.tid, W.we);
         bool any_in_range = false;
         for (int k = 0; k < nm; k++) { MirpMature m = matures[W.mature_off + k]; int l = m.end - m.start; if (!(l < pp.min_mature_len || l > pp.max_mature_len)) any_in_range = true; }
         if (nst > 0 && any_in_range) {
@@ -468,7 +502,7 @@ __global__ void __launch_bounds__(64, MIRP_PRED_WPS) predict_kernel(
                         if (ms.code == 0) {
                             ExprRes& ex = rx;
                             d_expression<REASONS>(alns, n_alns, pp.n_samples, W.tid, W.ws, W.we, ms.fold_s, ms.fold_e, m.start, m.end, ms.star_s, ms.star_e,
-                                         m.strand, pp.allow_3nt, ex, (REASONS && rrec && rstride > 21) ? rrec + 21 : nullptr, rstride - 21);
+                                         m.strand, pp.allow_3nt, ex, (REASONS && rrec && rstride > 21) ? rrec + 21 : nullptr, rstride - 21, wk0, wk1);
                             tm = ex.total_mature; ts = ex.total_star;
                             // 'max_imperfect_star' in exprinfo (MP:2161, 2631-2635): bit0 key present, bits1-2 which+1, bit3 max > 0
                             impf = (ex.has_imp_key ? 1 : 0) | ((ex.imp_which + 1) << 1) | ((ex.imp_which >= 0) ? 8 : 0);
