@@ -11,6 +11,11 @@
 namespace mirp {
 namespace v185 {
 
+__host__ __device__ inline size_t fold185_table_ints(int n_cap, int span) {
+    const size_t per = (size_t)(span + 2) * (size_t)(n_cap + 2);
+    return (per + 3) & ~(size_t)3;
+}
+
 __host__ __device__ inline size_t fold185_lds_bytes_base(int n_cap, int max_lines) {
     const size_t nc = (size_t)n_cap + 8;
     size_t b = sizeof(int) * (nc + 8 + 2 * (size_t)max_lines + (V_NT / 64) * 3 * V_BT_STACK + V_NT / 64 + 8);
@@ -36,9 +41,16 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
     unsigned char* S = (unsigned char*)(tetra + nc);       // nc
     unsigned char* seq = S + nc;                           // nc
     char* btbuf = (char*)(seq + nc);                       // (NT/64) * (nc + 8)
-    int* cbest = (int*)(smem + fold185_lds_bytes_base(n_cap, max_lines));      // nc: interior-loop minimum of the diagonal's cells
+    int* pcnt = (int*)(smem + fold185_lds_bytes_base(n_cap, max_lines));       // nc: split candidates of every column so far
+    int* cbest = pcnt + nc;                                // nc: interior-loop minimum of the diagonal's cells
     unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
     unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
+    // inner-pair terms of the loop energies ([t2][sq1][sp1] as shorts) and the stacking table out of LDS, as fold_generic_kernel
+    short* l_mmI = (short*)(smem + fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * (size_t)nc + 15) / 16) * 16);
+    short* l_stack = l_mmI + 200;
+    for (int x = threadIdx.x; x < 200; x += V_NT) l_mmI[x] = (short)min(P->mismatchI[x / 25][(x / 5) % 5][x % 5], 32767);
+    for (int x = threadIdx.x; x < 64; x += V_NT) l_stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = span;
     for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
@@ -74,9 +86,15 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
         }
         GTab185 T;
         T.ld = n_cap + 2; T.n = n; T.M = M;
+        const size_t tab = fold185_table_ints(n_cap, span);
         T.c = ws + (size_t)blockIdx.x * ws_slot_ints;
-        T.m = T.c + ws_slot_ints / 3;
-        T.dm = T.m + ws_slot_ints / 3;
+        T.m = T.c + tab;
+        T.dm = T.m + tab;
+        // split candidates of every column (round 5, as fold_generic_kernel): the cells (s, j) whose fML is realised strictly by one of the four stem terms
+        // (tests/tools/splitcand_gate185.c: identity of the tables with ML_BASE = 0); DML(i,j) = min(DML(i,j-1), min over column j's candidates)
+        int2* pool = reinterpret_cast<int2*>(T.dm + tab);          // [ld][pcap]
+        const int pcap = span + 2;
+        if constexpr (PHASE == 1) for (int x = tid; x <= n + 1; x += V_NT) pcnt[x] = 0;
         __syncthreads();
         Ctx<FoldParams185> X;
         X.P = P; X.S = S; X.tetra = tetra; X.f3 = f3; X.n = n; X.M = M;
@@ -108,13 +126,15 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
             if (n1max >= 0 && np > 0) {
                 const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
                 for (int t = wave; t < ntask; t += V_NT / 64) {
-                    const int blk = t / (n1max + 1), n1 = t - blk * (n1max + 1);
+                    const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: the loop shape (and loopE's branches) in scalar registers
+                    const int blk = tu / (n1max + 1), n1 = tu - blk * (n1max + 1);
                     const int k = blk * 64 + lane;
                     if (k < np) {
                         const int cell = plist[k];
                         const int i = cell + 1, j = i + d, p = i + 1 + n1;
                         const int type = ctype[cell];
                         const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1];
+                        const int o_mmI = l_mmI[type * 25 + si1 * 5 + sj1];          // the outer pair's term: once per task
                         int n2max = V_MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (V_TURN + 1)) n2max = d - n1 - 2 - (V_TURN + 1);
                         int best = V_INF;
@@ -125,7 +145,20 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                             int t2 = ptype(X, p, q);
                             if (!t2) continue;
                             t2 = rtype_of(t2);
-                            const int e = loopE(X, n1, n2, type, t2, si1, sj1, sp1, S[q + 1]) + cv;
+                            const int sq1 = S[q + 1];
+                            const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
+                            int e;
+                            if (ns >= 1 && !(ns == 1 && nl <= 2) && !(ns == 2 && nl == 2)) {
+                                const int x = (nl - ns) * P->ninio;          // every loop but 1x1, 1x2, 2x2 in this model (no 1xn / 2x3 tables)
+                                e = P->internal_loop[n1 + n2] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + l_mmI[t2 * 25 + sq1 * 5 + sp1];
+                            } else if (nl == 0) {
+                                e = l_stack[type * 8 + t2];
+                            } else if (ns == 0) {
+                                e = P->bulge[nl] + (nl == 1 ? (int)l_stack[type * 8 + t2] : (AU(X, type) + AU(X, t2)));
+                            } else {
+                                e = loopE(X, n1, n2, type, t2, si1, sj1, sp1, sq1);
+                            }
+                            e += cv;
                             best = e < best ? e : best;
                         }
                         if (best < V_INF) atomicMin(&cbest[cell], best);
@@ -153,8 +186,13 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                             best = v < best ? v : best;
                         }
                     }
-                    for (int k = i + V_TURN + 1 + sub; k <= j - V_TURN - 2; k += V_G) {
-                        const int e = T.Mm(i, k) + T.Mm(k + 1, j);
+                    if (sub == 0) mdec = T.DM(i, j - 1);
+                    const int pn = pcnt[j];
+                    const int2* pj = pool + (size_t)j * pcap;
+                    for (int k = sub; k < pn; k += V_G) {
+                        const int2 en = pj[k];
+                        if (en.x < i + V_TURN + 2) continue;          // fML(i, s-1) does not exist yet
+                        const int e = T.Mm(i, en.x - 1) + en.y;
                         mdec = e < mdec ? e : mdec;
                     }
                 }
@@ -167,14 +205,19 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                     const int newc = type ? best : V_INF;
                     int mm = T.Mm(i + 1, j);
                     int v = T.Mm(i, j - 1); mm = v < mm ? v : mm;
-                    v = newc + MLi(X, type); mm = v < mm ? v : mm;
-                    int t = ptype(X, i + 1, j);
-                    v = T.C(i + 1, j) + P->dangle5[t][S[i]] + MLi(X, t); mm = v < mm ? v : mm;
-                    t = ptype(X, i, j - 1);
-                    v = T.C(i, j - 1) + P->dangle3[t][S[j]] + MLi(X, t); mm = v < mm ? v : mm;
-                    t = ptype(X, i + 1, j - 1);
-                    v = T.C(i + 1, j - 1) + P->dangle5[t][S[i]] + P->dangle3[t][S[j]] + MLi(X, t); mm = v < mm ? v : mm;
                     mm = mdec < mm ? mdec : mm;
+                    int stem = newc + MLi(X, type);
+                    int t = ptype(X, i + 1, j);
+                    v = T.C(i + 1, j) + P->dangle5[t][S[i]] + MLi(X, t); stem = v < stem ? v : stem;
+                    t = ptype(X, i, j - 1);
+                    v = T.C(i, j - 1) + P->dangle3[t][S[j]] + MLi(X, t); stem = v < stem ? v : stem;
+                    t = ptype(X, i + 1, j - 1);
+                    v = T.C(i + 1, j - 1) + P->dangle5[t][S[i]] + P->dangle3[t][S[j]] + MLi(X, t); stem = v < stem ? v : stem;
+                    if (stem < mm) {          // realised strictly by a stem term: (i, j) is a split candidate of column j
+                        mm = stem;
+                        const int k = pcnt[j];
+                        if (k < pcap) { pool[(size_t)j * pcap + k] = make_int2(i, stem); pcnt[j] = k + 1; }
+                    }
                     T.c[(size_t)d * T.ld + i] = newc;
                     T.m[(size_t)d * T.ld + i] = mm;
                     T.dm[(size_t)d * T.ld + i] = mdec;
@@ -192,11 +235,13 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
 
 }  // namespace v185
 
-size_t fold185_lds_bytes(int n_cap, int max_lines) { return v185::fold185_lds_bytes_base(n_cap, max_lines) + (size_t)(4 + 2 + 1) * ((size_t)n_cap + 8) + 16; }
+size_t fold185_lds_bytes(int n_cap, int max_lines) {
+    return v185::fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * ((size_t)n_cap + 8) + 15) / 16) * 16 + sizeof(short) * (200 + 64) + 16;
+}
 
 size_t fold185_ws_slot_ints(int n_cap, int span) {
-    size_t per = (size_t)(span + 2) * (size_t)(n_cap + 2);
-    return 3 * ((per + 3) & ~(size_t)3);
+    // c, fML, DML, the split-candidate pool (two ints per entry, span + 2 entries per column)
+    return 3 * v185::fold185_table_ints(n_cap, span) + ((2 * (size_t)(n_cap + 2) * (size_t)(span + 2) + 3) & ~(size_t)3);
 }
 
 hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens,
