@@ -201,3 +201,29 @@ def test_window_views_and_streamed_reports_equal_the_whole_run(gpu_ctx, oracle, 
         for sub, files in ((".", cmp.common_files), ("readmapping", os.listdir(ref_dir / "readmapping"))):
             match, mismatch, errors = filecmp.cmpfiles(str(ref_dir / sub), str(d / sub), files, shallow=False)
             assert not mismatch and not errors and len(match) == len(files)
+
+
+def test_window_view_argument_checks(gpu_ctx):
+    """mirp_select_windows refuses ranges outside the window list, mirp_limit_windows refuses to run under a view, a view resets the fold state (the filter
+    then asks for a fold first), count < 0 restores the list."""
+    from mir_prefer_amd import capi
+    ds = synth.make_dataset([60000], 30, n_samples=1, seed=12, contig_names=["c1"])
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(ds.sorted_alns())
+    _, _, nwin = gpu_ctx.candidate(10, 100, 300, np.zeros(1, dtype=np.int32))
+    assert nwin > 10
+    with pytest.raises(capi.MirpError):
+        gpu_ctx.select_windows(0, nwin + 1)
+    with pytest.raises(capi.MirpError):
+        gpu_ctx.select_windows(-1, 2)
+    gpu_ctx.fold(300)
+    gpu_ctx.select_windows(2, 5)
+    with pytest.raises(capi.MirpError):          # the fold of the whole list is not the view's fold
+        gpu_ctx.predict_raw(1, 18, 23, False, True)
+    with pytest.raises(capi.MirpError):
+        gpu_ctx.limit_windows(3)
+    gpu_ctx.fold(300)
+    assert len(gpu_ctx.predict_raw(1, 18, 23, False, True)["status"]) == 5
+    gpu_ctx.select_windows(0, -1)
+    gpu_ctx.fold(300)
+    assert len(gpu_ctx.predict_raw(1, 18, 23, False, True)["status"]) == nwin
