@@ -287,7 +287,7 @@ def relaxation_count(seq_bytes, offs, lens, span):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
+def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=1.2, back_to_back=2):
     """The product CLI the way a user runs it: a FRESH `python -m mir_prefer_amd.cli pipeline <config>` process per run, clocked by this (parent)
     process from spawn to exit -- interpreter start, imports, library load, device context, first-touch of every allocation and code object, the four
     stages, every report file, the removal of the temporary folder and process teardown are all inside.  SAM + FASTA in -> gff3 / fasta / ss / csv /
@@ -307,14 +307,18 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
         env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
         env["MIRP_CLI_TIMINGS"] = os.path.join(tmp, "timings.json")
         recs = []
-        for rep in range(runs):
+        for rep in range(runs + back_to_back):
+            # `runs` isolated invocations, then `back_to_back` ones started the moment the previous process is gone.  Isolated = at least pause_s after the last
+            # process that used the GPU ended: a HIP process started right behind another one's exit waits 0.13 s in open("/dev/kfd") for the kernel driver's
+            # deferred teardown of that process (hipInit 0.17 - 0.22 s instead of 0.06 s, profiles/r5_hip_back_to_back.txt) -- the cost of a shell loop over
+            # data sets, not of one invocation, so it is reported beside the headline figure, not in it.
             # every run writes into a folder of its own and NOTHING is deleted until the whole bench is done (_E2E_TRASH): on the box's overlay file
             # system a burst of deletions makes the next seconds' file creations 6 - 9 x slower (10 -> 65 .. 97 us per file, profiles/tools/fs_regime.py),
             # which would charge the harness's own clean-up to the next run's 4,002 / 16,016 report files
             cfg = os.path.join(tmp, "config%d" % rep)
             with open(cfg, "w") as f:
                 f.write(cfg_text % os.path.join(tmp, "out%d" % rep))
-            if pause_s:
+            if pause_s and rep < runs:
                 time.sleep(pause_s)
             t0 = time.time()
             r = subprocess.run([sys.executable, "-m", "mir_prefer_amd.cli", "--fold-model", fold_model, "pipeline", cfg], env=env, cwd=tmp,
@@ -345,14 +349,17 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=0.0):
         fs_us = (time.time() - t) / 2000 * 1e6
         first = recs[0]
         dev_total = sum(first["device_s"].values())
-        return {"process_wall_s": first["process_wall_s"], "process_wall_s_all_runs": [round(x["process_wall_s"], 4) for x in recs],
+        return {"process_wall_s": first["process_wall_s"], "process_wall_s_all_runs": [round(x["process_wall_s"], 4) for x in recs[:runs]],
+                "process_wall_s_back_to_back": [round(x["process_wall_s"], 4) for x in recs[runs:]],
                 "device_s_all_runs": [round(sum(x["device_s"].values()), 4) for x in recs], "segments_s_all_runs": [x["segments_s"] for x in recs],
                 "device_s": dev_total, "host_s": first["process_wall_s"] - dev_total, "host_over_device": (first["process_wall_s"] - dev_total) / dev_total if dev_total else None,
                 "segments_s": first["segments_s"], "stage_device_s": first["device_s"], "files_under": os.path.dirname(tmp),
                 "input_bytes": in_bytes, "output_bytes": out_bytes, "loci": first["loci"], "small_report_files": n_small, "fs_create_us_per_file": round(fs_us, 1),
                 "note": "parent-side clock around a fresh `python -m mir_prefer_amd.cli pipeline <config>` process: interpreter start, imports, library load, "
                         "device context, first touch of allocations and code objects, stages, report files, removal of the temporary folder and exit all "
-                        "included; process_wall_s = the FIRST of the runs (each a new process, inputs in the page cache); segments_s = the child's own stamps: "
+                        "included; process_wall_s = the FIRST of the isolated runs (each a new process started >= 1.2 s after the previous GPU process ended, inputs in "
+                        "the page cache); process_wall_s_back_to_back = runs started the moment the previous one is reaped, which wait ~0.13 s in open(/dev/kfd) for "
+                        "the driver's deferred teardown of their predecessor; segments_s = the child's own stamps: "
                         "main = spawn -> entry of main() (interpreter + package import), imports = capi / numpy / pipeline, context = config parse + "
                         "library load + device context (the join on the early device-open thread), then the four stages -- a lean run (no -k, no -d) does fold + filter + "
                         "report files as ONE pipelined call inside the predict segment, so `fold` is 0 and `predict` carries the fold's device time --, "
@@ -828,12 +835,12 @@ def main():
                 line["e2e_wall_s"] = line["e2e"].get("process_wall_s")
                 shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
                 if shm and "error" not in line["e2e"]:
-                    other = e2e_process(ds, a.fold_model, shm, a.e2e_runs)
+                    other = e2e_process(ds, a.fold_model, shm, a.e2e_runs, back_to_back=0)
                     line["e2e"]["files_on_tmpfs"] = {k: other.get(k) for k in ("process_wall_s", "process_wall_s_all_runs", "segments_s", "files_under", "error") if k in other}
                 if not a.no_configs:
                     sp2, ns2, bg2, _, d2 = workload_specs("config2", 1)
                     c2, a2, sn2 = build_shard(sp2, set(range(len(sp2))), ns2, bg2)
-                    r2 = e2e_process(synth.Dataset(c2, sn2, a2, []), a.fold_model, None, max(1, a.e2e_runs - 1))
+                    r2 = e2e_process(synth.Dataset(c2, sn2, a2, []), a.fold_model, None, max(1, a.e2e_runs - 1), back_to_back=1)
                     r2["workload"] = d2
                     if r2.get("loci") is not None and r2["loci"] != EXPECTED_LOCI[("config2", a.fold_model)] and a.fold_model == "vienna-2.1.2":
                         r2["error"] = "result check failed: %d loci" % r2["loci"]

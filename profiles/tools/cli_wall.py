@@ -7,7 +7,7 @@ from mir_prefer_amd import synth
 wl = sys.argv[1] if len(sys.argv) > 1 else "config1"
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 base = (sys.argv[3] if len(sys.argv) > 3 else None) or None
-pause = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+pause = float(sys.argv[4]) if len(sys.argv) > 4 else 1.2
 specs, ns, bg, _, _ = bench.workload_specs(wl, 1)
 contigs, alns, samples = bench.build_shard(specs, set(range(len(specs))), ns, bg)
 r = bench.e2e_process(synth.Dataset(contigs, samples, alns, []), "vienna-2.1.2", base, runs, pause_s=pause)

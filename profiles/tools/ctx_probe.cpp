@@ -31,6 +31,16 @@ static int child(const char* mode, const char* lib) {
         T("hipMemsetAsync 6 GB + sync", { hipMemsetAsync(big, 0, 6ull << 30, st); hipStreamSynchronize(st); });
         T("hipMalloc 64 MB", { void* q; hipMalloc(&q, 64 << 20); });
         if (!std::strcmp(mode, "exit_free")) T("hipFree 6 GB", hipFree(big));
+        if (!std::strcmp(mode, "exit_hsa")) {          // release the runtime (and with it /dev/kfd) before the process ends: does the kernel-side teardown move in here?
+            typedef int (*shut_t)(void);
+            shut_t shut = (shut_t)dlsym(RTLD_DEFAULT, "hsa_shut_down");
+            std::printf("  hsa_shut_down %s\n", shut ? "found" : "not found");
+            if (shut) { int rc = -1; T("hsa_shut_down #1", rc = shut()); std::printf("  rc %d\n", rc); T("hsa_shut_down #2", rc = shut()); std::printf("  rc %d\n", rc); }
+            std::printf("  %-44s %8.2f ms\n", "child total before exit", 1e3 * (now() - t_start));
+            std::fflush(stdout);
+            _exit(0);
+        }
+        if (!std::strcmp(mode, "exit_reset")) { T("hipStreamDestroy", hipStreamDestroy(st)); T("hipDeviceReset", hipDeviceReset()); }
         std::printf("  %-44s %8.2f ms\n", "child total before exit", 1e3 * (now() - t_start));
         std::fflush(stdout);
         if (!std::strcmp(mode, "exit__exit")) _exit(0);
@@ -53,7 +63,7 @@ static int child(const char* mode, const char* lib) {
 int main(int argc, char** argv) {
     const char* lib = argc > 2 ? argv[2] : "mir-prefer_amd/libmirprefer.so";
     if (argc > 1 && std::strcmp(argv[1], "all")) return child(argv[1], lib);
-    const char* modes[] = {"bare", "bare", "lib", "lib", "exit_return", "exit__exit", "exit_quick", "exit_free"};
+    const char* modes[] = {"bare", "bare", "lib", "lib", "exit_return", "exit__exit", "exit_quick", "exit_free", "exit_reset", "exit_reset"};
     for (const char* m : modes) {
         std::printf("== %s\n", m); std::fflush(stdout);
         double t0 = now();
