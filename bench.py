@@ -305,7 +305,10 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=1.2, ba
         in_bytes = sum(os.path.getsize(p) for p in sams) + os.path.getsize(fa)
         env = dict(os.environ)
         env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-        env["MIRP_CLI_TIMINGS"] = os.path.join(tmp, "timings.json")
+        # the child's stamps go to the in-memory file system when there is one: written after its last stamp, on a busy overlay file system that one small
+        # file stalled 0.1 s in a journal commit and showed up as "exit" time (a user's run writes no such file)
+        tdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tmp
+        env["MIRP_CLI_TIMINGS"] = os.path.join(tdir, "mirp_timings_%d_%s.json" % (os.getpid(), os.path.basename(tmp)))
         recs = []
         for rep in range(runs + back_to_back):
             # `runs` isolated invocations, then `back_to_back` ones started the moment the previous process is gone.  Isolated = at least pause_s after the last
@@ -366,6 +369,10 @@ def e2e_process(ds, fold_model, base=None, runs=3, extra_cfg="", pause_s=1.2, ba
                         "removetmp, exit = end of main() -> process gone; stage_device_s = device time inside each stage"}
     finally:
         _E2E_TRASH.append(tmp)
+        try:
+            os.remove(env["MIRP_CLI_TIMINGS"])
+        except Exception:
+            pass
 
 
 _E2E_TRASH = []          # directories of the end-to-end legs, removed when the bench is done (see e2e_process)
