@@ -259,3 +259,19 @@ except capi.MirpError as e:
     assert r.returncode == 0 and len(out) == 2, (r.stdout, r.stderr[-1500:])
     assert out[0].startswith("ERROR1 ") and 1.5 < float(out[0].split()[1]) < 10 and "timed out waiting for rank 1" in out[0]
     assert out[1].startswith("ERROR2 0.0") and "aborted by an earlier failure" in out[1]
+
+
+def test_bench_eight_ranks_config3_on_one_gpu(tmp_path):
+    """BASELINE config[3]'s shape as the driver's 8-GPU run deals it -- 12 MSU7-sized contigs over 8 ranks, longest first, windows re-balanced before the fold, loci
+    gathered on rank 0 -- with all 8 ranks on this one GPU over the local transport, at 5 % of the size: the same windows and the same loci as the 1-rank run.
+    (The full-size run was done by hand in round 5: 218,293 windows, 50,074 loci on 8 ranks and on 1, profiles/r5_config3_8_ranks_one_gpu.json.)"""
+    common = ["--workload", "config3", "--genome-scale", "0.05", "--steps", "1", "--warmup", "1", "--no-configs", "--no-e2e", "--no-cpu-baseline", "--no-ingest"]
+    one = _bench_line(["--gpus", "1"] + common)
+    share = tmp_path / "share8"
+    share.mkdir()
+    line = _bench_line(["--gpus", "8"] + common, env={"MIRP_BENCH_SHARE_GPU": str(share)}, timeout=1500)
+    assert line["n_gpus"] == 8 and line["config"]["windows_total"] == one["config"]["windows_total"] > 5000
+    assert line["config"]["loci_found"] == one["config"]["loci_found"] > 1000
+    rk = line["ranks"]
+    assert sum(rk["contigs"]) == 12 and sum(rk["windows"]) == one["config"]["windows_total"] and sum(rk["windows_shipped"]) == sum(rk["windows_received"]) > 0
+    assert max(rk["windows"]) <= 1.12 * (sum(rk["windows"]) / 8.0)          # re-balanced to within the plan's 10 % band
