@@ -314,6 +314,13 @@ typedef struct { int32_t tid, start, end; } MirpRegion;
 int mirp_ingest_sams_gpu(mirp_ctx* ctx, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
                          int64_t n_regions, MirpSamData* out, double seconds[4]);
 
+/* mirp_ingest_sams_gpu in two halves: the host half (header + threaded tokenizer; no context, so it can run while the device is still being opened) and the
+ * device half (keep-region filter, stable (tid, pos) radix sort, the records resident as the context's alignments).  mirp_ingest_tokenized_gpu consumes and
+ * releases `tokenized`; mirp_free_tokenized releases one that was never handed over.  Same results as mirp_ingest_sams_gpu (MP:772-874). */
+int mirp_tokenize_sams(const char* const* paths, int32_t n_paths, int32_t n_threads, void** tokenized, char* errbuf, size_t errbuf_len);
+int mirp_ingest_tokenized_gpu(mirp_ctx* ctx, void* tokenized, const MirpRegion* keep_regions, int64_t n_regions, MirpSamData* out, double seconds[4]);
+void mirp_free_tokenized(void* tokenized);
+
 /* The same ingest sharded over the ranks of the context's communicator (mirp_dist_init; without one, or with one rank, it equals
  * mirp_ingest_sams_gpu): every rank tokenizes its own byte range of every SAM file, the records are routed to the rank that owns their
  * contig -- owner_of_tid[n_contigs], the same whole-contig partition the later stages use -- with one all-to-all over RCCL, and every rank

@@ -200,20 +200,13 @@ def _unpack_sam_data(lib, d):
 
 
 def ingest_sams(paths, n_threads=0, with_segments=False):
-    """Native multi-threaded SAM ingest, host sort (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns[, segs]).  An ingest of the
-    same files that the CLI started before its heavy imports (early.start_ingest) is adopted instead of run again."""
+    """Native multi-threaded SAM ingest, host sort (mirp_ingest_sams). -> (contig_names, contig_lens, sample_names, alns[, segs])."""
     lib = load_library()
-    got = early.take_ingest(paths)
-    if got is not None:
-        rc, d, msg = got
-        if rc != 0:
-            raise ValueError(msg)
-    else:
-        arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
-        d = SamData()
-        err = C.create_string_buffer(512)
-        if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
-            raise ValueError(err.value.decode())
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    d = SamData()
+    err = C.create_string_buffer(512)
+    if lib.mirp_ingest_sams(arr, len(paths), int(n_threads), C.byref(d), err, 512) != 0:
+        raise ValueError(err.value.decode())
     out = _unpack_sam_data(lib, d)
     return out if with_segments else out[:4]
 
@@ -544,6 +537,29 @@ class Context:
         # host_copy_s: the records copied out of the library's buffer into numpy arrays and the buffer released
         return cn, lens, sn, alns, segs, {"tokenize_s": sec[0], "upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3],
                                           "native_other_s": max(0.0, (t1 - t0) - sum(sec)), "host_copy_s": time.time() - t1}
+
+    def ingest_tokenized(self, paths, regions=None):
+        """The device half of ingest_sams for files whose tokenizer run the CLI started before its heavy imports (early.start_ingest): keep-region filter +
+        stable radix sort (mirp_ingest_tokenized_gpu).  Same return as ingest_sams."""
+        got = early.take_ingest(paths)
+        if got is None:
+            raise MirpError("ingest_tokenized: no tokenizer run was started for these files")
+        rc, tok, msg = got
+        if rc != 0:
+            raise ValueError(msg)
+        nreg = len(regions) if regions else 0
+        reg = (Region * max(nreg, 1))()
+        for k in range(nreg):
+            reg[k].tid, reg[k].start, reg[k].end = int(regions[k][0]), int(regions[k][1]), int(regions[k][2])
+        d = SamData()
+        sec = (C.c_double * 4)()
+        fn = self.lib.mirp_ingest_tokenized_gpu
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(SamData), C.POINTER(C.c_double)]
+        fn.restype = C.c_int
+        if fn(self.h, tok, C.cast(reg, C.c_void_p), nreg, C.byref(d), sec) != 0:
+            raise ValueError(self.lib.mirp_last_error(self.h).decode())
+        cn, lens, sn, alns, segs = _unpack_sam_data(self.lib, d)
+        return cn, lens, sn, alns, segs, {"tokenize_s": 0.0, "upload_filter_s": sec[1], "sort_s": sec[2], "download_s": sec[3]}
 
     def ingest_sams_shard(self, paths, owner_of_tid, regions=None, n_threads=0):
         """Sharded ingest (mirp_ingest_sams_shard): this rank tokenizes its byte range of every file, records travel to the rank that owns their

@@ -65,8 +65,8 @@ def main(argv=None):
         early.start_context(o["device"])
         if o["action"] == "pipeline" and opt["FASTA_FILE"]:
             early.start_fasta(opt["FASTA_FILE"])
-        if o["action"] in ("pipeline", "prepare") and not (opt["GFF_FILE_EXCLUDE"] or opt["GFF_FILE_INCLUDE"]):
-            early.start_ingest(opt["ALIGNMENT_FILE"])          # with a GFF mask the records are filtered and sorted on the device instead (mirp_ingest_sams_gpu)
+        if o["action"] in ("pipeline", "prepare"):
+            early.start_ingest(opt["ALIGNMENT_FILE"])          # the tokenizer (host half of mirp_ingest_sams_gpu); the device half follows in the prepare stage
     from . import capi, pipeline
     clock.mark("imports")
     opt["OUTPUT_DETAILS_FOR_DEBUG"] = o["debug"]

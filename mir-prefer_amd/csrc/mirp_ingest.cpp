@@ -408,18 +408,19 @@ extern "C" int mirp_ingest_sams(const char* const* paths, int32_t n_paths, int32
 // out by (file, source rank), i.e. in (sample, file offset) order, so the stable sort sees exactly the sequence the single-process ingest sees for
 // those contigs and ties resolve identically (first-seen maximum, MP:1457).
 static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions, int64_t n_regions,
-                       bool shard, const int32_t* owner_of_tid, MirpSamData* out, double seconds[4], const char* who) {
+                       bool shard, const int32_t* owner_of_tid, MirpSamData* out, double seconds[4], const char* who, Parsed* pre = nullptr) {
     if (!c) return -1;
-    if (!paths || n_paths < 1 || !out) return fail(c, -1, std::string(who) + ": bad argument");
+    if ((!paths && !pre) || n_paths < 1 || !out) return fail(c, -1, std::string(who) + ": bad argument");
     if (n_paths > MIRP_MAX_SAMPLES) return fail(c, -1, std::string(who) + ": too many samples");
     std::memset(out, 0, sizeof(*out));
     HIPCHK(c, hipSetDevice(c->device));
     const int W = shard ? c->dist_world : 1, me = shard ? c->dist_rank : 0;
     if (shard && W > 1 && !owner_of_tid) return fail(c, -1, std::string(who) + ": owner_of_tid is required with more than one rank");
     const double t0 = now_s();
-    Parsed P;
+    Parsed P_own;
+    Parsed& P = pre ? *pre : P_own;          // pre: the files were tokenized before the device was open (mirp_tokenize_sams)
     std::string err;
-    int bad = parse_all(paths, n_paths, n_threads, &P, &err, me, W) ? 1 : 0;
+    int bad = pre ? 0 : (parse_all(paths, n_paths, n_threads, &P, &err, me, W) ? 1 : 0);
     const int nc = (int)P.names.size();
     if (!bad && W > 1)
         for (int t = 0; t < nc && !bad; t++)
@@ -622,6 +623,32 @@ static int ingest_impl(mirp_ctx* c, const char* const* paths, int32_t n_paths, i
 extern "C" int mirp_ingest_sams_gpu(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,
                                     int64_t n_regions, MirpSamData* out, double seconds[4]) {
     return ingest_impl(c, paths, n_paths, n_threads, keep_regions, n_regions, false, nullptr, out, seconds, "mirp_ingest_sams_gpu");
+}
+
+// The host half of mirp_ingest_sams_gpu on its own, without a context: header + threaded tokenizer over every file.  A caller that starts it while the device is
+// still being opened (the CLI: early.py) hands the result to mirp_ingest_tokenized_gpu, which does the device half (keep-region filter, stable radix sort) and
+// releases it -- for a config[4] rank shard (2.65 GB of SAM text) that takes the 25-million-record host sort of mirp_ingest_sams off the path to the first stage.
+extern "C" int mirp_tokenize_sams(const char* const* paths, int32_t n_paths, int32_t n_threads, void** tokenized, char* errbuf, size_t errbuf_len) {
+    auto bail = [&](const std::string& m) { if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "%s", m.c_str()); return -1; };
+    if (!paths || n_paths < 1 || !tokenized) return bail("mirp_tokenize_sams: bad argument");
+    if (n_paths > MIRP_MAX_SAMPLES) return bail("mirp_tokenize_sams: too many samples");
+    *tokenized = nullptr;
+    Parsed* P = new Parsed();
+    std::string err;
+    if (parse_all(paths, n_paths, n_threads, P, &err)) { delete P; return bail(err); }
+    *tokenized = P;
+    return 0;
+}
+
+extern "C" void mirp_free_tokenized(void* tokenized) { delete (Parsed*)tokenized; }
+
+extern "C" int mirp_ingest_tokenized_gpu(mirp_ctx* c, void* tokenized, const MirpRegion* keep_regions, int64_t n_regions, MirpSamData* out, double seconds[4]) {
+    if (!c) return -1;
+    if (!tokenized) return fail(c, -1, "mirp_ingest_tokenized_gpu: bad argument");
+    Parsed* P = (Parsed*)tokenized;
+    const int rc = ingest_impl(c, nullptr, (int32_t)std::max<size_t>(P->per_file.size(), 1), 0, keep_regions, n_regions, false, nullptr, out, seconds, "mirp_ingest_tokenized_gpu", P);
+    delete P;
+    return rc;
 }
 
 extern "C" int mirp_ingest_sams_shard(mirp_ctx* c, const char* const* paths, int32_t n_paths, int32_t n_threads, const MirpRegion* keep_regions,

@@ -25,7 +25,7 @@ class SamData(C.Structure):
 _lib = None
 _contexts = {}      # device -> (thread, handle, result box)
 _fastas = {}        # path -> (thread, FastaData, error buffer, result box)
-_ingests = {}       # tuple of SAM paths -> (thread, SamData, error buffer, result box)
+_ingests = {}       # tuple of SAM paths -> (thread, tokenizer handle, error buffer, result box)
 
 
 def cdll():
@@ -89,23 +89,23 @@ def take_fasta(path):
 
 
 def start_ingest(paths):
-    """The host ingest of the SAM files (mirp_ingest_sams: tokenizer threads + stable host sort by (tid, pos)) while the device is still being opened;
-    the prepare stage adopts the records (pipeline.Pipeline._prepare_rank0) and only uploads them."""
+    """The host half of the SAM ingest (mirp_tokenize_sams: header + tokenizer threads) while the device is still being opened; the prepare stage hands the
+    result to the device half (Context.ingest_tokenized: keep-region filter + stable radix sort) as soon as the context is there."""
     lib = cdll()
     key = tuple(str(p) for p in paths)
     if lib is None or not key or key in _ingests or any(p.endswith(".gz") for p in key):
         return
-    fn = lib.mirp_ingest_sams
-    fn.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(SamData), C.c_char_p, C.c_size_t]      # as capi.load_library declares it
+    fn = lib.mirp_tokenize_sams
+    fn.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]      # as capi.load_library declares it
     fn.restype = C.c_int
     arr = (C.c_char_p * len(key))(*[p.encode() for p in key])
-    d, err, box = SamData(), C.create_string_buffer(512), {}
+    tok, err, box = C.c_void_p(), C.create_string_buffer(512), {}
 
     def run():
-        box["rc"] = fn(arr, len(key), 0, C.byref(d), err, 512)
+        box["rc"] = fn(arr, len(key), 0, C.byref(tok), err, 512)
     th = threading.Thread(target=run, daemon=True)
     th.start()
-    _ingests[key] = (th, d, err, box)
+    _ingests[key] = (th, tok, err, box)
 
 
 def has_ingest(paths):
@@ -113,7 +113,8 @@ def has_ingest(paths):
 
 
 def take_ingest(paths):
-    """-> (return code of mirp_ingest_sams, SamData, error text) of the ingest started for these paths, or None; handed out once (the caller frees)."""
+    """-> (return code of mirp_tokenize_sams, handle, error text) of the tokenizer run started for these paths, or None; handed out once (the caller passes the
+    handle to mirp_ingest_tokenized_gpu, which releases it)."""
     ent = _ingests.pop(tuple(str(p) for p in paths), None)
     if ent is None:
         return None

@@ -232,8 +232,8 @@ class Pipeline:
         try:
             if any(str(p).endswith(".gz") for p in paths):        # compressed inputs: host parser (same rules), host filter and sort
                 names, lens, samples, alns, segs = ingest.read_sams(paths, regions=regions, with_segments=True)
-            elif regions is None and early.has_ingest(paths):      # the CLI started the host ingest while the device was being opened: adopt it
-                names, lens, samples, alns, segs = capi.ingest_sams(paths, with_segments=True)
+            elif early.has_ingest(paths):      # the CLI started the tokenizer while the device was being opened: the device half (filter, sort) follows now
+                names, lens, samples, alns, segs, self.ingest_seconds = self.ctx.ingest_tokenized(paths, regions=regions)
             else:       # tokenizer on the host threads; keep-region filter and the stable (tid, pos) sort on the GPU (mirp_ingest_sams_gpu)
                 names, lens, samples, alns, segs, self.ingest_seconds = self.ctx.ingest_sams(paths, regions=regions)
         except ValueError as e:
