@@ -215,6 +215,9 @@ if __name__ == "__main__":
     if "mini185" in what:
         # the "mini" dataset with the RNALfold the reference bundles for Linux (1.8.5) on PATH instead of 2.1.2
         gen_pipeline_golden("mini185", [120000, 60000, 90000], ["Chr2", "Chr10", "Chr1"], 130, 2, 5, None, {}, rnalfold="RNALfold185")
+    if "mini400" in what:
+        # PRECURSOR_LEN = 400: window extension at another length, RNALfold -L 400 on windows of 400 / 425 nt (the generic fold kernels' domain)
+        gen_pipeline_golden("mini400", [90000, 50000], ["cB", "cA"], 60, 2, 17, None, {"PRECURSOR_LEN": 400})
     if "mini24" in what:
         # 24 ALIGNMENT_FILEs: more samples than one 16-entry register array held in rounds 1-4 (the reference has no limit, MP:3300-3308); both
         # no-star rules that look at every sample (MP:2316-2330) are in play with ALLOW_NO_STAR_EXPRESSION = Y

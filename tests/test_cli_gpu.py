@@ -32,7 +32,7 @@ def _setup(name, tmp_path):
     return exp, str(cfg), tmp_path / "out"
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24", "mini400"])
 def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
     exp, cfg, out = _setup(name, tmp_path)
     assert cli.main(["-k", "-d", "--fold-model", exp.get("fold_model", "vienna-2.1.2"), "pipeline", cfg]) == 0
@@ -81,7 +81,7 @@ def test_pipeline_verb_reproduces_reference_outputs(name, tmp_path):
 
 
 @pytest.mark.parametrize("chunks", [0, 7])
-@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24", "mini400"])
 def test_lean_pipeline_process_reproduces_reference_outputs(name, chunks, tmp_path):
     """`python -m mir_prefer_amd.cli pipeline <config>` as a user runs it -- a fresh process, no -k, no -d: the device context and the genome read start
     before the heavy imports (early.py), no stage artefact is written (they would be deleted at the end, MP:3630-3639), the report files come from one

@@ -181,7 +181,7 @@ def test_fold_stage_folds_once():
 import pytest
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24", "mini400"])
 def test_report_writers_match_reference_files(name, tmp_path):
     """mature.fa / precursor.fa / precursor.ss / detail.csv / detail.html / miRNA.stat.txt of the predict stage, byte for byte, from the reference's own
     result list (gen_mirna_fasta_ss_from_result MP:2963-3019, gen_mirna_info MP:2644-2728, gen_csv_table MP:2744-2779, MP:3585-3593)."""
@@ -218,7 +218,7 @@ def test_report_writers_match_reference_files(name, tmp_path):
         assert open(tmp_path / "rm" / fn).read() == text, fn
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24", "mini400"])
 def test_result_reports_one_call_matches_reference_files(name, tmp_path):
     """mirp_write_result_reports (the lean `pipeline` run's report path): the reference's RAW result list -- queue order, mature / star as the filter
     found them -- as flat records, shuffled; one native call must produce the reference's gff3, fasta / ss / csv / html / stat files and every

@@ -6,7 +6,7 @@ import pytest
 from mir_prefer_amd import records
 from tests import golden_util as gu
 
-CASES = ["mini", "mini3", "mini185", "mini24"]   # mini185: the "mini" dataset run with the bundled RNALfold 1.8.5 on PATH
+CASES = ["mini", "mini3", "mini185", "mini24", "mini400"]   # mini185: the "mini" dataset run with the bundled RNALfold 1.8.5 on PATH
 
 
 def test_lfold_matches_rnalfold212(oracle):

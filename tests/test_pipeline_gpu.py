@@ -19,7 +19,7 @@ def _gpu_record(m, ss, names):
             records.STRAND[m["strand"]], bool(m["has_star"])]
 
 
-@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24"])
+@pytest.mark.parametrize("name", ["mini", "mini3", "mini185", "mini24", "mini400"])
 def test_pipeline_matches_reference_fixture(name, gpu_ctx):
     c = gu.load_pipeline_case(name)
     gpu_ctx.set_fold_model(c["exp"].get("fold_model", "vienna-2.1.2"))
