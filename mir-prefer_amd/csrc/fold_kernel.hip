@@ -21,6 +21,7 @@ struct GTab {
     static constexpr bool kTiled = false;
     int* __restrict__ c;
     int* __restrict__ m;
+    int* __restrict__ g;           // c(p,q) + mismatchI of (p,q) seen as the INNER pair of a generic interior loop (INF where (p,q) is no pair): the fill's own copy
     unsigned short* __restrict__ tb;
     int ld;
     __device__ __forceinline__ int C(int d, int i) const { return c[(size_t)d * ld + i]; }
@@ -161,6 +162,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
         int2* pool = reinterpret_cast<int2*>(dml + 4 * (size_t)T.ld);      // [ld][pcap]
         const int pcap = fold_generic_pool_cap(n_cap, span);
         T.tb = reinterpret_cast<unsigned short*>(pool + (size_t)T.ld * pcap);      // [D + 1][ld] shorts
+        T.g = reinterpret_cast<int*>(T.tb) + ((tab_ints / 2 + 63) & ~(size_t)63);      // [D + 1][ld] ints, behind the trace-back codes (tab_ints shorts = half a table)
         if constexpr (PHASE == 1) {
             // diagonal TURN of fML must read as INF
             for (int x = tid; x <= n; x += GEN_NT) T.m[(size_t)TURN * T.ld + x] = INF;
@@ -196,7 +198,11 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
             __syncthreads();
             const int np = sh_misc[7];
             const int n1max = (d - 2 - (TURN + 1) < MAXLOOP) ? d - 2 - (TURN + 1) : MAXLOOP;      // q - p = d - n1 - n2 - 2 >= TURN + 1
+#ifdef MIRP_X_GEN_NOA               // timing experiment: no interior loops (tables wrong by construction)
+            if (false) {
+#else
             if (n1max >= 0) {
+#endif
                 const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
                 for (int t = wave; t < ntask; t += GEN_NT / 64) {
                     const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: loop shape and size terms in scalar registers
@@ -215,9 +221,23 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                         int n2max = MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (TURN + 1)) n2max = d - n1 - 2 - (TURN + 1);
                         const int* crow = T.c + (size_t)(d - n1 - 2) * T.ld + p;          // c(p, q) = crow[-n2 * ld]
+                        const int* grow = T.g + (size_t)(d - n1 - 2) * T.ld + p;
                         int best = INF, best_n2 = 0;
+                        // the first n2 values of a row are special shapes (bulge, 1 x n, 2 x 2, 2 x 3; every n2 when n1 <= 1): the general form below.  Behind them
+                        // the generic shapes -- three quarters of all candidates -- read ONE value, g(p,q) = c + the inner pair's mismatch term: the shape's size /
+                        // asymmetry term is scalar, the outer pair's term a register, so a candidate is a load, two adds and a compare (a non-pair reads INF)
+                        const int n2g0 = n1 <= 1 ? n2max + 1 : (n1 == 2 ? 4 : (n1 == 3 ? 3 : 2));
 #pragma unroll 8
-                        for (int n2 = 0; n2 <= n2max; n2++) {
+                        for (int n2 = n2g0; n2 <= n2max; n2++) {
+                            const int gv = grow[-(ptrdiff_t)n2 * T.ld];
+                            const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
+                            const int x = (nl - ns) * P->ninio;
+                            const int e = P->internal_loop[nl + ns] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + gv;
+                            if (e < best) { best = e; best_n2 = n2; }
+                        }
+                        int best_s = INF, best_s_n2 = 0;
+                        const int n2s = n2g0 - 1 < n2max ? n2g0 - 1 : n2max;
+                        for (int n2 = 0; n2 <= n2s; n2++) {
                             const int q = j - 1 - n2;
                             const int cv = crow[-(ptrdiff_t)n2 * T.ld];          // before the pair test: the loads of an unrolled group are in flight together
                             const int t2 = (int)((prow >> (3 * S[q])) & 7u);
@@ -242,8 +262,9 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                                 e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, sq1);         // 1x1, 1x2, 2x1, 2x2: the big tables
                             }
                             e += cv;
-                            if (e < best) { best = e; best_n2 = n2; }          // strict: the first n2 (largest q) among equals
+                            if (e < best_s) { best_s = e; best_s_n2 = n2; }          // strict: the first n2 (largest q) among equals
                         }
+                        if (best_s <= best) { best = best_s; best_n2 = best_s_n2; }          // the special shapes have the smaller n2: they win ties
                         if (best < INF) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(n1 << 5 | best_n2));
                     }
                 }
@@ -291,6 +312,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                 if (mm > INF) mm = INF;
                 T.c[(size_t)d * T.ld + i] = type ? best : INF;
                 T.tb[(size_t)d * T.ld + i] = (unsigned short)code;
+                T.g[(size_t)d * T.ld + i] = type ? best + (int)l_mmI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] : INF;
                 T.m[(size_t)d * T.ld + i] = mm;
                 dml[(size_t)(d & 3) * T.ld + i] = mdec;
             }
@@ -315,8 +337,8 @@ size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
     // c, fML, four diagonals of DML, the candidate pool (two ints per entry), the trace-back codes (a short per cell)
     const size_t ld = (size_t)n_cap + 2;
-    return 2 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63) +
-           ((fold_generic_table_ints(n_cap, span) / 2 + 63) & ~(size_t)63);
+    return 3 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63) +
+           ((fold_generic_table_ints(n_cap, span) / 2 + 63) & ~(size_t)63) + 64;          // (+ g: c with the inner-pair term of the generic interior loops)
 }
 
 void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs,
