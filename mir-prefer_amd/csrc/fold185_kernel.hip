@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
         // (tests/tools/splitcand_gate185.c: identity of the tables with ML_BASE = 0); DML(i,j) = min(DML(i,j-1), min over column j's candidates)
         int2* pool = reinterpret_cast<int2*>(T.dm + tab);          // [ld][pcap]
         const int pcap = span + 2;
+        int* gtab = reinterpret_cast<int*>(pool + (size_t)T.ld * pcap);          // c(p,q) + the inner pair's mismatch term, INF where (p,q) is no pair (as fold_generic_kernel's g)
         if constexpr (PHASE == 1) for (int x = tid; x <= n + 1; x += V_NT) pcnt[x] = 0;
         __syncthreads();
         Ctx<FoldParams185> X;
@@ -138,10 +139,20 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                         int n2max = V_MAXLOOP - n1;
                         if (n2max > d - n1 - 2 - (V_TURN + 1)) n2max = d - n1 - 2 - (V_TURN + 1);
                         int best = V_INF;
+                        // the row's first shapes (bulges, 1x1, 1x2, 2x2; every shape when n1 = 0) in the general form, its tail -- generic loops, all of them the
+                        // same formula in this model -- as a tight loop over the precombined table: a load, two adds and a compare per candidate
+                        const int n2t = n1 == 0 ? n2max + 1 : (n1 <= 2 ? 3 : 1);
+                        const int* grow = gtab + (size_t)(d - n1 - 2) * T.ld + p;
 #pragma unroll 8
-                        for (int n2 = 0; n2 <= n2max; n2++) {
+                        for (int n2 = n2t; n2 <= n2max; n2++) {
+                            const int x = (n1 > n2 ? n1 - n2 : n2 - n1) * P->ninio;
+                            const int e = P->internal_loop[n1 + n2] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + grow[-(ptrdiff_t)n2 * T.ld];
+                            best = e < best ? e : best;
+                        }
+                        const int n2s = n2t - 1 < n2max ? n2t - 1 : n2max;
+                        for (int n2 = 0; n2 <= n2s; n2++) {
                             const int q = j - 1 - n2;
-                            const int cv = T.C(p, q);          // before the pair test: the loads of an unrolled group are in flight together
+                            const int cv = T.C(p, q);
                             int t2 = ptype(X, p, q);
                             if (!t2) continue;
                             t2 = rtype_of(t2);
@@ -219,6 +230,7 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                         if (k < pcap) { pool[(size_t)j * pcap + k] = make_int2(i, stem); pcnt[j] = k + 1; }
                     }
                     T.c[(size_t)d * T.ld + i] = newc;
+                    gtab[(size_t)d * T.ld + i] = type ? newc + (int)l_mmI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] : V_INF;
                     T.m[(size_t)d * T.ld + i] = mm;
                     T.dm[(size_t)d * T.ld + i] = mdec;
                 }
@@ -241,7 +253,7 @@ size_t fold185_lds_bytes(int n_cap, int max_lines) {
 
 size_t fold185_ws_slot_ints(int n_cap, int span) {
     // c, fML, DML, the split-candidate pool (two ints per entry, span + 2 entries per column)
-    return 3 * v185::fold185_table_ints(n_cap, span) + ((2 * (size_t)(n_cap + 2) * (size_t)(span + 2) + 3) & ~(size_t)3);
+    return 4 * v185::fold185_table_ints(n_cap, span) + ((2 * (size_t)(n_cap + 2) * (size_t)(span + 2) + 3) & ~(size_t)3) + 4;          // (+ g)
 }
 
 hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens,
