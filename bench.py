@@ -838,6 +838,7 @@ def main():
                 # report files in 0.04 .. 0.5 s from one second to the next, profiles/tools/smallfiles.py); then config[2] (3 SAM files, 119 Mb FASTA).
                 ctx.close()          # a CLI user's GPU is not shared with a bench process that holds 20 GB of it
                 ctx = None
+                time.sleep(3.0)      # ... and the driver's deferred teardown of THIS process' context (20 GB) is not the first child's to wait for either
                 line["e2e"] = e2e_process(ds, a.fold_model, None, a.e2e_runs)
                 line["e2e_wall_s"] = line["e2e"].get("process_wall_s")
                 shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
