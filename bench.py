@@ -503,7 +503,8 @@ def main():
         world = tdist.get_world_size()
     rccl_error = None
     share_dir = os.environ.get("MIRP_BENCH_SHARE_GPU")      # dev: all ranks on GPU 0, the library's exchanges over its local transport (a directory)
-    ctx = capi.Context(0 if share_dir else local_rank)
+    one_device = bool(os.environ.get("MIRP_BENCH_ONE_DEVICE"))      # dev: all ranks on GPU 0 and RCCL tried all the same (it refuses: exercises the agreement below)
+    ctx = capi.Context(0 if (share_dir or one_device) else local_rank)
     if world > 1 and share_dir and os.environ.get("MIRP_BENCH_FORCE_GLOO"):      # dev: exercises the host-object exchange below on one GPU
         rccl_error = "forced (MIRP_BENCH_FORCE_GLOO)"
     elif world > 1 and share_dir:

@@ -275,3 +275,74 @@ def test_bench_eight_ranks_config3_on_one_gpu(tmp_path):
     rk = line["ranks"]
     assert sum(rk["contigs"]) == 12 and sum(rk["windows"]) == one["config"]["windows_total"] and sum(rk["windows_shipped"]) == sum(rk["windows_received"]) > 0
     assert max(rk["windows"]) <= 1.12 * (sum(rk["windows"]) / 8.0)          # re-balanced to within the plan's 10 % band
+
+
+def test_rccl_two_rank_rendezvous_on_one_gpu_is_refused_on_both_ranks(tmp_path):
+    """The one part of an N > 1 RCCL start this one-GPU box can execute for real: two processes draw / read the same ncclUniqueId and call
+    mirp_dist_init -- RCCL's socket bootstrap between the two ranks runs (interface discovery, the all-gather of the peers' device info), then RCCL
+    itself refuses the communicator because both ranks sit on device 0.  Both ranks must come back with that error (no hang, no half-made
+    communicator), and the context must still work as a 1-rank context afterwards."""
+    code = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from mir_prefer_amd import capi
+share, rank = sys.argv[2], int(sys.argv[3])
+ctx = capi.Context(0)
+idf = os.path.join(share, "id")
+if rank == 0:
+    uid = ctx.dist_unique_id()
+    with open(idf + ".tmp", "wb") as f:
+        f.write(bytes(uid))
+    os.rename(idf + ".tmp", idf)
+else:
+    t_end = time.time() + 60
+    while not os.path.exists(idf):
+        assert time.time() < t_end
+        time.sleep(0.01)
+    uid = open(idf, "rb").read()
+t = time.time()
+try:
+    ctx.dist_init(uid, rank, 2)
+    print("JOINED world=%d" % ctx.dist_world())
+except capi.MirpError as e:
+    print("REFUSED %.1f %s" % (time.time() - t, str(e).replace("\n", " ")))
+print("WORLD %d INFO %s" % (ctx.dist_world(), ctx.dist_comm_info()))
+out = ctx.gather_records(np.arange(8, dtype=np.int32).reshape(2, 4))          # a 1-rank context again
+print("GATHER %s" % out.ravel().tolist())
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code, ROOT, str(tmp_path), str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the two-rank RCCL rendezvous did not come back")
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        lines = [ln for ln in o.splitlines() if ln.split(" ")[0] in ("REFUSED", "JOINED", "WORLD", "GATHER")]          # RCCL prints its own warning on stdout
+        assert rc == 0 and len(lines) == 3, (rc, o[-3000:], e[-2000:])
+        assert lines[0].startswith("REFUSED ") and "CommInitRank" in lines[0], (lines[0], e[-1500:])
+        assert lines[1].startswith("WORLD 1 INFO") and "-1" in lines[1], lines[1]
+        assert lines[2] == "GATHER [0, 1, 2, 3, 4, 5, 6, 7]"
+
+
+def test_bench_agrees_on_a_refused_rccl_communicator():
+    """`bench.py --gpus 2` with both ranks on device 0 and RCCL asked for (MIRP_BENCH_ONE_DEVICE): RCCL refuses the communicator on both ranks; the ranks
+    agree on that over the host group and the run ends with exit code 3 and a message -- no line -- unless --allow-gloo asks for the loci lists to go
+    over the gloo host group, in which case the line says so and counts the same loci as the 1-rank run."""
+    import json
+    common = ["--workload", "config2", "--genome-scale", "0.04", "--steps", "1", "--warmup", "1", "--no-configs", "--no-e2e", "--no-cpu-baseline", "--no-ingest"]
+    env = dict(os.environ, MIRP_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "RCCL communicator not available" in r.stderr and "--allow-gloo" in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    one = _bench_line(["--gpus", "1"] + common)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-gloo"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["loci_found"] == one["config"]["loci_found"] and line["config"]["windows_total"] == one["config"]["windows_total"]
+    assert "gloo" in json.dumps(line["config"]) + json.dumps(line.get("ranks", {}))
