@@ -17,11 +17,19 @@ namespace mirp {
 #define MAXLOOP MIRP_MAXLOOP
 #define INF MIRP_INF
 
+#include <type_traits>
+typedef int int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
+typedef int int4a __attribute__((ext_vector_type(4), aligned(4)));
+
 struct GTab {
     static constexpr bool kTiled = false;
     int* __restrict__ c;
     int* __restrict__ m;
-    int* __restrict__ g;           // c(p,q) + mismatchI of (p,q) seen as the INNER pair of a generic interior loop (INF where (p,q) is no pair): the fill's own copy
+    // The fill's own read-only view of finished cells (round 5): one word per cell = c(p,q) + mismatchI of (p,q) seen as the INNER pair of a generic interior
+    // loop in the low 24 bits (signed; GEN_PINF where (p,q) is no pair) and the index of that term, rtype * 25 + S[q+1] * 5 + S[p-1], in the high byte --
+    // from which the other classes' terms follow through small LDS tables (bulge: TerminalAU - mismatchI, 1 x n: mismatch1nI - mismatchI, the rest: c itself).
+    // The interior-loop interval reads nothing else: a 32-diagonal ring of it is 4 bytes per cell.
+    int* __restrict__ w;
     unsigned short* __restrict__ tb;
     int ld;
     __device__ __forceinline__ int C(int d, int i) const { return c[(size_t)d * ld + i]; }
@@ -34,7 +42,11 @@ struct GTab {
 // ------------------------------------------------------------------------------------------
 // Generic kernel: tables in global workspace.
 // ------------------------------------------------------------------------------------------
+#ifndef GEN_NT
 #define GEN_NT 256
+#endif
+#define GEN_PINF 1500000           // 'no pair' in the 24-bit energy field of GTab::w: with every loop term added it stays below 2^21, so that energy * 1024 + shape is an int
+#define GEN_EMAX 1000000           // a candidate energy at or above this came from a GEN_PINF entry (real energies: a few hundred per nucleotide pair at most)
 #define GEN_AUX_BYTES(nc) ((((size_t)(4 + 8 + 2 + 1) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (64-bit keys, 8-aligned), plist (short), ctype (byte) per position
 
 __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines) {
@@ -91,11 +103,15 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     short* l_mmI = (short*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)nc));
     short* l_mm1n = l_mmI + 200;
     short* l_mm23 = l_mm1n + 200;
-    short* l_stack = l_mm23 + 200;                         // 64
+    short* l_xb = l_mm23 + 200;                            // bulge: TerminalAU of the inner pair - its mismatchI (what turns the table's word into c + TerminalAU)
+    short* l_x1 = l_xb + 200;                              // 1 x n: mismatch1nI - mismatchI
+    short* l_stack = l_x1 + 200;                           // 64
     for (int x = threadIdx.x; x < 200; x += GEN_NT) {
         const int t = x / 25, a = (x / 5) % 5, b = x % 5;
         // (the rows of pair type 0 hold INF and are never read: an interior candidate has a pair on both sides)
         l_mmI[x] = (short)min(P->mismatchI[t][a][b], 32767); l_mm1n[x] = (short)min(P->mismatch1nI[t][a][b], 32767); l_mm23[x] = (short)min(P->mismatch23I[t][a][b], 32767);
+        l_xb[x] = t ? (short)((t > 2 ? P->TerminalAU : 0) - P->mismatchI[t][a][b]) : (short)0;
+        l_x1[x] = t ? (short)(P->mismatch1nI[t][a][b] - P->mismatchI[t][a][b]) : (short)0;
     }
     for (int x = threadIdx.x; x < 64; x += GEN_NT) l_stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
     __syncthreads();
@@ -162,7 +178,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
         int2* pool = reinterpret_cast<int2*>(dml + 4 * (size_t)T.ld);      // [ld][pcap]
         const int pcap = fold_generic_pool_cap(n_cap, span);
         T.tb = reinterpret_cast<unsigned short*>(pool + (size_t)T.ld * pcap);      // [D + 1][ld] shorts
-        T.g = reinterpret_cast<int*>(T.tb) + ((tab_ints / 2 + 63) & ~(size_t)63);      // [D + 1][ld] ints, behind the trace-back codes (tab_ints shorts = half a table)
+        T.w = reinterpret_cast<int*>(T.tb) + ((tab_ints / 2 + 63) & ~(size_t)63);      // [D + 1][ld] ints, behind the trace-back codes (tab_ints shorts = half a table)
         if constexpr (PHASE == 1) {
             // diagonal TURN of fML must read as INF
             for (int x = tid; x <= n; x += GEN_NT) T.m[(size_t)TURN * T.ld + x] = INF;
@@ -203,69 +219,157 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
 #else
             if (n1max >= 0) {
 #endif
-                const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
+                // Task = (block of 64 paired cells, group of loop sizes s = n1 + n2).  All candidates of one size have their inner pair on ONE diagonal,
+                // dd = d - 2 - s, and a lane's candidates n1 = 0 .. s are the CONSECUTIVE cells p = i + 1 + n1 of that diagonal's row: four of them per 16-byte
+                // load, and every load of a size is issued before the first is used (the earlier order -- n1 outer, n2 inner, one 4-byte gather per
+                // candidate on 31 different diagonals, each waited for -- was bound by memory round trips).  Every candidate but nine reads ONE precombined
+                // value (c + the inner pair's term of its class; INF where (p,q) is no pair): size and asymmetry terms are scalar (P->gen_key), the outer
+                // pair's term a register, so a candidate is a multiply-add and a minimum.  (n1, n2) are wave-uniform.  Groups: sizes 0..6 (the shapes with
+                // their own tables, straight-line), 7..17, 18..24, 25..30 -- about equal work.
+                const int smax = n1max;
+                const int nblk = (np + 63) >> 6;
+                const int ngrp = smax < 7 ? 1 : smax < 18 ? 2 : smax < 25 ? 3 : 4;
+                const int ntask = nblk * ngrp;
+                const int ninio = P->ninio, max_ninio = P->MAX_NINIO;
                 for (int t = wave; t < ntask; t += GEN_NT / 64) {
-                    const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: loop shape and size terms in scalar registers
-                    const int blk = tu / (n1max + 1), n1 = tu - blk * (n1max + 1);
+                    const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: loop sizes and shapes in scalar registers
+                    const int blk = tu / ngrp, grp = tu - blk * ngrp;
                     const int k = blk * 64 + lane;
                     if (k < np) {
                         const int cell = plist[k];
-                        const int i = cell + 1, j = i + d, p = i + 1 + n1;
+                        const int i = cell + 1, j = i + d;
                         const int type = ctype[cell];
-                        const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1], Sp = S[p];
-                        // reversed pair type of (p, q) for this lane's p as five 3-bit fields indexed by the base code of q: {N A C G U} -> 0 or rtype (the loop
-                        // below would otherwise spend a quarter of its instructions in pair_type's 64-bit shifts)
-                        const unsigned prow = Sp == 1 ? (6u << 12) : Sp == 2 ? (2u << 9) : Sp == 3 ? ((1u << 6) | (4u << 12)) : Sp == 4 ? ((5u << 3) | (3u << 9)) : 0u;
+                        const int si1 = S[i + 1], sj1 = S[j - 1];
                         const int ij = type * 25 + si1 * 5 + sj1;
                         const int o_mmI = l_mmI[ij], o_mm1n = l_mm1n[ij], o_mm23 = l_mm23[ij];      // the outer pair's terms: once per task
-                        int n2max = MAXLOOP - n1;
-                        if (n2max > d - n1 - 2 - (TURN + 1)) n2max = d - n1 - 2 - (TURN + 1);
-                        const int* crow = T.c + (size_t)(d - n1 - 2) * T.ld + p;          // c(p, q) = crow[-n2 * ld]
-                        const int* grow = T.g + (size_t)(d - n1 - 2) * T.ld + p;
-                        int best = INF, best_n2 = 0;
-                        // the first n2 values of a row are special shapes (bulge, 1 x n, 2 x 2, 2 x 3; every n2 when n1 <= 1): the general form below.  Behind them
-                        // the generic shapes -- three quarters of all candidates -- read ONE value, g(p,q) = c + the inner pair's mismatch term: the shape's size /
-                        // asymmetry term is scalar, the outer pair's term a register, so a candidate is a load, two adds and a compare (a non-pair reads INF)
-                        const int n2g0 = n1 <= 1 ? n2max + 1 : (n1 == 2 ? 4 : (n1 == 3 ? 3 : 2));
-#pragma unroll 8
-                        for (int n2 = n2g0; n2 <= n2max; n2++) {
-                            const int gv = grow[-(ptrdiff_t)n2 * T.ld];
-                            const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
-                            const int x = (nl - ns) * P->ninio;
-                            const int e = P->internal_loop[nl + ns] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + gv;
-                            if (e < best) { best = e; best_n2 = n2; }
-                        }
-                        int best_s = INF, best_s_n2 = 0;
-                        const int n2s = n2g0 - 1 < n2max ? n2g0 - 1 : n2max;
-                        for (int n2 = 0; n2 <= n2s; n2++) {
-                            const int q = j - 1 - n2;
-                            const int cv = crow[-(ptrdiff_t)n2 * T.ld];          // before the pair test: the loads of an unrolled group are in flight together
-                            const int t2 = (int)((prow >> (3 * S[q])) & 7u);
-                            if (!t2) continue;
-                            const int sq1 = S[q + 1];
-                            const int pq = t2 * 25 + sq1 * 5 + sp1;
-                            const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
-                            int e;
-                            if (ns >= 2 && !(ns == 2 && nl <= 3)) {                             // generic loop (375 of the 496 shapes)
-                                const int x = (nl - ns) * P->ninio;
-                                e = P->internal_loop[nl + ns] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + l_mmI[pq];
-                            } else if (nl == 0) {
-                                e = l_stack[type * 8 + t2];
-                            } else if (ns == 0) {
-                                e = P->bulge[nl] + (nl == 1 ? (int)l_stack[type * 8 + t2] : ((type > 2 ? P->TerminalAU : 0) + (t2 > 2 ? P->TerminalAU : 0)));
-                            } else if (ns == 1 && nl >= 3) {
-                                const int x = (nl - 1) * P->ninio;
-                                e = P->internal_loop[nl + 1] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mm1n + l_mm1n[pq];
-                            } else if (ns == 2 && nl == 3) {
-                                e = P->internal_loop[5] + P->ninio + o_mm23 + l_mm23[pq];
-                            } else {
-                                e = e_intloop(P, n1, n2, type, t2, si1, sj1, sp1, sq1);         // 1x1, 1x2, 2x1, 2x2: the big tables
+                        const int tau = type > 2 ? P->TerminalAU : 0;
+                        // The cell's minimum over the task as ONE 32-bit key, energy * 1024 + (n1 << 5 | n2): among equal energies the smallest n1, then the smallest
+                        // n2 -- the loop the backtrack's search (p ascending, q descending) finds first.  (Energies of the generic path stay below 2^20 in
+                        // magnitude: GEN_PINF.)  A generic candidate is one v_mad_i32_i24 -- the instruction takes the word's 24-bit energy field as it is --
+                        // with the scalar key term of its shape (P->gen_key: size and asymmetry terms and the shape), and a minimum.
+                        int kmin = 0x7fffffff;
+                        const int c1024 = 1024;
+                        auto gen = [&](const int w, const int kterm) {
+                            int key;
+                            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(key) : "v"(w), "v"(c1024), "s"(kterm));
+                            return key;
+                        };
+                        auto w_e = [](const int w) { return (w << 8) >> 8; };                      // the word's energy (sign-extended 24 bits)
+                        auto w_in = [](const int w) { return (int)((unsigned)w >> 24); };          // the word's inner-pair index
+                        auto put = [&](const int e, const int shape) { const int key = e * 1024 + shape; kmin = key < kmin ? key : kmin; };
+                        auto put_bulge = [&](const int eb, const int w, const int shape) { put(eb + w_e(w) + (int)l_xb[w_in(w)], shape); };
+                        auto put_1n = [&](const int e1, const int w, const int shape) { put(e1 + w_e(w) + (int)l_x1[w_in(w)], shape); };
+                        const int* wlane = T.w + i + 1;          // candidate n1 of size s = wlane[(d - 2 - s) * ld + n1]
+                        // sizes s_lo .. s_hi (>= 7).  A size's cells n1 = 0 .. s: the first four (bulge, 1 x n, two generic), NCH - 1 further four-cell chunks -- loaded
+                        // without a branch (start clamped), reduced only when all four are generic shapes --, the last four generic ones (n1 = s - 5 .. s - 2: a chunk
+                        // of their own that may overlap the one before it, a minimum does not mind) and the last two (1 x n, bulge).  Every load of a size is
+                        // issued before the first is used.
+                        auto sizes = [&](auto nch_tag, const int s_lo, const int s_hi) {
+                            constexpr int NCH = decltype(nch_tag)::value;
+                            for (int s = s_lo; s <= s_hi; s++) {
+                                const int* wrow = wlane + (d - 2 - s) * T.ld;
+                                const int2a hi = *reinterpret_cast<const int2a*>(wrow + s - 1);
+                                const int4a tl = *reinterpret_cast<const int4a*>(wrow + s - 5);
+                                int4a ch[NCH];
+#pragma unroll
+                                for (int c4 = 0; c4 < NCH; c4++) ch[c4] = *reinterpret_cast<const int4a*>(wrow + (4 * c4 < s - 3 ? 4 * c4 : s - 3));
+                                const int* kc = reinterpret_cast<const int*>(P->gen_key[s - 6]);
+                                int kg = 0x7fffffff;
+                                { const int k0 = gen(ch[0][2], kc[2]), k1 = gen(ch[0][3], kc[3]); kg = k0 < kg ? k0 : kg; kg = k1 < kg ? k1 : kg; }
+#pragma unroll
+                                for (int c4 = 1; c4 < NCH; c4++)
+                                    if (4 * c4 + 3 <= s - 2) {
+#pragma unroll
+                                        for (int u = 0; u < 4; u++) { const int key = gen(ch[c4][u], kc[4 * c4 + u]); kg = key < kg ? key : kg; }
+                                    }
+#pragma unroll
+                                for (int u = 0; u < 4; u++) { const int key = gen(tl[u], kc[s - 5 + u]); kg = key < kg ? key : kg; }
+                                kg += o_mmI * 1024;
+                                kmin = kg < kmin ? kg : kmin;
+                                const int eb = P->bulge[s] + tau;
+                                const int x1 = (s - 2) * ninio;
+                                const int e1 = P->internal_loop[s] + (x1 < max_ninio ? x1 : max_ninio) + o_mm1n;
+                                put_bulge(eb, ch[0][0], s); put_1n(e1, ch[0][1], 1 << 5 | (s - 1)); put_1n(e1, hi[0], (s - 1) << 5 | 1); put_bulge(eb, hi[1], s << 5);
                             }
-                            e += cv;
-                            if (e < best_s) { best_s = e; best_s_n2 = n2; }          // strict: the first n2 (largest q) among equals
+                        };
+                        if (grp == 0) {
+                            // sizes 0 .. 6, straight-line: every load first (rows of sizes beyond smax -- the first diagonals only -- are read at a clamped row and
+                            // not used), then the shapes with (n1, n2) as compile-time constants
+                            const int sI[5] = {S[i], si1, S[i + 2], S[i + 3], S[i + 4]};          // S[i + x]
+                            const int sJ[5] = {S[j], sj1, S[j - 2], S[j - 3], S[j - 4]};          // S[j - x]
+                            const int* wr[7];
+#pragma unroll
+                            for (int s = 0; s < 7; s++) { const int dd = d - 2 - s; wr[s] = wlane + (dd > 0 ? dd : 0) * T.ld; }
+                            const int w0 = wr[0][0];
+                            const int2a w1 = *reinterpret_cast<const int2a*>(wr[1]);
+                            const int4a w2 = *reinterpret_cast<const int4a*>(wr[2]), w3 = *reinterpret_cast<const int4a*>(wr[3]), w4 = *reinterpret_cast<const int4a*>(wr[4]);
+                            const int w44 = wr[4][4];
+                            const int4a w5 = *reinterpret_cast<const int4a*>(wr[5]);
+                            const int2a w5b = *reinterpret_cast<const int2a*>(wr[5] + 4);
+                            const int4a w6 = *reinterpret_cast<const int4a*>(wr[6]), w6b = *reinterpret_cast<const int4a*>(wr[6] + 3);
+                            // reversed type of the inner pair (p, q) = (i + 1 + n1, j - 1 - n2), 0 = no pair
+                            auto t2of = [&](const int n1, const int n2) { return pair_type(sJ[1 + n2], sI[1 + n1]); };
+                            const int t00 = t2of(0, 0), t01 = t2of(0, 1), t10 = t2of(1, 0), t11 = t2of(1, 1), t12 = t2of(1, 2), t21 = t2of(2, 1), t22 = t2of(2, 2),
+                                      t23 = t2of(2, 3), t32 = t2of(3, 2);
+                            // the big tables (sq1 = S[q + 1] = sJ[n2], sp1 = S[p - 1] = sI[n1]); a missing pair reads row 0 and is masked below
+                            const int r11 = P->int11[type][t11][si1][sj1];
+                            const int r12 = P->int21[type][t12][si1][sJ[2]][sj1];
+                            const int r21 = P->int21[t21][type][sJ[1]][si1][sI[2]];
+                            const int r22 = P->int22[type][t22][si1][sI[2]][sJ[2]][sj1];
+                            const int b1 = P->bulge[1];
+                            auto cof = [&](const int w) { return w_e(w) - (int)l_mmI[w_in(w)]; };          // c(p,q) of a pair
+                            auto put_if = [&](const int t2, const int e, const int shape) { const int key = t2 ? e * 1024 + shape : 0x7fffffff; kmin = key < kmin ? key : kmin; };
+                            put_if(t00, (int)l_stack[type * 8 + t00] + cof(w0), 0);
+                            if (smax >= 1) {
+                                put_if(t01, b1 + (int)l_stack[type * 8 + t01] + cof(w1[0]), 0 << 5 | 1);
+                                put_if(t10, b1 + (int)l_stack[type * 8 + t10] + cof(w1[1]), 1 << 5 | 0);
+                            }
+                            if (smax >= 2) {
+                                const int eb = P->bulge[2] + tau;
+                                put_bulge(eb, w2[0], 0 << 5 | 2); put_if(t11, r11 + cof(w2[1]), 1 << 5 | 1); put_bulge(eb, w2[2], 2 << 5 | 0);
+                            }
+                            if (smax >= 3) {
+                                const int eb = P->bulge[3] + tau;
+                                put_bulge(eb, w3[0], 0 << 5 | 3); put_if(t12, r12 + cof(w3[1]), 1 << 5 | 2); put_if(t21, r21 + cof(w3[2]), 2 << 5 | 1); put_bulge(eb, w3[3], 3 << 5 | 0);
+                            }
+                            if (smax >= 4) {
+                                const int eb = P->bulge[4] + tau;
+                                const int x1 = 2 * ninio;
+                                const int e1 = P->internal_loop[4] + (x1 < max_ninio ? x1 : max_ninio) + o_mm1n;
+                                put_bulge(eb, w4[0], 0 << 5 | 4); put_1n(e1, w4[1], 1 << 5 | 3); put_if(t22, r22 + cof(w4[2]), 2 << 5 | 2); put_1n(e1, w4[3], 3 << 5 | 1);
+                                put_bulge(eb, w44, 4 << 5 | 0);
+                            }
+                            if (smax >= 5) {
+                                const int eb = P->bulge[5] + tau;
+                                const int x1 = 3 * ninio;
+                                const int e1 = P->internal_loop[5] + (x1 < max_ninio ? x1 : max_ninio) + o_mm1n;
+                                const int e23 = P->internal_loop[5] + ninio + o_mm23;
+                                put_bulge(eb, w5[0], 0 << 5 | 5); put_1n(e1, w5[1], 1 << 5 | 4);
+                                put_if(t23, e23 + (int)l_mm23[t23 * 25 + sJ[3] * 5 + sI[2]] + cof(w5[2]), 2 << 5 | 3);
+                                put_if(t32, e23 + (int)l_mm23[t32 * 25 + sJ[2] * 5 + sI[3]] + cof(w5[3]), 3 << 5 | 2);
+                                put_1n(e1, w5b[0], 4 << 5 | 1); put_bulge(eb, w5b[1], 5 << 5 | 0);
+                            }
+                            if (smax >= 6) {
+                                const int eb = P->bulge[6] + tau;
+                                const int x1 = 4 * ninio;
+                                const int e1 = P->internal_loop[6] + (x1 < max_ninio ? x1 : max_ninio) + o_mm1n;
+                                const int* kc = reinterpret_cast<const int*>(P->gen_key[0]);
+                                put_bulge(eb, w6[0], 0 << 5 | 6); put_1n(e1, w6[1], 1 << 5 | 5);
+                                int kg = gen(w6[2], kc[2]);
+                                { const int k3 = gen(w6[3], kc[3]), k4 = gen(w6b[1], kc[4]); kg = k3 < kg ? k3 : kg; kg = k4 < kg ? k4 : kg; }
+                                kg += o_mmI * 1024;
+                                kmin = kg < kmin ? kg : kmin;
+                                put_1n(e1, w6b[2], 5 << 5 | 1); put_bulge(eb, w6b[3], 6 << 5 | 0);
+                            }
+                        } else if (grp == 1) {
+                            sizes(std::integral_constant<int, 4>{}, 7, smax < 17 ? smax : 17);
+                        } else if (grp == 2) {
+                            sizes(std::integral_constant<int, 6>{}, 18, smax < 24 ? smax : 24);
+                        } else {
+                            sizes(std::integral_constant<int, 7>{}, 25, smax);
                         }
-                        if (best_s <= best) { best = best_s; best_n2 = best_s_n2; }          // the special shapes have the smaller n2: they win ties
-                        if (best < INF) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(n1 << 5 | best_n2));
+                        const int best = kmin >> 10;
+                        if (best < GEN_EMAX) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(kmin & 1023));
                     }
                 }
             }
@@ -312,7 +416,11 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                 if (mm > INF) mm = INF;
                 T.c[(size_t)d * T.ld + i] = type ? best : INF;
                 T.tb[(size_t)d * T.ld + i] = (unsigned short)code;
-                T.g[(size_t)d * T.ld + i] = type ? best + (int)l_mmI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] : INF;
+                {
+                    const int in = rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1];          // (i,j) as the inner pair of a later loop
+                    const int gq = best + (int)l_mmI[in];
+                    T.w[(size_t)d * T.ld + i] = type ? (in << 24) | ((gq < GEN_PINF ? gq : GEN_PINF) & 0xffffff) : GEN_PINF;
+                }
                 T.m[(size_t)d * T.ld + i] = mm;
                 dml[(size_t)(d & 3) * T.ld + i] = mdec;
             }
@@ -331,14 +439,14 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
 
 // split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
 size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
-    return fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (3 * 200 + 64) + 16;
+    return fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + 16;
 }
 
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
     // c, fML, four diagonals of DML, the candidate pool (two ints per entry), the trace-back codes (a short per cell)
     const size_t ld = (size_t)n_cap + 2;
     return 3 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63) +
-           ((fold_generic_table_ints(n_cap, span) / 2 + 63) & ~(size_t)63) + 64;          // (+ g: c with the inner-pair term of the generic interior loops)
+           ((fold_generic_table_ints(n_cap, span) / 2 + 63) & ~(size_t)63) + 64;          // (+ w: the interior-loop interval's view of c)
 }
 
 void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, const unsigned char* seqs, const long long* offs,

@@ -14,6 +14,7 @@ struct FoldParams {
     // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes).  An interior-loop candidate is ranked by the key
     // (energy term << 10) | (n1 << 5 | n2): the minimum key is the minimum energy and, among equal energies, the first shape in the
     // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
+    // (also read by the generic kernel, fold_kernel.hip: one v_mad_i32_i24 per generic candidate)
     unsigned gen_key[25][32];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
     unsigned kb0_key[31];         // bulge n1 = 0, n2 = u:   (bulge[u] + 2048) << 10 | u
     unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
@@ -73,6 +74,7 @@ struct FoldParams185 {
     int tetraE[32];               // bonus added to the hairpin energy (not a total, unlike Turner-2004)
     char tetra[32][8];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
+    unsigned gen_key[25][32];     // as FoldParams::gen_key (the generic kernel's interior-loop interval reads its key terms with scalar loads)
 };
 void mirp_fill_fold_params185(FoldParams185* p);
 

@@ -8,7 +8,8 @@
 
 static inline int clamp0(int v) { return v > 0 ? 0 : v; }
 
-static void fill_derived(FoldParams* p) {
+template <class PP>
+static void fill_gen_key(PP* p) {
     for (int u = 6; u <= MIRP_MAXLOOP; u++)
         for (int n1 = 0; n1 < 32; n1++) {          // n1 runs up to u - 2 = 28
             unsigned v = 65535u << 10;
@@ -18,6 +19,10 @@ static void fill_derived(FoldParams* p) {
             }
             p->gen_key[u - 6][n1] = v;
         }
+}
+
+static void fill_derived(FoldParams* p) {
+    fill_gen_key(p);
     p->gen_wing_d = p->ninio > 0 ? (p->MAX_NINIO + p->ninio - 1) / p->ninio : 1 << 20;
     for (int u = 6; u <= MIRP_MAXLOOP; u++) p->gen_wing_key[u - 6] = ((unsigned)(p->internal_loop[u] + p->MAX_NINIO) << 10) | 63u;
     // inner-pair terms of the bulge and 1 x n candidates relative to the ring entry (fold_lds_common.h: XB = TerminalAU - mismatchI, X1 = mismatch1nI -
@@ -109,6 +114,7 @@ void mirp_fill_fold_params185(FoldParams185* p) {
     p->TerminalAU = T99_TerminalAU;
     p->ninio = T99_ninio;
     p->MAX_NINIO = T99_MAX_NINIO;
+    fill_gen_key(p);
 }
 
 void mirp_fill_fold_params_t1999(FoldParams* p) {
