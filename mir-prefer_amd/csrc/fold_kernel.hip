@@ -20,6 +20,7 @@ namespace mirp {
 #include <type_traits>
 typedef int int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
 typedef int int4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef int int4q __attribute__((ext_vector_type(4), aligned(16)));
 
 struct GTab {
     static constexpr bool kTiled = false;
@@ -45,6 +46,11 @@ struct GTab {
 #ifndef GEN_NT
 #define GEN_NT 256
 #endif
+#ifndef GEN_FILL_WAVES
+#define GEN_FILL_WAVES 5
+#endif
+#define GEN_MIN_WAVES(phase) ((phase) == 1 ? GEN_FILL_WAVES : 1)      // waves per SIMD the register allocation aims for
+#define GEN_STAGE 512              // ints per wave of the interior-loop interval's staging buffer
 #define GEN_PINF 1500000           // 'no pair' in the 24-bit energy field of GTab::w: with every loop term added it stays below 2^21, so that energy * 1024 + shape is an int
 #define GEN_EMAX 1000000           // a candidate energy at or above this came from a GEN_PINF entry (real energies: a few hundred per nucleotide pair at most)
 #define GEN_AUX_BYTES(nc) ((((size_t)(4 + 8 + 2 + 1) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (64-bit keys, 8-aligned), plist (short), ctype (byte) per position
@@ -62,10 +68,13 @@ __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines)
     return (b + 15) & ~(size_t)15;
 }
 
+// row stride of a workspace table (a multiple of four ints: the interior-loop interval stages row segments with aligned 16-byte loads)
+__host__ __device__ inline int fold_generic_ld(int n_cap) { return (n_cap + 2 + 3) & ~3; }
+
 // one table (c or fML) of a workspace slot, in ints
 __host__ __device__ size_t fold_generic_table_ints(int n_cap, int span) {
     size_t D = (size_t)(span < n_cap ? span : n_cap) + 1;
-    size_t per = D * (size_t)(n_cap + 2);
+    size_t per = D * (size_t)fold_generic_ld(n_cap);
     return (per + 63) & ~(size_t)63;
 }
 
@@ -76,7 +85,7 @@ __host__ __device__ int fold_generic_pool_cap(int n_cap, int span) { return (spa
 // instantiations, launched back to back over a batch of at most `grid` windows (slot = blockIdx.x): the fill needs 74 VGPRs, the epilogue 163 -- as one
 // kernel the fill ran at the epilogue's occupancy (3 workgroups per CU instead of 6).
 template <int PHASE>
-__global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
+__global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs,
     const int* __restrict__ win_lens, const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints,
     int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines, char* __restrict__ out_ss,
@@ -106,6 +115,8 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
     short* l_xb = l_mm23 + 200;                            // bulge: TerminalAU of the inner pair - its mismatchI (what turns the table's word into c + TerminalAU)
     short* l_x1 = l_xb + 200;                              // 1 x n: mismatch1nI - mismatchI
     short* l_stack = l_x1 + 200;                           // 64
+    int* stage = reinterpret_cast<int*>(l_stack + 64);     // GEN_STAGE ints per wave: the row segment a block of paired cells reads for one loop size (interval A)
+    int* wcnt = stage + (GEN_NT / 64) * GEN_STAGE;         // 2 * waves: paired cells per wave and half-pass of the list compaction
     for (int x = threadIdx.x; x < 200; x += GEN_NT) {
         const int t = x / 25, a = (x / 5) % 5, b = x % 5;
         // (the rows of pair type 0 hold INF and are never read: an interior candidate has a pair on both sides)
@@ -165,7 +176,7 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
             spec[x] = s3; spec[nc + x] = s4; spec[2 * nc + x] = s6;
         }
         GTab T;
-        T.ld = n_cap + 2;
+        T.ld = fold_generic_ld(n_cap);
         const size_t tab_ints = fold_generic_table_ints(n_cap, span);
         T.c = ws + (size_t)blockIdx.x * ws_slot_ints;
         T.m = T.c + tab_ints;
@@ -199,20 +210,37 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
         const int lane = tid & 63, wave = tid >> 6;
         for (int d = TURN + 1; d <= D; d++) {
             const int ncell = n - d;
-            if (tid == 0) sh_misc[7] = 0;
-            __syncthreads();
-            for (int base = 0; base < ncell; base += GEN_NT) {
-                const int cell = base + tid;
-                int type = 0;
-                if (cell < ncell) { type = pair_type(S[cell + 1], S[cell + 1 + d]); ctype[cell] = (unsigned char)type; cbest[cell] = ~0ull; }
-                const unsigned long long bal = __ballot(type != 0);
-                int wbase = 0;
-                if (lane == 0 && bal) wbase = atomicAdd(&sh_misc[7], (int)__popcll(bal));
-                wbase = __shfl(wbase, 0);
-                if (type) plist[wbase + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+            // pair types of the diagonal's cells; the paired ones compacted into a list IN CELL ORDER (a block of 64 list entries is a stretch of the
+            // diagonal: interval A stages that stretch's row segments): two cells per thread and pass, the eight per-wave counts ordered through LDS
+            int np_run = 0;
+            for (int base = 0; base < ncell; base += 2 * GEN_NT) {
+                int type[2];
+                unsigned long long bal[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int cell = base + h * GEN_NT + tid;
+                    type[h] = 0;
+                    if (cell < ncell) { type[h] = pair_type(S[cell + 1], S[cell + 1 + d]); ctype[cell] = (unsigned char)type[h]; cbest[cell] = ~0ull; }
+                    bal[h] = __ballot(type[h] != 0);
+                    if (lane == 0) wcnt[h * (GEN_NT / 64) + wave] = (int)__popcll(bal[h]);
+                }
+                __syncthreads();
+                int before[2] = {0, 0}, total = 0;
+#pragma unroll
+                for (int x = 0; x < 2 * (GEN_NT / 64); x++) {
+                    const int v = wcnt[x];
+                    if (x < wave) before[0] += v;
+                    if (x < GEN_NT / 64 + wave) before[1] += v;
+                    total += v;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (type[h]) plist[np_run + before[h] + (int)__popcll(bal[h] & ((1ull << lane) - 1ull))] = (unsigned short)(base + h * GEN_NT + tid);
+                np_run += total;
+                if (base + 2 * GEN_NT < ncell) __syncthreads();          // (the counts are rewritten by the next pass)
             }
             __syncthreads();
-            const int np = sh_misc[7];
+            const int np = np_run;
             const int n1max = (d - 2 - (TURN + 1) < MAXLOOP) ? d - 2 - (TURN + 1) : MAXLOOP;      // q - p = d - n1 - n2 - 2 >= TURN + 1
 #ifdef MIRP_X_GEN_NOA               // timing experiment: no interior loops (tables wrong by construction)
             if (false) {
@@ -235,8 +263,10 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                     const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: loop sizes and shapes in scalar registers
                     const int blk = tu / ngrp, grp = tu - blk * ngrp;
                     const int k = blk * 64 + lane;
-                    if (k < np) {
-                        const int cell = plist[k];
+                    {
+                        // (the lanes behind the list's end, in its last block, run along on its last cell: the staged loads below are the whole wave's)
+                        const bool active = k < np;
+                        const int cell = plist[active ? k : np - 1];
                         const int i = cell + 1, j = i + d;
                         const int type = ctype[cell];
                         const int si1 = S[i + 1], sj1 = S[j - 1];
@@ -260,38 +290,75 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                         auto put_bulge = [&](const int eb, const int w, const int shape) { put(eb + w_e(w) + (int)l_xb[w_in(w)], shape); };
                         auto put_1n = [&](const int e1, const int w, const int shape) { put(e1 + w_e(w) + (int)l_x1[w_in(w)], shape); };
                         const int* wlane = T.w + i + 1;          // candidate n1 of size s = wlane[(d - 2 - s) * ld + n1]
-                        // sizes s_lo .. s_hi (>= 7).  A size's cells n1 = 0 .. s: the first four (bulge, 1 x n, two generic), NCH - 1 further four-cell chunks -- loaded
-                        // without a branch (start clamped), reduced only when all four are generic shapes --, the last four generic ones (n1 = s - 5 .. s - 2: a chunk
-                        // of their own that may overlap the one before it, a minimum does not mind) and the last two (1 x n, bulge).  Every load of a size is
-                        // issued before the first is used.
-                        auto sizes = [&](auto nch_tag, const int s_lo, const int s_hi) {
-                            constexpr int NCH = decltype(nch_tag)::value;
+                        // sizes s_lo .. s_hi (>= 7) straight from the table, a load per candidate: the fallback for blocks whose cells lie too far apart for the staging
+                        // buffer below (sparse pairs in long windows)
+                        auto sizes = [&](const int s_lo, const int s_hi) {
                             for (int s = s_lo; s <= s_hi; s++) {
                                 const int* wrow = wlane + (d - 2 - s) * T.ld;
-                                const int2a hi = *reinterpret_cast<const int2a*>(wrow + s - 1);
-                                const int4a tl = *reinterpret_cast<const int4a*>(wrow + s - 5);
-                                int4a ch[NCH];
-#pragma unroll
-                                for (int c4 = 0; c4 < NCH; c4++) ch[c4] = *reinterpret_cast<const int4a*>(wrow + (4 * c4 < s - 3 ? 4 * c4 : s - 3));
                                 const int* kc = reinterpret_cast<const int*>(P->gen_key[s - 6]);
                                 int kg = 0x7fffffff;
-                                { const int k0 = gen(ch[0][2], kc[2]), k1 = gen(ch[0][3], kc[3]); kg = k0 < kg ? k0 : kg; kg = k1 < kg ? k1 : kg; }
-#pragma unroll
-                                for (int c4 = 1; c4 < NCH; c4++)
-                                    if (4 * c4 + 3 <= s - 2) {
-#pragma unroll
-                                        for (int u = 0; u < 4; u++) { const int key = gen(ch[c4][u], kc[4 * c4 + u]); kg = key < kg ? key : kg; }
-                                    }
-#pragma unroll
-                                for (int u = 0; u < 4; u++) { const int key = gen(tl[u], kc[s - 5 + u]); kg = key < kg ? key : kg; }
+                                for (int n1 = 2; n1 <= s - 2; n1++) { const int key = gen(wrow[n1], kc[n1]); kg = key < kg ? key : kg; }
                                 kg += o_mmI * 1024;
                                 kmin = kg < kmin ? kg : kmin;
                                 const int eb = P->bulge[s] + tau;
                                 const int x1 = (s - 2) * ninio;
                                 const int e1 = P->internal_loop[s] + (x1 < max_ninio ? x1 : max_ninio) + o_mm1n;
-                                put_bulge(eb, ch[0][0], s); put_1n(e1, ch[0][1], 1 << 5 | (s - 1)); put_1n(e1, hi[0], (s - 1) << 5 | 1); put_bulge(eb, hi[1], s << 5);
+                                put_bulge(eb, wrow[0], s); put_1n(e1, wrow[1], 1 << 5 | (s - 1)); put_1n(e1, wrow[s - 1], (s - 1) << 5 | 1); put_bulge(eb, wrow[s], s << 5);
                             }
                         };
+                        // The same through LDS (the form that runs): the row segment the block's
+                        // cells read for one size -- from the first cell's p to the last cell's p + s, 200 words or so for 64 paired cells -- is loaded ONCE by the
+                        // wave (aligned 16 bytes per lane), written to the wave's staging buffer, and each lane reads its s + 1 consecutive words from there.  Lane by
+                        // lane the same words cost 17 cache-line accesses per 16-byte load and kept the CU's vector-memory path busy the whole time (counters:
+                        // profiles/EXPERIMENT_LOG.md); the loads of the next two sizes are in flight while a size is reduced.
+                        const int cell_lo = __builtin_amdgcn_readfirstlane(plist[blk * 64]);
+                        const int cell_hi = __builtin_amdgcn_readfirstlane(plist[blk * 64 + 63 < np ? blk * 64 + 63 : np - 1]);
+                        const int b0a = (cell_lo + 2) & ~3;                     // first staged position (p of the first cell, rounded down to 16 bytes)
+                        const int span_w = cell_hi + 2 - b0a;                   // the last cell's offset in the segment
+                        int* slot = stage + wave * GEN_STAGE;
+                        const int* sl = slot + (cell + 2 - b0a);                // this lane's candidate n1 = sl[n1]
+                        auto sizes_staged = [&](auto two_tag, const int s_lo, const int s_hi) {
+                            constexpr bool TWO = decltype(two_tag)::value;          // a second 256-word piece
+                            auto issue = [&](const int s, int4q& a, int4q& b) {
+                                const int* src = T.w + ((d - 2 - s) * T.ld + b0a) + 4 * lane;
+                                a = *reinterpret_cast<const int4q*>(src);
+                                if (TWO) b = *reinterpret_cast<const int4q*>(src + 256);
+                            };
+                            // one size: its segment from the registers to the buffer, the registers re-used for the load three sizes on, then the candidates
+                            auto step = [&](const int s, int4q& a, int4q& b) {
+                                *reinterpret_cast<int4q*>(slot + 4 * lane) = a;
+                                if (TWO) *reinterpret_cast<int4q*>(slot + 256 + 4 * lane) = b;
+                                if (s + 3 <= s_hi) issue(s + 3, a, b);
+                                const int4q* kq = reinterpret_cast<const int4q*>(P->gen_key2[s - 6]);          // key terms of n1 = 2 + 4 c .. 5 + 4 c: one scalar load
+                                const int4q kt = *reinterpret_cast<const int4q*>(P->gen_keyt[s - 6]);           // of n1 = s - 5 .. s - 2
+                                int kg = 0x7fffffff;
+                                // (rolled on purpose: with the chunk count a compile-time constant per size -- every read of a size under way before the first
+                                // candidate -- the kernel is seven bodies longer and 7 % slower)
+                                for (int c4 = 0; 4 * c4 + 5 <= s - 2; c4++) {
+                                    const int4q k4 = kq[c4];
+#pragma unroll
+                                    for (int u = 0; u < 4; u++) { const int key = gen(sl[2 + 4 * c4 + u], k4[u]); kg = key < kg ? key : kg; }
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; u++) { const int key = gen(sl[s - 5 + u], kt[u]); kg = key < kg ? key : kg; }          // (may overlap the last chunk)
+                                kg += o_mmI * 1024;
+                                kmin = kg < kmin ? kg : kmin;
+                                const int eb = P->bulge[s] + tau;
+                                const int x1 = (s - 2) * ninio;
+                                const int e1 = P->internal_loop[s] + (x1 < max_ninio ? x1 : max_ninio) + o_mm1n;
+                                put_bulge(eb, sl[0], s); put_1n(e1, sl[1], 1 << 5 | (s - 1)); put_1n(e1, sl[s - 1], (s - 1) << 5 | 1); put_bulge(eb, sl[s], s << 5);
+                            };
+                            int4q a0 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
+                            issue(s_lo, a0, b0);
+                            if (s_lo + 1 <= s_hi) issue(s_lo + 1, a1, b1);
+                            if (s_lo + 2 <= s_hi) issue(s_lo + 2, a2, b2);
+                            for (int s = s_lo; s <= s_hi; s += 3) {          // three sizes per turn: each has its own registers, nothing is moved
+                                step(s, a0, b0);
+                                if (s + 1 <= s_hi) step(s + 1, a1, b1);
+                                if (s + 2 <= s_hi) step(s + 2, a2, b2);
+                            }
+                        };
+                        const bool staged = span_w + 31 + 1 <= GEN_STAGE;
                         if (grp == 0) {
                             // sizes 0 .. 6, straight-line: every load first (rows of sizes beyond smax -- the first diagonals only -- are read at a clamped row and
                             // not used), then the shapes with (n1, n2) as compile-time constants
@@ -361,15 +428,17 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
                                 kmin = kg < kmin ? kg : kmin;
                                 put_1n(e1, w6b[2], 5 << 5 | 1); put_bulge(eb, w6b[3], 6 << 5 | 0);
                             }
-                        } else if (grp == 1) {
-                            sizes(std::integral_constant<int, 4>{}, 7, smax < 17 ? smax : 17);
-                        } else if (grp == 2) {
-                            sizes(std::integral_constant<int, 6>{}, 18, smax < 24 ? smax : 24);
+                        } else if (staged) {
+                            const int s_lo = grp == 1 ? 7 : grp == 2 ? 18 : 25, s_hi = grp == 1 ? (smax < 17 ? smax : 17) : grp == 2 ? (smax < 24 ? smax : 24) : smax;
+                            if (span_w + s_hi + 1 > 256) sizes_staged(std::true_type{}, s_lo, s_hi);
+                            else sizes_staged(std::false_type{}, s_lo, s_hi);
                         } else {
-                            sizes(std::integral_constant<int, 7>{}, 25, smax);
+                            if (grp == 1) sizes(7, smax < 17 ? smax : 17);
+                            else if (grp == 2) sizes(18, smax < 24 ? smax : 24);
+                            else sizes(25, smax);
                         }
                         const int best = kmin >> 10;
-                        if (best < GEN_EMAX) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(kmin & 1023));
+                        if (active && best < GEN_EMAX) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(kmin & 1023));
                     }
                 }
             }
@@ -439,12 +508,12 @@ __global__ void __launch_bounds__(GEN_NT) fold_generic_kernel(
 
 // split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
 size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
-    return fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + 16;
+    return fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + sizeof(int) * (GEN_NT / 64) * (GEN_STAGE + 2) + 16;
 }
 
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
     // c, fML, four diagonals of DML, the candidate pool (two ints per entry), the trace-back codes (a short per cell)
-    const size_t ld = (size_t)n_cap + 2;
+    const size_t ld = (size_t)fold_generic_ld(n_cap);
     return 3 * fold_generic_table_ints(n_cap, span) + ((4 * ld + 2 * ld * (size_t)fold_generic_pool_cap(n_cap, span) + 63) & ~(size_t)63) +
            ((fold_generic_table_ints(n_cap, span) / 2 + 63) & ~(size_t)63) + 64;          // (+ w: the interior-loop interval's view of c)
 }

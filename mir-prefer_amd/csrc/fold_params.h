@@ -10,12 +10,15 @@
 #define MIRP_RING_CSTR 354        // row stride (shorts) of the fill kernel's c ring: CSTR of fold_lds_common.h (static_assert there)
 #define MIRP_HP_MAX 3104          // hairpin size table (log-extrapolated above 30 on the host)
 
-struct FoldParams {
+struct alignas(16) FoldParams {
     // derived, read with scalar loads by the LDS fill kernel (wave-uniform loop shapes).  An interior-loop candidate is ranked by the key
     // (energy term << 10) | (n1 << 5 | n2): the minimum key is the minimum energy and, among equal energies, the first shape in the
     // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
     // (also read by the generic kernel, fold_kernel.hip: one v_mad_i32_i24 per generic candidate)
     unsigned gen_key[25][32];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
+    // the same terms as the generic kernel (fold_kernel.hip) reads them, four per scalar load: its chunks of four candidates start at n1 = 2, 6, ...
+    unsigned gen_key2[25][32];    // [u-6][m] = gen_key[u-6][m + 2]
+    unsigned gen_keyt[25][4];     // [u-6][x] = gen_key[u-6][u - 5 + x]: the last four generic shapes of a size, a chunk of their own
     unsigned kb0_key[31];         // bulge n1 = 0, n2 = u:   (bulge[u] + 2048) << 10 | u
     unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
     unsigned k1n0_key[31];        // 1 x k loop (n1 = 1, n2 = k): (internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048) << 10 | 1 << 5 | k
@@ -58,7 +61,7 @@ struct FoldParams {
 };
 
 // Energy model of the "vienna-1.8.5" compatibility mode (Turner-1999 parameters as shipped in ViennaRNA 1.8.5, dangles = 1).
-struct FoldParams185 {
+struct alignas(16) FoldParams185 {
     int stack[8][8];
     int bulge[31];
     int internal_loop[31];
@@ -74,7 +77,9 @@ struct FoldParams185 {
     int tetraE[32];               // bonus added to the hairpin energy (not a total, unlike Turner-2004)
     char tetra[32][8];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
-    unsigned gen_key[25][32];     // as FoldParams::gen_key (the generic kernel's interior-loop interval reads its key terms with scalar loads)
+    unsigned gen_key[25][32];     // as FoldParams::gen_key, gen_key2, gen_keyt (the generic kernel's interior-loop interval reads its key terms with scalar loads)
+    unsigned gen_key2[25][32];
+    unsigned gen_keyt[25][4];
 };
 void mirp_fill_fold_params185(FoldParams185* p);
 

@@ -19,6 +19,10 @@ static void fill_gen_key(PP* p) {
             }
             p->gen_key[u - 6][n1] = v;
         }
+    for (int u = 6; u <= MIRP_MAXLOOP; u++) {
+        for (int m = 0; m < 32; m++) p->gen_key2[u - 6][m] = m + 2 < 32 ? p->gen_key[u - 6][m + 2] : 65535u << 10;
+        for (int x = 0; x < 4; x++) p->gen_keyt[u - 6][x] = u - 5 + x >= 0 ? p->gen_key[u - 6][u - 5 + x] : 65535u << 10;
+    }
 }
 
 static void fill_derived(FoldParams* p) {

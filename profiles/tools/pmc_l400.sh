@@ -4,7 +4,7 @@
 LIB=${1:-mir-prefer_amd/libmirprefer.so}; MODEL=${2:-vienna-2.1.2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export MIRP_LIB=$PWD/$LIB
-for CTRS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM"; do
+for CTRS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR" "TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE" "SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
   TAG=l400_$(echo $CTRS | cut -d' ' -f1)
   rm -rf gpurun_out/pmc_$TAG
   timeout 200 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d gpurun_out/pmc_$TAG -- python3 profiles/tools/l400_time.py 400 $MODEL > gpurun_out/pmc_$TAG.log 2>&1
