@@ -7,12 +7,22 @@
 // small terms, exactly as the original): equality tests in the backtrack see the same numbers.
 #include <hip/hip_runtime.h>
 #include "fold185_device.h"
+#include <type_traits>
 
 namespace mirp {
 namespace v185 {
 
+#define V_STAGE 512               // ints per wave of the interior-loop interval's staging buffer
+#define V_FILL_WAVES 5            // waves per SIMD the fill's register allocation aims for
+typedef int v_int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
+typedef int v_int4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef int v_int4q __attribute__((ext_vector_type(4), aligned(16)));
+
+// row stride of a workspace table (a multiple of four ints: the interior-loop interval stages row segments with aligned 16-byte loads)
+__host__ __device__ inline int fold185_ld(int n_cap) { return (n_cap + 2 + 3) & ~3; }
+
 __host__ __device__ inline size_t fold185_table_ints(int n_cap, int span) {
-    const size_t per = (size_t)(span + 2) * (size_t)(n_cap + 2);
+    const size_t per = (size_t)(span + 2) * (size_t)fold185_ld(n_cap);
     return (per + 3) & ~(size_t)3;
 }
 
@@ -26,7 +36,7 @@ __host__ __device__ inline size_t fold185_lds_bytes_base(int n_cap, int max_line
 // PHASE 1 = fill, PHASE 2 = exterior sweep + backtracks, launched back to back over batches of `grid` windows (slot = blockIdx.x), as fold_generic_kernel:
 // the fill needs half the registers of the epilogue.
 template <int PHASE>
-__global__ void __launch_bounds__(V_NT) fold185_kernel(
+__global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_kernel(
     const FoldParams185* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
     char* __restrict__ out_ss, int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status) {
@@ -47,8 +57,14 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
     unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
     // inner-pair terms of the loop energies ([t2][sq1][sp1] as shorts) and the stacking table out of LDS, as fold_generic_kernel
     short* l_mmI = (short*)(smem + fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * (size_t)nc + 15) / 16) * 16);
-    short* l_stack = l_mmI + 200;
-    for (int x = threadIdx.x; x < 200; x += V_NT) l_mmI[x] = (short)min(P->mismatchI[x / 25][(x / 5) % 5][x % 5], 32767);
+    short* l_xb = l_mmI + 200;                             // bulge: TerminalAU of the inner pair - its mismatchI (what turns the table's word into c + TerminalAU)
+    short* l_stack = l_xb + 200;
+    int* stage = reinterpret_cast<int*>(l_stack + 64);     // V_STAGE ints per wave: the row segment a block of paired cells reads for one loop size
+    int* wcnt = stage + (V_NT / 64) * V_STAGE;             // 2 * waves: paired cells per wave and half-pass of the list compaction
+    for (int x = threadIdx.x; x < 200; x += V_NT) {
+        l_mmI[x] = (short)min(P->mismatchI[x / 25][(x / 5) % 5][x % 5], 32767);
+        l_xb[x] = x >= 25 ? (short)((x / 25 > 2 ? P->TerminalAU : 0) - P->mismatchI[x / 25][(x / 5) % 5][x % 5]) : (short)0;
+    }
     for (int x = threadIdx.x; x < 64; x += V_NT) l_stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
     __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,7 +101,7 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
             tetra[x] = b;
         }
         GTab185 T;
-        T.ld = n_cap + 2; T.n = n; T.M = M;
+        T.ld = fold185_ld(n_cap); T.n = n; T.M = M;
         const size_t tab = fold185_table_ints(n_cap, span);
         T.c = ws + (size_t)blockIdx.x * ws_slot_ints;
         T.m = T.c + tab;
@@ -94,7 +110,9 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
         // (tests/tools/splitcand_gate185.c: identity of the tables with ML_BASE = 0); DML(i,j) = min(DML(i,j-1), min over column j's candidates)
         int2* pool = reinterpret_cast<int2*>(T.dm + tab);          // [ld][pcap]
         const int pcap = span + 2;
-        int* gtab = reinterpret_cast<int*>(pool + (size_t)T.ld * pcap);          // c(p,q) + the inner pair's mismatch term, INF where (p,q) is no pair (as fold_generic_kernel's g)
+        // the interior-loop interval's view of finished cells, one word per cell (as fold_generic_kernel's w): c(p,q) + mismatchI of (p,q) seen as an inner pair in
+        // the low 24 bits (V_INF where (p,q) is no pair), the index of that term, rtype * 25 + S[q+1] * 5 + S[p-1], in the high byte
+        int* wtab = reinterpret_cast<int*>(pool + (size_t)T.ld * pcap);
         if constexpr (PHASE == 1) for (int x = tid; x <= n + 1; x += V_NT) pcnt[x] = 0;
         __syncthreads();
         Ctx<FoldParams185> X;
@@ -109,74 +127,184 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
         const int sub = tid % V_G;
         for (int d = V_TURN + 1; d <= Dmax; d++) {
             const int ncell = n - d;
-            if (tid == 0) red[V_NT / 64 + 7] = 0;
-            __syncthreads();
-            for (int base = 0; base < ncell; base += V_NT) {
-                const int cell = base + tid;
-                int type = 0;
-                if (cell < ncell) { type = ptype(X, cell + 1, cell + 1 + d); ctype[cell] = (unsigned char)type; cbest[cell] = V_INF; }
-                const unsigned long long bal = __ballot(type != 0);
-                int wbase = 0;
-                if (lane == 0 && bal) wbase = atomicAdd(&red[V_NT / 64 + 7], (int)__popcll(bal));
-                wbase = __shfl(wbase, 0);
-                if (type) plist[wbase + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)cell;
+            // pair types of the diagonal's cells; the paired ones compacted into a list IN CELL ORDER (a block of 64 list entries is a stretch of the
+            // diagonal, whose row segments interval A stages): two cells per thread and pass, the per-wave counts ordered through LDS
+            int np = 0;
+            for (int base = 0; base < ncell; base += 2 * V_NT) {
+                int type[2];
+                unsigned long long bal[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int cell = base + h * V_NT + tid;
+                    type[h] = 0;
+                    if (cell < ncell) { type[h] = ptype(X, cell + 1, cell + 1 + d); ctype[cell] = (unsigned char)type[h]; cbest[cell] = V_INF; }
+                    bal[h] = __ballot(type[h] != 0);
+                    if (lane == 0) wcnt[h * (V_NT / 64) + wave] = (int)__popcll(bal[h]);
+                }
+                __syncthreads();
+                int before[2] = {0, 0}, total = 0;
+#pragma unroll
+                for (int x = 0; x < 2 * (V_NT / 64); x++) {
+                    const int v = wcnt[x];
+                    if (x < wave) before[0] += v;
+                    if (x < V_NT / 64 + wave) before[1] += v;
+                    total += v;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (type[h]) plist[np + before[h] + (int)__popcll(bal[h] & ((1ull << lane) - 1ull))] = (unsigned short)(base + h * V_NT + tid);
+                np += total;
+                if (base + 2 * V_NT < ncell) __syncthreads();          // (the counts are rewritten by the next pass)
             }
             __syncthreads();
-            const int np = red[V_NT / 64 + 7];
             const int n1max = (d - 2 - (V_TURN + 1) < V_MAXLOOP) ? d - 2 - (V_TURN + 1) : V_MAXLOOP;
+#ifdef MIRP_X_GEN_NOA               // timing experiment: no interior loops (tables wrong by construction)
+            if (false) {
+#else
             if (n1max >= 0 && np > 0) {
-                const int nblk = (np + 63) >> 6, ntask = nblk * (n1max + 1);
+#endif
+                // Task = (block of 64 paired cells, group of loop sizes s = n1 + n2), as fold_generic_kernel: a size's inner pairs are consecutive cells of
+                // ONE diagonal's row (d - 2 - s); the block's segment of that row is loaded once by the wave (aligned 16 bytes per lane, three sizes in
+                // flight), staged in LDS, and each lane reads its s + 1 words from there.  A generic candidate -- every shape of this model but stack, bulge,
+                // 1 x 1, 1 x 2, 2 x 2 -- is one v_mad_i32_i24 (word's 24-bit energy field + the scalar size / asymmetry term) and a minimum.
+                const int smax = n1max;
+                const int nblk = (np + 63) >> 6;
+                const int ngrp = smax < 7 ? 1 : smax < 18 ? 2 : smax < 25 ? 3 : 4;
+                const int ntask = nblk * ngrp;
                 for (int t = wave; t < ntask; t += V_NT / 64) {
-                    const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: the loop shape (and loopE's branches) in scalar registers
-                    const int blk = tu / (n1max + 1), n1 = tu - blk * (n1max + 1);
+                    const int tu = __builtin_amdgcn_readfirstlane(t);          // the task is the wave's: loop sizes and shapes in scalar registers
+                    const int blk = tu / ngrp, grp = tu - blk * ngrp;
                     const int k = blk * 64 + lane;
-                    if (k < np) {
-                        const int cell = plist[k];
-                        const int i = cell + 1, j = i + d, p = i + 1 + n1;
-                        const int type = ctype[cell];
-                        const int si1 = S[i + 1], sj1 = S[j - 1], sp1 = S[p - 1];
-                        const int o_mmI = l_mmI[type * 25 + si1 * 5 + sj1];          // the outer pair's term: once per task
-                        int n2max = V_MAXLOOP - n1;
-                        if (n2max > d - n1 - 2 - (V_TURN + 1)) n2max = d - n1 - 2 - (V_TURN + 1);
-                        int best = V_INF;
-                        // the row's first shapes (bulges, 1x1, 1x2, 2x2; every shape when n1 = 0) in the general form, its tail -- generic loops, all of them the
-                        // same formula in this model -- as a tight loop over the precombined table: a load, two adds and a compare per candidate
-                        const int n2t = n1 == 0 ? n2max + 1 : (n1 <= 2 ? 3 : 1);
-                        const int* grow = gtab + (size_t)(d - n1 - 2) * T.ld + p;
-#pragma unroll 8
-                        for (int n2 = n2t; n2 <= n2max; n2++) {
-                            const int x = (n1 > n2 ? n1 - n2 : n2 - n1) * P->ninio;
-                            const int e = P->internal_loop[n1 + n2] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + grow[-(ptrdiff_t)n2 * T.ld];
-                            best = e < best ? e : best;
+                    // (the lanes behind the list's end, in its last block, run along on its last cell: the staged loads are the whole wave's)
+                    const bool active = k < np;
+                    const int cell = plist[active ? k : np - 1];
+                    const int i = cell + 1, j = i + d;
+                    const int type = ctype[cell];
+                    const int si1 = S[i + 1], sj1 = S[j - 1];
+                    const int o_mmI = l_mmI[type * 25 + si1 * 5 + sj1];          // the outer pair's term: once per task
+                    const int tau = AU(X, type);
+                    int best = 0x7fffffff;
+                    auto gen = [&](const int w, const int kterm) {
+                        int e;
+                        asm("v_mad_i32_i24 %0, %1, 1, %2" : "=v"(e) : "v"(w), "s"(kterm));
+                        return e;
+                    };
+                    auto w_e = [](const int w) { return (w << 8) >> 8; };                      // the word's energy (sign-extended 24 bits)
+                    auto w_in = [](const int w) { return (int)((unsigned)w >> 24); };          // the word's inner-pair index
+                    auto put = [&](const int e) { best = e < best ? e : best; };
+                    auto put_bulge = [&](const int eb, const int w) { put(eb + w_e(w) + (int)l_xb[w_in(w)]); };
+                    const int* wlane = wtab + i + 1;          // candidate n1 of size s = wlane[(d - 2 - s) * ld + n1]
+                    // sizes s_lo .. s_hi (>= 7) straight from the table, a load per candidate: the fallback for blocks whose cells lie too far apart for the
+                    // staging buffer (sparse pairs in long windows)
+                    auto sizes = [&](const int s_lo, const int s_hi) {
+                        for (int s = s_lo; s <= s_hi; s++) {
+                            const int* wrow = wlane + (d - 2 - s) * T.ld;
+                            int kg = 0x7fffffff;
+                            for (int n1 = 1; n1 <= s - 1; n1++) { const int e = gen(wrow[n1], P->gen_e[s][n1]); kg = e < kg ? e : kg; }
+                            put(kg + o_mmI);
+                            const int eb = P->bulge[s] + tau;
+                            put_bulge(eb, wrow[0]); put_bulge(eb, wrow[s]);
                         }
-                        const int n2s = n2t - 1 < n2max ? n2t - 1 : n2max;
-                        for (int n2 = 0; n2 <= n2s; n2++) {
-                            const int q = j - 1 - n2;
-                            const int cv = T.C(p, q);
-                            int t2 = ptype(X, p, q);
-                            if (!t2) continue;
-                            t2 = rtype_of(t2);
-                            const int sq1 = S[q + 1];
-                            const int nl = n1 > n2 ? n1 : n2, ns = n1 > n2 ? n2 : n1;          // wave-uniform
-                            int e;
-                            if (ns >= 1 && !(ns == 1 && nl <= 2) && !(ns == 2 && nl == 2)) {
-                                const int x = (nl - ns) * P->ninio;          // every loop but 1x1, 1x2, 2x2 in this model (no 1xn / 2x3 tables)
-                                e = P->internal_loop[n1 + n2] + (x < P->MAX_NINIO ? x : P->MAX_NINIO) + o_mmI + l_mmI[t2 * 25 + sq1 * 5 + sp1];
-                            } else if (nl == 0) {
-                                e = l_stack[type * 8 + t2];
-                            } else if (ns == 0) {
-                                e = P->bulge[nl] + (nl == 1 ? (int)l_stack[type * 8 + t2] : (AU(X, type) + AU(X, t2)));
-                            } else {
-                                e = loopE(X, n1, n2, type, t2, si1, sj1, sp1, sq1);
+                    };
+                    const int cell_lo = __builtin_amdgcn_readfirstlane(plist[blk * 64]);
+                    const int cell_hi = __builtin_amdgcn_readfirstlane(plist[blk * 64 + 63 < np ? blk * 64 + 63 : np - 1]);
+                    const int b0a = (cell_lo + 2) & ~3;                     // first staged position (p of the first cell, rounded down to 16 bytes)
+                    const int span_w = cell_hi + 2 - b0a;                   // the last cell's offset in the segment
+                    int* slot = stage + wave * V_STAGE;
+                    const int* sl = slot + (cell + 2 - b0a);                // this lane's candidate n1 = sl[n1]
+                    auto sizes_staged = [&](auto two_tag, const int s_lo, const int s_hi) {
+                        constexpr bool TWO = decltype(two_tag)::value;          // a second 256-word piece
+                        auto issue = [&](const int s, v_int4q& a, v_int4q& b) {
+                            const int* src = wtab + ((d - 2 - s) * T.ld + b0a) + 4 * lane;
+                            a = *reinterpret_cast<const v_int4q*>(src);
+                            if (TWO) b = *reinterpret_cast<const v_int4q*>(src + 256);
+                        };
+                        // one size: its segment from the registers to the buffer, the registers re-used for the load three sizes on, then the candidates
+                        auto step = [&](const int s, v_int4q& a, v_int4q& b) {
+                            *reinterpret_cast<v_int4q*>(slot + 4 * lane) = a;
+                            if (TWO) *reinterpret_cast<v_int4q*>(slot + 256 + 4 * lane) = b;
+                            if (s + 3 <= s_hi) issue(s + 3, a, b);
+                            const v_int4q* kq = reinterpret_cast<const v_int4q*>(P->gen_e1[s]);           // terms of n1 = 1 + 4 c .. 4 + 4 c: one scalar load
+                            const v_int4q kt = *reinterpret_cast<const v_int4q*>(P->gen_et[s]);            // of n1 = s - 4 .. s - 1
+                            int kg = 0x7fffffff;
+                            for (int c4 = 0; 4 * c4 + 4 <= s - 1; c4++) {
+                                const v_int4q k4 = kq[c4];
+#pragma unroll
+                                for (int u = 0; u < 4; u++) { const int e = gen(sl[1 + 4 * c4 + u], k4[u]); kg = e < kg ? e : kg; }
                             }
-                            e += cv;
-                            best = e < best ? e : best;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { const int e = gen(sl[s - 4 + u], kt[u]); kg = e < kg ? e : kg; }          // (may overlap the last chunk)
+                            put(kg + o_mmI);
+                            const int eb = P->bulge[s] + tau;
+                            put_bulge(eb, sl[0]); put_bulge(eb, sl[s]);
+                        };
+                        v_int4q a0 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
+                        issue(s_lo, a0, b0);
+                        if (s_lo + 1 <= s_hi) issue(s_lo + 1, a1, b1);
+                        if (s_lo + 2 <= s_hi) issue(s_lo + 2, a2, b2);
+                        for (int s = s_lo; s <= s_hi; s += 3) {          // three sizes per turn: each has its own registers, nothing is moved
+                            step(s, a0, b0);
+                            if (s + 1 <= s_hi) step(s + 1, a1, b1);
+                            if (s + 2 <= s_hi) step(s + 2, a2, b2);
                         }
-                        if (best < V_INF) atomicMin(&cbest[cell], best);
+                    };
+                    const bool staged = span_w + 31 + 1 <= V_STAGE;
+                    if (grp == 0) {
+                        // sizes 0 .. 6, straight-line: every load first (rows of sizes beyond smax -- the first diagonals only -- are read at a clamped row and
+                        // not used), then the shapes with (n1, n2) as compile-time constants
+                        const int sI[4] = {S[i], si1, S[i + 2], S[i + 3]};          // S[i + x]
+                        const int sJ[4] = {S[j], sj1, S[j - 2], S[j - 3]};          // S[j - x]
+                        const int* wr[7];
+#pragma unroll
+                        for (int s = 0; s < 7; s++) { const int dd = d - 2 - s; wr[s] = wlane + (dd > 0 ? dd : 0) * T.ld; }
+                        const int w0 = wr[0][0];
+                        const v_int2a w1 = *reinterpret_cast<const v_int2a*>(wr[1]);
+                        const v_int4a w2 = *reinterpret_cast<const v_int4a*>(wr[2]), w3 = *reinterpret_cast<const v_int4a*>(wr[3]), w4 = *reinterpret_cast<const v_int4a*>(wr[4]);
+                        const int w44 = wr[4][4];
+                        const v_int4a w5 = *reinterpret_cast<const v_int4a*>(wr[5]);
+                        const v_int2a w5b = *reinterpret_cast<const v_int2a*>(wr[5] + 4);
+                        const v_int4a w6 = *reinterpret_cast<const v_int4a*>(wr[6]), w6b = *reinterpret_cast<const v_int4a*>(wr[6] + 3);
+                        // reversed type of the inner pair (p, q) = (i + 1 + n1, j - 1 - n2), 0 = no pair
+                        auto t2of = [&](const int n1, const int n2) { return pair_type(sJ[1 + n2], sI[1 + n1]); };
+                        const int t00 = t2of(0, 0), t01 = t2of(0, 1), t10 = t2of(1, 0), t11 = t2of(1, 1), t12 = t2of(1, 2), t21 = t2of(2, 1), t22 = t2of(2, 2);
+                        // the big tables (sp1 = S[p - 1] = sI[n1], sq1 = S[q + 1] = sJ[n2]); a missing pair reads row 0 and is masked below
+                        const int r11 = loopE(X, 1, 1, type, t11, si1, sj1, sI[1], sJ[1]);
+                        const int r12 = loopE(X, 1, 2, type, t12, si1, sj1, sI[1], sJ[2]);
+                        const int r21 = loopE(X, 2, 1, type, t21, si1, sj1, sI[2], sJ[1]);
+                        const int r22 = loopE(X, 2, 2, type, t22, si1, sj1, sI[2], sJ[2]);
+                        const int b1 = P->bulge[1];
+                        auto cof = [&](const int w) { return w_e(w) - (int)l_mmI[w_in(w)]; };          // c(p,q) of a pair
+                        auto put_if = [&](const int t2, const int e) { if (t2) put(e); };
+                        auto put_gen = [&](const int s, const int n1, const int w) { put(w_e(w) + P->gen_e[s][n1] + o_mmI); };
+                        put_if(t00, (int)l_stack[type * 8 + t00] + cof(w0));
+                        if (smax >= 1) { put_if(t01, b1 + (int)l_stack[type * 8 + t01] + cof(w1[0])); put_if(t10, b1 + (int)l_stack[type * 8 + t10] + cof(w1[1])); }
+                        if (smax >= 2) { const int eb = P->bulge[2] + tau; put_bulge(eb, w2[0]); put_if(t11, r11 + cof(w2[1])); put_bulge(eb, w2[2]); }
+                        if (smax >= 3) { const int eb = P->bulge[3] + tau; put_bulge(eb, w3[0]); put_if(t12, r12 + cof(w3[1])); put_if(t21, r21 + cof(w3[2])); put_bulge(eb, w3[3]); }
+                        if (smax >= 4) {
+                            const int eb = P->bulge[4] + tau;
+                            put_bulge(eb, w4[0]); put_gen(4, 1, w4[1]); put_if(t22, r22 + cof(w4[2])); put_gen(4, 3, w4[3]); put_bulge(eb, w44);
+                        }
+                        if (smax >= 5) {
+                            const int eb = P->bulge[5] + tau;
+                            put_bulge(eb, w5[0]); put_gen(5, 1, w5[1]); put_gen(5, 2, w5[2]); put_gen(5, 3, w5[3]); put_gen(5, 4, w5b[0]); put_bulge(eb, w5b[1]);
+                        }
+                        if (smax >= 6) {
+                            const int eb = P->bulge[6] + tau;
+                            put_bulge(eb, w6[0]); put_gen(6, 1, w6[1]); put_gen(6, 2, w6[2]); put_gen(6, 3, w6[3]); put_gen(6, 4, w6b[1]); put_gen(6, 5, w6b[2]);
+                            put_bulge(eb, w6b[3]);
+                        }
+                    } else {
+                        const int s_lo = grp == 1 ? 7 : grp == 2 ? 18 : 25, s_hi = grp == 1 ? (smax < 17 ? smax : 17) : grp == 2 ? (smax < 24 ? smax : 24) : smax;
+                        if (!staged) sizes(s_lo, s_hi);
+                        else if (span_w + s_hi + 1 > 256) sizes_staged(std::true_type{}, s_lo, s_hi);
+                        else sizes_staged(std::false_type{}, s_lo, s_hi);
                     }
+                    if (active && best < V_INF) atomicMin(&cbest[cell], best);
                 }
             }
             __syncthreads();
+            // the cells in groups of V_G lanes (a thread per cell, as fold_generic_kernel's interval B, is slower here: this model's columns hold more split
+            // candidates -- any of four stem terms makes one -- and the serial loop over them then sets the pace: 0.41 -> 0.47 s at L = 400)
             for (int cell = tid / V_G; cell < ((ncell + V_NT / V_G - 1) / (V_NT / V_G)) * (V_NT / V_G); cell += V_NT / V_G) {
                 const bool live = cell < ncell;
                 const int i = cell + 1, j = i + d;
@@ -230,7 +358,10 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
                         if (k < pcap) { pool[(size_t)j * pcap + k] = make_int2(i, stem); pcnt[j] = k + 1; }
                     }
                     T.c[(size_t)d * T.ld + i] = newc;
-                    gtab[(size_t)d * T.ld + i] = type ? newc + (int)l_mmI[rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1]] : V_INF;
+                    {
+                        const int in = rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1];          // (i,j) as the inner pair of a later loop
+                        wtab[(size_t)d * T.ld + i] = type ? (in << 24) | ((newc + (int)l_mmI[in]) & 0xffffff) : V_INF;
+                    }
                     T.m[(size_t)d * T.ld + i] = mm;
                     T.dm[(size_t)d * T.ld + i] = mdec;
                 }
@@ -239,8 +370,12 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
         }
 
         } else {
+#ifdef MIRP_X_GEN_NOEPI             // timing experiment: fill only (results are empty)
+        if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; }
+#else
         epilogue<FoldParams185, GTab185, V_NT>(X, T, f3, starts, lens, btstk, red, btbuf, nc, win, max_lines, ss_stride, out_lines, out_ss, out_nlines,
                                                 out_mfe, out_status);
+#endif
         }
     }
 }
@@ -248,12 +383,12 @@ __global__ void __launch_bounds__(V_NT) fold185_kernel(
 }  // namespace v185
 
 size_t fold185_lds_bytes(int n_cap, int max_lines) {
-    return v185::fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * ((size_t)n_cap + 8) + 15) / 16) * 16 + sizeof(short) * (200 + 64) + 16;
+    return v185::fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * ((size_t)n_cap + 8) + 15) / 16) * 16 + sizeof(short) * (2 * 200 + 64) + sizeof(int) * (V_NT / 64) * (V_STAGE + 2) + 16;
 }
 
 size_t fold185_ws_slot_ints(int n_cap, int span) {
     // c, fML, DML, the split-candidate pool (two ints per entry, span + 2 entries per column)
-    return 4 * v185::fold185_table_ints(n_cap, span) + ((2 * (size_t)(n_cap + 2) * (size_t)(span + 2) + 3) & ~(size_t)3) + 4;          // (+ g)
+    return 4 * v185::fold185_table_ints(n_cap, span) + ((2 * (size_t)v185::fold185_ld(n_cap) * (size_t)(span + 2) + 3) & ~(size_t)3) + 4;          // (+ w)
 }
 
 hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens,

@@ -62,6 +62,12 @@ struct alignas(16) FoldParams {
 
 // Energy model of the "vienna-1.8.5" compatibility mode (Turner-1999 parameters as shipped in ViennaRNA 1.8.5, dangles = 1).
 struct alignas(16) FoldParams185 {
+    // derived, read with scalar loads by fold185_kernel's interior-loop interval (wave-uniform loop shapes): size + asymmetry term of the generic loops --
+    // in this model every loop but stack, bulge, 1 x 1, 1 x 2, 2 x 2 -- [u][n1] = internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio), and the same in the
+    // order the kernel's chunks of four candidates read it (one 16-byte scalar load each)
+    int gen_e[31][32];
+    int gen_e1[31][32];           // [u][m] = gen_e[u][m + 1]: chunks start at n1 = 1
+    int gen_et[31][4];            // [u][x] = gen_e[u][u - 4 + x]: the last four generic shapes of a size (n1 = u - 4 .. u - 1)
     int stack[8][8];
     int bulge[31];
     int internal_loop[31];
@@ -77,9 +83,6 @@ struct alignas(16) FoldParams185 {
     int tetraE[32];               // bonus added to the hairpin energy (not a total, unlike Turner-2004)
     char tetra[32][8];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
-    unsigned gen_key[25][32];     // as FoldParams::gen_key, gen_key2, gen_keyt (the generic kernel's interior-loop interval reads its key terms with scalar loads)
-    unsigned gen_key2[25][32];
-    unsigned gen_keyt[25][4];
 };
 void mirp_fill_fold_params185(FoldParams185* p);
 

@@ -118,7 +118,15 @@ void mirp_fill_fold_params185(FoldParams185* p) {
     p->TerminalAU = T99_TerminalAU;
     p->ninio = T99_ninio;
     p->MAX_NINIO = T99_MAX_NINIO;
-    fill_gen_key(p);
+    for (int u = 0; u <= MIRP_MAXLOOP; u++)
+        for (int n1 = 0; n1 < 32; n1++) {
+            const int y = std::abs(2 * n1 - u) * p->ninio;
+            p->gen_e[u][n1] = p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO);
+        }
+    for (int u = 0; u <= MIRP_MAXLOOP; u++) {
+        for (int m = 0; m < 32; m++) p->gen_e1[u][m] = p->gen_e[u][m + 1 < 32 ? m + 1 : 31];
+        for (int x = 0; x < 4; x++) p->gen_et[u][x] = p->gen_e[u][u - 4 + x >= 0 ? u - 4 + x : 0];
+    }
 }
 
 void mirp_fill_fold_params_t1999(FoldParams* p) {
