@@ -172,3 +172,33 @@ def test_generic_kernels_match_the_real_binaries_beyond_300(gpu_ctx):
         assert check_long_folds(fix, seqs, fold_many) == 800
     finally:
         gpu_ctx.set_fold_model("vienna-2.1.2")
+
+
+@pytest.mark.parametrize("model", ["vienna-2.1.2", "vienna-1.8.5"])
+def test_generic_kernels_on_long_windows_with_sparse_pairs(gpu_ctx, oracle, model):
+    """Windows of 600 .. 1,000 nt at spans of 500 .. 700 -- beyond the staging buffer of the generic kernels' interior-loop interval when the paired cells of a
+    diagonal lie far apart (A-rich sequence with a few U: 64 paired cells then span more than 480 positions, and the block takes the load-per-candidate form) --
+    and ordinary mixed sequence of the same lengths (two staged pieces per segment): structure lines and MFE equal the oracle's."""
+    import random
+    r = random.Random(20265)
+    seqs = []
+    for k in range(10):
+        n = r.randint(600, 1000)
+        if k % 2 == 0:      # sparse pairs: mostly A and C, a U or G here and there, one planted hairpin so that there is something to fold
+            s = [r.choice("AAAC") if r.random() < 0.93 else r.choice("UG") for _ in range(n)]
+            arm = "".join(r.choice("ACGU") for _ in range(25))
+            rc = "".join({"A": "U", "C": "G", "G": "C", "U": "A"}[c] for c in reversed(arm))
+            at = r.randint(50, n - 120)
+            s[at:at + 25] = arm; s[at + 40:at + 65] = rc
+            seqs.append("".join(s))
+        else:
+            seqs.append("".join(r.choice("ACGU") for _ in range(n)))
+    gpu_ctx.set_fold_model(model)
+    try:
+        for span in (500, 700):
+            got = gpu_ctx.fold_batch(seqs, span, max_lines=600)
+            for s, g in zip(seqs, got):
+                want = oracle.lfold(s.encode(), span, model=model)
+                assert g["status"] == 0 and g["mfe"] == want["mfe"] and g["lines"] == want["lines"], (model, span, len(s))
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")
