@@ -524,6 +524,10 @@ void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, cons
     // batches of `grid` windows: window b + k of the batch owns workspace slot k in both kernels (without a work list the kernels index the windows
     // directly, so the batch is addressed by shifted array bases; with one, by the shifted list)
     const size_t lds = fold_generic_lds_bytes(n_cap, max_lines);
+    if (lds > 64 * 1024) {          // windows of some 1,700 nt and more (PRECURSOR_LEN up to 3000, MP:167-184): one or two workgroups per CU
+        (void)hipFuncSetAttribute((const void*)fold_generic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)fold_generic_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     for (int b = 0; b < n_work; b += grid) {
         const int nb = n_work - b < grid ? n_work - b : grid;
         const int* wl = work_list ? work_list + b : nullptr;

@@ -213,7 +213,7 @@ static int predict_batch_impl(mirp_ctx* c, const MirpWindow* windows, int32_t n_
     if (pp->n_samples < 1 || pp->n_samples > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_predict_batch: n_samples out of range");
     if (ss_stride % 8 != 0) return fail(c, -1, "mirp_predict_batch: ss_stride must be a multiple of 8");
     HIPCHK(c, hipSetDevice(c->device));
-    if (mirp::predict_lds_bytes(max_lines, ss_stride) > 160 * 1024)
+    if (mirp::predict_lds_bytes_min(max_lines, ss_stride) > 160 * 1024)
         return fail(c, -5, "mirp_predict_batch: max_lines*ss_stride exceeds the LDS budget of the predict kernel");
     TmpDevice T;
     const size_t nl = (size_t)n_windows * max_lines;
@@ -324,7 +324,9 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         HIPCHK(c, hipGetLastError());
         return 0;
     };
-    if (!m185 && mirp::fold_generic_lds_bytes(n_cap, max_lines) > 64 * 1024) return fail(c, -5, "LDS budget exceeded (max_lines too large)");
+    if (!m185 && mirp::fold_generic_lds_bytes(n_cap, max_lines) > 160 * 1024) return fail(c, -5, "LDS budget exceeded (window or max_lines too large)");
+    // the generic kernel ranks interior-loop candidates by energy * 1024 + shape in 32 bits (fold_kernel.hip, GEN_EMAX): energies below 10^6 in magnitude
+    if (!m185 && n_cap > 5000) return fail(c, -5, "window longer than 5,000 nt");
     const int* work_list = nullptr;
     int n_generic = n_work;
     if (span <= mirp::fold_lds_max_span() && mirp::fold_lds_bytes(max_lines) <= 160 * 1024) {

@@ -27,6 +27,8 @@ struct PredictCaps { int p_cap, s_cap, m_cap, l_cap; };   // pieces per line, st
 PredictCaps predict_default_caps(int max_lines, int ss_stride);
 size_t predict_lds_bytes(int max_lines, int ss_stride);
 size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps);
+size_t predict_lds_bytes_min(int max_lines, int ss_stride);          // without the staged text (which moves to global memory when it does not fit)
+size_t predict_lds_bytes_min(int max_lines, int ss_stride, PredictCaps caps);
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
                           const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount = nullptr,

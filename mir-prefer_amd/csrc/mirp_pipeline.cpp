@@ -569,7 +569,7 @@ static int launch_predict_resident(mirp_ctx* c, const MirpPredictParams& pp, uns
                                           (MirpMirna*)c->p_out.p, (int*)c->p_nout.p, (int*)c->p_status.p, rcount, rpool, rcap, rstride, nullptr, 0, skip, &err, (int*)c->p_need.p))
         return fail(c, rc, "mirp_predict: " + err);
     if (c->n_side > 0) {
-        if (mirp::predict_lds_bytes(c->side_max_lines, c->fold_stride) > 160 * 1024)
+        if (mirp::predict_lds_bytes_min(c->side_max_lines, c->fold_stride) > 160 * 1024)
             return fail(c, -5, "mirp_predict: a window with more structure lines than the default capacity exceeds the LDS budget of the predict kernel at this PRECURSOR_LEN");
         if (int rc = mirp::run_predict_launch(c->stream, c->n_cu, c->v_windows(), (int)nw, (const MirpMature*)c->matures.p, (const MirpAln*)c->alns.p, c->n_alns,
                                               (const MirpFoldLine*)c->lines2.p, (const char*)c->ss2.p, c->fold_stride, c->side_max_lines, (const int*)c->nlines2.p, pp,
@@ -587,7 +587,7 @@ extern "C" int mirp_predict(mirp_ctx* c, const MirpPredictParams* pp, MirpMirna*
     if (!c->have_fold) return fail(c, -1, "mirp_predict: run mirp_fold first");
     if (pp->n_samples < 1 || pp->n_samples > MIRP_MAX_SAMPLES) return fail(c, -1, "mirp_predict: n_samples out of range");
     HIPCHK(c, hipSetDevice(c->device));
-    if (mirp::predict_lds_bytes(c->fold_max_lines, c->fold_stride) > 160 * 1024)
+    if (mirp::predict_lds_bytes_min(c->fold_max_lines, c->fold_stride) > 160 * 1024)
         return fail(c, -5, "mirp_predict: max_lines*ss_stride exceeds the LDS budget of the predict kernel");
     const long long nw = c->n_windows;
     const size_t w1 = (size_t)std::max<long long>(nw, 1);

@@ -325,7 +325,9 @@ __device__ void d_expression(const MirpAln* __restrict__ a, long long na, int n_
 
 // REASONS: the -d mode of the reference (check_loci's dict_why_not_miRNA_reasons, MP:2206-2347): every evaluated (mature, structure) pair is
 // appended to a record pool (rstride ints per record, layout in mirp_pipeline.cpp) together with one record per window; nothing else changes.
-template <bool REASONS>
+// GTEXT: the staged structure text lives in a global scratch area of the workgroup instead of LDS -- windows whose lines do not fit there (PRECURSOR_LEN in
+// the thousands: hundreds of lines of thousands of characters); everything else is the same code.
+template <bool REASONS, bool GTEXT>
 #ifndef MIRP_PRED_WPS
 #define MIRP_PRED_WPS 4
 #endif
@@ -335,15 +337,16 @@ __global__ void __launch_bounds__(64, MIRP_PRED_WPS) predict_kernel(
     int ss_stride, int max_lines, const int* __restrict__ n_lines, MirpPredictParams pp,
     MirpMirna* __restrict__ out /* [n_windows * MIRP_MAX_MIRNA_PER_WINDOW] */, int* __restrict__ n_out, int* __restrict__ status,
     unsigned int* __restrict__ rcount, int* __restrict__ rpool, unsigned int rcap, int rstride,
-    const int* __restrict__ wsel, int n_sel, const int* __restrict__ skip, const int* __restrict__ wslot, PredictCaps caps, int* __restrict__ need) {
+    const int* __restrict__ wsel, int n_sel, const int* __restrict__ skip, const int* __restrict__ wslot, PredictCaps caps, int* __restrict__ need,
+    unsigned* __restrict__ gtext) {
     // wsel == nullptr: every window w in [0, n_windows) with its fold output at slot w, except those with skip[w] >= 0 (folded again at full
     // line capacity: a second launch handles them); wsel != nullptr: the windows wsel[k], k in [0, n_sel), with their fold output at slot
     // wslot[k] (wslot == nullptr: slot k).  need (optional): need[3 w] = structures, need[3 w + 1] = pieces of one line, need[3 w + 2] = staged lines the window has.
     extern __shared__ __align__(16) unsigned char smem[];
     const int wpl = (ss_stride + 15) >> 4;                                // packed words per line
-    unsigned* textw = (unsigned*)smem;                                   // l_cap * wpl: only the lines phase 1 looks at (printed, >= minlen) are staged
     const int max_structs = caps.s_cap, PW_MAX_PIECES = caps.p_cap, PW_MAX_MATURES = caps.m_cap, L_CAP = caps.l_cap;
-    PStruct* sts = (PStruct*)(smem + (((size_t)L_CAP * wpl * 4 + 15) & ~(size_t)15)); // max_structs
+    unsigned* textw = GTEXT ? gtext + (size_t)blockIdx.x * L_CAP * wpl : (unsigned*)smem;      // l_cap * wpl: only the lines phase 1 looks at (printed, >= minlen) are staged
+    PStruct* sts = (PStruct*)(smem + (GTEXT ? (size_t)0 : (((size_t)L_CAP * wpl * 4 + 15) & ~(size_t)15))); // max_structs
     PStruct* slot = sts + max_structs;                                // 64 * p_cap
     int* cnts = (int*)(slot + 64 * PW_MAX_PIECES);                       // 64
     int* morder = cnts + 64;                                             // m_cap: mature indices in stable depth-descending order (MP:2241)
@@ -609,14 +612,33 @@ PredictCaps predict_default_caps(int max_lines, int ss_stride) {
     return c;
 }
 
-size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps) {
-    size_t b = (((size_t)caps.l_cap * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15);
+size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps, bool text_in_lds) {
+    size_t b = text_in_lds ? (((size_t)caps.l_cap * ((ss_stride + 15) >> 4) * 4 + 15) & ~(size_t)15) : 0;
     b += sizeof(PStruct) * ((size_t)caps.s_cap + 64 * (size_t)caps.p_cap);
     b += sizeof(int) * (64 + (size_t)caps.m_cap);
     b += sizeof(unsigned short) * ((size_t)max_lines + (size_t)caps.l_cap);
     return (b + 15) & ~(size_t)15;
 }
+size_t predict_lds_bytes(int max_lines, int ss_stride, PredictCaps caps) { return predict_lds_bytes(max_lines, ss_stride, caps, true); }
 size_t predict_lds_bytes(int max_lines, int ss_stride) { return predict_lds_bytes(max_lines, ss_stride, predict_default_caps(max_lines, ss_stride)); }
+// what has to fit whatever the lines' number and length (structures, pieces, matures): the staged text itself moves to global memory when it does not
+size_t predict_lds_bytes_min(int max_lines, int ss_stride, PredictCaps caps) { return predict_lds_bytes(max_lines, ss_stride, caps, false); }
+size_t predict_lds_bytes_min(int max_lines, int ss_stride) { return predict_lds_bytes(max_lines, ss_stride, predict_default_caps(max_lines, ss_stride), false); }
+
+template <bool REASONS, bool GTEXT>
+static hipError_t launch_predict_as(hipStream_t stream, int grid, size_t lds, const MirpWindow* windows, int n_windows, const MirpMature* matures,
+                                    const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
+                                    const int* n_lines, MirpPredictParams pp, MirpMirna* out, int* n_out, int* status, unsigned int* rcount, int* rpool,
+                                    unsigned int rcap, int rstride, const int* wsel, int n_sel, const int* skip, const int* wslot, PredictCaps caps, int* need, unsigned* gtext) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)predict_kernel<REASONS, GTEXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((predict_kernel<REASONS, GTEXT>), dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
+                       max_lines, n_lines, pp, out, n_out, status, REASONS ? rcount : nullptr, REASONS ? rpool : nullptr, REASONS ? rcap : 0u, REASONS ? rstride : 0,
+                       wsel, n_sel, skip, wslot, caps, need, gtext);
+    return hipGetLastError();
+}
 
 hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* windows, int n_windows, const MirpMature* matures,
                           const MirpAln* alns, long long n_alns, const MirpFoldLine* lines, const char* ss, int ss_stride, int max_lines,
@@ -627,18 +649,30 @@ hipError_t launch_predict(hipStream_t stream, int grid, const MirpWindow* window
 #ifdef MIRP_PRED_LDS_PAD
     lds += MIRP_PRED_LDS_PAD;      // timing experiment: fewer resident windows per CU
 #endif
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(rpool ? (const void*)predict_kernel<true> : (const void*)predict_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    if (lds <= 160 * 1024) {
+        if (rpool)
+            return launch_predict_as<true, false>(stream, grid, lds, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
+                                                  rcount, rpool, rcap, rstride, wsel, n_sel, skip, wslot, caps, need, nullptr);
+        return launch_predict_as<false, false>(stream, grid, lds, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
+                                               rcount, rpool, rcap, rstride, wsel, n_sel, skip, wslot, caps, need, nullptr);
     }
+    // the staged text does not fit in LDS: a scratch area per workgroup in global memory (a few workgroups: the area is l_cap lines of ss_stride / 4 bytes each),
+    // allocated and released around the launch -- the path of PRECURSOR_LEN in the thousands, not of the benchmark
+    lds = predict_lds_bytes(max_lines, ss_stride, caps, false);
+    const size_t per = (size_t)caps.l_cap * ((ss_stride + 15) >> 4) * 4;
+    grid = (int)std::max<size_t>(1, std::min<size_t>((size_t)grid, ((size_t)2 << 30) / std::max<size_t>(per, 1)));
+    unsigned* gtext = nullptr;
+    hipError_t e = hipMalloc((void**)&gtext, per * (size_t)grid + 16);
+    if (e != hipSuccess) return e;
     if (rpool)
-        hipLaunchKernelGGL(predict_kernel<true>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                           max_lines, n_lines, pp, out, n_out, status, rcount, rpool, rcap, rstride, wsel, n_sel, skip, wslot, caps, need);
+        e = launch_predict_as<true, true>(stream, grid, lds, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
+                                          rcount, rpool, rcap, rstride, wsel, n_sel, skip, wslot, caps, need, gtext);
     else
-        hipLaunchKernelGGL(predict_kernel<false>, dim3(grid), dim3(64), lds, stream, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride,
-                           max_lines, n_lines, pp, out, n_out, status, nullptr, nullptr, 0u, 0, wsel, n_sel, skip, wslot, caps, need);
-    return hipGetLastError();
+        e = launch_predict_as<false, true>(stream, grid, lds, windows, n_windows, matures, alns, n_alns, lines, ss, ss_stride, max_lines, n_lines, pp, out, n_out, status,
+                                           rcount, rpool, rcap, rstride, wsel, n_sel, skip, wslot, caps, need, gtext);
+    const hipError_t e2 = hipStreamSynchronize(stream);
+    (void)hipFree(gtext);
+    return e != hipSuccess ? e : e2;
 }
 
 // records of the first pass that belong to windows which are run again: r[0] = -1 (the host drops them)
@@ -703,7 +737,7 @@ int run_predict_launch(hipStream_t stream, int n_cu, const MirpWindow* windows, 
             caps.l_cap = std::max(caps.l_cap, std::min(h_need[3 * (size_t)w + 2], max_lines));
             caps.m_cap = std::max(caps.m_cap, h_w[(size_t)w].n_matures);
         }
-        if (predict_lds_bytes(max_lines, ss_stride, caps) > 160 * 1024) {
+        if (predict_lds_bytes_min(max_lines, ss_stride, caps) > 160 * 1024) {
             *err = "a window has more structures / candidate matures than the filter kernel can hold in LDS (" + std::to_string(caps.s_cap) + " structures, " +
                    std::to_string(caps.m_cap) + " matures)";
             return -5;

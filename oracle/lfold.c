@@ -294,7 +294,10 @@ static int backtrack(const Fold *F, int start, int jend, char *out, int cap) {
     return L;
 }
 
+static __thread OracleTextSink *g_text;      /* set by oracle_lfold_text: lines go there, whatever their number and length */
+
 static void emit(OracleFoldResult *R, const char *body, int lead_dot, int energy, int start) {
+    if (g_text) { oracle_sink_add(g_text, lead_dot ? "." : "", body, energy, start); return; }
     if (R->n_lines >= ORACLE_MAX_LINES) { R->overflow = 1; return; }
     OracleFoldLine *l = &R->lines[R->n_lines++];
     int o = 0;
@@ -383,3 +386,17 @@ int oracle_lfold(const char *seq_in, int n, int span, OracleFoldResult *R) {
     free(F.seq); free(F.S); free(F.c); free(F.fML); free(F.pt); free(F.f3);
     return rc;
 }
+
+int oracle_lfold185_sink(const char *seq, int n, int span, OracleFoldResult *R, OracleTextSink *k);
+
+int oracle_lfold_text(const char *seq, int n, int span, int model, char **text, int *n_lines, int *mfe) {
+    OracleTextSink k = {(char *)calloc(1, 64), 0, 64, 0};
+    OracleFoldResult *R = (OracleFoldResult *)malloc(sizeof(OracleFoldResult));
+    int rc;
+    if (model == 1) rc = oracle_lfold185_sink(seq, n, span, R, &k);
+    else { g_text = &k; rc = oracle_lfold(seq, n, span, R); g_text = NULL; }
+    *text = k.buf; *n_lines = k.n_lines; *mfe = R->mfe;
+    free(R);
+    return rc;
+}
+void oracle_free_text(char *text) { free(text); }

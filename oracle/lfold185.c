@@ -276,7 +276,10 @@ static int backtrack(const Fold *F, int start, int maxdist, char *out, int cap) 
     return L;
 }
 
+static __thread OracleTextSink *g_text;      /* set through oracle_lfold185_sink: lines go there, whatever their number and length */
+
 static void emit(OracleFoldResult *R, const char *body, int energy, int start) {
+    if (g_text) { oracle_sink_add(g_text, "", body, energy, start); return; }
     if (R->n_lines >= ORACLE_MAX_LINES) { R->overflow = 1; return; }
     OracleFoldLine *l = &R->lines[R->n_lines++];
     strncpy(l->ss, body, ORACLE_MAX_SS - 1);
@@ -344,5 +347,12 @@ int oracle_lfold185(const char *seq_in, int n, int span, OracleFoldResult *R) {
     R->mfe = F.f3[1];
     free(prev); free(cur);
     free(F.seq); free(F.S); free(F.c); free(F.fML); free(F.pt); free(F.f3);
+    return rc;
+}
+
+int oracle_lfold185_sink(const char *seq, int n, int span, OracleFoldResult *R, OracleTextSink *k) {
+    g_text = k;
+    const int rc = oracle_lfold185(seq, n, span, R);
+    g_text = NULL;
     return rc;
 }

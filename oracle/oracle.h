@@ -2,12 +2,15 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 #define ORACLE_MAX_LINES 384
-#define ORACLE_MAX_SS 1152   /* lines of PRECURSOR_LEN up to 1000 (+50 +dangles) */
+#define ORACLE_MAX_SS 3200   /* lines of PRECURSOR_LEN up to 3000 (+50 +dangles), the upper limit of the reference (MP:167-184) */
 
 typedef struct {
     char ss[ORACLE_MAX_SS]; /* dot-bracket text exactly as RNALfold prints it (incl. dangle dots) */
@@ -22,6 +25,18 @@ typedef struct {
     int mfe;                /* f3[1], 0.01 kcal/mol */
     OracleFoldLine lines[ORACLE_MAX_LINES];
 } OracleFoldResult;
+
+/* Any number of lines of any length (PRECURSOR_LEN up to 3000): the same folds with the lines as text, "structure energy start\n" each, in a malloc'd
+   buffer the caller frees with oracle_free_text; model 0 = vienna-2.1.2, 1 = vienna-1.8.5. 0 = ok. */
+typedef struct { char *buf; size_t len, cap; int n_lines; } OracleTextSink;
+int oracle_lfold_text(const char *seq, int n, int span, int model, char **text, int *n_lines, int *mfe);
+void oracle_free_text(char *text);
+static inline void oracle_sink_add(OracleTextSink *k, const char *lead, const char *body, int energy, int start) {
+    const size_t need = strlen(lead) + strlen(body) + 40;
+    if (k->len + need > k->cap) { k->cap = (k->cap + need) * 2; k->buf = (char *)realloc(k->buf, k->cap); }
+    k->len += (size_t)sprintf(k->buf + k->len, "%s%s %d %d\n", lead, body, energy, start);
+    k->n_lines++;
+}
 
 /* RNALfold -L span on one sequence (vienna-2.1.2 flavour: Turner-2004, dangles=2). 0 = ok. */
 int oracle_lfold(const char *seq, int n, int span, OracleFoldResult *out);

@@ -166,8 +166,24 @@ def gen_long():
     gen_golden.dump_gz(fix, os.path.join(GOLD, "long_folds.json.gz"))
 
 
+def gen_xl():
+    """tests/golden/xl_folds.json.gz: both RNALfold binaries at span 3000 -- PRECURSOR_LEN's upper limit in the reference (MP:167-184) -- on a window of
+    3,020 nt and one of 1,500 nt (tests/seqgen.xl_windows)."""
+    seqs = seqgen.xl_windows()
+    fix = {"generator": "RNALfold 2.1.2 / 1.8.5 (bundled binaries), -L 3000, default dangles; digests as headline_folds.json.gz", "n": len(seqs),
+           "seq_digests": base64.b64encode(b"".join(seq_digest(s) for s in seqs)).decode(), "folds": {}}
+    for model, binary in MODELS:
+        res = real_folds(os.path.join(ORA_BIN, binary), seqs, 3000)
+        fix["folds"]["%s/%d" % (model, 3000)] = {"digests": base64.b64encode(b"".join(fold_digest(x["lines"], x["mfe"]) for x in res)).decode(),
+                                                 "mfe": [x["mfe"] for x in res], "n_lines": [len(x["lines"]) for x in res]}
+        print("xl", model, len(res), "windows,", [len(x["lines"]) for x in res], "lines")
+    gen_golden.dump_gz(fix, os.path.join(GOLD, "xl_folds.json.gz"))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["folds", "mid"]
+    if "xl" in what:
+        gen_xl()
     if "long" in what:
         gen_long()
     if "folds" in what:

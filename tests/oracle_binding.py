@@ -9,7 +9,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 MAX_LINES = 384
-MAX_SS = 1152
+MAX_SS = 3200
 
 
 class FoldLine(C.Structure):
@@ -86,6 +86,10 @@ class Oracle:
         lib.oracle_lfold.restype = C.c_int
         lib.oracle_lfold185.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(FoldResult)]
         lib.oracle_lfold185.restype = C.c_int
+        lib.oracle_lfold_text.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.oracle_lfold_text.restype = C.c_int
+        lib.oracle_free_text.argtypes = [C.c_void_p]
+        lib.oracle_free_text.restype = None
         lib.oracle_free.argtypes = [C.c_void_p]
         lib.oracle_free.restype = None
         vp, sz = C.c_void_p, C.c_size_t
@@ -188,6 +192,17 @@ class Oracle:
         """Returns {'lines': [(ss, energy_dcal, start)], 'mfe': int} exactly as RNALfold -L prints (RNALfold 2.1.2 by default,
         model="vienna-1.8.5" for the Turner-1999 / dangles-1 flavour)."""
         b = seq.encode() if isinstance(seq, str) else bytes(seq)
+        if min(len(b), int(span)) + 60 >= MAX_SS or len(b) > 1500:      # longer or more lines than the fixed-size result holds (PRECURSOR_LEN above 1000): the text form
+            text, nl, mfe = C.c_void_p(), C.c_int(), C.c_int()
+            rc = self.lib.oracle_lfold_text(b, len(b), int(span), 1 if model == "vienna-1.8.5" else 0, C.byref(text), C.byref(nl), C.byref(mfe))
+            try:
+                if rc != 0:
+                    raise RuntimeError("oracle_lfold_text rc=%d" % rc)
+                rows = C.string_at(text.value).decode().splitlines()
+            finally:
+                self.lib.oracle_free_text(text)
+            assert len(rows) == nl.value
+            return {"lines": [(x.split(" ")[0], int(x.split(" ")[1]), int(x.split(" ")[2])) for x in rows], "mfe": mfe.value}
         r = FoldResult()
         fn = self.lib.oracle_lfold185 if model == "vienna-1.8.5" else self.lib.oracle_lfold
         rc = fn(b, len(b), int(span), C.byref(r))

@@ -80,3 +80,11 @@ def long_windows():
         s = stress_family(r, i % 5)
         seqs.append((s + "".join(r.choice("ACGU") for _ in range(r.randint(20, 90))) + s[::-1] + s)[:r.randint(360, 470)])
     return seqs
+
+
+def xl_windows():
+    """PRECURSOR_LEN at the reference's upper limit (3000, MP:167-184): a window of 3,020 nt and one of 1,500 nt, folded at span 3000 in
+    tests/golden/xl_folds.json.gz."""
+    r = random.Random(3000)
+    s = "".join(r.choice("ACGU") for _ in range(3020))
+    return [s, s[700:2200]]

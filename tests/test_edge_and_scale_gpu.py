@@ -72,6 +72,42 @@ def test_other_precursor_lengths_match_oracle(L, gpu_ctx, oracle):
     assert _gpu_records(out, names) == [mirna_record(m, names) for _, m in result]
 
 
+def test_precursor_length_2500_through_the_whole_path(gpu_ctx, oracle):
+    """PRECURSOR_LEN in the thousands (the reference accepts up to 3000, MP:167-184) from the candidate stage to the loci list: windows of 2,500 nt and more go
+    through the generic fold kernels (over 64 KB of LDS), carry hundreds of structure lines of thousands of characters -- the filter kernel then keeps the
+    staged text in global memory instead of LDS -- and the windows, every structure line and the loci equal the oracle chain's."""
+    import concurrent.futures as cf
+    L = 2500
+    ds = synth.make_dataset([40000, 30000], 6, n_samples=2, seed=2500, contig_names=["k2", "k1"], edge_cases=True)
+    names, alns = ds.contig_names, ds.sorted_alns()
+    cut, gap = 8, 80
+    _, peaks = oracle.coverage_peaks(alns, ds.contig_lens, cut)
+    win = oracle.make_windows(peaks, alns, ds.contigs, _order(names), gap, L, cut * 0.5)
+    gpu_ctx.load_genome(ds.contigs)
+    gpu_ctx.load_alignments(alns)
+    _, _, nwin = gpu_ctx.candidate(cut, gap, L, _order(names))
+    assert nwin == len(win["windows"]) and 4 <= nwin <= 40
+    gpu_ctx.fold(L)
+    raw = gpu_ctx.get_fold()
+    assert (raw["status"] == 0).all()
+    with cf.ThreadPoolExecutor(16) as ex:      # the oracle's folds side by side (ctypes releases the GIL): seconds each at this length
+        folds = list(ex.map(lambda b: oracle.lfold(win["seq"][b["seq_off"]:b["seq_off"] + b["seq_len"]].tobytes(), L), win["windows"]))
+    from mir_prefer_amd import capi
+    structs = []
+    for k, r in enumerate(folds):
+        wl, ws = capi.fold_window_lines(raw, k)          # (windows with more lines than the main buffers hold live in the side buffers)
+        got = [(ws[j, :wl[j]["len"]].tobytes().decode(), int(wl[j]["energy"]), int(wl[j]["start"])) for j in range(raw["n_lines"][k]) if wl[j]["printed"]]
+        assert got == r["lines"], k
+        assert raw["mfe"][k] == r["mfe"]
+        structs.append(oracle.structures_from_lines(r["lines"], 55))
+    assert max(len(r["lines"]) for r in folds) > 150
+    out = gpu_ctx.predict(2, 18, 24, True, True)
+    case = {"cfg": {"MIN_MATURE_LEN": 18, "MAX_MATURE_LEN": 24, "ALLOW_3NT_OVERHANG": "Y", "ALLOW_NO_STAR_EXPRESSION": "Y"}, "win": win,
+            "sample_names": ds.sample_names, "alns": alns}
+    _, result = run_predict(case, oracle, structs)
+    assert _gpu_records(out, names) == [mirna_record(m, names) for _, m in result] and len(result) >= 1
+
+
 def test_full_size_config1_properties(gpu_ctx, oracle):
     """BASELINE config[1] size: 30,427,671-bp contig, 12,000 loci (~20 k windows)."""
     G = 30427671

@@ -202,3 +202,20 @@ def test_generic_kernels_on_long_windows_with_sparse_pairs(gpu_ctx, oracle, mode
                 assert g["status"] == 0 and g["mfe"] == want["mfe"] and g["lines"] == want["lines"], (model, span, len(s))
     finally:
         gpu_ctx.set_fold_model("vienna-2.1.2")
+
+
+def test_fold_at_the_largest_precursor_length(gpu_ctx):
+    """PRECURSOR_LEN = 3000, the reference's upper limit (MP:167-184): a window of 3,020 nt and one of 1,500 nt at span 3000 through the generic kernels (more
+    than 64 KB of LDS per workgroup, 200 MB of workspace per window) against digests of the real RNALfold 2.1.2 / 1.8.5 output (tests/golden/xl_folds.json.gz)."""
+    from tests.test_oracle_golden import check_long_folds, xl_fold_fixture
+    fix, seqs = xl_fold_fixture()
+
+    def fold_many(s, span, model):
+        gpu_ctx.set_fold_model(model)
+        out = gpu_ctx.fold_batch(s, span, max_lines=1200)
+        assert all(g["status"] == 0 for g in out)
+        return [(g["lines"], g["mfe"]) for g in out]
+    try:
+        assert check_long_folds(fix, seqs, fold_many) == 4
+    finally:
+        gpu_ctx.set_fold_model("vienna-2.1.2")

@@ -447,3 +447,30 @@ def test_long_windows_match_real_rnalfold(oracle):
     from tests.test_whole_workload_gpu import oracle_fold_all
     fix, seqs = long_fold_fixture()
     assert check_long_folds(fix, seqs, lambda s, span, model: oracle_fold_all(s, span, model)) == 800
+
+
+def xl_fold_fixture():
+    import base64
+    from tests import seqgen
+    from tests.golden.tools_digest import seq_digest
+    fix = gu.load_json("xl_folds.json.gz")
+    seqs = seqgen.xl_windows()
+    assert len(seqs) == fix["n"] and b"".join(seq_digest(s) for s in seqs) == base64.b64decode(fix["seq_digests"])
+    return fix, seqs
+
+
+def test_largest_precursor_length_matches_real_rnalfold(oracle):
+    """PRECURSOR_LEN = 3000, the reference's upper limit (MP:167-184): the oracle against digests of the real binaries' output at span 3000
+    (tests/golden/xl_folds.json.gz) -- the 1,500-nt window under both models and the 3,020-nt window under vienna-2.1.2, side by side (its vienna-1.8.5 fold
+    alone takes the oracle a minute: the GPU twin, tests/test_fold_gpu.py, checks all four against the digests)."""
+    import base64
+    import concurrent.futures as cf
+    from tests.golden.tools_digest import fold_digest
+    fix, seqs = xl_fold_fixture()
+    jobs = [("vienna-2.1.2", 0), ("vienna-2.1.2", 1), ("vienna-1.8.5", 1)]
+    with cf.ThreadPoolExecutor(len(jobs)) as ex:      # ctypes releases the GIL
+        res = list(ex.map(lambda mk: oracle.lfold(seqs[mk[1]].encode(), 3000, model=mk[0]), jobs))
+    for (model, k), r in zip(jobs, res):
+        exp = fix["folds"]["%s/3000" % model]
+        assert r["mfe"] == exp["mfe"][k] and len(r["lines"]) == exp["n_lines"][k]
+        assert fold_digest(r["lines"], r["mfe"]) == base64.b64decode(exp["digests"])[6 * k:6 * k + 6], (model, k)
