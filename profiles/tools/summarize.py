@@ -36,6 +36,14 @@ shutil.copy(glob.glob("gpurun_out/%s_stats/*/*kernel_stats.csv" % tag)[0], "prof
 f185 = glob.glob("gpurun_out/%s_stats185/*/*kernel_stats.csv" % tag)
 if f185:
     shutil.copy(f185[0], "profiles/%s_vienna185_kernel_stats.csv" % tag)
+for sub, name in (("L400", "L400_kernel_stats.csv"), ("L400_185", "L400_vienna185_kernel_stats.csv")):
+    fl = glob.glob("gpurun_out/%s_%s/*/*kernel_stats.csv" % (tag, sub))
+    if fl:
+        shutil.copy(fl[0], "profiles/%s_%s" % (tag, name))
+for name in ("L400_counters.txt", "L400_vienna185_counters.txt"):
+    fl = glob.glob("gpurun_out/%s_%s" % (tag, name))
+    if fl:
+        shutil.copy(fl[0], "profiles/%s_%s" % (tag, name))
 # profiles/CURRENT.json: what bench.py reports as roofline.traffic / roofline.pipe_busy, with the commit the counters were collected at
 import subprocess
 stats = {r["Name"].split("(")[0].replace("void ", "").strip(): float(r["AverageNs"]) for r in csv.DictReader(open("profiles/%s_kernel_stats.csv" % tag))}
