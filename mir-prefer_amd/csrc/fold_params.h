@@ -16,9 +16,6 @@ struct alignas(16) FoldParams {
     // backtrack's search order (p ascending, q descending), which is what the trace-back code of the cell must name.
     // (also read by the generic kernel, fold_kernel.hip: one v_mad_i32_i24 per generic candidate)
     unsigned gen_key[25][32];     // generic loops [u-6][n1], 2 <= n1 <= u-2: (internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)) << 10 | n1 << 5 | (u - n1)
-    // the same terms as the generic kernel (fold_kernel.hip) reads them, four per scalar load: its chunks of four candidates start at n1 = 2, 6, ...
-    unsigned gen_key2[25][32];    // [u-6][m] = gen_key[u-6][m + 2]
-    unsigned gen_keyt[25][4];     // [u-6][x] = gen_key[u-6][u - 5 + x]: the last four generic shapes of a size, a chunk of their own
     unsigned kb0_key[31];         // bulge n1 = 0, n2 = u:   (bulge[u] + 2048) << 10 | u
     unsigned kb1_key[31];         // bulge n1 = u, n2 = 0:   (bulge[u] + 2048) << 10 | u << 5
     unsigned k1n0_key[31];        // 1 x k loop (n1 = 1, n2 = k): (internal_loop[k+1] + min(MAX_NINIO, (k-1) ninio) + 2048) << 10 | 1 << 5 | k
@@ -54,6 +51,10 @@ struct alignas(16) FoldParams {
     char hexa[4][12];
     int ML_closing, ML_intern, TerminalAU, ninio, MAX_NINIO;
     int n_tri, n_tetra, n_hexa;   // motifs in use
+    // (behind the tables of the LDS-resident fill kernel, whose layout -- and scalar-cache footprint -- they must not move)
+    // the same terms as the generic kernel (fold_kernel.hip) reads them, four per scalar load: its chunks of four candidates start at n1 = 2, 6, ...
+    alignas(16) unsigned gen_key2[25][32];    // [u-6][m] = gen_key[u-6][m + 2]
+    alignas(16) unsigned gen_keyt[25][4];     // [u-6][x] = gen_key[u-6][u - 5 + x]: the last four generic shapes of a size, a chunk of their own
     // the three big tables last: everything above stays within the immediate-offset range of scalar loads
     int int11[8][8][5][5];
     int int21[8][8][5][5][5];
