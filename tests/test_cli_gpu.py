@@ -356,3 +356,30 @@ def test_lean_pipeline_relative_paths_and_log(tmp_path):
     assert open(tmp_path / "res" / "deep" / "mini_miRNA.gff3").read() == exp["gff3"]
     assert os.path.exists(tmp_path / "res" / "deep" / "mini.log")
     assert sorted(os.listdir(tmp_path / "res" / "deep" / "readmapping")) == sorted(exp["readmapping"])
+
+
+def test_pipeline_process_at_precursor_length_2000(tmp_path):
+    """PRECURSOR_LEN = 2000 (the reference accepts 60 .. 3000, MP:167-184) through the command line: the lean `pipeline` process (streamed fold / filter /
+    reports) and `-k pipeline` (stage by stage, artefacts kept) write the same result files; the kept RNALfold text holds windows of about 2,000 nt whose
+    structure lines are as long."""
+    from mir_prefer_amd import synth
+    import filecmp
+    ds = synth.make_dataset([60000, 40000], 10, n_samples=2, seed=2000, contig_names=["k2", "k1"], edge_cases=True)
+    sams = ds.write_sams(str(tmp_path))
+    ds.write_fasta(str(tmp_path / "g.fa"))
+    for name, extra in (("lean", []), ("keep", ["-k"])):
+        (tmp_path / ("config_" + name)).write_text("FASTA_FILE = %s\nALIGNMENT_FILE = %s\nOUTFOLDER = %s\nNAME_PREFIX = xl\nPRECURSOR_LEN = 2000\nREADS_DEPTH_CUTOFF = 8\n"
+                                                   "MAX_GAP = 80\n" % (tmp_path / "g.fa", ", ".join(sams), tmp_path / name))
+        r = _run_cli(extra + ["pipeline", str(tmp_path / ("config_" + name))], tmp_path, env={"MIRP_STREAM_CHUNKS": "2"})
+        assert r.returncode == 0, r.stderr[-1200:]
+    files = [f for f in os.listdir(tmp_path / "keep") if os.path.isfile(tmp_path / "keep" / f)]
+    assert "xl_miRNA.gff3" in files and os.path.getsize(tmp_path / "keep" / "xl_miRNA.gff3") > 0
+    match, mismatch, errors = filecmp.cmpfiles(str(tmp_path / "keep"), str(tmp_path / "lean"), files, shallow=False)
+    assert not mismatch and not errors, (mismatch, errors)
+    rm = sorted(os.listdir(tmp_path / "keep" / "readmapping"))
+    assert rm and rm == sorted(os.listdir(tmp_path / "lean" / "readmapping"))
+    match, mismatch, errors = filecmp.cmpfiles(str(tmp_path / "keep" / "readmapping"), str(tmp_path / "lean" / "readmapping"), rm, shallow=False)
+    assert not mismatch and not errors
+    fold = open(tmp_path / "keep" / "xl_tmp" / "xl_rnalfoldoutput_0").read().splitlines()
+    seqs = [ln for ln in fold if ln and ln[0] in "ACGUTN"]
+    assert seqs and max(len(s) for s in seqs) > 1900 and max(len(ln.split(" ")[0]) for ln in fold if ln and ln[0] in ".(") > 1500
