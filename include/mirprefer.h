@@ -89,6 +89,9 @@ int mirp_set_fold_model(mirp_ctx* ctx, int32_t model);
  * n_lines[n_seqs], mfe[n_seqs] (0.01 kcal/mol, RNALfold's final " (%6.2f)" line), status[n_seqs]
  * (0 ok, 1 = more than max_lines structures: the first max_lines are returned and n_lines holds the number the sequence needs,
  * <0 = error for that sequence).
+ * Any span: up to 300 (and sequences up to 350 nt) on the LDS-resident kernels, beyond that -- PRECURSOR_LEN up to the reference's limit of 3000
+ * (MP:167-184) -- on the generic kernels (tables in a global workspace).  Sequences longer than about 4,000 nt (LDS of one workgroup; 5,000 nt: the
+ * 32-bit ranking of interior loops) are refused with -5 and a message, not truncated.
  */
 int mirp_fold_batch(mirp_ctx* ctx, const char* seqs, const int64_t* offsets, int32_t n_seqs, int32_t span,
                     int32_t max_lines, MirpFoldLine** lines, char** ss, int32_t* ss_stride, int32_t** n_lines,
