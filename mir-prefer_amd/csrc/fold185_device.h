@@ -34,11 +34,12 @@ struct GTab185 {   // int32 tables in a global workspace (fold185_kernel)
     int* __restrict__ c;
     int* __restrict__ m;
     int* __restrict__ dm;
+    const unsigned short* __restrict__ tb = nullptr;   // trace-back codes of the fill (round 5): 1 + (n1 << 5 | n2) = the interior loop the backtrack's search would find first, 0 = none
     int ld, n, M;
     __device__ __forceinline__ int C(int i, int j) const { const int d = j - i; return (d <= V_TURN || d > M || i < 1 || j > n) ? V_INF : c[(size_t)d * ld + i]; }
     __device__ __forceinline__ int Mm(int i, int j) const { const int d = j - i; return (d <= V_TURN || d > M || i < 1 || j > n) ? V_INF : m[(size_t)d * ld + i]; }
     __device__ __forceinline__ int DM(int i, int j) const { const int d = j - i; return (d <= V_TURN || d > M || i < 1 || j > n) ? V_INF : dm[(size_t)d * ld + i]; }
-    __device__ __forceinline__ int TB(int, int) const { return -1; }   // no trace-back codes: the backtrack searches
+    __device__ __forceinline__ int TB(int i, int j) const { const int d = j - i; return !tb ? -1 : (d <= V_TURN || d > M || i < 1 || j > n) ? 0 : (int)tb[(size_t)d * ld + i]; }
 };
 
 template <class PT>

@@ -113,6 +113,8 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
         // the interior-loop interval's view of finished cells, one word per cell (as fold_generic_kernel's w): c(p,q) + mismatchI of (p,q) seen as an inner pair in
         // the low 24 bits (V_INF where (p,q) is no pair), the index of that term, rtype * 25 + S[q+1] * 5 + S[p-1], in the high byte
         int* wtab = reinterpret_cast<int*>(pool + (size_t)T.ld * pcap);
+        unsigned short* tbtab = reinterpret_cast<unsigned short*>(wtab + tab);          // trace-back codes, a short per cell
+        T.tb = tbtab;
         if constexpr (PHASE == 1) for (int x = tid; x <= n + 1; x += V_NT) pcnt[x] = 0;
         __syncthreads();
         Ctx<FoldParams185> X;
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                 for (int h = 0; h < 2; h++) {
                     const int cell = base + h * V_NT + tid;
                     type[h] = 0;
-                    if (cell < ncell) { type[h] = ptype(X, cell + 1, cell + 1 + d); ctype[cell] = (unsigned char)type[h]; cbest[cell] = V_INF; }
+                    if (cell < ncell) { type[h] = ptype(X, cell + 1, cell + 1 + d); ctype[cell] = (unsigned char)type[h]; cbest[cell] = 0x7fffffff; }
                     bal[h] = __ballot(type[h] != 0);
                     if (lane == 0) wcnt[h * (V_NT / 64) + wave] = (int)__popcll(bal[h]);
                 }
@@ -183,16 +185,19 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                     const int si1 = S[i + 1], sj1 = S[j - 1];
                     const int o_mmI = l_mmI[type * 25 + si1 * 5 + sj1];          // the outer pair's term: once per task
                     const int tau = AU(X, type);
+                    // the cell's minimum over the task as ONE 32-bit key, energy * 1024 + (n1 << 5 | n2): among equal energies the loop the backtrack's search
+                    // (p ascending, q descending) finds first -- the cell's trace-back code (energies stay below 2^21: V_INF plus small terms)
                     int best = 0x7fffffff;
+                    const int c1024 = 1024;
                     auto gen = [&](const int w, const int kterm) {
                         int e;
-                        asm("v_mad_i32_i24 %0, %1, 1, %2" : "=v"(e) : "v"(w), "s"(kterm));
+                        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(e) : "v"(w), "v"(c1024), "s"(kterm));
                         return e;
                     };
                     auto w_e = [](const int w) { return (w << 8) >> 8; };                      // the word's energy (sign-extended 24 bits)
                     auto w_in = [](const int w) { return (int)((unsigned)w >> 24); };          // the word's inner-pair index
-                    auto put = [&](const int e) { best = e < best ? e : best; };
-                    auto put_bulge = [&](const int eb, const int w) { put(eb + w_e(w) + (int)l_xb[w_in(w)]); };
+                    auto put = [&](const int e, const int shape) { const int key = e * 1024 + shape; best = key < best ? key : best; };
+                    auto put_bulge = [&](const int eb, const int w, const int shape) { put(eb + w_e(w) + (int)l_xb[w_in(w)], shape); };
                     const int* wlane = wtab + i + 1;          // candidate n1 of size s = wlane[(d - 2 - s) * ld + n1]
                     // sizes s_lo .. s_hi (>= 7) straight from the table, a load per candidate: the fallback for blocks whose cells lie too far apart for the
                     // staging buffer (sparse pairs in long windows)
@@ -201,9 +206,10 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                             const int* wrow = wlane + (d - 2 - s) * T.ld;
                             int kg = 0x7fffffff;
                             for (int n1 = 1; n1 <= s - 1; n1++) { const int e = gen(wrow[n1], P->gen_e[s][n1]); kg = e < kg ? e : kg; }
-                            put(kg + o_mmI);
+                            kg += o_mmI * 1024;
+                            best = kg < best ? kg : best;
                             const int eb = P->bulge[s] + tau;
-                            put_bulge(eb, wrow[0]); put_bulge(eb, wrow[s]);
+                            put_bulge(eb, wrow[0], s); put_bulge(eb, wrow[s], s << 5);
                         }
                     };
                     const int cell_lo = __builtin_amdgcn_readfirstlane(plist[blk * 64]);
@@ -234,9 +240,10 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                             }
 #pragma unroll
                             for (int u = 0; u < 4; u++) { const int e = gen(sl[s - 4 + u], kt[u]); kg = e < kg ? e : kg; }          // (may overlap the last chunk)
-                            put(kg + o_mmI);
+                            kg += o_mmI * 1024;
+                            best = kg < best ? kg : best;
                             const int eb = P->bulge[s] + tau;
-                            put_bulge(eb, sl[0]); put_bulge(eb, sl[s]);
+                            put_bulge(eb, sl[0], s); put_bulge(eb, sl[s], s << 5);
                         };
                         v_int4q a0 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
                         issue(s_lo, a0, b0);
@@ -274,24 +281,27 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                         const int r22 = loopE(X, 2, 2, type, t22, si1, sj1, sI[2], sJ[2]);
                         const int b1 = P->bulge[1];
                         auto cof = [&](const int w) { return w_e(w) - (int)l_mmI[w_in(w)]; };          // c(p,q) of a pair
-                        auto put_if = [&](const int t2, const int e) { if (t2) put(e); };
-                        auto put_gen = [&](const int s, const int n1, const int w) { put(w_e(w) + P->gen_e[s][n1] + o_mmI); };
-                        put_if(t00, (int)l_stack[type * 8 + t00] + cof(w0));
-                        if (smax >= 1) { put_if(t01, b1 + (int)l_stack[type * 8 + t01] + cof(w1[0])); put_if(t10, b1 + (int)l_stack[type * 8 + t10] + cof(w1[1])); }
-                        if (smax >= 2) { const int eb = P->bulge[2] + tau; put_bulge(eb, w2[0]); put_if(t11, r11 + cof(w2[1])); put_bulge(eb, w2[2]); }
-                        if (smax >= 3) { const int eb = P->bulge[3] + tau; put_bulge(eb, w3[0]); put_if(t12, r12 + cof(w3[1])); put_if(t21, r21 + cof(w3[2])); put_bulge(eb, w3[3]); }
+                        auto put_if = [&](const int t2, const int e, const int shape) { if (t2) put(e, shape); };
+                        auto put_gen = [&](const int s, const int n1, const int w) { const int key = (w_e(w) + o_mmI) * 1024 + P->gen_e[s][n1]; best = key < best ? key : best; };
+                        put_if(t00, (int)l_stack[type * 8 + t00] + cof(w0), 0);
+                        if (smax >= 1) { put_if(t01, b1 + (int)l_stack[type * 8 + t01] + cof(w1[0]), 0 << 5 | 1); put_if(t10, b1 + (int)l_stack[type * 8 + t10] + cof(w1[1]), 1 << 5 | 0); }
+                        if (smax >= 2) { const int eb = P->bulge[2] + tau; put_bulge(eb, w2[0], 0 << 5 | 2); put_if(t11, r11 + cof(w2[1]), 1 << 5 | 1); put_bulge(eb, w2[2], 2 << 5 | 0); }
+                        if (smax >= 3) {
+                            const int eb = P->bulge[3] + tau;
+                            put_bulge(eb, w3[0], 0 << 5 | 3); put_if(t12, r12 + cof(w3[1]), 1 << 5 | 2); put_if(t21, r21 + cof(w3[2]), 2 << 5 | 1); put_bulge(eb, w3[3], 3 << 5 | 0);
+                        }
                         if (smax >= 4) {
                             const int eb = P->bulge[4] + tau;
-                            put_bulge(eb, w4[0]); put_gen(4, 1, w4[1]); put_if(t22, r22 + cof(w4[2])); put_gen(4, 3, w4[3]); put_bulge(eb, w44);
+                            put_bulge(eb, w4[0], 0 << 5 | 4); put_gen(4, 1, w4[1]); put_if(t22, r22 + cof(w4[2]), 2 << 5 | 2); put_gen(4, 3, w4[3]); put_bulge(eb, w44, 4 << 5 | 0);
                         }
                         if (smax >= 5) {
                             const int eb = P->bulge[5] + tau;
-                            put_bulge(eb, w5[0]); put_gen(5, 1, w5[1]); put_gen(5, 2, w5[2]); put_gen(5, 3, w5[3]); put_gen(5, 4, w5b[0]); put_bulge(eb, w5b[1]);
+                            put_bulge(eb, w5[0], 0 << 5 | 5); put_gen(5, 1, w5[1]); put_gen(5, 2, w5[2]); put_gen(5, 3, w5[3]); put_gen(5, 4, w5b[0]); put_bulge(eb, w5b[1], 5 << 5 | 0);
                         }
                         if (smax >= 6) {
                             const int eb = P->bulge[6] + tau;
-                            put_bulge(eb, w6[0]); put_gen(6, 1, w6[1]); put_gen(6, 2, w6[2]); put_gen(6, 3, w6[3]); put_gen(6, 4, w6b[1]); put_gen(6, 5, w6b[2]);
-                            put_bulge(eb, w6b[3]);
+                            put_bulge(eb, w6[0], 0 << 5 | 6); put_gen(6, 1, w6[1]); put_gen(6, 2, w6[2]); put_gen(6, 3, w6[3]); put_gen(6, 4, w6b[1]); put_gen(6, 5, w6b[2]);
+                            put_bulge(eb, w6b[3], 6 << 5 | 0);
                         }
                     } else {
                         const int s_lo = grp == 1 ? 7 : grp == 2 ? 18 : 25, s_hi = grp == 1 ? (smax < 17 ? smax : 17) : grp == 2 ? (smax < 24 ? smax : 24) : smax;
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                         else if (span_w + s_hi + 1 > 256) sizes_staged(std::true_type{}, s_lo, s_hi);
                         else sizes_staged(std::false_type{}, s_lo, s_hi);
                     }
-                    if (active && best < V_INF) atomicMin(&cbest[cell], best);
+                    if (active && (best >> 10) < V_INF) atomicMin(&cbest[cell], best);
                 }
             }
             __syncthreads();
@@ -308,11 +318,16 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
             for (int cell = tid / V_G; cell < ((ncell + V_NT / V_G - 1) / (V_NT / V_G)) * (V_NT / V_G); cell += V_NT / V_G) {
                 const bool live = cell < ncell;
                 const int i = cell + 1, j = i + d;
-                int type = 0, best = V_INF, mdec = V_INF;
+                int type = 0, best = V_INF, mdec = V_INF, hp = V_INF, il = V_INF, shape = 0;
                 if (live) {
                     type = ctype[cell];
                     if (type) {
-                        if (sub == 0) { best = hairpin(X, i, j, type); const int il = cbest[cell]; best = il < best ? il : best; }
+                        if (sub == 0) {
+                            hp = hairpin(X, i, j, type);
+                            const int key = cbest[cell];
+                            il = key == 0x7fffffff ? V_INF : key >> 10; shape = key & 1023;
+                            best = il < hp ? il : hp;
+                        }
                         const int si1 = S[i + 1], sj1 = S[j - 1];
                         if (sub == 1 % V_G) {
                             const int tt = rtype_of(type);
@@ -358,6 +373,8 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                         if (k < pcap) { pool[(size_t)j * pcap + k] = make_int2(i, stem); pcnt[j] = k + 1; }
                     }
                     T.c[(size_t)d * T.ld + i] = newc;
+                    // the loop realises c unless the hairpin does as well or better, or the multiloop strictly better: the order of the backtrack's tests
+                    tbtab[(size_t)d * T.ld + i] = (unsigned short)((type && il < hp && il == best) ? 1 + shape : 0);
                     {
                         const int in = rtype_of(type) * 25 + S[j + 1] * 5 + S[i - 1];          // (i,j) as the inner pair of a later loop
                         wtab[(size_t)d * T.ld + i] = type ? (in << 24) | ((newc + (int)l_mmI[in]) & 0xffffff) : V_INF;
@@ -388,7 +405,7 @@ size_t fold185_lds_bytes(int n_cap, int max_lines) {
 
 size_t fold185_ws_slot_ints(int n_cap, int span) {
     // c, fML, DML, the split-candidate pool (two ints per entry, span + 2 entries per column)
-    return 4 * v185::fold185_table_ints(n_cap, span) + ((2 * (size_t)v185::fold185_ld(n_cap) * (size_t)(span + 2) + 3) & ~(size_t)3) + 4;          // (+ w)
+    return 4 * v185::fold185_table_ints(n_cap, span) + ((v185::fold185_table_ints(n_cap, span) / 2 + 3) & ~(size_t)3) + ((2 * (size_t)v185::fold185_ld(n_cap) * (size_t)(span + 2) + 3) & ~(size_t)3) + 4;          // (+ w, + the trace-back codes)
 }
 
 hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, const unsigned char* seqs, const long long* offs, const int* lens,

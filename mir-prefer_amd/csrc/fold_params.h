@@ -64,9 +64,10 @@ struct alignas(16) FoldParams {
 // Energy model of the "vienna-1.8.5" compatibility mode (Turner-1999 parameters as shipped in ViennaRNA 1.8.5, dangles = 1).
 struct alignas(16) FoldParams185 {
     // derived, read with scalar loads by fold185_kernel's interior-loop interval (wave-uniform loop shapes): size + asymmetry term of the generic loops --
-    // in this model every loop but stack, bulge, 1 x 1, 1 x 2, 2 x 2 -- [u][n1] = internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio), and the same in the
-    // order the kernel's chunks of four candidates read it (one 16-byte scalar load each)
-    int gen_e[31][32];
+    // in this model every loop but stack, bulge, 1 x 1, 1 x 2, 2 x 2 --: internal_loop[u] + min(MAX_NINIO, |2 n1 - u| ninio)
+    // -- as keys, term << 10 | n1 << 5 | n2 (the minimum key is the minimum energy and, among equal energies, the loop the backtrack's search finds first:
+    // the trace-back code of the cell), and in the order the kernel's chunks of four candidates read them (one 16-byte scalar load each)
+    int gen_e[31][32];            // the keys of size u, [u][n1]
     int gen_e1[31][32];           // [u][m] = gen_e[u][m + 1]: chunks start at n1 = 1
     int gen_et[31][4];            // [u][x] = gen_e[u][u - 4 + x]: the last four generic shapes of a size (n1 = u - 4 .. u - 1)
     int stack[8][8];

@@ -121,7 +121,7 @@ void mirp_fill_fold_params185(FoldParams185* p) {
     for (int u = 0; u <= MIRP_MAXLOOP; u++)
         for (int n1 = 0; n1 < 32; n1++) {
             const int y = std::abs(2 * n1 - u) * p->ninio;
-            p->gen_e[u][n1] = p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO);
+            p->gen_e[u][n1] = ((p->internal_loop[u] + (y < p->MAX_NINIO ? y : p->MAX_NINIO)) << 10) | ((n1 & 31) << 5) | ((u - n1) & 31);
         }
     for (int u = 0; u <= MIRP_MAXLOOP; u++) {
         for (int m = 0; m < 32; m++) p->gen_e1[u][m] = p->gen_e[u][m + 1 < 32 ? m + 1 : 31];
