@@ -22,7 +22,9 @@ namespace v185 {
 #define V_MAXLOOP 30
 #define V_INF 1000000
 #define V_NT 256
-#define V_G 8
+#ifndef V_G
+#define V_G 4          // lanes per cell of the generic kernel's interval B (L = 400: 2 -> 0.346 s, 4 -> 0.329, 8 -> 0.364, 16 -> 0.458)
+#endif
 #define V_BT_STACK 192
 #ifndef MIRP_EPI_DMAX
 #define MIRP_EPI_DMAX 300   // largest pair distance a tiled archive holds (fold_epilogue.h)
