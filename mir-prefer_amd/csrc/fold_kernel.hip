@@ -50,6 +50,9 @@ struct GTab {
 #define GEN_FILL_WAVES 5
 #endif
 #define GEN_MIN_WAVES(phase) ((phase) == 1 ? GEN_FILL_WAVES : 1)      // waves per SIMD the register allocation aims for
+#ifndef GEN_PU
+#define GEN_PU 4                  // split candidates of a column whose reads are in flight together (interval B)
+#endif
 #define GEN_STAGE 512              // ints per wave of the interior-loop interval's staging buffer
 #define GEN_PINF 1500000           // 'no pair' in the 24-bit energy field of GTab::w: with every loop term added it stays below 2^21, so that energy * 1024 + shape is an int
 #define GEN_EMAX 1000000           // a candidate energy at or above this came from a GEN_PINF entry (real energies: a few hundred per nucleotide pair at most)
@@ -208,6 +211,13 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
         //     c(p, q) are neighbours on ONE diagonal (d - n1 - n2 - 2); the minimum per cell is merged with an LDS atomic;
         //  B  a thread per cell: hairpin, multiloop closing from the DML ring, DML(i,j) from DML(i,j-1) and the column's split candidates, fML.
         const int lane = tid & 63, wave = tid >> 6;
+#ifdef MIRP_X_GEN_CLOCKS              // dev: where a wave's time goes (printed by wave 0 of block 0 for its first window)
+        long long ck_0 = 0, ck_small = 0, ck_large = 0, ck_b = 0, ck_wait = 0, ck_t = clock64();
+        int ck_nsmall = 0, ck_nlarge = 0;
+#define CK(acc) do { const long long now_ = clock64(); acc += now_ - ck_t; ck_t = now_; } while (0)
+#else
+#define CK(acc) do { } while (0)
+#endif
         for (int d = TURN + 1; d <= D; d++) {
             const int ncell = n - d;
             // pair types of the diagonal's cells; the paired ones compacted into a list IN CELL ORDER (a block of 64 list entries is a stretch of the
@@ -239,7 +249,9 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                 np_run += total;
                 if (base + 2 * GEN_NT < ncell) __syncthreads();          // (the counts are rewritten by the next pass)
             }
+            CK(ck_0);
             __syncthreads();
+            CK(ck_wait);
             const int np = np_run;
             const int n1max = (d - 2 - (TURN + 1) < MAXLOOP) ? d - 2 - (TURN + 1) : MAXLOOP;      // q - p = d - n1 - n2 - 2 >= TURN + 1
 #ifdef MIRP_X_GEN_NOA               // timing experiment: no interior loops (tables wrong by construction)
@@ -252,11 +264,11 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                 // load, and every load of a size is issued before the first is used (the earlier order -- n1 outer, n2 inner, one 4-byte gather per
                 // candidate on 31 different diagonals, each waited for -- was bound by memory round trips).  Every candidate but nine reads ONE precombined
                 // value (c + the inner pair's term of its class; INF where (p,q) is no pair): size and asymmetry terms are scalar (P->gen_key), the outer
-                // pair's term a register, so a candidate is a multiply-add and a minimum.  (n1, n2) are wave-uniform.  Groups: sizes 0..6 (the shapes with
-                // their own tables, straight-line), 7..17, 18..24, 25..30 -- about equal work.
+                // pair's term a register, so a candidate is a multiply-add and a minimum.  (n1, n2) are wave-uniform.  Groups: sizes 0..9 (0..6: the shapes with
+                // their own tables, straight-line), 10..17, 18..24, 25..30 -- about equal work by the waves' clocks (a wave keeps its group: the task stride is the group count).
                 const int smax = n1max;
                 const int nblk = (np + 63) >> 6;
-                const int ngrp = smax < 7 ? 1 : smax < 18 ? 2 : smax < 25 ? 3 : 4;
+                const int ngrp = smax < 10 ? 1 : smax < 18 ? 2 : smax < 25 ? 3 : 4;
                 const int ntask = nblk * ngrp;
                 const int ninio = P->ninio, max_ninio = P->MAX_NINIO;
                 for (int t = wave; t < ntask; t += GEN_NT / 64) {
@@ -428,24 +440,38 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                                 kmin = kg < kmin ? kg : kmin;
                                 put_1n(e1, w6b[2], 5 << 5 | 1); put_bulge(eb, w6b[3], 6 << 5 | 0);
                             }
-                        } else if (staged) {
-                            const int s_lo = grp == 1 ? 7 : grp == 2 ? 18 : 25, s_hi = grp == 1 ? (smax < 17 ? smax : 17) : grp == 2 ? (smax < 24 ? smax : 24) : smax;
-                            if (span_w + s_hi + 1 > 256) sizes_staged(std::true_type{}, s_lo, s_hi);
-                            else sizes_staged(std::false_type{}, s_lo, s_hi);
-                        } else {
-                            if (grp == 1) sizes(7, smax < 17 ? smax : 17);
-                            else if (grp == 2) sizes(18, smax < 24 ? smax : 24);
-                            else sizes(25, smax);
                         }
+                        if (grp != 0 || smax >= 7) {          // the sizes from 7 on: 7 .. 9 ride with the small group
+                            const int s_lo = grp == 0 ? 7 : grp == 1 ? 10 : grp == 2 ? 18 : 25;
+                            const int s_top = grp == 0 ? 9 : grp == 1 ? 17 : grp == 2 ? 24 : 30, s_hi = smax < s_top ? smax : s_top;
+                            if (!staged) sizes(s_lo, s_hi);
+                            else if (span_w + s_hi + 1 > 256) sizes_staged(std::true_type{}, s_lo, s_hi);
+                            else sizes_staged(std::false_type{}, s_lo, s_hi);
+                        }
+#ifdef MIRP_X_GEN_CLOCKS
+                        if (grp == 0) { CK(ck_small); ck_nsmall++; } else { CK(ck_large); ck_nlarge++; }
+#endif
                         const int best = kmin >> 10;
                         if (active && best < GEN_EMAX) atomicMin(&cbest[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(kmin & 1023));
                     }
                 }
             }
+            CK(ck_large);
             __syncthreads();
+            CK(ck_wait);
+            // (two cells per thread a pass, each step for both cells before the next, was tried: 14 spilled VGPRs under the five-wave budget and 0.168 -> 0.192 s)
             for (int cell = tid; cell < ncell; cell += GEN_NT) {
                 const int i = cell + 1, j = i + d;
                 const int type = ctype[cell];
+                // everything that depends on the cell alone is asked for first -- the column's first GEN_PU split candidates, the DML ring, fML of diagonal
+                // d - 1 -- so that the reads the candidates name are the second round trip of the cell, not the third
+                const int pn = pcnt[j];
+                const int2* pj = pool + (size_t)j * pcap;
+                int2 en0[GEN_PU];
+#pragma unroll
+                for (int u = 0; u < GEN_PU; u++) en0[u] = pj[u < pn ? u : (pn > 0 ? pn - 1 : 0)];          // (entries behind the last one repeat it: a minimum does not mind)
+                int mdec = dml[(size_t)((d - 1) & 3) * T.ld + i];
+                const int m1 = T.M(d - 1, i + 1), m2 = T.M(d - 1, i);
                 int best = INF;
                 int code = 0;
                 if (type) {
@@ -460,19 +486,24 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                     if (dec < best) { best = dec; code = 0; }          // strictly better than every interior loop: the backtrack finds no loop and searches the split
                     if (best > INF) best = INF;
                 }
-                // DML(i,j): DML(i,j-1) and the candidates of column j (those far enough from i for fML(i,s-1) to exist)
-                int mdec = dml[(size_t)((d - 1) & 3) * T.ld + i];
-                const int pn = pcnt[j];
-                const int2* pj = pool + (size_t)j * pcap;
-                for (int k = 0; k < pn; k++) {
-                    const int2 en = pj[k];
-                    if (en.x < i + TURN + 2) continue;
-                    const int e = T.M(en.x - 1 - i, i) + en.y;
-                    mdec = e < mdec ? e : mdec;
+                // DML(i,j): DML(i,j-1) and the candidates of column j (those far enough from i for fML(i,s-1) to exist), GEN_PU a turn: their entries, then
+                // their fML reads, are in flight together (one at a time the loop was a chain of 2 pn dependent round trips, and interval B the longest part of
+                // a window's diagonal)
+                for (int k = 0; k < pn; k += GEN_PU) {
+                    int2 en[GEN_PU];
+#pragma unroll
+                    for (int u = 0; u < GEN_PU; u++) en[u] = k == 0 ? en0[u] : pj[k + u < pn ? k + u : pn - 1];
+                    int fm[GEN_PU];
+#pragma unroll
+                    for (int u = 0; u < GEN_PU; u++) { const int s0 = en[u].x < i + TURN + 2 ? i + TURN + 2 : en[u].x; fm[u] = T.M(s0 - 1 - i, i); }      // (a clamped read where fML(i, s-1) does not exist yet)
+#pragma unroll
+                    for (int u = 0; u < GEN_PU; u++) {
+                        const int e = fm[u] + en[u].y;
+                        if (en[u].x >= i + TURN + 2) mdec = e < mdec ? e : mdec;
+                    }
                 }
                 if (mdec > INF) mdec = INF;
-                int mm = T.M(d - 1, i + 1);
-                const int m2 = T.M(d - 1, i);
+                int mm = m1;
                 mm = m2 < mm ? m2 : mm;
                 mm = mdec < mm ? mdec : mm;
                 if (type) {
@@ -493,8 +524,14 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                 T.m[(size_t)d * T.ld + i] = mm;
                 dml[(size_t)(d & 3) * T.ld + i] = mdec;
             }
+            CK(ck_b);
             __syncthreads();
+            CK(ck_wait);
         }
+#ifdef MIRP_X_GEN_CLOCKS
+        if (blockIdx.x == 0 && w == 0 && lane == 0)
+            printf("[gen clocks] wave %d n %d: phase0 %lld small %lld (%d tasks) large %lld (%d tasks) B %lld barrier-wait %lld\n", wave, n, ck_0, ck_small, ck_nsmall, ck_large, ck_nlarge, ck_b, ck_wait);
+#endif
         } else {
 #ifdef MIRP_X_GEN_NOEPI             // timing experiment: fill only (results are empty)
         if (tid == 0) { out_nlines[win] = 0; out_mfe[win] = 0; out_status[win] = 0; }
