@@ -23,7 +23,7 @@ namespace v185 {
 #define V_INF 1000000
 #define V_NT 256
 #ifndef V_G
-#define V_G 4          // lanes per cell of the generic kernel's interval B (L = 400: 2 -> 0.346 s, 4 -> 0.329, 8 -> 0.364, 16 -> 0.458)
+#define V_G 2          // lanes per cell of the generic kernel's interval B (L = 400, four candidates a lane and turn: 1 -> 0.304 s, 2 -> 0.278, 4 -> 0.288, 8 -> 0.345)
 #endif
 #define V_BT_STACK 192
 #ifndef MIRP_EPI_DMAX

@@ -12,6 +12,9 @@
 namespace mirp {
 namespace v185 {
 
+#ifndef V_PU
+#define V_PU 4                   // split candidates of a column a lane reads together (interval B)
+#endif
 #define V_STAGE 512               // ints per wave of the interior-loop interval's staging buffer
 #define V_FILL_WAVES 5            // waves per SIMD the fill's register allocation aims for
 typedef int v_int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
@@ -343,11 +346,20 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                     if (sub == 0) mdec = T.DM(i, j - 1);
                     const int pn = pcnt[j];
                     const int2* pj = pool + (size_t)j * pcap;
-                    for (int k = sub; k < pn; k += V_G) {
-                        const int2 en = pj[k];
-                        if (en.x < i + V_TURN + 2) continue;          // fML(i, s-1) does not exist yet
-                        const int e = T.Mm(i, en.x - 1) + en.y;
-                        mdec = e < mdec ? e : mdec;
+                    // V_PU candidates a lane and turn: their entries, then their fML reads, are in flight together (one at a time the loop was a chain of dependent
+                    // round trips: the longest part of interval B); entries behind the last one repeat it (a minimum does not mind)
+                    for (int k = sub; k < pn; k += V_G * V_PU) {
+                        int2 en[V_PU];
+#pragma unroll
+                        for (int u = 0; u < V_PU; u++) en[u] = pj[k + u * V_G < pn ? k + u * V_G : pn - 1];
+                        int fm[V_PU];
+#pragma unroll
+                        for (int u = 0; u < V_PU; u++) fm[u] = T.Mm(i, (en[u].x < i + V_TURN + 2 ? i + V_TURN + 2 : en[u].x) - 1);      // (a clamped read where fML(i, s-1) does not exist yet)
+#pragma unroll
+                        for (int u = 0; u < V_PU; u++) {
+                            const int e = fm[u] + en[u].y;
+                            if (en[u].x >= i + V_TURN + 2) mdec = e < mdec ? e : mdec;
+                        }
                     }
                 }
 #pragma unroll
