@@ -20,7 +20,7 @@ for k in range(n_sets):
         sams = ds.write_sams(tmp, sq_order=r.sample(range(nc), nc))
         ds.write_fasta(os.path.join(tmp, "g.fa"))
         model = r.choice(["vienna-2.1.2", "vienna-1.8.5"])
-        extra = "ALLOW_3NT_OVERHANG = %s\nALLOW_NO_STAR_EXPRESSION = %s\nPRECURSOR_LEN = %d\n" % (r.choice("YN"), r.choice("YN"), r.choice([300, 300, 250, 320]))
+        extra = "ALLOW_3NT_OVERHANG = %s\nALLOW_NO_STAR_EXPRESSION = %s\nPRECURSOR_LEN = %d\n" % (r.choice("YN"), r.choice("YN"), r.choice([300, 300, 250, 320, 420, 900]))
         outs = {}
         for mode, flags, env in (("lean", [], {"MIRP_STREAM_CHUNKS": str(r.choice([0, 1, 2, 5, 9]))}), ("keep", ["-k"], {})):
             cfg = os.path.join(tmp, "cfg_" + mode)
