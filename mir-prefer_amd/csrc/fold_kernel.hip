@@ -74,6 +74,12 @@ __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines)
 // row stride of a workspace table (a multiple of four ints: the interior-loop interval stages row segments with aligned 16-byte loads)
 __host__ __device__ inline int fold_generic_ld(int n_cap) { return (n_cap + 2 + 3) & ~3; }
 
+// the fill kernel's share of the base carve-up: the sequence codes and the special-hairpin table (everything else above is the epilogue's)
+__host__ __device__ size_t fold_generic_lds_bytes_base_fill(int n_cap) {
+    const int nc = n_cap + 8;
+    return ((size_t)(sizeof(int) * 8 + sizeof(short) * 3 * nc + 2 * nc) + 15) & ~(size_t)15;
+}
+
 // one table (c or fML) of a workspace slot, in ints
 __host__ __device__ size_t fold_generic_table_ints(int n_cap, int span) {
     size_t D = (size_t)(span < n_cap ? span : n_cap) + 1;
@@ -96,23 +102,37 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
     extern __shared__ __align__(16) unsigned char smem[];
     // LDS carve-up (n_cap = max window length this launch supports)
     const int nc = n_cap + 8;
-    int* f3 = (int*)smem;                                  // nc ints
-    int* starts = f3 + nc;                                 // max_lines
-    int* lens = starts + max_lines;                        // max_lines
-    int* btstk = lens + max_lines;                         // (NT/64)*3*BT_STACK
-    int* sh_misc = btstk + (GEN_NT / 64) * 3 * BT_STACK;   // 8
-    short* spec = (short*)(sh_misc + 8);                   // 3*nc
-    unsigned char* S = (unsigned char*)(spec + 3 * nc);    // nc
-    unsigned char* seq = S + nc;                           // nc
-    char* btbuf = (char*)(seq + nc);                       // (NT/64)*nc
-    int* pcnt = (int*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines));      // nc: split candidates of every column so far
+    // (the two kernels have their own layouts: the epilogue needs none of the fill's lists, tables and staging buffers, the fill none of the epilogue's
+    // line and backtrack buffers -- 24 KB instead of 33 at n = 425 lets five of its workgroups share a CU's LDS)
+    int *f3 = nullptr, *starts = nullptr, *lens = nullptr, *btstk = nullptr, *sh_misc;
+    short* spec;
+    unsigned char *S, *seq;
+    char* btbuf = nullptr;
+    if constexpr (PHASE == 1) {
+        sh_misc = (int*)smem;                              // 8
+        spec = (short*)(sh_misc + 8);                      // 3*nc
+        S = (unsigned char*)(spec + 3 * nc);               // nc
+        seq = S + nc;                                      // nc
+    } else {
+        f3 = (int*)smem;                                   // nc ints
+        starts = f3 + nc;                                  // max_lines
+        lens = starts + max_lines;                         // max_lines
+        btstk = lens + max_lines;                          // (NT/64)*3*BT_STACK
+        sh_misc = btstk + (GEN_NT / 64) * 3 * BT_STACK;    // 8
+        spec = (short*)(sh_misc + 8);                      // 3*nc
+        S = (unsigned char*)(spec + 3 * nc);               // nc
+        seq = S + nc;                                      // nc
+        btbuf = (char*)(seq + nc);                         // (NT/64)*nc
+    }
+    const size_t base_bytes = PHASE == 1 ? fold_generic_lds_bytes_base_fill(n_cap) : fold_generic_lds_bytes_base(n_cap, max_lines);
+    int* pcnt = (int*)(smem + base_bytes);      // nc: split candidates of every column so far (from here on: the fill's alone)
     unsigned long long* cbest = (unsigned long long*)(pcnt + nc + (nc & 1));      // nc: interior-loop minimum of the diagonal's cells as a key
                                                            // (energy + 2^30) << 10 | n1 << 5 | n2: the minimum names the first loop in the backtrack's search order
     unsigned short* plist = (unsigned short*)(cbest + 2 * nc); // nc: the diagonal's paired cells  (cbest, ctype: [diagonal & 1][nc] -- interval A of d + 1 runs beside interval B of d)
     unsigned char* ctype = (unsigned char*)(plist + nc);   // 2 nc: pair type of the diagonal's cells
     // inner-pair terms of the interior-loop energies, [t2][sq1][sp1] as shorts, and the stacking table: read per candidate -- out of LDS, not through
     // the texture addresser (the interval was bound by vector-memory instructions, one per table look-up and lane: DESIGN.md 4, "Generic kernels")
-    short* l_mmI = (short*)(smem + fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)nc));
+    short* l_mmI = (short*)(smem + base_bytes + GEN_AUX_BYTES((size_t)nc));
     short* l_mm1n = l_mmI + 200;
     short* l_mm23 = l_mm1n + 200;
     short* l_xb = l_mm23 + 200;                            // bulge: TerminalAU of the inner pair - its mismatchI (what turns the table's word into c + TerminalAU)
@@ -120,6 +140,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
     short* l_stack = l_x1 + 200;                           // 64
     int* stage = reinterpret_cast<int*>(l_stack + 64);     // GEN_STAGE ints per wave: the row segment a block of paired cells reads for one loop size (interval A)
     int* wcnt = stage + (GEN_NT / 64) * GEN_STAGE;         // 2 * waves: paired cells per wave and half-pass of the list compaction
+    if constexpr (PHASE == 1) {
     for (int x = threadIdx.x; x < 200; x += GEN_NT) {
         const int t = x / 25, a = (x / 5) % 5, b = x % 5;
         // (the rows of pair type 0 hold INF and are never read: an interior candidate has a pair on both sides)
@@ -128,6 +149,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
         l_x1[x] = t ? (short)(P->mismatch1nI[t][a][b] - P->mismatchI[t][a][b]) : (short)0;
     }
     for (int x = threadIdx.x; x < 64; x += GEN_NT) l_stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
+    }
     __syncthreads();
 
     const int tid = threadIdx.x;
@@ -556,8 +578,13 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
 }
 
 // split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
+static size_t fold_generic_lds_bytes_fill(int n_cap) {
+    return fold_generic_lds_bytes_base_fill(n_cap) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + sizeof(int) * (GEN_NT / 64) * (GEN_STAGE + 2) + 16;
+}
+// what the larger of the two kernels takes (the budget check of the caller)
 size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
-    return fold_generic_lds_bytes_base(n_cap, max_lines) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + sizeof(int) * (GEN_NT / 64) * (GEN_STAGE + 2) + 16;
+    const size_t a = fold_generic_lds_bytes_fill(n_cap), b = fold_generic_lds_bytes_base(n_cap, max_lines);
+    return a > b ? a : b;
 }
 
 size_t fold_generic_ws_slot_ints(int n_cap, int span) {
@@ -572,11 +599,10 @@ void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, cons
                          int ss_stride, MirpFoldLine* out_lines, char* out_ss, int* out_nlines, int* out_mfe, int* out_status) {
     // batches of `grid` windows: window b + k of the batch owns workspace slot k in both kernels (without a work list the kernels index the windows
     // directly, so the batch is addressed by shifted array bases; with one, by the shifted list)
-    const size_t lds = fold_generic_lds_bytes(n_cap, max_lines);
-    if (lds > 64 * 1024) {          // windows of some 1,700 nt and more (PRECURSOR_LEN up to 3000, MP:167-184): one or two workgroups per CU
-        (void)hipFuncSetAttribute((const void*)fold_generic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)fold_generic_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    const size_t lds1 = fold_generic_lds_bytes_fill(n_cap), lds2 = fold_generic_lds_bytes_base(n_cap, max_lines);
+    // windows of some 2,000 nt and more (PRECURSOR_LEN up to 3000, MP:167-184): one or two workgroups per CU
+    if (lds1 > 64 * 1024) (void)hipFuncSetAttribute((const void*)fold_generic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (lds2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)fold_generic_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     for (int b = 0; b < n_work; b += grid) {
         const int nb = n_work - b < grid ? n_work - b : grid;
         const int* wl = work_list ? work_list + b : nullptr;
@@ -587,9 +613,9 @@ void launch_fold_generic(hipStream_t stream, int grid, const FoldParams* P, cons
         int* on = work_list ? out_nlines : out_nlines + b;
         int* om = work_list ? out_mfe : out_mfe + b;
         int* ost = work_list ? out_status : out_status + b;
-        hipLaunchKernelGGL(fold_generic_kernel<1>, dim3(nb), dim3(GEN_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride,
+        hipLaunchKernelGGL(fold_generic_kernel<1>, dim3(nb), dim3(GEN_NT), lds1, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride,
                            ol, os, on, om, ost);
-        hipLaunchKernelGGL(fold_generic_kernel<2>, dim3(nb), dim3(GEN_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride,
+        hipLaunchKernelGGL(fold_generic_kernel<2>, dim3(nb), dim3(GEN_NT), lds2, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride,
                            ol, os, on, om, ost);
     }
 }
