@@ -1,3 +1,4 @@
+"""Dev tool: the process-level end-to-end figures of a bench line on stdin.  usage: python bench.py --no-ingest --no-cpu-baseline | python profiles/tools/e2e_show.py"""
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); e=d["e2e"]
 print(e["process_wall_s_all_runs"], e["process_wall_s_back_to_back"])

@@ -1,3 +1,5 @@
+"""Dev tool: the resident path (candidate -> fold -> filter) at PRECURSOR_LEN = 1000 and 3000 on a small synthetic dataset: window count, fold time, statuses, the
+largest number of structure lines, loci.  usage (GPU box): python profiles/tools/l3000_probe.py      (MIRP_LIB=<variant> for A/B builds)"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Dev tool: texture-addresser / L1 counters (TA_BUSY, TCP accesses and stalls, TD_BUSY) of the generic fill kernel at PRECURSOR_LEN = 400, one rocprofv3 --pmc pass per group.
+#   gpurun -- 'bash profiles/tools/pmc_l400_ta.sh'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export MIRP_LIB=$PWD/mir-prefer_amd/libmirprefer.so
 for CTRS in "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
