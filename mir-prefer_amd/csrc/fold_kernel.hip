@@ -56,7 +56,7 @@ struct GTab {
 #define GEN_STAGE 512              // ints per wave of the interior-loop interval's staging buffer
 #define GEN_PINF 1500000           // 'no pair' in the 24-bit energy field of GTab::w: with every loop term added it stays below 2^21, so that energy * 1024 + shape is an int
 #define GEN_EMAX 1000000           // a candidate energy at or above this came from a GEN_PINF entry (real energies: a few hundred per nucleotide pair at most)
-#define GEN_AUX_BYTES(nc) ((((size_t)(4 + 16 + 2 + 2) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (64-bit keys, 8-aligned; two diagonals), plist (short), ctype (byte; two diagonals) per position
+#define GEN_AUX_BYTES(nc) ((((size_t)(4 + 8 + 2 + 2) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (32-bit keys; two diagonals), plist (short), ctype (byte; two diagonals) per position
 
 __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines) {
     const int nc = n_cap + 8;
@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
     }
     const size_t base_bytes = PHASE == 1 ? fold_generic_lds_bytes_base_fill(n_cap) : fold_generic_lds_bytes_base(n_cap, max_lines);
     int* pcnt = (int*)(smem + base_bytes);      // nc: split candidates of every column so far (from here on: the fill's alone)
-    unsigned long long* cbest = (unsigned long long*)(pcnt + nc + (nc & 1));      // nc: interior-loop minimum of the diagonal's cells as a key
-                                                           // (energy + 2^30) << 10 | n1 << 5 | n2: the minimum names the first loop in the backtrack's search order
+    int* cbest = pcnt + nc;                                // 2 nc: interior-loop minimum of the diagonal's cells as the tasks' key, energy * 1024 + (n1 << 5 | n2): the
+                                                           // minimum names the first loop in the backtrack's search order (0x7fffffff: none)
     unsigned short* plist = (unsigned short*)(cbest + 2 * nc); // nc: the diagonal's paired cells  (cbest, ctype: [diagonal & 1][nc] -- interval A of d + 1 runs beside interval B of d)
     unsigned char* ctype = (unsigned char*)(plist + nc);   // 2 nc: pair type of the diagonal's cells
     // inner-pair terms of the interior-loop energies, [t2][sq1][sp1] as shorts, and the stacking table: read per candidate -- out of LDS, not through
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
         // its share of both, so the turn takes the slowest wave's SUM, not the slowest of A plus the slowest of B, and a diagonal costs two barriers, not three.
         for (int d = TURN + 1; d <= D + 1; d++) {
             unsigned char* const ctA = ctype + (d & 1) * nc;
-            unsigned long long* const cbA = cbest + (d & 1) * nc;
+            int* const cbA = cbest + (d & 1) * nc;
             if (d <= D) {
             const int ncell = n - d;
             // pair types of the diagonal's cells; the paired ones compacted into a list IN CELL ORDER (a block of 64 list entries is a stretch of the
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                 for (int h = 0; h < 2; h++) {
                     const int cell = base + h * GEN_NT + tid;
                     type[h] = 0;
-                    if (cell < ncell) { type[h] = pair_type(S[cell + 1], S[cell + 1 + d]); ctA[cell] = (unsigned char)type[h]; cbA[cell] = ~0ull; }
+                    if (cell < ncell) { type[h] = pair_type(S[cell + 1], S[cell + 1 + d]); ctA[cell] = (unsigned char)type[h]; cbA[cell] = 0x7fffffff; }
                     bal[h] = __ballot(type[h] != 0);
                     if (lane == 0) wcnt[h * (GEN_NT / 64) + wave] = (int)__popcll(bal[h]);
                 }
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                         if (grp == 0) { CK(ck_small); ck_nsmall++; } else { CK(ck_large); ck_nlarge++; }
 #endif
                         const int best = kmin >> 10;
-                        if (active && best < GEN_EMAX) atomicMin(&cbA[cell], ((unsigned long long)(unsigned)(best + (1 << 30)) << 10) | (unsigned)(kmin & 1023));
+                        if (active && best < GEN_EMAX) atomicMin(&cbA[cell], kmin);
                     }
                 }
             }
@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
             const int d = d_turn - 1;          // interval B works on the diagonal before the one interval A just did
             const int ncell = n - d;
             const unsigned char* const ctB = ctype + (d & 1) * nc;
-            const unsigned long long* const cbB = cbest + (d & 1) * nc;
+            const int* const cbB = cbest + (d & 1) * nc;
             // (two cells per thread a pass, each step for both cells before the next, was tried: 14 spilled VGPRs under the five-wave budget and 0.168 -> 0.192 s)
             for (int cell = tid; cell < ncell; cell += GEN_NT) {
                 const int i = cell + 1, j = i + d;
@@ -510,9 +510,9 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                 if (type) {
                     const int hp = e_hairpin(X, i, j, type);
                     best = hp;
-                    const unsigned long long key = cbB[cell];
-                    const int il = key == ~0ull ? INF : (int)(unsigned)(key >> 10) - (1 << 30);
-                    if (il < best) { best = il; code = 1 + (int)(key & 1023u); }          // the hairpin does not realise c and this loop does (unless the multiloop below wins)
+                    const int key = cbB[cell];
+                    const int il = key == 0x7fffffff ? INF : key >> 10;
+                    if (il < best) { best = il; code = 1 + (key & 1023); }          // the hairpin does not realise c and this loop does (unless the multiloop below wins)
                     // multiloop closed by (i,j): DML(i+1, j-1), kept from diagonal d-2
                     int dec = dml[(size_t)((d - 2) & 3) * T.ld + i + 1];
                     dec += P->ML_closing + e_mlstem(P, rtype_of(type), S[j - 1], S[i + 1]);
