@@ -53,6 +53,7 @@ struct GTab {
 #ifndef GEN_PU
 #define GEN_PU 4                  // split candidates of a column whose reads are in flight together (interval B)
 #endif
+#define GEN_PL_MAXN 2500            // longest window whose split candidates fit the packed LDS copy (12 bits of position would allow 4,095; 20 bits of energy: 340 per pair)
 #define GEN_STAGE 512              // ints per wave of the interior-loop interval's staging buffer
 #define GEN_PINF 1500000           // 'no pair' in the 24-bit energy field of GTab::w: with every loop term added it stays below 2^21, so that energy * 1024 + shape is an int
 #define GEN_EMAX 1000000           // a candidate energy at or above this came from a GEN_PINF entry (real energies: a few hundred per nucleotide pair at most)
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
     short* l_stack = l_x1 + 200;                           // 64
     int* stage = reinterpret_cast<int*>(l_stack + 64);     // GEN_STAGE ints per wave: the row segment a block of paired cells reads for one loop size (interval A)
     int* wcnt = stage + (GEN_NT / 64) * GEN_STAGE;         // 2 * waves: paired cells per wave and half-pass of the list compaction
+    int* pl4 = wcnt + 2 * (GEN_NT / 64);                  // 4 nc: the first four split candidates of every column, packed s << 20 | (fML & 0xfffff) (interval B; windows up to GEN_PL_MAXN nt)
     if constexpr (PHASE == 1) {
     for (int x = threadIdx.x; x < 200; x += GEN_NT) {
         const int t = x / 25, a = (x / 5) % 5, b = x % 5;
@@ -501,8 +503,15 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                 const int pn = pcnt[j];
                 const int2* pj = pool + (size_t)j * pcap;
                 int2 en0[GEN_PU];
+                static_assert(GEN_PU == 4, "the LDS copy of a column's first candidates is four packed words");
+                if (n_cap <= GEN_PL_MAXN) {          // (launch-uniform) the column's first four candidates out of LDS: the reads they name go out with the cell's own
+                    const int4q pk = *reinterpret_cast<const int4q*>(pl4 + 4 * j);
 #pragma unroll
-                for (int u = 0; u < GEN_PU; u++) en0[u] = pj[u < pn ? u : (pn > 0 ? pn - 1 : 0)];          // (entries behind the last one repeat it: a minimum does not mind)
+                    for (int u = 0; u < GEN_PU; u++) { const int v = pk[u < pn ? u : (pn > 0 ? pn - 1 : 0)]; en0[u] = make_int2((int)((unsigned)v >> 20), (v << 12) >> 12); }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < GEN_PU; u++) en0[u] = pj[u < pn ? u : (pn > 0 ? pn - 1 : 0)];          // (entries behind the last one repeat it: a minimum does not mind)
+                }
                 int mdec = dml[(size_t)((d - 1) & 3) * T.ld + i];
                 const int m1 = T.M(d - 1, i + 1), m2 = T.M(d - 1, i);
                 int best = INF;
@@ -543,7 +552,11 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                     const int e = best + ml_term(X, i, j, type);
                     if (e < mm) {          // realised strictly by the pair term: (i,j) is a split candidate of column j
                         mm = e;
-                        if (pn < pcap) { pool[(size_t)j * pcap + pn] = make_int2(i, e); pcnt[j] = pn + 1; }
+                        if (pn < pcap) {
+                            pool[(size_t)j * pcap + pn] = make_int2(i, e);
+                            if (n_cap <= GEN_PL_MAXN && pn < 4) pl4[4 * j + pn] = (i << 20) | (e & 0xfffff);
+                            pcnt[j] = pn + 1;
+                        }
                     }
                 }
                 if (mm > INF) mm = INF;
@@ -579,7 +592,8 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
 
 // split-candidate counts, interior-loop minima, paired-cell list and pair types of a diagonal behind the base carve-up
 static size_t fold_generic_lds_bytes_fill(int n_cap) {
-    return fold_generic_lds_bytes_base_fill(n_cap) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + sizeof(int) * (GEN_NT / 64) * (GEN_STAGE + 2) + 16;
+    return fold_generic_lds_bytes_base_fill(n_cap) + GEN_AUX_BYTES((size_t)(n_cap + 8)) + sizeof(short) * (5 * 200 + 64) + sizeof(int) * (GEN_NT / 64) * (GEN_STAGE + 2) + 16 +
+           (n_cap <= GEN_PL_MAXN ? sizeof(int) * 4 * (size_t)(n_cap + 8) : 0);
 }
 // what the larger of the two kernels takes (the budget check of the caller)
 size_t fold_generic_lds_bytes(int n_cap, int max_lines) {
