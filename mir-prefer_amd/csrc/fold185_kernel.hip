@@ -15,6 +15,8 @@ namespace v185 {
 #ifndef V_PU
 #define V_PU 4                   // split candidates of a column a lane reads together (interval B)
 #endif
+#define V_PL_MAXN 2500           // longest window whose split candidates get the packed LDS copy (12 bits of position, 20 of energy)
+#define V_PL_FLAG 0x40000000
 #define V_STAGE 512               // ints per wave of the interior-loop interval's staging buffer
 #define V_FILL_WAVES 5            // waves per SIMD the fill's register allocation aims for
 typedef int v_int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
@@ -36,6 +38,9 @@ __host__ __device__ inline size_t fold185_lds_bytes_base(int n_cap, int max_line
     return (b + 15) & ~(size_t)15;
 }
 
+// the fill kernel's share of the base carve-up: tetraloop bonuses and the sequence codes
+__host__ __device__ inline size_t fold185_lds_bytes_base_fill(int n_cap) { return ((size_t)4 * ((size_t)n_cap + 8) + 15) & ~(size_t)15; }
+
 // PHASE 1 = fill, PHASE 2 = exterior sweep + backtracks, launched back to back over batches of `grid` windows (slot = blockIdx.x), as fold_generic_kernel:
 // the fill needs half the registers of the epilogue.
 template <int PHASE>
@@ -45,30 +50,45 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
     char* __restrict__ out_ss, int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int nc = n_cap + 8;
-    int* f3 = (int*)smem;                                  // nc + 8
-    int* starts = f3 + nc + 8;                             // max_lines
-    int* lens = starts + max_lines;                        // max_lines
-    int* btstk = lens + max_lines;                         // (NT/64) * 3 * V_BT_STACK
-    int* red = btstk + (V_NT / 64) * 3 * V_BT_STACK;       // NT/64 + 8
-    short* tetra = (short*)(red + V_NT / 64 + 8);          // nc
-    unsigned char* S = (unsigned char*)(tetra + nc);       // nc
-    unsigned char* seq = S + nc;                           // nc
-    char* btbuf = (char*)(seq + nc);                       // (NT/64) * (nc + 8)
-    int* pcnt = (int*)(smem + fold185_lds_bytes_base(n_cap, max_lines));       // nc: split candidates of every column so far
+    // (the two kernels have their own layouts, as fold_generic_kernel: the fill needs the sequence codes and the tetraloop bonuses of the base carve-up, nothing else)
+    int *f3 = nullptr, *starts = nullptr, *lens = nullptr, *btstk = nullptr, *red = nullptr;
+    short* tetra;
+    unsigned char *S, *seq;
+    char* btbuf = nullptr;
+    if constexpr (PHASE == 1) {
+        tetra = (short*)smem;                              // nc
+        S = (unsigned char*)(tetra + nc);                  // nc
+        seq = S + nc;                                      // nc
+    } else {
+        f3 = (int*)smem;                                   // nc + 8
+        starts = f3 + nc + 8;                              // max_lines
+        lens = starts + max_lines;                         // max_lines
+        btstk = lens + max_lines;                          // (NT/64) * 3 * V_BT_STACK
+        red = btstk + (V_NT / 64) * 3 * V_BT_STACK;        // NT/64 + 8
+        tetra = (short*)(red + V_NT / 64 + 8);             // nc
+        S = (unsigned char*)(tetra + nc);                  // nc
+        seq = S + nc;                                      // nc
+        btbuf = (char*)(seq + nc);                         // (NT/64) * (nc + 8)
+    }
+    const size_t base_bytes = PHASE == 1 ? fold185_lds_bytes_base_fill(n_cap) : fold185_lds_bytes_base(n_cap, max_lines);
+    int* pcnt = (int*)(smem + base_bytes);       // nc: split candidates of every column so far (| V_PL_FLAG: one of its first four does not fit the packed LDS copy)
     int* cbest = pcnt + nc;                                // nc: interior-loop minimum of the diagonal's cells
     unsigned short* plist = (unsigned short*)(cbest + nc); // nc: the diagonal's paired cells
     unsigned char* ctype = (unsigned char*)(plist + nc);   // nc: pair type of the diagonal's cells
     // inner-pair terms of the loop energies ([t2][sq1][sp1] as shorts) and the stacking table out of LDS, as fold_generic_kernel
-    short* l_mmI = (short*)(smem + fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * (size_t)nc + 15) / 16) * 16);
+    short* l_mmI = (short*)(smem + base_bytes + (((size_t)(4 + 4 + 2 + 1) * (size_t)nc + 15) / 16) * 16);
     short* l_xb = l_mmI + 200;                             // bulge: TerminalAU of the inner pair - its mismatchI (what turns the table's word into c + TerminalAU)
     short* l_stack = l_xb + 200;
     int* stage = reinterpret_cast<int*>(l_stack + 64);     // V_STAGE ints per wave: the row segment a block of paired cells reads for one loop size
     int* wcnt = stage + (V_NT / 64) * V_STAGE;             // 2 * waves: paired cells per wave and half-pass of the list compaction
+    int* pl4 = wcnt + 2 * (V_NT / 64);                    // 4 nc: the first four split candidates of every column, packed s << 20 | (fML & 0xfffff) (interval B; windows up to V_PL_MAXN nt)
+    if constexpr (PHASE == 1) {
     for (int x = threadIdx.x; x < 200; x += V_NT) {
         l_mmI[x] = (short)min(P->mismatchI[x / 25][(x / 5) % 5][x % 5], 32767);
         l_xb[x] = x >= 25 ? (short)((x / 25 > 2 ? P->TerminalAU : 0) - P->mismatchI[x / 25][(x / 5) % 5][x % 5]) : (short)0;
     }
     for (int x = threadIdx.x; x < 64; x += V_NT) l_stack[x] = (short)min(P->stack[x >> 3][x & 7], 32767);
+    }
     __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = span;
@@ -90,7 +110,7 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
             seq[x] = ch;
             S[x] = ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'U' ? 4 : 0;
         }
-        for (int x = tid; x < nc + 8; x += V_NT) f3[x] = 0;
+        if constexpr (PHASE == 2) for (int x = tid; x < nc + 8; x += V_NT) f3[x] = 0;
         __syncthreads();
         if (tid == 0) { S[0] = S[n]; S[n + 1] = S[1]; }
         for (int x = tid; x <= n; x += V_NT) {
@@ -344,11 +364,22 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                         }
                     }
                     if (sub == 0) mdec = T.DM(i, j - 1);
-                    const int pn = pcnt[j];
+                    const int pnf = pcnt[j], pn = pnf & ~V_PL_FLAG;
                     const int2* pj = pool + (size_t)j * pcap;
+                    int kstart = sub;
+                    if (n_cap <= V_PL_MAXN && !(pnf & V_PL_FLAG)) {
+                        // the column's first four candidates out of LDS (lane `sub` takes sub and sub + 2): the fML reads they name go out with the cell's own reads
+                        const v_int4q pk = *reinterpret_cast<const v_int4q*>(pl4 + 4 * j);
+                        const int v0 = sub ? pk[1] : pk[0], v1 = sub ? pk[3] : pk[2];
+                        const int s0 = (int)((unsigned)v0 >> 20), s1 = (int)((unsigned)v1 >> 20);
+                        const int f0 = T.Mm(i, (s0 < i + V_TURN + 2 ? i + V_TURN + 2 : s0) - 1), f1 = T.Mm(i, (s1 < i + V_TURN + 2 ? i + V_TURN + 2 : s1) - 1);
+                        if (sub < pn && s0 >= i + V_TURN + 2) { const int e = f0 + ((v0 << 12) >> 12); mdec = e < mdec ? e : mdec; }
+                        if (sub + 2 < pn && s1 >= i + V_TURN + 2) { const int e = f1 + ((v1 << 12) >> 12); mdec = e < mdec ? e : mdec; }
+                        kstart = 4 + sub;
+                    }
                     // V_PU candidates a lane and turn: their entries, then their fML reads, are in flight together (one at a time the loop was a chain of dependent
                     // round trips: the longest part of interval B); entries behind the last one repeat it (a minimum does not mind)
-                    for (int k = sub; k < pn; k += V_G * V_PU) {
+                    for (int k = kstart; k < pn; k += V_G * V_PU) {
                         int2 en[V_PU];
 #pragma unroll
                         for (int u = 0; u < V_PU; u++) en[u] = pj[k + u * V_G < pn ? k + u * V_G : pn - 1];
@@ -381,8 +412,16 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                     v = T.C(i + 1, j - 1) + P->dangle5[t][S[i]] + P->dangle3[t][S[j]] + MLi(X, t); stem = v < stem ? v : stem;
                     if (stem < mm) {          // realised strictly by a stem term: (i, j) is a split candidate of column j
                         mm = stem;
-                        const int k = pcnt[j];
-                        if (k < pcap) { pool[(size_t)j * pcap + k] = make_int2(i, stem); pcnt[j] = k + 1; }
+                        const int kf = pcnt[j], k = kf & ~V_PL_FLAG;
+                        if (k < pcap) {
+                            pool[(size_t)j * pcap + k] = make_int2(i, stem);
+                            int flag = kf & V_PL_FLAG;
+                            if (n_cap <= V_PL_MAXN && k < 4) {
+                                if (stem >= -(1 << 19) && stem < (1 << 19)) pl4[4 * j + k] = (i << 20) | (stem & 0xfffff);
+                                else flag = V_PL_FLAG;          // (this model's arithmetic is uncapped: a stem term of INF-sized parts can be a candidate)
+                            }
+                            pcnt[j] = (k + 1) | flag;
+                        }
                     }
                     T.c[(size_t)d * T.ld + i] = newc;
                     // the loop realises c unless the hairpin does as well or better, or the multiloop strictly better: the order of the backtrack's tests
@@ -411,8 +450,14 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
 
 }  // namespace v185
 
+static size_t fold185_lds_bytes_fill(int n_cap) {
+    return v185::fold185_lds_bytes_base_fill(n_cap) + (((size_t)(4 + 4 + 2 + 1) * ((size_t)n_cap + 8) + 15) / 16) * 16 + sizeof(short) * (2 * 200 + 64) +
+           sizeof(int) * (V_NT / 64) * (V_STAGE + 2) + 16 + (n_cap <= V_PL_MAXN ? sizeof(int) * 4 * ((size_t)n_cap + 8) : 0);
+}
+// what the larger of the two kernels takes (the budget check of the caller)
 size_t fold185_lds_bytes(int n_cap, int max_lines) {
-    return v185::fold185_lds_bytes_base(n_cap, max_lines) + (((size_t)(4 + 4 + 2 + 1) * ((size_t)n_cap + 8) + 15) / 16) * 16 + sizeof(short) * (2 * 200 + 64) + sizeof(int) * (V_NT / 64) * (V_STAGE + 2) + 16;
+    const size_t a = fold185_lds_bytes_fill(n_cap), b = v185::fold185_lds_bytes_base(n_cap, max_lines);
+    return a > b ? a : b;
 }
 
 size_t fold185_ws_slot_ints(int n_cap, int span) {
@@ -424,10 +469,13 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
                           const int* work_list, int n_work,
                           int span, int n_cap, int* ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* out_lines, char* out_ss,
                           int* out_nlines, int* out_mfe, int* out_status) {
-    const size_t lds = fold185_lds_bytes(n_cap, max_lines);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)v185::fold185_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)v185::fold185_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds1 = fold185_lds_bytes_fill(n_cap), lds2 = v185::fold185_lds_bytes_base(n_cap, max_lines);
+    if (lds1 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)v185::fold185_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+    }
+    if (lds2 > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)v185::fold185_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
     }
     for (int b = 0; b < n_work; b += grid) {          // batches of `grid` windows: window b + k owns workspace slot k in both kernels
@@ -440,9 +488,9 @@ hipError_t launch_fold185(hipStream_t stream, int grid, const FoldParams185* P, 
         int* on = work_list ? out_nlines : out_nlines + b;
         int* om = work_list ? out_mfe : out_mfe + b;
         int* ost = work_list ? out_status : out_status + b;
-        hipLaunchKernelGGL(v185::fold185_kernel<1>, dim3(nb), dim3(V_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride, ol, os, on,
+        hipLaunchKernelGGL(v185::fold185_kernel<1>, dim3(nb), dim3(V_NT), lds1, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride, ol, os, on,
                            om, ost);
-        hipLaunchKernelGGL(v185::fold185_kernel<2>, dim3(nb), dim3(V_NT), lds, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride, ol, os, on,
+        hipLaunchKernelGGL(v185::fold185_kernel<2>, dim3(nb), dim3(V_NT), lds2, stream, P, seqs, o2, l2, wl, nb, span, n_cap, ws, ws_slot_ints, max_lines, ss_stride, ol, os, on,
                            om, ost);
     }
     return hipGetLastError();
