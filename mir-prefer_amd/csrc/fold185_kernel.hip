@@ -17,6 +17,9 @@ namespace v185 {
 #endif
 #define V_PL_MAXN 2500           // longest window whose split candidates get the packed LDS copy (12 bits of position, 20 of energy)
 #define V_PL_FLAG 0x40000000
+#ifndef V_PLN
+#define V_PLN 8                  // candidates of a column kept in LDS
+#endif
 #define V_STAGE 512               // ints per wave of the interior-loop interval's staging buffer
 #define V_FILL_WAVES 5            // waves per SIMD the fill's register allocation aims for
 typedef int v_int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
@@ -81,7 +84,7 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
     short* l_stack = l_xb + 200;
     int* stage = reinterpret_cast<int*>(l_stack + 64);     // V_STAGE ints per wave: the row segment a block of paired cells reads for one loop size
     int* wcnt = stage + (V_NT / 64) * V_STAGE;             // 2 * waves: paired cells per wave and half-pass of the list compaction
-    int* pl4 = wcnt + 2 * (V_NT / 64);                    // 4 nc: the first four split candidates of every column, packed s << 20 | (fML & 0xfffff) (interval B; windows up to V_PL_MAXN nt)
+    int* pl4 = wcnt + 2 * (V_NT / 64);                    // V_PLN nc: the first V_PLN split candidates of every column, packed s << 20 | (fML & 0xfffff) (interval B; windows up to V_PL_MAXN nt)
     if constexpr (PHASE == 1) {
     for (int x = threadIdx.x; x < 200; x += V_NT) {
         l_mmI[x] = (short)min(P->mismatchI[x / 25][(x / 5) % 5][x % 5], 32767);
@@ -368,17 +371,19 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                     const int2* pj = pool + (size_t)j * pcap;
                     int kstart = sub;
                     if (n_cap <= V_PL_MAXN && !(pnf & V_PL_FLAG)) {
-                        // the column's first four candidates out of LDS (lane `sub` takes sub and sub + 2): the fML reads they name go out with the cell's own reads
-                        const v_int4q pk = *reinterpret_cast<const v_int4q*>(pl4 + 4 * j);
-                        const int v0 = sub ? pk[1] : pk[0], v1 = sub ? pk[3] : pk[2];
-                        const int s0 = (int)((unsigned)v0 >> 20), s1 = (int)((unsigned)v1 >> 20);
-                        const int f0 = T.Mm(i, (s0 < i + V_TURN + 2 ? i + V_TURN + 2 : s0) - 1), f1 = T.Mm(i, (s1 < i + V_TURN + 2 ? i + V_TURN + 2 : s1) - 1);
-                        if (sub < pn && s0 >= i + V_TURN + 2) { const int e = f0 + ((v0 << 12) >> 12); mdec = e < mdec ? e : mdec; }
-                        if (sub + 2 < pn && s1 >= i + V_TURN + 2) { const int e = f1 + ((v1 << 12) >> 12); mdec = e < mdec ? e : mdec; }
-                        kstart = 4 + sub;
+                        // the column's first V_PLN candidates out of LDS (lane `sub` takes sub, sub + V_G, ...): the fML reads they name go out with the cell's own reads
+                        int vv[V_PLN / V_G], ff[V_PLN / V_G];
+#pragma unroll
+                        for (int u = 0; u < V_PLN / V_G; u++) vv[u] = pl4[V_PLN * j + sub + u * V_G];
+#pragma unroll
+                        for (int u = 0; u < V_PLN / V_G; u++) { const int s0 = (int)((unsigned)vv[u] >> 20); ff[u] = T.Mm(i, (s0 < i + V_TURN + 2 ? i + V_TURN + 2 : s0) - 1); }
+#pragma unroll
+                        for (int u = 0; u < V_PLN / V_G; u++) {
+                            const int s0 = (int)((unsigned)vv[u] >> 20);
+                            if (sub + u * V_G < pn && s0 >= i + V_TURN + 2) { const int e = ff[u] + ((vv[u] << 12) >> 12); mdec = e < mdec ? e : mdec; }
+                        }
+                        kstart = V_PLN + sub;
                     }
-                    // V_PU candidates a lane and turn: their entries, then their fML reads, are in flight together (one at a time the loop was a chain of dependent
-                    // round trips: the longest part of interval B); entries behind the last one repeat it (a minimum does not mind)
                     for (int k = kstart; k < pn; k += V_G * V_PU) {
                         int2 en[V_PU];
 #pragma unroll
@@ -416,8 +421,8 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
                         if (k < pcap) {
                             pool[(size_t)j * pcap + k] = make_int2(i, stem);
                             int flag = kf & V_PL_FLAG;
-                            if (n_cap <= V_PL_MAXN && k < 4) {
-                                if (stem >= -(1 << 19) && stem < (1 << 19)) pl4[4 * j + k] = (i << 20) | (stem & 0xfffff);
+                            if (n_cap <= V_PL_MAXN && k < V_PLN) {
+                                if (stem >= -(1 << 19) && stem < (1 << 19)) pl4[V_PLN * j + k] = (i << 20) | (stem & 0xfffff);
                                 else flag = V_PL_FLAG;          // (this model's arithmetic is uncapped: a stem term of INF-sized parts can be a candidate)
                             }
                             pcnt[j] = (k + 1) | flag;
@@ -452,7 +457,7 @@ __global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_k
 
 static size_t fold185_lds_bytes_fill(int n_cap) {
     return v185::fold185_lds_bytes_base_fill(n_cap) + (((size_t)(4 + 4 + 2 + 1) * ((size_t)n_cap + 8) + 15) / 16) * 16 + sizeof(short) * (2 * 200 + 64) +
-           sizeof(int) * (V_NT / 64) * (V_STAGE + 2) + 16 + (n_cap <= V_PL_MAXN ? sizeof(int) * 4 * ((size_t)n_cap + 8) : 0);
+           sizeof(int) * (V_NT / 64) * (V_STAGE + 2) + 16 + (n_cap <= V_PL_MAXN ? sizeof(int) * V_PLN * ((size_t)n_cap + 8) : 0);
 }
 // what the larger of the two kernels takes (the budget check of the caller)
 size_t fold185_lds_bytes(int n_cap, int max_lines) {
