@@ -47,7 +47,7 @@ struct GTab {
 #define GEN_NT 256
 #endif
 #ifndef GEN_FILL_WAVES
-#define GEN_FILL_WAVES 5
+#define GEN_FILL_WAVES 6
 #endif
 #define GEN_MIN_WAVES(phase) ((phase) == 1 ? GEN_FILL_WAVES : 1)      // waves per SIMD the register allocation aims for
 #ifndef GEN_PU
@@ -411,11 +411,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                             for (int s = 0; s < 7; s++) { const int dd = d - 2 - s; wr[s] = wlane + (dd > 0 ? dd : 0) * T.ld; }
                             const int w0 = wr[0][0];
                             const int2a w1 = *reinterpret_cast<const int2a*>(wr[1]);
-                            const int4a w2 = *reinterpret_cast<const int4a*>(wr[2]), w3 = *reinterpret_cast<const int4a*>(wr[3]), w4 = *reinterpret_cast<const int4a*>(wr[4]);
-                            const int w44 = wr[4][4];
-                            const int4a w5 = *reinterpret_cast<const int4a*>(wr[5]);
-                            const int2a w5b = *reinterpret_cast<const int2a*>(wr[5] + 4);
-                            const int4a w6 = *reinterpret_cast<const int4a*>(wr[6]), w6b = *reinterpret_cast<const int4a*>(wr[6] + 3);
+                            const int4a w2 = *reinterpret_cast<const int4a*>(wr[2]), w3 = *reinterpret_cast<const int4a*>(wr[3]);
                             // reversed type of the inner pair (p, q) = (i + 1 + n1, j - 1 - n2), 0 = no pair
                             auto t2of = [&](const int n1, const int n2) { return pair_type(sJ[1 + n2], sI[1 + n1]); };
                             const int t00 = t2of(0, 0), t01 = t2of(0, 1), t10 = t2of(1, 0), t11 = t2of(1, 1), t12 = t2of(1, 2), t21 = t2of(2, 1), t22 = t2of(2, 2),
@@ -441,6 +437,13 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                                 const int eb = P->bulge[3] + tau;
                                 put_bulge(eb, w3[0], 0 << 5 | 3); put_if(t12, r12 + cof(w3[1]), 1 << 5 | 2); put_if(t21, r21 + cof(w3[2]), 2 << 5 | 1); put_bulge(eb, w3[3], 3 << 5 | 0);
                             }
+                            // (the words of the sizes 4 .. 6 are asked for here, behind the sizes 0 .. 3: all ten loads up front were the kernel's register peak -- with
+                            // them in two halves it fits 79 VGPRs without new spills, six waves per SIMD: six workgroups per CU wherever LDS allows, windows up to 400 nt)
+                            const int4a w4 = *reinterpret_cast<const int4a*>(wr[4]);
+                            const int w44 = wr[4][4];
+                            const int4a w5 = *reinterpret_cast<const int4a*>(wr[5]);
+                            const int2a w5b = *reinterpret_cast<const int2a*>(wr[5] + 4);
+                            const int4a w6 = *reinterpret_cast<const int4a*>(wr[6]), w6b = *reinterpret_cast<const int4a*>(wr[6] + 3);
                             if (smax >= 4) {
                                 const int eb = P->bulge[4] + tau;
                                 const int x1 = 2 * ninio;
