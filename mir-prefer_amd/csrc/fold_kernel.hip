@@ -57,7 +57,7 @@ struct GTab {
 #define GEN_STAGE 512              // ints per wave of the interior-loop interval's staging buffer
 #define GEN_PINF 1500000           // 'no pair' in the 24-bit energy field of GTab::w: with every loop term added it stays below 2^21, so that energy * 1024 + shape is an int
 #define GEN_EMAX 1000000           // a candidate energy at or above this came from a GEN_PINF entry (real energies: a few hundred per nucleotide pair at most)
-#define GEN_AUX_BYTES(nc) ((((size_t)(4 + 8 + 2 + 2) * (nc) + 8) + 15) / 16 * 16)      // pcnt (int), cbest (32-bit keys; two diagonals), plist (short), ctype (byte; two diagonals) per position
+#define GEN_AUX_BYTES(nc) ((((size_t)(8 + 2 + 2 + 2) * (nc) + 8) + 15) / 16 * 16)      // cbest (32-bit keys; two diagonals), pcnt (short), plist (short), ctype (byte; two diagonals) per position
 
 __host__ __device__ size_t fold_generic_lds_bytes_base(int n_cap, int max_lines) {
     const int nc = n_cap + 8;
@@ -78,7 +78,7 @@ __host__ __device__ inline int fold_generic_ld(int n_cap) { return (n_cap + 2 + 
 // the fill kernel's share of the base carve-up: the sequence codes and the special-hairpin table (everything else above is the epilogue's)
 __host__ __device__ size_t fold_generic_lds_bytes_base_fill(int n_cap) {
     const int nc = n_cap + 8;
-    return ((size_t)(sizeof(int) * 8 + sizeof(short) * 3 * nc + 2 * nc) + 15) & ~(size_t)15;
+    return ((size_t)(sizeof(int) * 8 + sizeof(short) * 3 * nc + nc) + 15) & ~(size_t)15;
 }
 
 // one table (c or fML) of a workspace slot, in ints
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
         sh_misc = (int*)smem;                              // 8
         spec = (short*)(sh_misc + 8);                      // 3*nc
         S = (unsigned char*)(spec + 3 * nc);               // nc
-        seq = S + nc;                                      // nc
+        seq = nullptr;                                     // (set below: the window's letters are needed for the special-hairpin table only, and sit in the staging buffer meanwhile)
     } else {
         f3 = (int*)smem;                                   // nc ints
         starts = f3 + nc;                                  // max_lines
@@ -126,10 +126,10 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
         btbuf = (char*)(seq + nc);                         // (NT/64)*nc
     }
     const size_t base_bytes = PHASE == 1 ? fold_generic_lds_bytes_base_fill(n_cap) : fold_generic_lds_bytes_base(n_cap, max_lines);
-    int* pcnt = (int*)(smem + base_bytes);      // nc: split candidates of every column so far (from here on: the fill's alone)
-    int* cbest = pcnt + nc;                                // 2 nc: interior-loop minimum of the diagonal's cells as the tasks' key, energy * 1024 + (n1 << 5 | n2): the
-                                                           // minimum names the first loop in the backtrack's search order (0x7fffffff: none)
-    unsigned short* plist = (unsigned short*)(cbest + 2 * nc); // nc: the diagonal's paired cells  (cbest, ctype: [diagonal & 1][nc] -- interval A of d + 1 runs beside interval B of d)
+    int* cbest = (int*)(smem + base_bytes);                // 2 nc: interior-loop minimum of the diagonal's cells as the tasks' key, energy * 1024 + (n1 << 5 | n2): the
+                                                           // minimum names the first loop in the backtrack's search order (0x7fffffff: none)  (from here on: the fill's alone)
+    unsigned short* pcnt = (unsigned short*)(cbest + 2 * nc);      // nc: split candidates of every column so far
+    unsigned short* plist = pcnt + nc;                     // nc: the diagonal's paired cells  (cbest, ctype: [diagonal & 1][nc] -- interval A of d + 1 runs beside interval B of d)
     unsigned char* ctype = (unsigned char*)(plist + nc);   // 2 nc: pair type of the diagonal's cells
     // inner-pair terms of the interior-loop energies, [t2][sq1][sp1] as shorts, and the stacking table: read per candidate -- out of LDS, not through
     // the texture addresser (the interval was bound by vector-memory instructions, one per table look-up and lane: DESIGN.md 4, "Generic kernels")
@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
     short* l_stack = l_x1 + 200;                           // 64
     int* stage = reinterpret_cast<int*>(l_stack + 64);     // GEN_STAGE ints per wave: the row segment a block of paired cells reads for one loop size (interval A)
     int* wcnt = stage + (GEN_NT / 64) * GEN_STAGE;         // 2 * waves: paired cells per wave and half-pass of the list compaction
+    if constexpr (PHASE == 1) seq = reinterpret_cast<unsigned char*>(stage);          // nc <= 4 * (GEN_NT / 64) * GEN_STAGE bytes (checked by the host: windows up to 8,184 nt)
     int* pl4 = wcnt + 2 * (GEN_NT / 64);                  // 4 nc: the first four split candidates of every column, packed s << 20 | (fML & 0xfffff) (interval B; windows up to GEN_PL_MAXN nt)
     if constexpr (PHASE == 1) {
     for (int x = threadIdx.x; x < 200; x += GEN_NT) {
@@ -558,7 +559,7 @@ __global__ void __launch_bounds__(GEN_NT, GEN_MIN_WAVES(PHASE)) fold_generic_ker
                         if (pn < pcap) {
                             pool[(size_t)j * pcap + pn] = make_int2(i, e);
                             if (n_cap <= GEN_PL_MAXN && pn < 4) pl4[4 * j + pn] = (i << 20) | (e & 0xfffff);
-                            pcnt[j] = pn + 1;
+                            pcnt[j] = (unsigned short)(pn + 1);
                         }
                     }
                 }
