@@ -22,6 +22,9 @@ namespace v185 {
 #endif
 #define V_STAGE 512               // ints per wave of the interior-loop interval's staging buffer
 #define V_FILL_WAVES 5            // waves per SIMD the fill's register allocation aims for
+#ifndef V_EPI_WAVES
+#define V_EPI_WAVES 8             // (as fold_generic_kernel: the epilogue is latency-bound, eight workgroups per CU with spills beat three without: 0.251 -> 0.242 s at L = 400)
+#endif
 typedef int v_int2a __attribute__((ext_vector_type(2), aligned(4)));      // consecutive cells of a table row from any 4-byte boundary
 typedef int v_int4a __attribute__((ext_vector_type(4), aligned(4)));
 typedef int v_int4q __attribute__((ext_vector_type(4), aligned(16)));
@@ -47,7 +50,7 @@ __host__ __device__ inline size_t fold185_lds_bytes_base_fill(int n_cap) { retur
 // PHASE 1 = fill, PHASE 2 = exterior sweep + backtracks, launched back to back over batches of `grid` windows (slot = blockIdx.x), as fold_generic_kernel:
 // the fill needs half the registers of the epilogue.
 template <int PHASE>
-__global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : 1) fold185_kernel(
+__global__ void __launch_bounds__(V_NT, PHASE == 1 ? V_FILL_WAVES : V_EPI_WAVES) fold185_kernel(
     const FoldParams185* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     const int* __restrict__ work_list, int n_work, int span, int n_cap, int* __restrict__ ws, size_t ws_slot_ints, int max_lines, int ss_stride, MirpFoldLine* __restrict__ out_lines,
     char* __restrict__ out_ss, int* __restrict__ out_nlines, int* __restrict__ out_mfe, int* __restrict__ out_status) {

@@ -49,7 +49,10 @@ struct GTab {
 #ifndef GEN_FILL_WAVES
 #define GEN_FILL_WAVES 6
 #endif
-#define GEN_MIN_WAVES(phase) ((phase) == 1 ? GEN_FILL_WAVES : 1)      // waves per SIMD the register allocation aims for
+#ifndef GEN_EPI_WAVES
+#define GEN_EPI_WAVES 8                   // (the epilogue is a chain of round trips to the workspace: 148 VGPRs and three workgroups per CU take 0.142 s at L = 400, 64 with spills and eight 0.133)
+#endif
+#define GEN_MIN_WAVES(phase) ((phase) == 1 ? GEN_FILL_WAVES : GEN_EPI_WAVES)      // waves per SIMD the register allocation aims for
 #ifndef GEN_PU
 #define GEN_PU 4                  // split candidates of a column whose reads are in flight together (interval B)
 #endif
