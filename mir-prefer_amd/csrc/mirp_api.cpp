@@ -305,7 +305,7 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         if (m185) {
             if (mirp::fold185_lds_bytes(n_cap, max_lines) > 160 * 1024) return fail(c, -5, "LDS budget exceeded (vienna-1.8.5 kernel: window or max_lines too large)");
             const size_t slot = mirp::fold185_ws_slot_ints(n_cap, span);
-            int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 32, ((size_t)64 << 30) / (slot * 4)));      // windows per batch (fill kernel, then epilogue kernel)
+            int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 96, ((size_t)128 << 30) / (slot * 4)));      // windows per batch (fill kernel, then epilogue kernel)
             slots = std::min(slots, n_generic);
             if (c->ws.ensure((size_t)slots * slot * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
             hipError_t e = mirp::launch_fold185(c->stream, slots, c->d_params185, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot,
@@ -314,9 +314,10 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             return 0;
         }
         const size_t slot_ints = mirp::fold_generic_ws_slot_ints(n_cap, span);          // c, fML, DML ring, split-candidate pool of one window
-        int wg_per_cu = 32;         // windows in flight per CU and batch (the hardware keeps as many resident as registers and LDS allow: 5 of the fill, 3 of the epilogue)
+        int wg_per_cu = 96;         // windows per CU and batch (the hardware keeps as many resident as registers and LDS allow: 6 of the fill, 8 of the epilogue): one batch for
+                                    // 20,000 windows -- every batch ends with a tail of idle CUs (three batches of 8,192: 0.075 s at L = 301, one: 0.069), and 288 GB hold the 45 - 75 GB
         if (const char* e = std::getenv("MIRP_GENERIC_WG_PER_CU")) wg_per_cu = std::max(1, std::atoi(e));      // dev: occupancy experiments (profiles/tools/l400_time.py)
-        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * wg_per_cu, ((size_t)64 << 30) / (slot_ints * 4)));      // PRECURSOR_LEN = 3000: 160 MB a slot
+        int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * wg_per_cu, ((size_t)128 << 30) / (slot_ints * 4)));      // PRECURSOR_LEN = 3000: 160 MB a slot
         slots = std::min(slots, n_generic);
         if (c->ws.ensure((size_t)slots * slot_ints * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
         mirp::launch_fold_generic(c->stream, slots, c->d_params, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot_ints,
