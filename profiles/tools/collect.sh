@@ -17,6 +17,6 @@ tail -1 gpurun_out/${TAG}_stats185.log | cut -c1-200
 # 7. the generic path (PRECURSOR_LEN = 400: fold_generic_kernel / fold185_kernel over config[1]'s 19,686 windows, two folds each): kernel stats and the fill kernel's counters
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_L400 -- python3 profiles/tools/l400_time.py 400 > gpurun_out/${TAG}_L400.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_L400_185 -- python3 profiles/tools/l400_time.py 400 vienna-1.8.5 > gpurun_out/${TAG}_L400_185.log 2>&1
-( tail -2 gpurun_out/${TAG}_L400.log; echo "counters of fold_generic_kernel<1>, sums over the six launches of two folds (rocprofv3 --pmc, one pass per group):"; bash profiles/tools/pmc_l400.sh 2>&1 | grep "^l400" ) > gpurun_out/${TAG}_L400_counters.txt
-( tail -2 gpurun_out/${TAG}_L400_185.log; echo "counters of fold185_kernel<1>, sums over the six launches of two folds:"; bash profiles/tools/pmc_l400.sh mir-prefer_amd/libmirprefer.so vienna-1.8.5 2>&1 | grep "^l400" ) > gpurun_out/${TAG}_L400_vienna185_counters.txt
+( tail -2 gpurun_out/${TAG}_L400.log; echo "counters of fold_generic_kernel<1>, sums over the launches of two folds (rocprofv3 --pmc, one pass per group):"; bash profiles/tools/pmc_l400.sh 2>&1 | grep "^l400" ) > gpurun_out/${TAG}_L400_counters.txt
+( tail -2 gpurun_out/${TAG}_L400_185.log; echo "counters of fold185_kernel<1>, sums over the launches of two folds:"; bash profiles/tools/pmc_l400.sh mir-prefer_amd/libmirprefer.so vienna-1.8.5 2>&1 | grep "^l400" ) > gpurun_out/${TAG}_L400_vienna185_counters.txt
 tail -3 gpurun_out/${TAG}_L400_counters.txt | cut -c1-200
