@@ -307,7 +307,10 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
             const size_t slot = mirp::fold185_ws_slot_ints(n_cap, span);
             int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * 96, ((size_t)128 << 30) / (slot * 4)));      // windows per batch (fill kernel, then epilogue kernel)
             slots = std::min(slots, n_generic);
-            if (c->ws.ensure((size_t)slots * slot * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
+            while (c->ws.ensure((size_t)slots * slot * 4)) {          // (the device may be shared: take fewer windows per batch before giving up)
+                if (slots <= 1) return fail(c, -6, "device allocation failed (fold workspace)");
+                slots = (slots + 1) / 2; (void)hipGetLastError();
+            }
             hipError_t e = mirp::launch_fold185(c->stream, slots, c->d_params185, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot,
                                                 max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
             if (e != hipSuccess) return fail(c, -2, std::string("fold (vienna-1.8.5) kernel launch failed: ") + hipGetErrorString(e));
@@ -319,7 +322,10 @@ int mirp_run_fold(mirp_ctx* c, const unsigned char* d_seqs, const long long* d_o
         if (const char* e = std::getenv("MIRP_GENERIC_WG_PER_CU")) wg_per_cu = std::max(1, std::atoi(e));      // dev: occupancy experiments (profiles/tools/l400_time.py)
         int slots = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cu * wg_per_cu, ((size_t)128 << 30) / (slot_ints * 4)));      // PRECURSOR_LEN = 3000: 160 MB a slot
         slots = std::min(slots, n_generic);
-        if (c->ws.ensure((size_t)slots * slot_ints * 4)) return fail(c, -6, "device allocation failed (fold workspace)");
+        while (c->ws.ensure((size_t)slots * slot_ints * 4)) {          // (the device may be shared: take fewer windows per batch before giving up)
+            if (slots <= 1) return fail(c, -6, "device allocation failed (fold workspace)");
+            slots = (slots + 1) / 2; (void)hipGetLastError();
+        }
         mirp::launch_fold_generic(c->stream, slots, c->d_params, d_seqs, d_offs, d_lens, work_list, n_generic, span, n_cap, (int*)c->ws.p, slot_ints,
                                   max_lines, stride, d_lines, d_ss, d_nlines, d_mfe, d_status);
         HIPCHK(c, hipGetLastError());
