@@ -46,8 +46,13 @@ namespace mirp {
 // {s-1, j, fML(s,j)} behind the window's fML triangle; phase A2 maps LANE = POOL ENTRY: the entry's column j holds exactly one cell of the
 // diagonal at hand, (j-d, j), which it relaxes with one gather + one LDS atomic minimum.  A row's thread carries DML(i,j-1) in a register.
 // A window whose pool overflows (tandem repeats) or whose length leaves no room for one is handed to the dense instantiation (second launch).
+// MIRP_FILL_ATTR (dev builds): extra attributes of the fill kernel, e.g. -DMIRP_FILL_ATTR='__attribute__((amdgpu_num_vgpr(52)))' -- gfx950 doubles the
+// request (unified register file), 52 caps the kernel at 104 VGPRs
+#ifndef MIRP_FILL_ATTR
+#define MIRP_FILL_ATTR
+#endif
 template <int MODEL, bool SPARSE>
-__global__ void __launch_bounds__(LNT) fold_lds_kernel(
+__global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
     const FoldParams* __restrict__ P, const unsigned char* __restrict__ seqs, const long long* __restrict__ offs, const int* __restrict__ win_lens,
     int n_work, int win_base, int span, short* __restrict__ slabs, size_t slab_shorts, int* __restrict__ win_state,
     unsigned int* __restrict__ work_counter, int* __restrict__ fallback_list,
