@@ -112,6 +112,11 @@ __global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
     int* rbt = misc + 48;                                           // [ARCH_RB]: row-block offsets of the window's archive slabs (arch_rowblk_off)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Issue priority (s_setprio, round 6): the four waves with the longest interior-loop roles (12-15: the four- and five-row generic jobs) yield to the
+    // other twelve when a SIMD's arbiter has a choice -- every SIMD holds exactly one of them.  The interval's critical path runs through the waves that
+    // own phase-B cells and then their own roles, not through the longest role: raising waves 12-15 instead costs 7 % (63.5 ms), a graded map 14 %,
+    // switching the priority around phase B costs more than it gains; this map: 59.55 -> 59.12 ms (profiles/experiments/r6_fill_setprio.txt).
+    if (wave < 12) __builtin_amdgcn_s_setprio(1);
     const int nc = CSTR;
     // Appends this thread's cell (i, pair type t; t = 0: none) to the paired-cell list of diagonal dd: ballot compaction inside the wave, one
     // LDS atomic per wave for its range.  The order of the ranges depends on which wave arrives first; nothing depends on the order of a
