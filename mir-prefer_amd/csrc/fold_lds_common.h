@@ -197,6 +197,10 @@ static_assert(lds_layout<0>().total <= 160 * 1024 && lds_layout<1>().total <= 16
 // stacked pair), um = largest admissible n1 + n2 (inner pair keeps q - p >= TURN + 1).  Running minima are biased uint (65535 = none).
 typedef const volatile __attribute__((address_space(3))) unsigned short* lds_vu16;   // LDS reads that must stay narrow (see a1_gen_row)
 typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8;
+typedef const volatile __attribute__((address_space(3))) unsigned* lds_vu32;
+#ifndef MIRP_A1_WPACK
+#define MIRP_A1_WPACK 2      // 0: 16-bit reads of the generic rows (rounds 3-5), 1: the wings as aligned dwords, 2: whole rows as aligned dwords (round 6)
+#endif
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 #if MIRP_A1_CODES4
 typedef unsigned char pax_t;          // the p codes (xt_pcode < 256) as bytes: copy 0 of their four shifted copies
@@ -215,6 +219,8 @@ struct A1 {
     const unsigned char* code4 = nullptr;      // MIRP_A1_CODES4: [4][CODE_STR] copy c of qbr shifted by c bytes, then the same of the p codes as bytes
     int r0, um, n;
     const int* __restrict__ rowtab;    // FoldParams::ring_rowoff[r0 & 31]: ring-row offset (shorts) of loop size u, i.e. ((r0 - u) & 31) * CSTR
+    const unsigned short* rba = nullptr;       // a1_gen_row_w: cring + i + 1 rounded down to a dword, and the end masks of the lane's parity
+    unsigned w_lo = 0, w_hie = 0, w_hio = 0, w_sh = 0;
 };
 
 // generic loops (n1, n2 >= 2) of size U: one contiguous run of ring row r0 - U.  The reads stay 16-bit on purpose (volatile keeps the
@@ -222,6 +228,26 @@ struct A1 {
 // natural alignment is replayed at 64 cycles per wave-instruction on gfx950, against 2 cycles for a 16-bit read.
 template <bool CHECK, int U>
 __device__ __forceinline__ void a1_gen_row(const A1& a, const unsigned short* rb, unsigned& bg) {
+    if constexpr (MIRP_A1_WPACK == 2 && !CHECK && U >= 8) {
+        // (round 6) the row as aligned dwords, every entry out of a realigned register (see a1_gen_row_w): half the LDS passes of 16-bit reads
+        lds_vu32 rq = (lds_vu32)(a.rba + a.rowtab[U]);
+        constexpr int m1 = (U - 2) >> 1;
+        unsigned dw[m1 + 2];
+#pragma unroll
+        for (int k = 1; k <= m1 + 1; k++) dw[k] = rq[k];
+        const unsigned c1024 = 1024u;
+#pragma unroll
+        for (int m = 1; m <= m1; m++) {
+            const unsigned re = __builtin_amdgcn_alignbit(dw[m + 1], dw[m], a.w_sh);      // entries 2 m, 2 m + 1
+            unsigned e;
+            asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(e) : "v"(re), "v"(c1024), "s"(a.P->gen_key[U - 6][2 * m]));
+            bg = e < bg ? e : bg;
+            if (2 * m + 1 <= U - 2) {
+                asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(e) : "v"(re), "v"(c1024), "s"(a.P->gen_key[U - 6][2 * m + 1]));
+                bg = e < bg ? e : bg;
+            }
+        }
+    } else
     if (!CHECK || U <= a.um) {
         lds_vu16 rp = (lds_vu16)(rb + a.rowtab[U]);
         unsigned v[U - 3];      // all reads of the run in flight before the first use
@@ -243,8 +269,70 @@ __device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
 // is added once; only the 2 WD - 1 or fewer candidates around n1 = n2 pay an add of their own.  The wing minimum names no shape: its key
 // carries code 63, and a cell that ends up with that code has its loop found by the epilogue (TB_GENERIC, bt_search_unnamed) -- rarely,
 // MFE structures seldom hold loops that lopsided.  A row of U has U - 3 candidates: 54 VALU instructions before, 20 now at U = 30.
+// Round 6: the wings as ALIGNED 32-bit reads, two ring entries each.  A wing's minimum does not care which entry came from where, so the reads need not start
+// at the lane's own (2-byte) boundary: they cover the wing from the aligned dword below it -- an entry more at the inner end lands on a centre candidate,
+// whose own key is smaller than the wing key of the same entry, at the outer ends the lane's parity masks (A1::w_lo / w_hie / w_hio) turn the 1 x n / bulge
+// neighbours into INF -- and v_pk_min_u16 folds two entries per instruction as v_min3_u32 did.  A 16-bit read moves 2 of the 4 bytes a lane's bank slot
+// carries: 27 reads of row 30 become 17.  Only rows whose wings hold three entries or more (U >= 14), not on the first diagonals (CHECK).
 template <bool CHECK, int WD, int U>
 __device__ __forceinline__ void a1_gen_row_w(const A1& a, const unsigned short* rb, unsigned& bg) {
+    constexpr int nL = (U - WD) / 2, nR = (U + WD + 1) / 2;      // last entry of the left wing, first of the right one
+    if constexpr (MIRP_A1_WPACK == 2 && !CHECK && nL >= 4) {
+        // the whole row as contiguous aligned dwords; the centre's entries come out of the same registers: v_alignbit by the lane's parity puts entries
+        // (2 m, 2 m + 1) into one register, v_mad_u32_u16 takes either half (op_sel) times 1024 plus the candidate's scalar key term
+        lds_vu32 rq = (lds_vu32)(a.rba + a.rowtab[U]);
+        constexpr int kL1 = (1 + nL) >> 1, kR0 = nR >> 1, kR1 = (U - 1) >> 1;
+        constexpr int m0 = (nL + 1) >> 1, m1 = (nR - 1) >> 1;
+        static_assert(m1 + 1 <= kR1, "the centre's realigned dwords lie inside the row's reads");
+        unsigned dw[kR1 + 1];
+#pragma unroll
+        for (int k = 1; k <= kR1; k++) dw[k] = rq[k];
+        unsigned re[m1 - m0 + 1];
+#pragma unroll
+        for (int m = m0; m <= m1; m++) re[m - m0] = __builtin_amdgcn_alignbit(dw[m + 1], dw[m], a.w_sh);
+        us2 mm, t;
+        { const unsigned f = dw[1] | a.w_lo; __builtin_memcpy(&mm, &f, 4); }
+#pragma unroll
+        for (int k = 2; k <= kL1; k++) { __builtin_memcpy(&t, &dw[k], 4); mm = __builtin_elementwise_min(mm, t); }
+#pragma unroll
+        for (int k = kR0; k < kR1; k++) { __builtin_memcpy(&t, &dw[k], 4); mm = __builtin_elementwise_min(mm, t); }
+        { const unsigned l = dw[kR1] | ((U & 1) ? a.w_hio : a.w_hie); __builtin_memcpy(&t, &l, 4); mm = __builtin_elementwise_min(mm, t); }
+        const unsigned w0 = mm[0], w1 = mm[1], w = w0 < w1 ? w0 : w1;
+        { const unsigned k = (w << 10) + a.P->gen_wing_key[U - 6]; bg = k < bg ? k : bg; }
+        const unsigned c1024 = 1024u;
+#pragma unroll
+        for (int n1 = nL + 1; n1 < nR; n1++) {
+            unsigned e;
+            if (n1 & 1) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(e) : "v"(re[(n1 >> 1) - m0]), "v"(c1024), "s"(a.P->gen_key[U - 6][n1]));
+            else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(e) : "v"(re[(n1 >> 1) - m0]), "v"(c1024), "s"(a.P->gen_key[U - 6][n1]));
+            bg = e < bg ? e : bg;
+        }
+    } else
+    if constexpr (MIRP_A1_WPACK && !CHECK && nL >= 4) {
+        lds_vu16 rp = (lds_vu16)(rb + a.rowtab[U]);
+        lds_vu32 rq = (lds_vu32)(a.rba + a.rowtab[U]);           // the aligned dword at or below entry 0 (row offsets are whole dwords)
+        constexpr int kL0 = 1, kL1 = (1 + nL) >> 1, kR0 = nR >> 1, kR1 = (U - 1) >> 1;
+        static_assert(kL1 < kR0 && nR - nL - 1 >= 2, "the wings' dwords stay apart and over-cover centre candidates only");
+        unsigned wl[kL1 - kL0 + 1], wr[kR1 - kR0 + 1], c[nR - nL - 1];
+#pragma unroll
+        for (int k = kL0; k <= kL1; k++) wl[k - kL0] = rq[k];
+#pragma unroll
+        for (int n1 = nL + 1; n1 < nR; n1++) c[n1 - nL - 1] = rp[n1];
+#pragma unroll
+        for (int k = kR0; k <= kR1; k++) wr[k - kR0] = rq[k];
+        wl[0] |= a.w_lo;
+        wr[kR1 - kR0] |= (U & 1) ? a.w_hio : a.w_hie;
+        us2 m, t;
+        __builtin_memcpy(&m, &wl[0], 4);
+#pragma unroll
+        for (int k = 1; k <= kL1 - kL0; k++) { __builtin_memcpy(&t, &wl[k], 4); m = __builtin_elementwise_min(m, t); }
+#pragma unroll
+        for (int k = 0; k <= kR1 - kR0; k++) { __builtin_memcpy(&t, &wr[k], 4); m = __builtin_elementwise_min(m, t); }
+        const unsigned w0 = m[0], w1 = m[1], w = w0 < w1 ? w0 : w1;
+        { const unsigned k = (w << 10) + a.P->gen_wing_key[U - 6]; bg = k < bg ? k : bg; }
+#pragma unroll
+        for (int n1 = nL + 1; n1 < nR; n1++) { const unsigned e = (c[n1 - nL - 1] << 10) + a.P->gen_key[U - 6][n1]; bg = e < bg ? e : bg; }
+    } else
     if (!CHECK || U <= a.um) {
         lds_vu16 rp = (lds_vu16)(rb + a.rowtab[U]);
         unsigned v[U - 3];      // all reads of the run in flight before the first use
@@ -276,20 +364,33 @@ __device__ __forceinline__ void a1_gen_row_w(const A1& a, const unsigned short* 
     }
 }
 template <bool CHECK, int... Us>
-__device__ __forceinline__ unsigned a1_generic(const A1& a, int i, int j, int mm_outer) {
+__device__ __forceinline__ unsigned a1_generic(const A1& a0, int i, int j, int mm_outer) {
     unsigned bg = KEY_INF;
-    const unsigned short* rb = a.cring + i + 1;
+    const unsigned short* rb = a0.cring + i + 1;
+    A1 a = a0;
+    if constexpr (MIRP_A1_WPACK == 2 && !CHECK) {
+        const unsigned par = ((unsigned)(size_t)(lds_vu16)rb >> 1) & 1u;
+        a.rba = rb - par; a.w_sh = par * 16u;
+    }
     (a1_gen_row<CHECK, Us>(a, rb, bg), ...);
     return a1_key(bg, -32768 + mm_outer);      // mm_outer = mismatchI of the outer pair (i, j), fetched by the caller ahead of the rows
 }
 template <bool CHECK, int WD, int... Us>
-__device__ __forceinline__ unsigned a1_generic_w(const A1& a, int i, int j, int mm_outer) {
+__device__ __forceinline__ unsigned a1_generic_w(const A1& a0, int i, int j, int mm_outer) {
     unsigned bg = KEY_INF;
 #ifdef MIRP_X_GENBCAST          // timing experiment: every lane reads the same ring columns (no bank conflicts in the generic rows)
-    const unsigned short* rb = a.cring + 40 + (i & 1);
+    const unsigned short* rb = a0.cring + 40 + (i & 1);
 #else
-    const unsigned short* rb = a.cring + i + 1;
+    const unsigned short* rb = a0.cring + i + 1;
 #endif
+    A1 a = a0;
+    if constexpr (MIRP_A1_WPACK && !CHECK) {
+        // entry n1 of a row sits at halfword (par + n1) of the aligned base: the dword below the left wing holds entry 1 (1 x n) when par is set, the dword
+        // at the right wing's end entry U - 1 (U even, par clear), entries U - 1 and U (U odd, par clear) or entry U - 1 (U odd, par set)
+        const unsigned par = ((unsigned)(size_t)(lds_vu16)rb >> 1) & 1u;
+        a.rba = rb - par;
+        a.w_lo = par ? 0xffffu : 0u; a.w_hie = par ? 0u : 0xffff0000u; a.w_hio = par ? 0xffff0000u : 0xffffffffu; a.w_sh = par * 16u;
+    }
     (a1_gen_row_w<CHECK, WD, Us>(a, rb, bg), ...);
     return a1_key(bg, -32768 + mm_outer);
 }
