@@ -198,6 +198,9 @@ static_assert(lds_layout<0>().total <= 160 * 1024 && lds_layout<1>().total <= 16
 typedef const volatile __attribute__((address_space(3))) unsigned short* lds_vu16;   // LDS reads that must stay narrow (see a1_gen_row)
 typedef const volatile __attribute__((address_space(3))) unsigned char* lds_vu8;
 typedef const volatile __attribute__((address_space(3))) unsigned* lds_vu32;
+#ifndef MIRP_A1_SMALLPACK
+#define MIRP_A1_SMALLPACK 10     // short generic rows (U < 13) from this size on through realigned dwords as well (8: no gain, 10: -0.3 %)
+#endif
 #ifndef MIRP_A1_WPACK
 #define MIRP_A1_WPACK 2      // 0: 16-bit reads of the generic rows (rounds 3-5), 1: the wings as aligned dwords, 2: whole rows as aligned dwords (round 6)
 #endif
@@ -277,6 +280,30 @@ __device__ __forceinline__ unsigned a1_key(unsigned b, int adj) {
 template <bool CHECK, int WD, int U>
 __device__ __forceinline__ void a1_gen_row_w(const A1& a, const unsigned short* rb, unsigned& bg) {
     constexpr int nL = (U - WD) / 2, nR = (U + WD + 1) / 2;      // last entry of the left wing, first of the right one
+    if constexpr (MIRP_A1_WPACK == 2 && !CHECK && nL < 4 && U >= MIRP_A1_SMALLPACK) {
+        // short rows (wings of at most two entries): every entry out of a realigned register, the wing entries with the wing's key term
+        lds_vu32 rq = (lds_vu32)(a.rba + a.rowtab[U]);
+        constexpr int m1 = (U - 2) >> 1;
+        unsigned dw[m1 + 2];
+#pragma unroll
+        for (int k = 1; k <= m1 + 1; k++) dw[k] = rq[k];
+        const unsigned c1024 = 1024u;
+#pragma unroll
+        for (int m = 1; m <= m1; m++) {
+            const unsigned re = __builtin_amdgcn_alignbit(dw[m + 1], dw[m], a.w_sh);      // entries 2 m, 2 m + 1
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int n1 = 2 * m + h, dd = 2 * n1 - U;
+                if (n1 <= U - 2) {
+                    const unsigned kt = (dd <= -WD || dd >= WD) ? a.P->gen_wing_key[U - 6] : a.P->gen_key[U - 6][n1];
+                    unsigned e;
+                    if (h) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(e) : "v"(re), "v"(c1024), "s"(kt));
+                    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(e) : "v"(re), "v"(c1024), "s"(kt));
+                    bg = e < bg ? e : bg;
+                }
+            }
+        }
+    } else
     if constexpr (MIRP_A1_WPACK == 2 && !CHECK && nL >= 4) {
         // the whole row as contiguous aligned dwords; the centre's entries come out of the same registers: v_alignbit by the lane's parity puts entries
         // (2 m, 2 m + 1) into one register, v_mad_u32_u16 takes either half (op_sel) times 1024 plus the candidate's scalar key term
