@@ -249,6 +249,13 @@ __global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
         int sp_ncpad = 0, sp_nsub = 0, sp_pair = 0, sp_sub = 0, sp_so1 = 0, sp_si1 = 0, sp_so2 = 0, sp_si2 = 0;
         int sp_snap = 0;          // sparse splits: pool size as read one interval ago (wave-uniform)
         int dml_carry = INF;      // sparse splits: DML(i, j-1) of this thread's row i = tid + 1 (phase B carries it from diagonal to diagonal)
+#ifndef MIRP_PB_BASES
+#define MIRP_PB_BASES 1
+#endif
+        // (MIRP_PB_BASES, round 6) phase B of the default model takes its bases out of two registers: the row's own three once per window, the far side's five as a window that slides by one
+        // base per diagonal (a row's thread owns cell (i, i + d) in interval d) -- one byte read per cell and interval instead of eight
+        int pb_si = 0;            // S[i-1] | S[i] << 3 | S[i+1] << 6
+        int pb_sj = 0;            // S[j-1] | S[j] << 3 | S[j+1] << 6 | S[j+2] << 9 | S[j+3] << 12 of the cell of the coming phase B
         int a1_done = 0;      // phase A1: cells of the next diagonal's list already relaxed (wave-uniform)
         const int abase = tid < 8 * ARCH_RB ? rbt[tid >> 3] + (tid & 7) - 32 : 0;   // archive offset of (d, i = tid + 1) is abase + 8 d
         int a1_ncp = __builtin_amdgcn_readfirstlane(lcnt[0]);   // phase A1: length of the next diagonal's list (first: diagonal 6)
@@ -827,9 +834,15 @@ __global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
                 const int i = x + 1, j = i + d, u = d - 1;
                 // ---- round 1
                 lds_vu8 Sv = (lds_vu8)S;
+#if MIRP_PB_BASES
+                const int s_im1 = pb_si & 7, s_i = (pb_si >> 3) & 7, s_ip1 = (pb_si >> 6) & 7, s_jm1 = pb_sj & 7, s_j = (pb_sj >> 3) & 7, s_jp1 = (pb_sj >> 6) & 7;
+                const int s_j2 = (pb_sj >> 9) & 7, s_j3 = (pb_sj >> 12) & 7;
+                pb_sj = (pb_sj >> 3) | ((int)Sv[j + 4] << 12);      // (S holds LCAP + 8 bytes: in range for every j <= n)
+#else
                 const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
                 const int s_j3 = Sv[j + 3 <= n ? j + 3 : n];          // far end of cell (i, j+3): the paired-cell list of diagonal d+3
                 const int s_j2 = Sv[j + 2 <= n ? j + 2 : n];          // its 5' neighbour, for the entry's outer-pair table index
+#endif
                 int md = mdec[i];
                 if constexpr (SPARSE) { md = dml_carry < md ? dml_carry : md; dml_carry = md; }      // DML(i,j) = min(DML(i,j-1), candidate splits)
                 const unsigned kk = ckey[i];
@@ -1099,6 +1112,14 @@ __global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
             sp_snap = __builtin_amdgcn_readfirstlane(tot);
             __syncthreads();
         };
+        if constexpr (MODEL == 0 && MIRP_PB_BASES != 0) {
+            if (tid < n - 4) {
+                const int i = tid + 1, j = i + 4;
+                lds_vu8 Sv = (lds_vu8)S;
+                pb_si = (int)Sv[i - 1] | ((int)Sv[i] << 3) | ((int)Sv[i + 1] << 6);
+                pb_sj = (int)Sv[j - 1] | ((int)Sv[j] << 3) | ((int)Sv[j + 1] << 6) | ((int)Sv[j + 2] << 9) | ((int)Sv[j + 3] << 12);
+            }
+        }
         if (Dm >= 4) phaseA(4);
         __syncthreads();
         if (dbg_cycles && tid == 0) { long long t = clock64(); tA += t - t0; t0 = t; }
