@@ -966,8 +966,14 @@ __global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
                 const int i = x + 1, j = i + d, u = d - 1;
                 // ---- round 1: everything addressed by (i, j, d) alone
                 lds_vu8 Sv = (lds_vu8)S;
+#if MIRP_PB_BASES
+                const int s_im1 = pb_si & 7, s_i = (pb_si >> 3) & 7, s_ip1 = (pb_si >> 6) & 7, s_jm1 = pb_sj & 7, s_j = (pb_sj >> 3) & 7, s_jp1 = (pb_sj >> 6) & 7;
+                const int s_j2 = (pb_sj >> 9) & 7, s_j3 = (pb_sj >> 12) & 7;
+                pb_sj = (pb_sj >> 3) | ((int)Sv[j + 4] << 12);
+#else
                 const int s_im1 = Sv[i - 1], s_i = Sv[i], s_ip1 = Sv[i + 1], s_jm1 = Sv[j - 1], s_j = Sv[j], s_jp1 = Sv[j + 1];
                 const int s_j3 = Sv[j + 3 <= n ? j + 3 : n], s_j2 = Sv[j + 2 <= n ? j + 2 : n];
+#endif
                 int md = mdec[i];
                 if constexpr (SPARSE) { md = dml_carry < md ? dml_carry : md; dml_carry = md; }
                 const unsigned kk = ckey[i];
@@ -1112,7 +1118,7 @@ __global__ void __launch_bounds__(LNT) MIRP_FILL_ATTR fold_lds_kernel(
             sp_snap = __builtin_amdgcn_readfirstlane(tot);
             __syncthreads();
         };
-        if constexpr (MODEL == 0 && MIRP_PB_BASES != 0) {
+        if constexpr (MIRP_PB_BASES != 0) {
             if (tid < n - 4) {
                 const int i = tid + 1, j = i + 4;
                 lds_vu8 Sv = (lds_vu8)S;
